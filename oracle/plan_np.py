@@ -1,0 +1,181 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  Never imported by the product path.
+
+Bit-exact NumPy restatement of the build's *device* sampler + batch planner (kernel K1,
+``top-k-rec_amd/csrc/sampler.hip``).  Distribution = the reference's
+``BPR._uniform_user_sampling`` (single/bpr.py:155-165): u ~ U(tr_users) with replacement,
+i ~ U(tr_data[u]) (file order, duplicates kept), j ~ U{0..n_items-1} rejected while
+j in tr_data[u].  The random STREAM is the build's own (Philox4x32-10, counter-based) --
+the reference is unseeded (global legacy numpy RNG), so no stream exists to reproduce;
+the verbatim legacy sampler lives in ``ref_np.legacy_uniform_user_sampler`` (pinned by G2).
+
+Stream definition (everything below is integer arithmetic; the HIP kernel must match
+bit for bit):
+  key      = (seed & 0xffffffff, seed >> 32)
+  counter  = (g & 0xffffffff, g >> 32, round, 0)       g = first_triplet + b*B + t
+  round 0  : w = philox(counter);  u = tr_users[mulhi64(w0|w1<<32, n_tr)]
+                                   i = pos_cols[row_ptr[u] + mulhi64(w2|w3<<32, deg(u))]
+  round r>0: two negative candidates  mulhi64(w0|w1<<32, n_items), mulhi64(w2|w3<<32, n_items)
+             taken in that order; first one not in tr_data[u] wins; r = 1, 2, ... MAX_ROUNDS
+             After MAX_ROUNDS (only reachable when a user has rated almost every item) the
+             last candidate is advanced cyclically (j+1 mod n_items) until it is not in
+             tr_data[u], at most n_items steps (a user who rated EVERY item makes the
+             reference spin forever; here the candidate comes back unchanged).
+  mulhi64(x, n) = floor(x * n / 2**64)
+
+Plan definition (per batch of B triplets, consumed by the step kernels):
+  user occurrences   t = 0..B-1 sorted by (u[t], t)           -> occ[p]    = (i[t], j[t])
+  item occurrences   o = 0..2B-1 (o<B: item i[o], role 0; else item j[o-B], role 1)
+                     sorted by (item[o], o)                    -> occ[B+p] = (u[t], other | role<<31)
+  tasks              one per unique user (ascending id) then one per unique item
+                     (ascending id): (row | kind<<31, occ_start, occ_count, 0); unused
+                     slots up to 3B hold (-1, 0, 0, 0).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+U32 = np.uint32
+U64 = np.uint64
+MAX_ROUNDS = 64
+
+_M0, _M1 = U64(0xD2511F53), U64(0xCD9E8D57)
+_W0, _W1 = 0x9E3779B9, 0xBB67AE85
+_MASK = U64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al., Random123) on arrays of uint32 counters/keys."""
+    c0, c1, c2, c3 = (np.asarray(x, dtype=U64) & _MASK for x in (c0, c1, c2, c3))
+    k0 = int(k0) & 0xFFFFFFFF
+    k1 = int(k1) & 0xFFFFFFFF
+    for rnd in range(10):
+        p0 = _M0 * c0
+        p1 = _M1 * c2
+        hi0, lo0 = p0 >> U64(32), p0 & _MASK
+        hi1, lo1 = p1 >> U64(32), p1 & _MASK
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ U64(k0)), lo1, (hi0 ^ c3 ^ U64(k1)), lo0
+        k0 = (k0 + _W0) & 0xFFFFFFFF
+        k1 = (k1 + _W1) & 0xFFFFFFFF
+    return c0.astype(U32), c1.astype(U32), c2.astype(U32), c3.astype(U32)
+
+
+def mulhi64(lo, hi, n):
+    """floor((hi<<32 | lo) * n / 2**64) for uint32 arrays lo, hi and 0 < n < 2**32."""
+    lo = np.asarray(lo, dtype=U64)
+    hi = np.asarray(hi, dtype=U64)
+    n = np.asarray(n, dtype=U64)
+    return ((hi * n + ((lo * n) >> U64(32))) >> U64(32)).astype(np.int64)
+
+
+def build_csr(tr_data, n_users):
+    """tr_data (uidx -> [iidx...]) -> row_ptr[n_users+1], pos_cols (file order, duplicates
+    kept), cols_sorted (per-row ascending copy used for the membership test)."""
+    row_ptr = np.zeros(n_users + 1, dtype=np.int64)
+    for u, items in tr_data.items():
+        row_ptr[u + 1] = len(items)
+    row_ptr = np.cumsum(row_ptr)
+    pos = np.zeros(int(row_ptr[-1]), dtype=np.int32)
+    srt = np.zeros(int(row_ptr[-1]), dtype=np.int32)
+    for u, items in tr_data.items():
+        a = np.asarray(items, dtype=np.int32)
+        pos[row_ptr[u]:row_ptr[u + 1]] = a
+        srt[row_ptr[u]:row_ptr[u + 1]] = np.sort(a)
+    return row_ptr.astype(np.int32), pos, srt
+
+
+def _member(u, j, row_ptr, cols_sorted, n_items):
+    """j in tr_data[u] via one global searchsorted over (u*n_items + col) keys."""
+    deg = np.diff(row_ptr.astype(np.int64))
+    owner = np.repeat(np.arange(len(deg), dtype=np.int64), deg)
+    keys = owner * int(n_items) + cols_sorted.astype(np.int64)       # ascending overall
+    q = u.astype(np.int64) * int(n_items) + j.astype(np.int64)
+    p = np.searchsorted(keys, q)
+    p = np.minimum(p, max(len(keys) - 1, 0))
+    return (keys[p] == q) if len(keys) else np.zeros(len(q), dtype=bool)
+
+
+def sample_triplets(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed, first_triplet, count):
+    """`count` consecutive triplets of the device stream starting at global index
+    `first_triplet` -> (u, i, j) int32 arrays."""
+    tr_users = np.asarray(tr_users, dtype=np.int32)
+    g = np.arange(count, dtype=np.uint64) + np.uint64(first_triplet)
+    c0, c1 = (g & _MASK).astype(U32), (g >> U64(32)).astype(U32)
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    zeros = np.zeros(count, dtype=U32)
+    w0, w1, w2, w3 = philox4x32_10(c0, c1, zeros, zeros, k0, k1)
+    u = tr_users[mulhi64(w0, w1, len(tr_users))]
+    start = row_ptr[u].astype(np.int64)
+    deg = row_ptr[u + 1].astype(np.int64) - start
+    i = pos_cols[start + mulhi64(w2, w3, deg)]
+    j = np.zeros(count, dtype=np.int32)
+    pending = np.arange(count)
+    for rnd in range(1, MAX_ROUNDS + 1):
+        if len(pending) == 0:
+            break
+        w0, w1, w2, w3 = philox4x32_10(c0[pending], c1[pending], np.full(len(pending), rnd, dtype=U32),
+                                       zeros[pending], k0, k1)
+        ca = mulhi64(w0, w1, n_items).astype(np.int32)
+        cb = mulhi64(w2, w3, n_items).astype(np.int32)
+        ra = _member(u[pending], ca, row_ptr, cols_sorted, n_items)
+        rb = _member(u[pending], cb, row_ptr, cols_sorted, n_items)
+        j[pending] = np.where(~ra, ca, cb)          # if both rejected, cb stays as "last candidate"
+        pending = pending[ra & rb]
+    for p in pending:                                # cyclic-scan fallback, see module docstring
+        lo, hi = int(row_ptr[u[p]]), int(row_ptr[u[p] + 1])
+        rated = set(cols_sorted[lo:hi].tolist())
+        cand = int(j[p])
+        for _ in range(int(n_items)):
+            if cand not in rated:
+                break
+            cand = (cand + 1) % int(n_items)
+        j[p] = cand
+    return u.astype(np.int32), i.astype(np.int32), j
+
+
+def plan_batch(u, i, j):
+    """Plan of ONE batch (see module docstring) -> (task int32[3B,4], occ int32[3B,2])."""
+    B = len(u)
+    task = np.zeros((3 * B, 4), dtype=np.int32)
+    task[:, 0] = -1
+    occ = np.zeros((3 * B, 2), dtype=np.int32)
+    # users
+    order = np.argsort(u.astype(np.int64), kind='stable')
+    su = u[order]
+    occ[:B, 0] = i[order]
+    occ[:B, 1] = j[order]
+    heads = np.flatnonzero(np.r_[True, su[1:] != su[:-1]])
+    ends = np.r_[heads[1:], B]
+    nu = len(heads)
+    task[:nu, 0] = su[heads]
+    task[:nu, 1] = heads
+    task[:nu, 2] = ends - heads
+    # items
+    item = np.concatenate([i, j]).astype(np.int64)
+    order = np.argsort(item, kind='stable')
+    si = item[order]
+    t = order % B
+    role = (order >= B)
+    other = np.where(role, i[t], j[t]).astype(np.int64)
+    occ[B:, 0] = u[t]
+    occ[B:, 1] = (other | (role.astype(np.int64) << 31)).astype(np.uint32).view(np.int32)
+    heads = np.flatnonzero(np.r_[True, si[1:] != si[:-1]])
+    ends = np.r_[heads[1:], 2 * B]
+    ni = len(heads)
+    task[nu:nu + ni, 0] = (si[heads] | (1 << 31)).astype(np.uint32).view(np.int32)
+    task[nu:nu + ni, 1] = B + heads
+    task[nu:nu + ni, 2] = ends - heads
+    return task, occ
+
+
+def sample_and_plan(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed, first_triplet,
+                    n_batches, B):
+    """What ``tkr_sample_plan`` produces for n_batches batches: (u,i,j)[n_batches*B],
+    task[n_batches,3B,4], occ[n_batches,3B,2]."""
+    u, i, j = sample_triplets(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed,
+                              first_triplet, n_batches * B)
+    tasks = np.zeros((n_batches, 3 * B, 4), dtype=np.int32)
+    occs = np.zeros((n_batches, 3 * B, 2), dtype=np.int32)
+    for b in range(n_batches):
+        sl = slice(b * B, (b + 1) * B)
+        tasks[b], occs[b] = plan_batch(u[sl], i[sl], j[sl])
+    return u, i, j, tasks, occs

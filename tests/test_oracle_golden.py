@@ -1,0 +1,97 @@
+"""Pin the CPU oracle (oracle/ref_np.py) to the golden vectors captured from the
+reference's own code (tests/golden/make_golden.py): G1 loader, G2 legacy sampler,
+G3 text I/O, G4-G7 evaluate CLI (stdout + per-user filtered lists)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_np as R
+
+
+def test_g1_loader(golden_dir):
+    d = os.path.join(golden_dir, 'g1')
+    exp = json.load(open(os.path.join(d, 'expected.json')))
+    got = R.load_training(os.path.join(d, 'uid'), os.path.join(d, 'vid'), os.path.join(d, 'tr.txt'))
+    assert got['uids'] == exp['uids'] and got['iids'] == exp['iids']
+    assert [list(p) for p in got['data']] == exp['data']
+    assert got['n_users'] == exp['n_users'] and got['n_items'] == exp['n_items']
+    assert got['epoch_sample_limit'] == exp['epoch_sample_limit']
+    assert {str(k): list(v) for k, v in got['tr_data'].items()} == exp['tr_data']
+    assert list(got['tr_data'].keys()) == [int(k) for k in exp['tr_data'].keys()]   # insertion order
+    assert got['tr_users'] == exp['tr_users']
+    # the duplicate-id quirk (utils.py:10-16): u2 re-pointed, u5 shares its index
+    assert exp['uids']['u2'] == exp['uids']['u5'] == 4 and exp['n_users'] == 5
+
+
+def test_g2_legacy_sampler_stream(golden_dir):
+    d = os.path.join(golden_dir, 'g2')
+    exp = np.load(os.path.join(d, 'expected.npz'))
+    m = R.load_training(os.path.join(d, 'uid'), os.path.join(d, 'vid'), os.path.join(d, 'f0tr.txt'))
+    np.random.seed(123)
+    gen = R.legacy_uniform_user_sampler(m['tr_users'], m['tr_data'], m['n_items'], 16)
+    for b in range(exp['ub'].shape[0]):
+        ub, ib, jb = next(gen)
+        assert str(ub.dtype) == str(exp['ub_dtype']) and str(ib.dtype) == str(exp['ib_dtype'])
+        np.testing.assert_array_equal(ub, exp['ub'][b])
+        np.testing.assert_array_equal(ib, exp['ib'][b])
+        np.testing.assert_array_equal(jb, exp['jb'][b])
+
+
+def test_g3_text_io(golden_dir, tmp_path):
+    d = os.path.join(golden_dir, 'g3')
+    exp = np.load(os.path.join(d, 'expected.npz'))
+    ids = json.load(open(os.path.join(d, 'ids.json')))
+    R.write_embed_text(str(tmp_path / 'm' / 'mat.dat'), exp['mat'])      # also creates the parent dir
+    R.write_embed_text(str(tmp_path / 'm' / 'bias.dat'), exp['bias'])
+    for name in ('mat.dat', 'bias.dat'):
+        assert open(tmp_path / 'm' / name, 'rb').read() == open(os.path.join(d, name), 'rb').read()
+    np.testing.assert_array_equal(R.read_embed_text(os.path.join(d, 'mat.dat')), exp['back_all'])
+    np.testing.assert_array_equal(R.read_embed_text(os.path.join(d, 'mat.dat'), ids), exp['back_ids'])
+    np.testing.assert_array_equal(R.read_embed_text(os.path.join(d, 'bias.dat'), ids), exp['back_bias'])
+    assert R.read_embed_text(os.path.join(d, 'missing.dat')) is None
+
+
+def _lists(data, model, sc, total, step=5):
+    uids = R.read_id_list(os.path.join(data, 'uid'))
+    vids = R.read_id_list(os.path.join(data, 'vid'))
+    rated = R.read_history(os.path.join(data, 'f0tr.txt'))
+    U = R.read_embed_text(os.path.join(model, 'final-U.dat'), uids)
+    V = R.read_embed_text(os.path.join(model, 'final-V.dat'), vids)
+    bp = os.path.join(model, 'final-B.dat')
+    b = R.read_embed_text(bp, vids) if os.path.exists(bp) else None
+    idl = os.path.join(data, 'f0te.%s.idl' % sc)
+    teids, teivt = R.read_id_list(idl), R.read_inverse_id_list(idl)
+    tests = R.read_test_likes(os.path.join(data, 'f0te.%s.txt' % sc), teids)
+    return R.evaluate_scenario(U, V, b, uids, vids, rated, teids, teivt, tests, step, total,
+                               canonical=True, return_lists=True)[1]
+
+
+@pytest.mark.parametrize('g,scs', [('g4', ['im', 'om']), ('g5', ['im', 'om']), ('g6', ['all'])])
+def test_g456_cli_and_lists(golden_dir, g, scs):
+    d = os.path.join(golden_dir, g)
+    exp = json.load(open(os.path.join(d, 'expected.json')))
+    data, model = os.path.join(d, 'data'), os.path.join(d, 'model')
+    assert R.evaluate_cli(data, model, scenarios=scs) == exp['stdout']
+    assert R.evaluate_cli(data, model, scenarios=scs, canonical=False) == exp['stdout']
+    if 'stdout_s3_t10' in exp:
+        assert R.evaluate_cli(data, model, step=3, total=10, scenarios=['om', 'im']) == exp['stdout_s3_t10']
+    for sc in scs:
+        assert exp['tie_free'][sc]
+        assert _lists(data, model, sc, 30) == exp['lists'][sc]
+
+
+def test_g7_edge_cases(golden_dir):
+    d = os.path.join(golden_dir, 'g7')
+    exp = json.load(open(os.path.join(d, 'expected.json')))
+    data, model = os.path.join(d, 'data'), os.path.join(d, 'model')
+    for run in exp['runs']:
+        assert R.evaluate_cli(data, model, step=run['step'], total=run['total'], scenarios=['sm']) == run['stdout']
+        assert _lists(data, model, 'sm', run['total'], run['step']) == run['lists']
+
+
+def test_batches_per_epoch_f7():
+    assert R.batches_per_epoch(10**6, 256) == 3906
+    assert R.batches_per_epoch(10e5, 256) == 3906
+    assert R.batches_per_epoch(512, 256) == 2
