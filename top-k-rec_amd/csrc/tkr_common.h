@@ -1,0 +1,82 @@
+// Shared device helpers for the top-k-rec MI355X (gfx950) kernels.  wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TKR_WAVE 64
+
+// Library error codes (negative); positive return values are hipError_t.
+#define TKR_OK 0
+#define TKR_EINVAL (-1)
+#define TKR_EUNSUPPORTED (-2)
+
+#define TKR_CHECK(expr)                       \
+    do {                                      \
+        hipError_t _e = (expr);               \
+        if (_e != hipSuccess) return (int)_e; \
+    } while (0)
+
+#define TKR_LAUNCH_CHECK()                    \
+    do {                                      \
+        hipError_t _e = hipGetLastError();    \
+        if (_e != hipSuccess) return (int)_e; \
+    } while (0)
+
+namespace tkr {
+
+// ---- Philox4x32-10 (Salmon et al.), the build's counter-based stream -----------------
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+
+// floor((hi<<32 | lo) * n / 2^64), 0 < n < 2^32
+__device__ __forceinline__ uint32_t mulhi64(uint32_t lo, uint32_t hi, uint32_t n) {
+    return (uint32_t)__umul64hi(((uint64_t)hi << 32) | lo, (uint64_t)n);
+}
+
+// ---- wave64 reductions ----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, TKR_WAVE);
+    return v;
+}
+
+__device__ __forceinline__ void wave_sum2(float& a, float& b) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        a += __shfl_xor(a, m, TKR_WAVE);
+        b += __shfl_xor(b, m, TKR_WAVE);
+    }
+}
+
+__device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float bcast_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// sigma(-x) and log(1+exp(-x)) in the stable forms the oracle uses (oracle/ref_np.py).
+__device__ __forceinline__ float sigmoid_neg(float x) {
+    const float e = expf(-fabsf(x));
+    return x >= 0.f ? e / (1.f + e) : 1.f / (1.f + e);
+}
+__device__ __forceinline__ float softplus_neg(float x) { return fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x))); }
+
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+}  // namespace tkr

@@ -1,0 +1,180 @@
+"""Device-side state and step loop behind BPR.train (the work single/bpr.py:107-153 hands to a
+TensorFlow session in the reference).  PyTorch-ROCm owns memory and streams; all numerics are
+HIP kernels reached through the C ABI (tkr_hip).  Nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+import tkr_hip
+
+RHO, EPS = 0.9, 1e-10          # tf.train.RMSPropOptimizer defaults (decay, epsilon)
+MAX_PLAN_BATCHES = 4096        # batches planned per K1 launch (84 B of plan per triplet)
+
+
+def default_device():
+    if not torch.cuda.is_available():
+        raise tkr_hip.TkrError('no MI355X visible to PyTorch-ROCm: BPR/VBPR training runs only on the '
+                               'HIP path (there is no CPU fallback)')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+class TrainingCSR:
+    """tr_data / tr_users (single/bpr.py:63-65) as device CSR for K1."""
+
+    def __init__(self, tr_data: dict, tr_users, n_users: int, device):
+        deg = np.zeros(n_users, dtype=np.int64)
+        for u, items in tr_data.items():
+            deg[u] = len(items)
+        row_ptr = np.zeros(n_users + 1, dtype=np.int64)
+        np.cumsum(deg, out=row_ptr[1:])
+        order = sorted(tr_data.keys())
+        pos = np.fromiter((it for u in order for it in tr_data[u]), dtype=np.int32, count=int(row_ptr[-1])) \
+            if len(order) else np.zeros(0, np.int32)
+        self._finish(row_ptr, pos, np.asarray(list(tr_users), dtype=np.int32), device)
+
+    @classmethod
+    def from_arrays(cls, row_ptr, pos_cols, tr_users, device):
+        self = cls.__new__(cls)
+        self._finish(np.asarray(row_ptr, dtype=np.int64), np.asarray(pos_cols, dtype=np.int32),
+                     np.asarray(tr_users, dtype=np.int32), device)
+        return self
+
+    def _finish(self, row_ptr, pos, tr_users, device):
+        assert row_ptr[-1] < 2 ** 31
+        owner = np.repeat(np.arange(len(row_ptr) - 1, dtype=np.int64), np.diff(row_ptr))
+        big = int(pos.max()) + 1 if len(pos) else 1
+        srt = (np.sort(owner * big + pos) % big).astype(np.int32)        # per-row ascending copy
+        self.row_ptr = torch.from_numpy(row_ptr.astype(np.int32)).to(device)
+        self.pos_cols = torch.from_numpy(pos).to(device)
+        self.cols_sorted = torch.from_numpy(srt).to(device)
+        self.tr_users = torch.from_numpy(tr_users).to(device)
+        self.nnz = int(row_ptr[-1])
+
+
+class PlanBuffers:
+    """Output of K1 for up to ``cap`` batches of ``B`` triplets."""
+
+    def __init__(self, cap: int, B: int, device):
+        self.cap, self.B = cap, B
+        i32 = dict(dtype=torch.int32, device=device)
+        self.u = torch.empty(cap * B, **i32)
+        self.i = torch.empty(cap * B, **i32)
+        self.j = torch.empty(cap * B, **i32)
+        self.task = torch.empty(cap * 3 * B * 4, **i32)
+        self.occ = torch.empty(cap * 3 * B * 2, **i32)
+        self.loss = torch.zeros(cap, dtype=torch.float32, device=device)
+
+
+class DoubleTable:
+    """A parameter table + its RMSProp slot, double-buffered for K2 ([2][n][k], see
+    csrc/bpr_step.hip).  ``stamp`` is shared by tables updated together."""
+
+    def __init__(self, n, k, device, init=None, gen=None):
+        shape = (2, n, k) if k else (2, n)
+        self.p = torch.zeros(shape, dtype=torch.float32, device=device)
+        self.ms = torch.ones(shape, dtype=torch.float32, device=device)
+        if init is not None:
+            self.p[0].normal_(0.0, init, generator=gen)
+
+    def current(self, stamp):
+        sel = (stamp & 1).long()
+        idx = torch.arange(self.p.shape[1], device=self.p.device)
+        return self.p[sel, idx], self.ms[sel, idx]
+
+    def assign(self, stamp_zeroed_values, ms=None):
+        """write values into buffer 0 (caller resets the stamp's buffer bit to 0)"""
+        self.p[0].copy_(stamp_zeroed_values)
+        if ms is not None:
+            self.ms[0].copy_(ms)
+
+
+class BprEngine:
+    """Tables + sampler + step loop of one BPR model on one GPU."""
+
+    def __init__(self, n_users, n_items, k, hp, device=None, seed=None):
+        self.device = device or default_device()
+        self.n_users, self.n_items, self.k = n_users, n_items, k
+        self.hp = hp
+        self.seed = int(seed if seed is not None else np.random.SeedSequence().entropy % (2 ** 63))
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(self.seed & 0x7FFFFFFFFFFFFFFF)
+        # single/bpr.py:77-79: U, V ~ N(0, 0.01); b = 0.  RMSProp `rms` slots start at one.
+        self.U = DoubleTable(n_users, k, self.device, 0.01, gen)
+        self.V = DoubleTable(n_items, k, self.device, 0.01, gen)
+        self.b = DoubleTable(n_items, 0, self.device)
+        self.ustamp = torch.zeros(n_users, dtype=torch.int32, device=self.device)
+        self.istamp = torch.zeros(n_items, dtype=torch.int32, device=self.device)
+        self.serial = 0                 # batches applied so far (stamps hold serial<<1|buf)
+        self.triplets_drawn = 0         # position in the counter-based sample stream
+        self.plan = None
+        self._state = None
+
+    # ---- C-ABI state struct ------------------------------------------------------------
+    def state(self):
+        hp = self.hp
+        st = tkr_hip.BprState()
+        st.U, st.msU, st.ustamp = self.U.p.data_ptr(), self.U.ms.data_ptr(), self.ustamp.data_ptr()
+        st.V, st.msV = self.V.p.data_ptr(), self.V.ms.data_ptr()
+        st.b, st.msb, st.istamp = self.b.p.data_ptr(), self.b.ms.data_ptr(), self.istamp.data_ptr()
+        st.n_users, st.n_items, st.k = self.n_users, self.n_items, self.k
+        st.mode = 0 if hp['mode'] == 'l2' else 1
+        st.lu, st.li, st.lj, st.lb, st.lr = hp['lu'], hp['li'], hp['lj'], hp['lb'], hp['lr']
+        st.rho, st.eps = RHO, EPS
+        return st
+
+    # ---- parameter access (host <-> current buffers) -----------------------------------------
+    def get(self, name):
+        table, stamp = {'U': (self.U, self.ustamp), 'V': (self.V, self.istamp), 'b': (self.b, self.istamp)}[name]
+        return table.current(stamp)
+
+    def set_users(self, U=None, msU=None):
+        cur, ms = self.U.current(self.ustamp)
+        self.U.assign(cur if U is None else self._dev(U), ms if msU is None else self._dev(msU))
+        self.ustamp.bitwise_and_(~1)
+
+    def set_items(self, V=None, b=None, msV=None, msb=None):
+        cv, mv = self.V.current(self.istamp)
+        cb, mb = self.b.current(self.istamp)
+        self.V.assign(cv if V is None else self._dev(V), mv if msV is None else self._dev(msV))
+        self.b.assign(cb if b is None else self._dev(b).reshape(-1), mb if msb is None else self._dev(msb).reshape(-1))
+        self.istamp.bitwise_and_(~1)
+
+    def _dev(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(self.device, torch.float32)
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    # ---- the loop ------------------------------------------------------------------------------
+    def _ensure_plan(self, n_batches, B):
+        cap = min(n_batches, MAX_PLAN_BATCHES)
+        if self.plan is None or self.plan.B != B or self.plan.cap < cap:
+            self.plan = PlanBuffers(cap, B, self.device)
+        return self.plan
+
+    def _renormalise_serial(self):
+        self.ustamp.bitwise_and_(1)
+        self.istamp.bitwise_and_(1)
+        self.serial = 0
+
+    def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True):
+        """sample + plan + step for n_batches consecutive batches; returns the per-batch
+        losses of the LAST chunk as a device tensor (or None)."""
+        plan = self._ensure_plan(n_batches, B)
+        done, loss = 0, None
+        while done < n_batches:
+            nb = min(plan.cap, n_batches - done)
+            if self.serial + nb >= (1 << 30) - 1:
+                self._renormalise_serial()
+            tkr_hip.sample_plan(csr.tr_users, csr.row_ptr, csr.pos_cols, csr.cols_sorted, self.n_items,
+                                self.seed, self.triplets_drawn, nb, B, plan.u, plan.i, plan.j, plan.task, plan.occ)
+            if want_loss:
+                plan.loss[:nb].zero_()
+            tkr_hip.bpr_run(self.state(), plan.task, plan.occ, B, nb, self.serial + 1,
+                            plan.loss if want_loss else None)
+            self.serial += nb
+            self.triplets_drawn += nb * B
+            done += nb
+            loss = plan.loss[:nb] if want_loss else None
+        return loss

@@ -1,0 +1,199 @@
+"""BPR matrix factorisation trained on MI355X (class API of the reference's single/bpr.py).
+
+    model = BPR(k=50)
+    model.load_training_data('data/uid', 'data/vid', 'data/f0tr.txt')
+    model.train(epochs=5, batch_size=256, epoch_sample_limit=10**6)
+    model.export_embeddings('embed/bpr')
+
+Constructor, method names, arguments, public attributes and result arrays (``fue``, ``fie``,
+``fib``) follow single/bpr.py:19-183.  What differs is where the work runs: the
+(u,i,j) draw (bpr.py:155-165), the loss/gradient/RMSProp step (bpr.py:81-100,141) are HIP
+kernels (csrc/sampler.hip, csrc/bpr_step.hip) on tables held in HBM.
+
+Deliberate deviations from reference quirks:
+  * ``epoch_sample_limit`` may be an integral float (train.py passes 10e5; bpr.py:111 asserts int)
+  * an unknown ``sampling`` string raises ValueError (reference: TypeError on a None sampler)
+  * the loss is evaluated with a stable softplus (identical wherever log(1+exp(-x)) is finite)
+  * the checkpoint written by export_model is a torch file holding parameters + RMSProp slots
+    (the reference writes a TF Saver checkpoint under the same name, ``weights``)
+Extra keyword-only arguments (``seed``, ``device``, ``verbose``) default to reference behaviour.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from utils import get_data_from_file, get_id_dict_from_file, tprint
+from .rec import REC
+from . import _engine
+
+
+class BPR(REC):
+    def __init__(self, k: int, lambda_u: float = 2.5e-3, lambda_i: float = 2.5e-3, lambda_j: float = 2.5e-4,
+                 lambda_b: float = 0, lr: float = 1.0e-4, mode: str = 'l2') -> None:
+        self.k = k
+        self.lu, self.li, self.lj, self.lb = lambda_u, lambda_i, lambda_j, lambda_b
+        self.lr = lr
+        self.mode = mode
+        self.uids = self.iids = self.data = None
+        self.epoch_sample_limit = None
+        self.n_users = self.n_items = None
+        self.tr_data = self.tr_users = None
+        self.pred = self.obj = self.solver = None      # TF graph handles in the reference; unused
+        self.fue = self.fie = self.fib = None
+        self._eng = None        # device tables (the reference's tf.Session + variables)
+        self._csr = None        # device CSR of tr_data
+        self.last_epoch_loss = None
+
+    # ------------------------------------------------------------------ data (bpr.py:51-69)
+    def load_training_data(self, uid_file: str, iid_file: str, tr_file: str, data_copy: bool = False) -> None:
+        tprint('Load training data from %s' % (tr_file))
+        self.uids = get_id_dict_from_file(uid_file)
+        self.iids = get_id_dict_from_file(iid_file)
+        self.data = get_data_from_file(tr_file, self.uids, self.iids)
+        self.epoch_sample_limit = len(self.data)
+        assert isinstance(self.uids, dict)
+        assert isinstance(self.iids, dict)
+        self.n_users = len(self.uids)
+        assert self.n_users > 0
+        self.n_items = len(self.iids)
+        assert self.n_items > 0
+        self.tr_data = self._data_to_training_dict(self.data, self.uids, self.iids)
+        assert isinstance(self.tr_data, dict)
+        self.tr_users = list(self.tr_data.keys())
+        self._csr = None
+        if not data_copy:
+            del self.data
+        tprint('Loading finished!')
+
+    def _data_to_training_dict(self, data: list, users: dict, items: dict):
+        """user index -> item indices in file order, duplicates preserved (bpr.py:167-171)."""
+        grouped = defaultdict(list)
+        for uid, iid in data:
+            grouped[users[uid]].append(items[iid])
+        return grouped
+
+    # ------------------------------------------------------------------ model (bpr.py:71-101)
+    def _hyper(self):
+        return dict(lu=self.lu, li=self.li, lj=self.lj, lb=self.lb, lr=self.lr, mode=self.mode)
+
+    def _make_engine(self, device, seed):
+        return _engine.BprEngine(self.n_users, self.n_items, self.k, self._hyper(), device, seed)
+
+    def build_graph(self, *, device=None, seed=None):
+        """Allocate and initialise the model tables in HBM (user_embed / item_embed ~ N(0, 0.01),
+        item_bias = 0, RMSProp slots = 1; bpr.py:77-79,100).  The reference returns the three
+        feed placeholders; there is nothing to feed here, so the engine is returned instead."""
+        self._eng = self._make_engine(device, seed)
+        if self._csr is None or self._csr.row_ptr.device != self._eng.device:
+            self._csr = _engine.TrainingCSR(self.tr_data, self.tr_users, self.n_users, self._eng.device)
+        return self._eng
+
+    # ------------------------------------------------------------------ train (bpr.py:103-153)
+    def _warm_start(self):
+        """bpr.py:127-135: text-imported (or previous) fue/fie/fib override the fresh init."""
+        if self.fue is not None:
+            tprint('Initialize user embeddings')
+            self._eng.set_users(U=self.fue)
+        if self.fie is not None:
+            tprint('Initialize item embeddings')
+            self._eng.set_items(V=self.fie)
+        if self.fib is not None:
+            tprint('Initialize item biases')
+            self._eng.set_items(b=np.asarray(self.fib).ravel())
+
+    def _collect(self):
+        """bpr.py:151-153"""
+        self.fue = self._eng.get('U')[0].cpu().numpy()
+        self.fie = self._eng.get('V')[0].cpu().numpy()
+        self.fib = self._eng.get('b')[0].reshape(-1, 1).cpu().numpy()
+
+    def train(self, sampling: str = 'user uniform', epochs: int = 5, batch_size: int = 256,
+              epoch_sample_limit: int = None, model_path: str = None, *, seed=None, device=None,
+              verbose: bool = True):
+        assert isinstance(sampling, str)
+        assert isinstance(epochs, int)
+        assert isinstance(batch_size, int)
+        if epoch_sample_limit is not None:
+            assert float(epoch_sample_limit) == int(epoch_sample_limit), 'epoch_sample_limit must be integral'
+            self.epoch_sample_limit = int(epoch_sample_limit)
+        if sampling != 'user uniform':
+            raise ValueError("unknown sampling %r (only 'user uniform' exists, bpr.py:115-117)" % sampling)
+        batch_limit = self.epoch_sample_limit // batch_size + 1
+        n_batches = batch_limit - 1                      # bno runs 1 .. batch_limit-1 (bpr.py:138-147)
+        if n_batches < 1:
+            raise ValueError('epoch_sample_limit < batch_size: the reference loop would never terminate')
+        self.build_graph(device=device, seed=seed)
+        if model_path is not None:
+            assert isinstance(model_path, str)
+            tprint("Initialize weights with the previous trained model")
+            self.import_embeddings(model_path)
+        tprint('Training parameters: lu=%.6f, li=%.6f, lj=%.6f, lb=%.6f' % (self.lu, self.li, self.lj, self.lb))
+        tprint('Learning rate is %.6f, regularization mode is %s' % (self.lr, self.mode))
+        tprint('Training for %d epochs of %d batches using %s sampler' % (epochs, batch_limit, sampling))
+        self._warm_start()
+        for eid in range(epochs):
+            t0 = time.time()
+            loss = self._run_epoch(n_batches, batch_size)
+            torch.cuda.synchronize(self._eng.device)
+            spent = time.time() - t0
+            self.last_epoch_loss = loss
+            if verbose:
+                sys.stderr.write('\rEpoch=%3d, batch=%6d, loss=%8.4f, time=%4.4fs' % (eid + 1, n_batches, loss, spent / n_batches))
+                sys.stderr.write(' ... total time collapse %8.4fs' % spent)
+                sys.stderr.flush()
+                print()
+        self._collect()
+
+    def _run_epoch(self, n_batches, batch_size):
+        losses = self._eng.run_batches(self._csr, n_batches, batch_size, want_loss=True)
+        return float(losses[-1])
+
+    # ------------------------------------------------------------------ sampler (bpr.py:155-165)
+    def _uniform_user_sampling(self, batch_size: int):
+        """Generator of (ub, ib, jb) numpy batches drawn by the device sampler (K1): u uniform over
+        tr_users, i uniform over tr_data[u], j uniform over items not in tr_data[u]."""
+        device = self._eng.device if self._eng is not None else _engine.default_device()
+        if self._csr is None:
+            self._csr = _engine.TrainingCSR(self.tr_data, self.tr_users, self.n_users, device)
+        import tkr_hip
+        plan = _engine.PlanBuffers(1, batch_size, device)
+        seed = int(np.random.SeedSequence().entropy % (2 ** 63)) if self._eng is None else self._eng.seed
+        drawn = 0
+        while True:
+            tkr_hip.sample_plan(self._csr.tr_users, self._csr.row_ptr, self._csr.pos_cols, self._csr.cols_sorted,
+                                self.n_items, seed ^ 0x5DEECE66D, drawn, 1, batch_size,
+                                plan.u, plan.i, plan.j, plan.task, plan.occ)
+            drawn += batch_size
+            yield plan.u.cpu().numpy().astype(np.int64), plan.i.cpu().numpy(), plan.j.cpu().numpy()
+
+    # ------------------------------------------------------------------ checkpoint (bpr.py:173-183)
+    def _checkpoint_tensors(self):
+        e = self._eng
+        out = {}
+        for name in ('U', 'V', 'b'):
+            p, ms = e.get(name)
+            out[name], out['ms_' + name] = p.cpu(), ms.cpu()
+        return out
+
+    def _restore_tensors(self, blob):
+        e = self._eng
+        e.set_users(U=blob['U'], msU=blob['ms_U'])
+        e.set_items(V=blob['V'], b=blob['b'], msV=blob['ms_V'], msb=blob['ms_b'])
+
+    def import_model(self, model_path: str) -> None:
+        file_path = os.path.join(model_path, 'weights')
+        if os.path.exists(file_path) and self._eng is not None:
+            tprint('Restoring model tables from path %s' % (file_path))
+            self._restore_tensors(torch.load(file_path, map_location='cpu'))
+
+    def export_model(self, model_path: str) -> None:
+        if os.path.exists(model_path) and self._eng is not None:
+            file_path = os.path.join(model_path, 'weights')
+            tprint('Saving model tables to path %s' % (file_path))
+            torch.save(self._checkpoint_tensors(), file_path)
