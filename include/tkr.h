@@ -37,28 +37,35 @@ int tkr_version(void);
  *   seed, first_triplet      counter-based stream position (triplet g = first_triplet + b*B + t);
  *   ctl                      optional device int64[1]: batch index added to the stream position at
  *                            run time (lets one captured hipGraph walk through an epoch)
+ *   ucnt[n_users], icnt[n_items]   running number of updates of every row (in/out); parity = which
+ *                            of the two table buffers currently holds the row
+ *   touch_u[n_users*16], touch_i[n_items*16]   scratch bitmaps, all-zero on entry and on exit
  *   out_u/out_i/out_j        [n_batches*B]
- *   task                     [n_batches][3B][4]  (row | kind<<31, occ_start, occ_count, 0); -1 = unused
- *   occ                      [n_batches][3B][2]  user occurrence: (i, j); item occurrence: (u, other|role<<31)
- * batch_size <= 8192.  Output is bit-exact against oracle/plan_np.py. */
+ *   task                     [n_batches][3B][4]  (row | kind<<31, occ_start, occ_count, parity); -1 = unused
+ *   occ                      [n_batches][3B][2]  user occurrence: (i, j); item occurrence: (u, other|role<<31);
+ *                            bit 30 of every id = parity of that row
+ *   rec                      [n_batches][tkr_plan_max_blocks(B)*16][16]  per-wave launch records
+ *   hdr                      [n_batches][4]  (workgroups used, light tasks, heavy tasks, tasks)
+ * batch_size <= 8192, n_batches <= 512, ids < 2^30.  Output is bit-exact against oracle/plan_np.py. */
+int tkr_plan_max_blocks(int32_t batch_size);
 int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,
-                    const int32_t* cols_sorted, int32_t n_items, uint64_t seed, uint64_t first_triplet,
-                    const int64_t* ctl, int32_t n_batches, int32_t batch_size, int32_t* out_u, int32_t* out_i,
-                    int32_t* out_j, int32_t* task, int32_t* occ, void* stream);
+                    const int32_t* cols_sorted, int32_t n_users, int32_t n_items, uint64_t seed,
+                    uint64_t first_triplet, const int64_t* ctl, int32_t n_batches, int32_t batch_size,
+                    int32_t* ucnt, int32_t* icnt, uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u,
+                    int32_t* out_i, int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr,
+                    void* stream);
 
 /* ---- K2: BPR mini-batch step ---------------------------------------------------------------
  * Replaces sess.run([solver, obj]) (single/bpr.py:141) on the graph of single/bpr.py:81-100.
  * Double-buffered tables: U, msU are [2][n_users][k]; V, msV [2][n_items][k]; b, msb [2][n_items];
- * ustamp[n_users], istamp[n_items] = (serial<<1 | buffer holding the current row), 0 initially. */
+ * the buffer holding row r is (ucnt[r] & 1) resp. (icnt[r] & 1) -- see K1. */
 typedef struct {
     float* U;
     float* msU;
-    int32_t* ustamp;
     float* V;
     float* msV;
     float* b;
     float* msb;
-    int32_t* istamp;
     int32_t n_users, n_items, k;
     int32_t mode;            /* 0 = 'l2' (single/bpr.py:92-95), 1 = L1 variant (:96-99) */
     float lu, li, lj, lb;    /* lambda_u, lambda_i, lambda_j, lambda_b (single/bpr.py:20) */
@@ -66,14 +73,11 @@ typedef struct {
     float rho, eps;          /* TF defaults 0.9, 1e-10 */
 } tkr_bpr_state;
 
-/* one batch; serial in [1, 2^30) strictly increasing over the life of the tables;
- * loss_out (nullable) device float, the batch objective is ADDED to it */
-int tkr_bpr_step(const tkr_bpr_state* st, const int32_t* task, const int32_t* occ, int32_t batch_size,
-                 int32_t serial, float* loss_out, void* stream);
-/* n_batches consecutive batches of a plan (the inner loop of single/bpr.py:139-147);
- * loss_out (nullable) is float[n_batches], pre-zeroed by the caller */
-int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* task, const int32_t* occ, int32_t batch_size,
-                int32_t n_batches, int32_t first_serial, float* loss_out, void* stream);
+/* n_batches consecutive batches of a plan (the inner loop of single/bpr.py:139-147), one launch
+ * each, in plan order; loss_out (nullable) is float[n_batches], pre-zeroed by the caller: the
+ * batch objective (single/bpr.py:93-99) is added to loss_out[b] */
+int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ, const int32_t* hdr,
+                int32_t batch_size, int32_t n_batches, float* loss_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,8 +27,20 @@ Plan definition (per batch of B triplets, consumed by the step kernels):
   item occurrences   o = 0..2B-1 (o<B: item i[o], role 0; else item j[o-B], role 1)
                      sorted by (item[o], o)                    -> occ[B+p] = (u[t], other | role<<31)
   tasks              one per unique user (ascending id) then one per unique item
-                     (ascending id): (row | kind<<31, occ_start, occ_count, 0); unused
+                     (ascending id): (row | kind<<31, occ_start, occ_count, parity); unused
                      slots up to 3B hold (-1, 0, 0, 0).
+  parity             which of the two table buffers holds a row's value at the START of the
+                     batch = (number of earlier batches that updated the row) & 1, from the
+                     running per-row update counters ucnt / icnt.  Stored in task[.,3] for the
+                     task's own row and in bit 30 of every occ id for the partner rows.
+Launch plan (what the step kernel actually reads; derived from the above):
+  a task with <= LIGHT_MAX occurrences is LIGHT (one wave), otherwise HEAVY (a team of TEAM
+  waves = one workgroup, wave w takes occurrences w, w+TEAM, ...).  Workgroups hold TEAM wave
+  records; light tasks fill workgroups 0..nlb-1 in task order, heavy task h is workgroup nlb+h.
+  wave record = 16 int32: [0] row|kind<<31 (-1 = idle)  [1] parity | team<<8 | rank<<16
+                          [2] occurrences of this wave   [3] index of its first occurrence
+                          [4..11] its first <=4 occurrences (a,b)   [12] task occ_count  [13..15] 0
+  header per batch = (workgroups used, light tasks, heavy tasks, tasks).
 """
 from __future__ import annotations
 
@@ -37,6 +49,9 @@ import numpy as np
 U32 = np.uint32
 U64 = np.uint64
 MAX_ROUNDS = 64
+LIGHT_MAX = 4          # occurrences a single wave handles (csrc/sampler.hip kLightMax)
+TEAM = 16              # waves per workgroup / per heavy task (csrc/bpr_step.hip)
+PAR_BIT = 1 << 30
 
 _M0, _M1 = U64(0xD2511F53), U64(0xCD9E8D57)
 _W0, _W1 = 0x9E3779B9, 0xBB67AE85
@@ -167,15 +182,75 @@ def plan_batch(u, i, j):
     return task, occ
 
 
+def max_blocks(B):
+    """workgroups a batch can need: light tasks 16 per group + heavy tasks (>= 5 occurrences each)"""
+    return (3 * B + TEAM - 1) // TEAM + (3 * B) // (LIGHT_MAX + 1)
+
+
+def resolve_parity(task, occ, B, ucnt, icnt):
+    """Patch parities into one batch's plan (in place) and bump the update counters."""
+    live = np.flatnonzero(task[:, 0] != -1)
+    rows = task[live, 0] & 0x7FFFFFFF
+    is_item = task[live, 0] < 0
+    par = np.zeros(len(live), dtype=np.int32)
+    par[is_item] = icnt[rows[is_item]] & 1
+    par[~is_item] = ucnt[rows[~is_item]] & 1
+    task[live, 3] = par
+    uo = occ[:B]                                     # user occurrences: (i, j) both items
+    uo[:, 0] |= ((icnt[uo[:, 0]] & 1) << 30).astype(np.int32)
+    uo[:, 1] |= ((icnt[uo[:, 1]] & 1) << 30).astype(np.int32)
+    io = occ[B:]                                     # item occurrences: (u, other|role<<31)
+    other = io[:, 1] & 0x3FFFFFFF
+    io[:, 1] |= ((icnt[other] & 1) << 30).astype(np.int32)
+    io[:, 0] |= ((ucnt[io[:, 0]] & 1) << 30).astype(np.int32)
+    ucnt[rows[~is_item]] += 1
+    icnt[rows[is_item]] += 1
+
+
+def launch_plan(task, occ, B):
+    """wave records + header of one batch (see module docstring)."""
+    nblk = max_blocks(B)
+    rec = np.zeros((nblk * TEAM, 16), dtype=np.int32)
+    live = np.flatnonzero(task[:, 0] != -1)
+    light = [t for t in live if task[t, 2] <= LIGHT_MAX]
+    heavy = [t for t in live if task[t, 2] > LIGHT_MAX]
+    nlb = (len(light) + TEAM - 1) // TEAM
+    rec[: nlb * TEAM, 0] = -1
+    for slot, t in enumerate(light):
+        rowk, start, cnt, par = task[t]
+        rec[slot, 0:4] = (rowk, par | (1 << 8), cnt, start)
+        rec[slot, 4:4 + 2 * cnt] = occ[start:start + cnt].reshape(-1)
+        rec[slot, 12] = cnt
+    for h, t in enumerate(heavy):
+        rowk, start, cnt, par = task[t]
+        for w in range(TEAM):
+            mine = np.arange(start + w, start + cnt, TEAM)
+            r = rec[(nlb + h) * TEAM + w]
+            r[0:4] = (rowk, par | (TEAM << 8) | (w << 16), len(mine), start + w)
+            first = occ[mine[:4]].reshape(-1)
+            r[4:4 + len(first)] = first
+            r[12] = cnt
+    hdr = np.array([nlb + len(heavy), len(light), len(heavy), len(live)], dtype=np.int32)
+    return rec, hdr
+
+
 def sample_and_plan(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed, first_triplet,
-                    n_batches, B):
+                    n_batches, B, ucnt=None, icnt=None, n_users=None):
     """What ``tkr_sample_plan`` produces for n_batches batches: (u,i,j)[n_batches*B],
-    task[n_batches,3B,4], occ[n_batches,3B,2]."""
+    task[n_batches,3B,4], occ[n_batches,3B,2], rec[n_batches, max_blocks*TEAM, 16],
+    hdr[n_batches,4]; ucnt/icnt (int32 update counters) are advanced in place."""
+    n_users = n_users if n_users is not None else len(row_ptr) - 1
+    ucnt = np.zeros(n_users, dtype=np.int32) if ucnt is None else ucnt
+    icnt = np.zeros(n_items, dtype=np.int32) if icnt is None else icnt
     u, i, j = sample_triplets(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed,
                               first_triplet, n_batches * B)
     tasks = np.zeros((n_batches, 3 * B, 4), dtype=np.int32)
     occs = np.zeros((n_batches, 3 * B, 2), dtype=np.int32)
+    recs = np.zeros((n_batches, max_blocks(B) * TEAM, 16), dtype=np.int32)
+    hdrs = np.zeros((n_batches, 4), dtype=np.int32)
     for b in range(n_batches):
         sl = slice(b * B, (b + 1) * B)
         tasks[b], occs[b] = plan_batch(u[sl], i[sl], j[sl])
-    return u, i, j, tasks, occs
+        resolve_parity(tasks[b], occs[b], B, ucnt, icnt)
+        recs[b], hdrs[b] = launch_plan(tasks[b], occs[b], B)
+    return u, i, j, tasks, occs, recs, hdrs

@@ -38,49 +38,65 @@ def _dev(a, dt=torch.int32):
     return torch.from_numpy(np.ascontiguousarray(a)).to('cuda', dt)
 
 
-def _run_plan(hip, tr, tr_users, n_users, n_items, seed, first, nb, B):
+def _run_plan(hip, tr, tr_users, n_users, n_items, seed, first, nb, B, chunks=1):
+    """run K1 for `chunks` consecutive calls of nb batches -> (got, exp) of the LAST call, plus objects"""
+    from single import _engine
     row_ptr, pos, srt = P.build_csr(tr, n_users)
-    out = [torch.empty(nb * B, dtype=torch.int32, device='cuda') for _ in range(3)]
-    task = torch.empty(nb * 3 * B * 4, dtype=torch.int32, device='cuda')
-    occ = torch.empty(nb * 3 * B * 2, dtype=torch.int32, device='cuda')
-    hip.sample_plan(_dev(np.asarray(tr_users, np.int32)), _dev(row_ptr), _dev(pos), _dev(srt), n_items, seed, first,
-                    nb, B, out[0], out[1], out[2], task, occ)
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), torch.device('cuda'))
+    np.testing.assert_array_equal(csr.cols_sorted.cpu().numpy(), srt)
+    cnt = _engine.UpdateCounters(n_users, n_items, torch.device('cuda'))
+    plan = _engine.PlanBuffers(nb, B, torch.device('cuda'))
+    plan.rec.zero_()
+    ucnt, icnt = np.zeros(n_users, np.int32), np.zeros(n_items, np.int32)
+    for c in range(chunks):
+        hip.sample_plan(csr, n_users, n_items, seed, first + c * nb * B, nb, B, cnt, plan)
+        exp = P.sample_and_plan(tr_users, row_ptr, pos, srt, n_items, seed, first + c * nb * B, nb, B, ucnt, icnt)
     torch.cuda.synchronize()
-    exp = P.sample_and_plan(tr_users, row_ptr, pos, srt, n_items, seed, first, nb, B)
-    got = [o.cpu().numpy() for o in out] + [task.cpu().numpy().reshape(nb, 3 * B, 4), occ.cpu().numpy().reshape(nb, 3 * B, 2)]
-    return got, exp
+    got = [plan.u.cpu().numpy(), plan.i.cpu().numpy(), plan.j.cpu().numpy(),
+           plan.task.cpu().numpy().reshape(nb, 3 * B, 4), plan.occ.cpu().numpy().reshape(nb, 3 * B, 2),
+           plan.rec.cpu().numpy().reshape(nb, -1, 16), plan.hdr.cpu().numpy().reshape(nb, 4)]
+    np.testing.assert_array_equal(cnt.ucnt.cpu().numpy(), ucnt)
+    np.testing.assert_array_equal(cnt.icnt.cpu().numpy(), icnt)
+    assert int(cnt.touch_u.abs().sum()) == 0 and int(cnt.touch_i.abs().sum()) == 0
+    return got, exp, plan
 
 
-@pytest.mark.parametrize('n_users,n_items,B,nb', [(60, 40, 32, 5), (300, 150, 256, 7), (300, 150, 100, 3),
-                                                  (5000, 900, 1024, 3), (5000, 900, 8192, 2), (40, 30, 1, 4)])
-def test_sample_plan_bit_exact(hip, n_users, n_items, B, nb):
+@pytest.mark.parametrize('n_users,n_items,B,nb,chunks', [(60, 40, 32, 5, 1), (300, 150, 256, 7, 3), (300, 150, 100, 3, 2),
+                                                         (5000, 900, 1024, 3, 1), (5000, 900, 8192, 2, 2), (40, 30, 1, 4, 1),
+                                                         (300, 150, 64, 512, 2)])
+def test_sample_plan_bit_exact(hip, n_users, n_items, B, nb, chunks):
     tr, tr_users = _toy(n_users, n_items, seed=n_users + B)
-    got, exp = _run_plan(hip, tr, tr_users, n_users, n_items, seed=0x1234567890ABCDEF, first=(1 << 33) + 17, nb=nb, B=B)
-    for name, g, e in zip(('u', 'i', 'j', 'task', 'occ'), got, exp):
-        np.testing.assert_array_equal(g, e, err_msg=name)
+    got, exp, _ = _run_plan(hip, tr, tr_users, n_users, n_items, seed=0x1234567890ABCDEF, first=(1 << 33) + 17, nb=nb,
+                            B=B, chunks=chunks)
+    for name, g, e in zip(('u', 'i', 'j', 'task', 'occ', 'rec', 'hdr'), got, exp):
+        if name == 'rec':                       # only the used workgroups are defined
+            for b in range(nb):
+                used = exp[6][b, 0] * 16
+                np.testing.assert_array_equal(g[b, :used], e[b, :used], err_msg='rec batch %d' % b)
+        else:
+            np.testing.assert_array_equal(g, e, err_msg=name)
 
 
 def test_sample_plan_ctl_offset(hip):
     """the device-side batch base (ctl) walks the same stream as first_triplet does"""
+    from single import _engine
     tr, tr_users = _toy(200, 90, seed=1)
     row_ptr, pos, srt = P.build_csr(tr, 200)
     B, nb = 64, 4
+    dev = torch.device('cuda')
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
     ctl = torch.tensor([5], dtype=torch.int64, device='cuda')
-    out = [torch.empty(nb * B, dtype=torch.int32, device='cuda') for _ in range(3)]
-    task = torch.empty(nb * 3 * B * 4, dtype=torch.int32, device='cuda')
-    occ = torch.empty(nb * 3 * B * 2, dtype=torch.int32, device='cuda')
-    hip.sample_plan(_dev(np.asarray(tr_users, np.int32)), _dev(row_ptr), _dev(pos), _dev(srt), 90, 77, 1000, nb, B,
-                    out[0], out[1], out[2], task, occ, ctl=ctl)
+    plan = _engine.PlanBuffers(nb, B, dev)
+    hip.sample_plan(csr, 200, 90, 77, 1000, nb, B, _engine.UpdateCounters(200, 90, dev), plan, ctl=ctl)
     u, i, j = P.sample_triplets(tr_users, row_ptr, pos, srt, 90, 77, 1000 + 5 * B, nb * B)
-    np.testing.assert_array_equal(out[0].cpu().numpy(), u)
-    np.testing.assert_array_equal(out[2].cpu().numpy(), j)
+    np.testing.assert_array_equal(plan.u.cpu().numpy(), u)
+    np.testing.assert_array_equal(plan.j.cpu().numpy(), j)
 
 
 def _state_struct(hip, T, n_users, n_items, k, hp):
     st = hip.BprState()
-    st.U, st.msU, st.ustamp = T['U'].data_ptr(), T['msU'].data_ptr(), T['ustamp'].data_ptr()
+    st.U, st.msU = T['U'].data_ptr(), T['msU'].data_ptr()
     st.V, st.msV, st.b, st.msb = T['V'].data_ptr(), T['msV'].data_ptr(), T['b'].data_ptr(), T['msb'].data_ptr()
-    st.istamp = T['istamp'].data_ptr()
     st.n_users, st.n_items, st.k = n_users, n_items, k
     st.mode = 0 if hp['mode'] == 'l2' else 1
     st.lu, st.li, st.lj, st.lb, st.lr = hp['lu'], hp['li'], hp['lj'], hp['lb'], hp['lr']
@@ -95,13 +111,11 @@ def _tables(ref, n_users, n_items, k):
         T[name] = torch.zeros(shape, device='cuda')
         T[name][0] = torch.from_numpy(ref[name]).cuda()
         T['ms' + name] = torch.ones(shape, device='cuda')
-    T['ustamp'] = torch.zeros(n_users, dtype=torch.int32, device='cuda')
-    T['istamp'] = torch.zeros(n_items, dtype=torch.int32, device='cuda')
     return T
 
 
-def _current(T, name, stamp):
-    sel = (T[stamp] & 1).long()
+def _current(T, name, cnt):
+    sel = (torch.from_numpy(cnt).cuda() & 1).long()
     idx = torch.arange(T[name].shape[1], device='cuda')
     return T[name][sel, idx].cpu().numpy()
 
@@ -117,24 +131,25 @@ def test_bpr_step_parity(hip, k, B, nb, mode, lr):
     ref['b'][:] = (rng.standard_normal(n_items) * 0.01).astype(np.float32)
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=lr, mode=mode)
     T = _tables(ref, n_users, n_items, k)
-    got, exp = _run_plan(hip, tr, tr_users, n_users, n_items, seed=42, first=0, nb=nb, B=B)
-    task, occ = _dev(exp[3].reshape(-1)), _dev(exp[4].reshape(-1))
+    got, exp, plan = _run_plan(hip, tr, tr_users, n_users, n_items, seed=42, first=0, nb=nb, B=B)
     loss = torch.zeros(nb, device='cuda')
-    hip.bpr_run(_state_struct(hip, T, n_users, n_items, k, hp), task, occ, B, nb, 1, loss)
+    hip.bpr_run(_state_struct(hip, T, n_users, n_items, k, hp), plan, B, nb, loss)
     torch.cuda.synchronize()
     ref_loss = []
     u, i, j = exp[0], exp[1], exp[2]
+    ucnt, icnt = np.zeros(n_users, np.int32), np.zeros(n_items, np.int32)
     for b in range(nb):
         sl = slice(b * B, (b + 1) * B)
         ref_loss.append(R.bpr_step(ref, u[sl], i[sl], j[sl], hp))
+        ucnt[np.unique(u[sl])] += 1
+        icnt[np.unique(np.concatenate([i[sl], j[sl]]))] += 1
     # fp32 tolerance: |dP| per step <= lr/sqrt(0.1) ~ 0.16 at lr=0.05, compared at 1e-5 abs + 2e-4 rel
-    for name, stamp in (('U', 'ustamp'), ('V', 'istamp'), ('b', 'istamp')):
-        np.testing.assert_allclose(_current(T, name, stamp), ref[name], rtol=2e-4, atol=1e-5, err_msg=name)
-        np.testing.assert_allclose(_current(T, 'ms' + name, stamp), ref['ms' + name], rtol=2e-4, atol=1e-7, err_msg='ms' + name)
+    for name, cnt in (('U', ucnt), ('V', icnt), ('b', icnt)):
+        np.testing.assert_allclose(_current(T, name, cnt), ref[name], rtol=2e-4, atol=1e-5, err_msg=name)
+        np.testing.assert_allclose(_current(T, 'ms' + name, cnt), ref['ms' + name], rtol=2e-4, atol=1e-7, err_msg='ms' + name)
     np.testing.assert_allclose(loss.cpu().numpy(), np.array(ref_loss), rtol=1e-4)
-    # untouched rows are bit-identical to the init and their stamps are still zero
-    touched_u = np.zeros(n_users, bool); touched_u[u] = True
-    assert np.all(T['ustamp'].cpu().numpy()[~touched_u] == 0)
+    # rows never sampled keep their initial value in buffer 0 and an untouched buffer 1
+    assert np.all(T['U'][1].cpu().numpy()[ucnt == 0] == 0)
 
 
 def test_bpr_step_is_deterministic(hip):
@@ -142,21 +157,22 @@ def test_bpr_step_is_deterministic(hip):
     n_users, n_items, k, B, nb = 300, 80, 128, 256, 8
     tr, tr_users = _toy(n_users, n_items, seed=9, all_but_one=False)
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=0.01, mode='l2')
-    _, exp = _run_plan(hip, tr, tr_users, n_users, n_items, seed=3, first=0, nb=nb, B=B)
+    _, exp, plan = _run_plan(hip, tr, tr_users, n_users, n_items, seed=3, first=0, nb=nb, B=B)
     outs = []
     for _ in range(2):
         ref = R.init_bpr_state(n_users, n_items, k, np.random.Generator(np.random.PCG64(0)))
         T = _tables(ref, n_users, n_items, k)
-        hip.bpr_run(_state_struct(hip, T, n_users, n_items, k, hp), _dev(exp[3].reshape(-1)), _dev(exp[4].reshape(-1)), B, nb, 1, None)
+        hip.bpr_run(_state_struct(hip, T, n_users, n_items, k, hp), plan, B, nb, None)
         torch.cuda.synchronize()
-        outs.append([_current(T, n, s) for n, s in (('U', 'ustamp'), ('V', 'istamp'), ('b', 'istamp'))])
+        outs.append([T[n].cpu().numpy() for n in ('U', 'V', 'b', 'msU', 'msV', 'msb')])
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
 
 
 def test_abi_rejects_bad_arguments(hip):
     st = hip.BprState()
-    rc = hip.lib().tkr_bpr_step(C.byref(st), None, None, 256, 1, None, None)
-    assert rc == -1
-    assert hip.lib().tkr_sample_plan(None, 0, None, None, None, 10, 0, 0, None, 1, 256, None, None, None, None, None, None) == -1
-    assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 10, 0, 0, None, 1, 16384, None, None, None, None, None, None) == -2
+    assert hip.lib().tkr_bpr_run(C.byref(st), None, None, None, 256, 1, None, None) == -1
+    args = [None] * 24
+    assert hip.lib().tkr_sample_plan(None, 0, None, None, None, 5, 10, 0, 0, None, 1, 256, *([None] * 11), None) == -1
+    assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 1, 16384, *([None] * 11), None) == -2
+    assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 513, 256, *([None] * 11), None) == -2

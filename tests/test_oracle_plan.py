@@ -78,7 +78,9 @@ def test_plan_layout():
     tr, tr_users, n_items = _toy()
     csr = P.build_csr(tr, 60)
     B = 32
-    u, i, j, tasks, occs = P.sample_and_plan(tr_users, *csr, n_items, 11, 0, 3, B)
+    ucnt, icnt = np.zeros(60, np.int32), np.zeros(n_items, np.int32)
+    u, i, j, tasks, occs, recs, hdrs = P.sample_and_plan(tr_users, *csr, n_items, 11, 0, 3, B, ucnt, icnt)
+    seen_u, seen_i = np.zeros(60, np.int32), np.zeros(n_items, np.int32)
     for b in range(3):
         ub, ib, jb = (x[b * B:(b + 1) * B] for x in (u, i, j))
         task, occ = tasks[b], occs[b]
@@ -91,13 +93,33 @@ def test_plan_layout():
         assert rows[nu:].tolist() == sorted(set(ib.tolist()) | set(jb.tolist()))
         assert live[:nu, 2].sum() == B and live[nu:, 2].sum() == 2 * B
         assert np.all(task[len(live):, 0] == -1)
-        for row, start, cnt, _ in live[:nu]:
+        M = 0x3fffffff
+        for row, start, cnt, par in live[:nu]:
             ts = np.flatnonzero(ub == row)
-            assert occ[start:start + cnt, 0].tolist() == ib[ts].tolist()
-            assert occ[start:start + cnt, 1].tolist() == jb[ts].tolist()
-        for rk, start, cnt, _ in live[nu:]:
+            assert par == seen_u[row] & 1
+            assert (occ[start:start + cnt, 0] & M).tolist() == ib[ts].tolist()
+            assert (occ[start:start + cnt, 1] & M).tolist() == jb[ts].tolist()
+            assert ((occ[start:start + cnt, 0] >> 30) & 1).tolist() == (seen_i[ib[ts]] & 1).tolist()
+        for rk, start, cnt, par in live[nu:]:
             row = rk & 0x7fffffff
+            assert par == seen_i[row] & 1
             exp = [(int(ub[t]), int(jb[t]), 0) for t in np.flatnonzero(ib == row)] + \
                   [(int(ub[t]), int(ib[t]), 1) for t in np.flatnonzero(jb == row)]
-            got = [(int(a), int(o & 0x7fffffff), int((o >> 31) & 1)) for a, o in occ[start:start + cnt]]
+            got = [(int(a & M), int(o & M), int((o >> 31) & 1)) for a, o in occ[start:start + cnt]]
             assert got == exp
+            assert [int((a >> 30) & 1) for a, _ in occ[start:start + cnt]] == [int(seen_u[e[0]] & 1) for e in exp]
+        # launch plan: every task appears once; heavy tasks are split over a team of 16 waves
+        rec, hdr = recs[b], hdrs[b]
+        assert hdr[3] == len(live) and hdr[1] + hdr[2] == hdr[3]
+        used = rec[: hdr[0] * P.TEAM]
+        nlb = (hdr[1] + P.TEAM - 1) // P.TEAM
+        lightrec = used[: nlb * P.TEAM]
+        assert [r for r in lightrec[:, 0] if r != -1] == [t[0] for t in live if t[2] <= P.LIGHT_MAX]
+        for h, t in enumerate([t for t in live if t[2] > P.LIGHT_MAX]):
+            team = used[(nlb + h) * P.TEAM:(nlb + h + 1) * P.TEAM]
+            assert np.all(team[:, 0] == t[0]) and team[:, 2].sum() == t[2] and np.all(team[:, 12] == t[2])
+            assert ((team[:, 1] >> 16) & 0xff).tolist() == list(range(P.TEAM))
+        seen_u[np.unique(ub)] += 1
+        seen_i[np.unique(np.concatenate([ib, jb]))] += 1
+    np.testing.assert_array_equal(seen_u, ucnt)
+    np.testing.assert_array_equal(seen_i, icnt)

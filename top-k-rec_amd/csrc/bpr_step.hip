@@ -5,17 +5,20 @@
 // single/bpr.py:81-100: 5 embedding_lookups, x_uij, log(1+exp(-x)) + regularisers, autodiff
 // to IndexedSlices, unique + segment-sum of duplicate rows, SparseApplyRMSProp on U, V, b.
 //
-// Work decomposition: one 64-lane wave per *unique touched row* of the batch (plan from K1).
-// A wave owns its row: it re-derives s_t = sigma(-x_t) for each of the row's occurrences
-// from the partner rows, sums the per-occurrence gradients in plan order (the sequential
-// segment-sum order of the oracle), applies RMSProp once and writes the row back.
+// Work decomposition (plan from K1): one 64-lane wave per *unique touched row* of the batch;
+// rows with more than 4 occurrences get a team of 16 waves (one workgroup) whose partial
+// gradients are combined through LDS in wave order.  A wave owns its row: it re-derives
+// s_t = sigma(-x_t) for each of its occurrences from the partner rows, sums the
+// per-occurrence gradients, applies RMSProp once and writes the row back.
 //
-// Every gather must see PRE-step values while other waves of the same launch write
-// POST-step values.  Parameters are therefore kept in two buffers per table with a per-row
-// stamp  (serial<<1 | buffer-holding-the-current-value):  the owner writes the new row to
-// the *other* buffer and re-stamps; a reader that finds this launch's serial in the stamp
-// takes the other buffer, i.e. the old value.  No inter-workgroup ordering is needed inside
-// a launch; visibility between batches comes from the kernel boundary.
+// Every gather must see PRE-step values while other waves of the same launch write POST-step
+// values.  Tables are double-buffered ([2][n][k]); the planner knows how often each row has
+// been updated, so the record of every wave carries the parity (= buffer) of its own row and
+// of every partner row: read buffer p, write buffer p^1.  No stamp lookup, no inter-workgroup
+// ordering inside a launch; visibility between batches comes from the kernel boundary.
+//
+// Latency structure per wave: [64-B record] -> [all rows of <=4 occurrences + own row + slot]
+// -> compute -> store.  Two dependent memory levels.
 //
 // Roofline: HBM / cache-bandwidth bound gather-scatter.  Algorithmic bytes per triplet
 // (no credit for in-batch duplicates): 3 rows x (param+ms) x (read+write)
@@ -25,10 +28,9 @@
 
 namespace tkr {
 
-constexpr int kStepThreads = 256;                 // 4 waves per workgroup
-constexpr int kWavesPerWG = kStepThreads / TKR_WAVE;
-
-struct RowRef { const float* p; };
+constexpr int kTeam = 16;                          // waves per workgroup (oracle/plan_np.py TEAM)
+constexpr int kStepThreads = kTeam * TKR_WAVE;     // 1024
+constexpr int kIdMask = 0x3fffffff;
 
 template <int NE>
 __device__ __forceinline__ void load_row(const float* __restrict__ base, int k, int lane, float (&r)[NE]) {
@@ -55,216 +57,260 @@ __device__ __forceinline__ void dot2(const float (&a)[NE], const float (&b1)[NE]
     d2 = p2;
 }
 
-// which buffer holds the value of a row as of the START of batch `serial`
-__device__ __forceinline__ int pre_step_buffer(int stamp, int serial) {
-    return (stamp & 1) ^ (int)((stamp >> 1) == serial);
+struct Acc {            // per-wave accumulators besides the row gradient
+    float gb;           // item tasks: bias gradient
+    float loss_lane;    // user tasks: per-lane regulariser partial
+    float loss_x;       // user tasks: wave-uniform part (softplus + bias regulariser)
+};
+
+// G occurrences of a USER row: oa = i | par<<30, ob = j | par<<30
+template <int NE, int G>
+__device__ __forceinline__ void user_group(const tkr_bpr_state& st, int lane, const int (&oa)[4], const int (&ob)[4],
+                                           const float (&ur)[NE], float (&g)[NE], Acc& acc) {
+    const int k = st.k;
+    const size_t istride = (size_t)st.n_items * k;
+    float vi[G][NE], vj[G][NE], bi[G], bj[G];
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        const int i = oa[q] & kIdMask, pi = (oa[q] >> 30) & 1;
+        const int j = ob[q] & kIdMask, pj = (ob[q] >> 30) & 1;
+        load_row<NE>(st.V + pi * istride + (size_t)i * k, k, lane, vi[q]);
+        load_row<NE>(st.V + pj * istride + (size_t)j * k, k, lane, vj[q]);
+        bi[q] = st.b[(size_t)pi * st.n_items + i];
+        bj[q] = st.b[(size_t)pj * st.n_items + j];
+    }
+    const bool l2 = (st.mode == 0);
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        float xui, xuj;
+        dot2<NE>(ur, vi[q], vj[q], xui, xuj);
+        const float x = bi[q] - bj[q] + xui - xuj;
+        const float s = sigmoid_neg(x);
+        acc.loss_x += softplus_neg(x);
+        if (l2) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                g[e] += -s * (vi[q][e] - vj[q][e]) + st.lu * ur[e];
+                acc.loss_lane += 0.5f * (ur[e] * ur[e] * st.lu + vi[q][e] * vi[q][e] * st.li + vj[q][e] * vj[q][e] * st.lj);
+            }
+            acc.loss_x += 0.5f * (bi[q] * bi[q] + bj[q] * bj[q]) * st.lb;
+        } else {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                g[e] += -s * (vi[q][e] - vj[q][e]) + st.lu * sgn(ur[e]);
+                acc.loss_lane += fabsf(ur[e]) * st.lu + fabsf(vi[q][e]) * st.li + fabsf(vj[q][e]) * st.lj;
+            }
+            acc.loss_x += (fabsf(bi[q]) + fabsf(bj[q])) * st.lb;
+        }
+    }
+}
+
+// G occurrences of an ITEM row: oa = u | par<<30, ob = other | par<<30 | role<<31
+template <int NE, int G>
+__device__ __forceinline__ void item_group(const tkr_bpr_state& st, int lane, const int (&oa)[4], const int (&ob)[4],
+                                           const float (&vr)[NE], float br, float (&g)[NE], Acc& acc) {
+    const int k = st.k;
+    const size_t ustride = (size_t)st.n_users * k, istride = (size_t)st.n_items * k;
+    float uu[G][NE], vo[G][NE], bo[G];
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        const int u = oa[q] & kIdMask, pu = (oa[q] >> 30) & 1;
+        const int o = ob[q] & kIdMask, po = (ob[q] >> 30) & 1;
+        load_row<NE>(st.U + pu * ustride + (size_t)u * k, k, lane, uu[q]);
+        load_row<NE>(st.V + po * istride + (size_t)o * k, k, lane, vo[q]);
+        bo[q] = st.b[(size_t)po * st.n_items + o];
+    }
+    const bool l2 = (st.mode == 0);
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        const bool role_j = ob[q] < 0;
+        float dr, dn;                                  // <u, v_row>, <u, v_other>
+        dot2<NE>(uu[q], vr, vo[q], dr, dn);
+        // role i: row is the positive item  x = b_r - b_o + <u,v_r> - <u,v_o>
+        // role j: row is the negative item  x = b_o - b_r + <u,v_o> - <u,v_r>
+        const float x = role_j ? (bo[q] - br + dn - dr) : (br - bo[q] + dr - dn);
+        const float s = sigmoid_neg(x);
+        const float sg = role_j ? s : -s;
+        const float lam = role_j ? st.lj : st.li;
+        if (l2) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) g[e] += sg * uu[q][e] + lam * vr[e];
+            acc.gb += sg + st.lb * br;
+        } else {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) g[e] += sg * uu[q][e] + lam * sgn(vr[e]);
+            acc.gb += sg + st.lb * sgn(br);
+        }
+    }
+}
+
+template <int NE, bool ITEM>
+__device__ __forceinline__ void run_group(const tkr_bpr_state& st, int lane, int n, const int (&oa)[4],
+                                          const int (&ob)[4], const float (&row)[NE], float br, float (&g)[NE],
+                                          Acc& acc) {
+    if constexpr (ITEM) {
+        switch (n) {
+            case 1: item_group<NE, 1>(st, lane, oa, ob, row, br, g, acc); break;
+            case 2: item_group<NE, 2>(st, lane, oa, ob, row, br, g, acc); break;
+            case 3: item_group<NE, 3>(st, lane, oa, ob, row, br, g, acc); break;
+            default: item_group<NE, 4>(st, lane, oa, ob, row, br, g, acc); break;
+        }
+    } else {
+        switch (n) {
+            case 1: user_group<NE, 1>(st, lane, oa, ob, row, g, acc); break;
+            case 2: user_group<NE, 2>(st, lane, oa, ob, row, g, acc); break;
+            case 3: user_group<NE, 3>(st, lane, oa, ob, row, g, acc); break;
+            default: user_group<NE, 4>(st, lane, oa, ob, row, g, acc); break;
+        }
+    }
 }
 
 template <int NE>
 __global__ __launch_bounds__(kStepThreads) void bpr_step_kernel(
-    tkr_bpr_state st, const int4* __restrict__ task_all, const int2* __restrict__ occ,
-    int serial, float* __restrict__ loss_out) {
+    tkr_bpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
+    const int4* __restrict__ hdr, float* __restrict__ loss_out) {
+    __shared__ float red[kTeam][NE * TKR_WAVE + 1];
     const int lane = threadIdx.x & (TKR_WAVE - 1);
-    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerWG + (threadIdx.x >> 6));
-    const int4 tk = task_all[w];
-    const int rowk = __builtin_amdgcn_readfirstlane(tk.x);
-    if (rowk == -1) return;
-    const int start = __builtin_amdgcn_readfirstlane(tk.y);
-    const int count = __builtin_amdgcn_readfirstlane(tk.z);
-    const bool is_item = rowk < 0;          // kind bit = sign bit
-    const int row = rowk & 0x7fffffff;
+    const int wave = threadIdx.x >> 6;
+    const int4 h = *hdr;                         // (workgroups used, light tasks, heavy tasks, tasks)
+    const int n_blocks = __builtin_amdgcn_readfirstlane(h.x);
+    const int nlb = (__builtin_amdgcn_readfirstlane(h.y) + kTeam - 1) / kTeam;
     const int k = st.k;
     const size_t ustride = (size_t)st.n_users * k, istride = (size_t)st.n_items * k;
-    const bool l2 = (st.mode == 0);
 
-    if (!is_item) {
-        // ------------------------------------------------ user row: owns U[row]
-        const int cb = st.ustamp[row] & 1;           // only this wave re-stamps the row
-        float ur[NE], ms[NE], g[NE];
-        load_row<NE>(st.U + cb * ustride + (size_t)row * k, k, lane, ur);
-        load_row<NE>(st.msU + cb * ustride + (size_t)row * k, k, lane, ms);
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const bool heavy = blk >= nlb;           // workgroup-uniform
+        const int word = (lane < 16) ? rec_all[((size_t)blk * kTeam + wave) * 16 + lane] : 0;
+        const int rowk = bcast_i(word, 0);
+        if (rowk == -1) continue;                // idle wave of the last light group (never in a heavy group)
+        const int meta = bcast_i(word, 1);
+        const int n_occ = bcast_i(word, 2);
+        const int first = bcast_i(word, 3);
+        const int par = meta & 1, team = (meta >> 8) & 0xff;
+        const bool is_item = rowk < 0;
+        const int row = rowk & 0x7fffffff;
+
+        float own[NE], g[NE];
 #pragma unroll
-        for (int q = 0; q < NE; ++q) g[q] = 0.f;
-        float loss_lane = 0.f, loss_x = 0.f;
-        for (int c0 = 0; c0 < count; c0 += TKR_WAVE) {
-            const int nc = min(count - c0, TKR_WAVE);
-            int io = 0, jo = 0, ibuf = 0, jbuf = 0;
-            float bio = 0.f, bjo = 0.f;
-            if (lane < nc) {
-                const int2 oc = occ[start + c0 + lane];
-                io = oc.x; jo = oc.y;
-                ibuf = pre_step_buffer(st.istamp[io], serial);
-                jbuf = pre_step_buffer(st.istamp[jo], serial);
-                bio = st.b[(size_t)ibuf * st.n_items + io];
-                bjo = st.b[(size_t)jbuf * st.n_items + jo];
+        for (int e = 0; e < NE; ++e) g[e] = 0.f;
+        Acc acc = {0.f, 0.f, 0.f};
+        const float* src = is_item ? st.V + par * istride + (size_t)row * k : st.U + par * ustride + (size_t)row * k;
+        load_row<NE>(src, k, lane, own);
+        const float br = is_item ? st.b[(size_t)par * st.n_items + row] : 0.f;
+
+        for (int done = 0; done < n_occ; done += 4) {
+            const int n = min(4, n_occ - done);
+            int oa[4], ob[4];
+            if (done == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { oa[q] = bcast_i(word, 4 + 2 * q); ob[q] = bcast_i(word, 5 + 2 * q); }
+            } else {                              // very heavy rows: fetch the next 4 occurrences
+                int2 o = make_int2(0, 0);
+                if (lane < n) o = occ[first + (done + lane) * team];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { oa[q] = bcast_i(o.x, q); ob[q] = bcast_i(o.y, q); }
             }
-            for (int m = 0; m < nc; ++m) {
-                const int i_m = bcast_i(io, m), j_m = bcast_i(jo, m);
-                const float bi = bcast_f(bio, m), bj = bcast_f(bjo, m);
-                float vi[NE], vj[NE];
-                load_row<NE>(st.V + bcast_i(ibuf, m) * istride + (size_t)i_m * k, k, lane, vi);
-                load_row<NE>(st.V + bcast_i(jbuf, m) * istride + (size_t)j_m * k, k, lane, vj);
-                float xui, xuj;
-                dot2<NE>(ur, vi, vj, xui, xuj);
-                const float x = bi - bj + xui - xuj;
-                const float s = sigmoid_neg(x);
-                loss_x += softplus_neg(x);
-                if (l2) {
-#pragma unroll
-                    for (int q = 0; q < NE; ++q) {
-                        g[q] += -s * (vi[q] - vj[q]) + st.lu * ur[q];
-                        loss_lane += 0.5f * (ur[q] * ur[q] * st.lu + vi[q] * vi[q] * st.li + vj[q] * vj[q] * st.lj);
-                    }
-                    loss_x += 0.5f * (bi * bi + bj * bj) * st.lb;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < NE; ++q) {
-                        g[q] += -s * (vi[q] - vj[q]) + st.lu * sgn(ur[q]);
-                        loss_lane += fabsf(ur[q]) * st.lu + fabsf(vi[q]) * st.li + fabsf(vj[q]) * st.lj;
-                    }
-                    loss_x += (fabsf(bi) + fabsf(bj)) * st.lb;
-                }
-            }
+            if (is_item) run_group<NE, true>(st, lane, n, oa, ob, own, br, g, acc);
+            else run_group<NE, false>(st, lane, n, oa, ob, own, 0.f, g, acc);
         }
-        float* Uo = st.U + (cb ^ 1) * ustride + (size_t)row * k;
-        float* Mo = st.msU + (cb ^ 1) * ustride + (size_t)row * k;
-#pragma unroll
-        for (int q = 0; q < NE; ++q) {
-            const int e = lane + q * TKR_WAVE;
-            if (e < k) {
-                const float m2 = st.rho * ms[q] + (1.f - st.rho) * g[q] * g[q];
-                Mo[e] = m2;
-                Uo[e] = ur[q] - st.lr * g[q] / sqrtf(m2 + st.eps);
-            }
-        }
-        if (lane == 0) st.ustamp[row] = (serial << 1) | (cb ^ 1);
-        if (loss_out) {
-            const float tot = wave_sum(loss_lane) + loss_x;     // loss_x is wave-uniform
+
+        if (!is_item && loss_out) {
+            const float tot = wave_sum(acc.loss_lane) + acc.loss_x;
             if (lane == 0) atomicAdd(loss_out, tot);
         }
-        return;
-    }
 
-    // ---------------------------------------------------- item row: owns V[row], b[row]
-    const int cb = st.istamp[row] & 1;
-    float vr[NE], ms[NE], g[NE];
-    load_row<NE>(st.V + cb * istride + (size_t)row * k, k, lane, vr);
-    load_row<NE>(st.msV + cb * istride + (size_t)row * k, k, lane, ms);
-    const float br = st.b[(size_t)cb * st.n_items + row];
-    const float msbr = st.msb[(size_t)cb * st.n_items + row];
-    float gb = 0.f;
+        if (heavy) {                               // combine the team's partial gradients in wave order
 #pragma unroll
-    for (int q = 0; q < NE; ++q) g[q] = 0.f;
-    for (int c0 = 0; c0 < count; c0 += TKR_WAVE) {
-        const int nc = min(count - c0, TKR_WAVE);
-        int uo = 0, oo = 0, ubuf = 0, obuf = 0;
-        float boo = 0.f;
-        if (lane < nc) {
-            const int2 oc = occ[start + c0 + lane];
-            uo = oc.x; oo = oc.y;                       // oo: other item | role<<31
-            const int other = oo & 0x7fffffff;
-            ubuf = pre_step_buffer(st.ustamp[uo], serial);
-            obuf = pre_step_buffer(st.istamp[other], serial);
-            boo = st.b[(size_t)obuf * st.n_items + other];
+            for (int e = 0; e < NE; ++e) red[wave][lane + e * TKR_WAVE] = g[e];
+            if (lane == 0) red[wave][NE * TKR_WAVE] = acc.gb;
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    float s = 0.f;
+                    for (int w = 0; w < kTeam; ++w) s += red[w][lane + e * TKR_WAVE];
+                    g[e] = s;
+                }
+                float s = 0.f;
+                for (int w = 0; w < kTeam; ++w) s += red[w][NE * TKR_WAVE];
+                acc.gb = s;
+            }
+            __syncthreads();
+            if (wave != 0) continue;
         }
-        for (int m = 0; m < nc; ++m) {
-            const int u_m = bcast_i(uo, m), o_m = bcast_i(oo, m);
-            const bool role_j = o_m < 0;
-            const int other = o_m & 0x7fffffff;
-            const float bo = bcast_f(boo, m);
-            float uu[NE], vo[NE];
-            load_row<NE>(st.U + bcast_i(ubuf, m) * ustride + (size_t)u_m * k, k, lane, uu);
-            load_row<NE>(st.V + bcast_i(obuf, m) * istride + (size_t)other * k, k, lane, vo);
-            float dr, dn;                                  // <u, v_row>, <u, v_other>
-            dot2<NE>(uu, vr, vo, dr, dn);
-            // role i: row is the positive item  x = b_r - b_o + <u,v_r> - <u,v_o>
-            // role j: row is the negative item  x = b_o - b_r + <u,v_o> - <u,v_r>
-            const float x = role_j ? (bo - br + dn - dr) : (br - bo + dr - dn);
-            const float s = sigmoid_neg(x);
-            const float sg = role_j ? s : -s;
-            const float lam = role_j ? st.lj : st.li;
-            if (l2) {
+
+        // ---- RMSProp on the owned row (TF SparseApplyRMSProp, momentum 0), written to buffer par^1
+        float ms[NE];
+        const float* msrc = is_item ? st.msV + par * istride + (size_t)row * k : st.msU + par * ustride + (size_t)row * k;
+        load_row<NE>(msrc, k, lane, ms);
+        float* po = is_item ? st.V + (par ^ 1) * istride + (size_t)row * k : st.U + (par ^ 1) * ustride + (size_t)row * k;
+        float* mo = is_item ? st.msV + (par ^ 1) * istride + (size_t)row * k : st.msU + (par ^ 1) * ustride + (size_t)row * k;
 #pragma unroll
-                for (int q = 0; q < NE; ++q) g[q] += sg * uu[q] + lam * vr[q];
-                gb += sg + st.lb * br;
-            } else {
-#pragma unroll
-                for (int q = 0; q < NE; ++q) g[q] += sg * uu[q] + lam * sgn(vr[q]);
-                gb += sg + st.lb * sgn(br);
+        for (int e = 0; e < NE; ++e) {
+            const int c = lane + e * TKR_WAVE;
+            if (c < k) {
+                const float m2 = st.rho * ms[e] + (1.f - st.rho) * g[e] * g[e];
+                mo[c] = m2;
+                po[c] = own[e] - st.lr * g[e] / sqrtf(m2 + st.eps);
             }
         }
-    }
-    float* Vo = st.V + (cb ^ 1) * istride + (size_t)row * k;
-    float* Mo = st.msV + (cb ^ 1) * istride + (size_t)row * k;
-#pragma unroll
-    for (int q = 0; q < NE; ++q) {
-        const int e = lane + q * TKR_WAVE;
-        if (e < k) {
-            const float m2 = st.rho * ms[q] + (1.f - st.rho) * g[q] * g[q];
-            Mo[e] = m2;
-            Vo[e] = vr[q] - st.lr * g[q] / sqrtf(m2 + st.eps);
+        if (is_item && lane == 0) {
+            const float msb = st.msb[(size_t)par * st.n_items + row];
+            const float m2 = st.rho * msb + (1.f - st.rho) * acc.gb * acc.gb;
+            st.msb[(size_t)(par ^ 1) * st.n_items + row] = m2;
+            st.b[(size_t)(par ^ 1) * st.n_items + row] = br - st.lr * acc.gb / sqrtf(m2 + st.eps);
         }
     }
-    if (lane == 0) {
-        const float m2 = st.rho * msbr + (1.f - st.rho) * gb * gb;
-        st.msb[(size_t)(cb ^ 1) * st.n_items + row] = m2;
-        st.b[(size_t)(cb ^ 1) * st.n_items + row] = br - st.lr * gb / sqrtf(m2 + st.eps);
-        st.istamp[row] = (serial << 1) | (cb ^ 1);
-    }
+}
+
+static int step_grid(int B) {
+    // enough workgroups for every light task plus a handful of teams; the kernel grid-strides
+    const int light = (3 * B + kTeam - 1) / kTeam;
+    int grid = light + 16;
+    if (grid > 2048) grid = 2048;
+    return grid;
 }
 
 template <int NE>
-static int launch_step(const tkr_bpr_state& st, const int32_t* task, const int32_t* occ, int B, int serial,
+static int launch_step(const tkr_bpr_state& st, const int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
                        float* loss_out, hipStream_t stream) {
-    const int n_waves = 3 * B;
-    const int grid = (n_waves + kWavesPerWG - 1) / kWavesPerWG;
-    hipLaunchKernelGGL(bpr_step_kernel<NE>, dim3(grid), dim3(kStepThreads), 0, stream, st,
-                       reinterpret_cast<const int4*>(task), reinterpret_cast<const int2*>(occ), serial, loss_out);
+    hipLaunchKernelGGL(bpr_step_kernel<NE>, dim3(step_grid(B)), dim3(kStepThreads), 0, stream, st, rec,
+                       reinterpret_cast<const int2*>(occ), reinterpret_cast<const int4*>(hdr), loss_out);
     return (int)hipGetLastError();
 }
 
-static int dispatch_step(const tkr_bpr_state& st, const int32_t* task, const int32_t* occ, int B, int serial,
+static int dispatch_step(const tkr_bpr_state& st, const int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
                          float* loss_out, hipStream_t stream) {
     switch ((st.k + TKR_WAVE - 1) / TKR_WAVE) {
-        case 1: return launch_step<1>(st, task, occ, B, serial, loss_out, stream);
-        case 2: return launch_step<2>(st, task, occ, B, serial, loss_out, stream);
-        case 3: return launch_step<3>(st, task, occ, B, serial, loss_out, stream);
-        case 4: return launch_step<4>(st, task, occ, B, serial, loss_out, stream);
+        case 1: return launch_step<1>(st, rec, occ, hdr, B, loss_out, stream);
+        case 2: return launch_step<2>(st, rec, occ, hdr, B, loss_out, stream);
+        case 3: return launch_step<3>(st, rec, occ, hdr, B, loss_out, stream);
+        case 4: return launch_step<4>(st, rec, occ, hdr, B, loss_out, stream);
         default: return TKR_EUNSUPPORTED;       // k > 256
     }
 }
 
 }  // namespace tkr
 
+extern "C" int tkr_plan_max_blocks(int32_t batch_size);
+
 static int check_state(const tkr_bpr_state* st) {
-    if (!st || !st->U || !st->msU || !st->V || !st->msV || !st->b || !st->msb || !st->ustamp || !st->istamp)
-        return TKR_EINVAL;
+    if (!st || !st->U || !st->msU || !st->V || !st->msV || !st->b || !st->msb) return TKR_EINVAL;
     if (st->n_users <= 0 || st->n_items <= 0 || st->k <= 0) return TKR_EINVAL;
     if (st->k > 256) return TKR_EUNSUPPORTED;
     return TKR_OK;
 }
 
-extern "C" int tkr_bpr_step(const tkr_bpr_state* st, const int32_t* task, const int32_t* occ,
-                            int32_t batch_size, int32_t serial, float* loss_out, void* stream) {
+extern "C" int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ, const int32_t* hdr,
+                           int32_t batch_size, int32_t n_batches, float* loss_out, void* stream) {
     const int rc = check_state(st);
     if (rc != TKR_OK) return rc;
-    if (!task || !occ || batch_size <= 0 || serial <= 0 || serial >= (1 << 30)) return TKR_EINVAL;
-    return tkr::dispatch_step(*st, task, occ, batch_size, serial, loss_out, (hipStream_t)stream);
-}
-
-extern "C" int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* task, const int32_t* occ,
-                           int32_t batch_size, int32_t n_batches, int32_t first_serial, float* loss_out,
-                           void* stream) {
-    const int rc = check_state(st);
-    if (rc != TKR_OK) return rc;
-    if (!task || !occ || batch_size <= 0 || n_batches < 0 || first_serial <= 0 ||
-        (int64_t)first_serial + n_batches >= (1 << 30))
-        return TKR_EINVAL;
-    const size_t stride_t = (size_t)3 * batch_size * 4, stride_o = (size_t)3 * batch_size * 2;
+    if (!rec || !occ || !hdr || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
+    const size_t stride_r = (size_t)tkr_plan_max_blocks(batch_size) * tkr::kTeam * 16;
+    const size_t stride_o = (size_t)3 * batch_size * 2;
     for (int b = 0; b < n_batches; ++b) {
-        const int r = tkr::dispatch_step(*st, task + b * stride_t, occ + b * stride_o, batch_size,
-                                         first_serial + b, loss_out ? loss_out + b : nullptr,
-                                         (hipStream_t)stream);
+        const int r = tkr::dispatch_step(*st, rec + b * stride_r, occ + b * stride_o, hdr + (size_t)b * 4, batch_size,
+                                         loss_out ? loss_out + b : nullptr, (hipStream_t)stream);
         if (r != 0) return r;
     }
     return TKR_OK;

@@ -9,8 +9,13 @@
 // oracle/plan_np.py and must match it bit for bit:
 //   draw   : Philox4x32-10 keyed by the seed, counter = global triplet index + round
 //   sort   : LDS bitonic sort of 64-bit (row<<32 | occurrence) keys -> stable grouping
-//   plan   : task[3B] = (row|kind<<31, occ_start, occ_count, 0), occ[3B] = per-occurrence
+//   plan   : task[3B] = (row|kind<<31, occ_start, occ_count, parity), occ[3B] = per-occurrence
 //            partner ids in group order (users first, then items; i-roles before j-roles)
+//   parity : which of the two table buffers holds each row at the start of the batch
+//            (= number of earlier updates of the row, mod 2), resolved here so that the step
+//            kernel needs no dependent lookup: K1a marks (row, batch) in a per-row bitmap,
+//            K1b turns prefix popcounts into parity bits and writes the 64-byte per-wave
+//            launch records, K1c folds the bitmap into the running update counters.
 //
 // HBM traffic per triplet: 8 B row_ptr pair + 4 B positive + ~4*log2(deg) B membership
 // probes + 12 B triplet + 24 B occ + <=48 B task  ~= 0.1 KB; latency-bound, not on the
@@ -21,6 +26,9 @@ namespace tkr {
 
 constexpr int kPlanThreads = 256;
 constexpr int kMaxRounds = 64;   // oracle/plan_np.py MAX_ROUNDS
+constexpr int kLightMax = 4;     // oracle/plan_np.py LIGHT_MAX: occurrences one wave handles
+constexpr int kTeam = 16;        // oracle/plan_np.py TEAM: waves per workgroup / heavy task
+constexpr int kTouchWords = 16;  // bitmap words per row -> at most 512 batches per call
 
 __device__ __forceinline__ bool is_member(const int32_t* __restrict__ cols_sorted, int lo, int hi, int item) {
     int a = lo, b = hi;
@@ -78,7 +86,8 @@ __device__ __forceinline__ void bitonic_sort(uint64_t* keys, int n) {
 // number of groups (uniform across the block).  `slot0` = first task slot to fill,
 // `occ0` = occ offset of sorted position 0, `kind` = 0 users / 1 items.
 __device__ __forceinline__ int emit_tasks(const uint64_t* keys, int n, int4* task, int slot0, int occ0,
-                                          int kind, int* scan /*LDS [kPlanThreads+1]*/) {
+                                          int kind, int* scan /*LDS [kPlanThreads+1]*/,
+                                          uint32_t* __restrict__ touch, int batch) {
     const int per = (n + kPlanThreads - 1) / kPlanThreads;
     const int beg = min((int)threadIdx.x * per, n), end = min(beg + per, n);
     int cnt = 0;
@@ -100,6 +109,7 @@ __device__ __forceinline__ int emit_tasks(const uint64_t* keys, int n, int4* tas
             int q = p + 1;
             while (q < n && (uint32_t)(keys[q] >> 32) == row) ++q;
             task[slot0 + s] = make_int4((int)(row | ((uint32_t)kind << 31)), occ0 + p, q - p, 0);
+            atomicOr(&touch[(size_t)row * kTouchWords + (batch >> 5)], 1u << (batch & 31));
             ++s;
         }
     }
@@ -111,7 +121,8 @@ __global__ __launch_bounds__(kPlanThreads) void sample_plan_kernel(
     const int32_t* __restrict__ pos_cols, const int32_t* __restrict__ cols_sorted, uint32_t n_items,
     uint64_t seed, uint64_t first_triplet, const int64_t* __restrict__ ctl, int B, int npad_items,
     int32_t* __restrict__ out_u, int32_t* __restrict__ out_i, int32_t* __restrict__ out_j,
-    int4* __restrict__ task_all, int2* __restrict__ occ_all) {
+    int4* __restrict__ task_all, int2* __restrict__ occ_all, uint32_t* __restrict__ touch_u,
+    uint32_t* __restrict__ touch_i) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                       // [npad_items]
     int* scan = reinterpret_cast<int*>(smem + (size_t)npad_items * 8);        // [kPlanThreads+1]
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(kPlanThreads) void sample_plan_kernel(
     for (int t = threadIdx.x; t < npad_u; t += kPlanThreads)
         keys[t] = (t < B) ? (((uint64_t)(uint32_t)bu[t] << 32) | (uint32_t)t) : ~0ull;
     bitonic_sort(keys, npad_u);
-    const int n_uq = emit_tasks(keys, B, task, 0, 0, 0, scan);
+    const int n_uq = emit_tasks(keys, B, task, 0, 0, 0, scan, touch_u, b);
     for (int p = threadIdx.x; p < B; p += kPlanThreads) {
         const int t = (int)(uint32_t)keys[p];
         occ[p] = make_int2(bi[t], bj[t]);
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(kPlanThreads) void sample_plan_kernel(
         keys[o] = key;
     }
     bitonic_sort(keys, npad_items);
-    const int n_iq = emit_tasks(keys, 2 * B, task, n_uq, B, 1, scan);
+    const int n_iq = emit_tasks(keys, 2 * B, task, n_uq, B, 1, scan, touch_i, b);
     for (int p = threadIdx.x; p < 2 * B; p += kPlanThreads) {
         const int o = (int)(uint32_t)keys[p];
         const bool role = o >= B;
@@ -167,16 +178,152 @@ __global__ __launch_bounds__(kPlanThreads) void sample_plan_kernel(
     for (int s = n_uq + n_iq + threadIdx.x; s < 3 * B; s += kPlanThreads) task[s] = make_int4(-1, 0, 0, 0);
 }
 
+// ---- K1b: parities + per-wave launch records ------------------------------------------------
+__device__ __forceinline__ int parity_of(const int32_t* __restrict__ cnt, const uint32_t* __restrict__ touch,
+                                         int row, int batch) {
+    const uint32_t* w = touch + (size_t)row * kTouchWords;
+    int c = cnt[row];
+    const int full = batch >> 5;
+    for (int q = 0; q < full; ++q) c += __popc(w[q]);
+    c += __popc(w[full] & ((1u << (batch & 31)) - 1u));
+    return c & 1;
+}
+
+__device__ __forceinline__ int block_exclusive_scan2(int a, int b, int* scan /*LDS [2*(T+1)]*/, int& tot_a,
+                                                      int& tot_b, int& ex_b) {
+    int* sa = scan;
+    int* sb = scan + kPlanThreads + 1;
+    sa[threadIdx.x + 1] = a;
+    sb[threadIdx.x + 1] = b;
+    if (threadIdx.x == 0) { sa[0] = 0; sb[0] = 0; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int t = 1; t <= kPlanThreads; ++t) { sa[t] += sa[t - 1]; sb[t] += sb[t - 1]; }
+    __syncthreads();
+    tot_a = sa[kPlanThreads];
+    tot_b = sb[kPlanThreads];
+    ex_b = sb[threadIdx.x];
+    return sa[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
+    int B, int rec_stride /*records per batch*/, int4* __restrict__ task_all, int2* __restrict__ occ_all,
+    const int32_t* __restrict__ ucnt, const int32_t* __restrict__ icnt, const uint32_t* __restrict__ touch_u,
+    const uint32_t* __restrict__ touch_i, int32_t* __restrict__ rec_all, int4* __restrict__ hdr_all) {
+    __shared__ int scan[2 * (kPlanThreads + 1)];
+    const int b = blockIdx.x;
+    int4* task = task_all + (size_t)b * 3 * B;
+    int2* occ = occ_all + (size_t)b * 3 * B;
+    int32_t* rec = rec_all + (size_t)b * rec_stride * 16;
+
+    for (int s = threadIdx.x; s < 3 * B; s += kPlanThreads) {
+        int4 t = task[s];
+        if (t.x != -1) {
+            const int row = t.x & 0x7fffffff;
+            t.w = (t.x < 0) ? parity_of(icnt, touch_i, row, b) : parity_of(ucnt, touch_u, row, b);
+            task[s] = t;
+        }
+    }
+    for (int p = threadIdx.x; p < B; p += kPlanThreads) {           // user occurrences: (i, j)
+        int2 o = occ[p];
+        o.x |= parity_of(icnt, touch_i, o.x, b) << 30;
+        o.y |= parity_of(icnt, touch_i, o.y, b) << 30;
+        occ[p] = o;
+    }
+    for (int p = threadIdx.x; p < 2 * B; p += kPlanThreads) {       // item occurrences: (u, other|role<<31)
+        int2 o = occ[B + p];
+        o.x |= parity_of(ucnt, touch_u, o.x, b) << 30;
+        o.y |= parity_of(icnt, touch_i, o.y & 0x3fffffff, b) << 30;
+        occ[B + p] = o;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // classify: light (one wave) / heavy (a team); slots by prefix rank in task order
+    const int per = (3 * B + kPlanThreads - 1) / kPlanThreads;
+    const int beg = min((int)threadIdx.x * per, 3 * B), end = min(beg + per, 3 * B);
+    int nl = 0, nh = 0;
+    for (int s = beg; s < end; ++s) {
+        const int4 t = task[s];
+        if (t.x != -1) { if (t.z <= kLightMax) ++nl; else ++nh; }
+    }
+    int tot_l, tot_h, hi;
+    int li = block_exclusive_scan2(nl, nh, scan, tot_l, tot_h, hi);
+    const int nlb = (tot_l + kTeam - 1) / kTeam;
+    for (int s = beg; s < end; ++s) {
+        const int4 t = task[s];
+        if (t.x == -1) continue;
+        if (t.z <= kLightMax) {
+            int32_t* r = rec + (size_t)li * 16;
+            r[0] = t.x; r[1] = t.w | (1 << 8); r[2] = t.z; r[3] = t.y;
+            for (int q = 0; q < kLightMax; ++q) {
+                const int2 o = (q < t.z) ? occ[t.y + q] : make_int2(0, 0);
+                r[4 + 2 * q] = o.x; r[5 + 2 * q] = o.y;
+            }
+            r[12] = t.z; r[13] = 0; r[14] = 0; r[15] = 0;
+            ++li;
+        } else {
+            for (int w = 0; w < kTeam; ++w) {
+                int32_t* r = rec + ((size_t)(nlb + hi) * kTeam + w) * 16;
+                const int mine = (t.z > w) ? (t.z - w + kTeam - 1) / kTeam : 0;
+                r[0] = t.x; r[1] = t.w | (kTeam << 8) | (w << 16); r[2] = mine; r[3] = t.y + w;
+                for (int q = 0; q < 4; ++q) {
+                    const int2 o = (q < mine) ? occ[t.y + w + q * kTeam] : make_int2(0, 0);
+                    r[4 + 2 * q] = o.x; r[5 + 2 * q] = o.y;
+                }
+                r[12] = t.z; r[13] = 0; r[14] = 0; r[15] = 0;
+            }
+            ++hi;
+        }
+    }
+    for (int s = tot_l + threadIdx.x; s < nlb * kTeam; s += kPlanThreads) {      // idle waves of the last light group
+        int32_t* r = rec + (size_t)s * 16;
+        r[0] = -1;
+        for (int q = 1; q < 16; ++q) r[q] = 0;
+    }
+    if (threadIdx.x == 0) hdr_all[b] = make_int4(nlb + tot_h, tot_l, tot_h, tot_l + tot_h);
+}
+
+// ---- K1c: fold the chunk's touch bitmap into the update counters and clear it --------------
+__global__ void commit_kernel(int n_users, int n_items, int32_t* __restrict__ ucnt, int32_t* __restrict__ icnt,
+                              uint32_t* __restrict__ touch_u, uint32_t* __restrict__ touch_i) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_users + n_items) return;
+    int32_t* cnt = (r < n_users) ? ucnt + r : icnt + (r - n_users);
+    uint4* w = reinterpret_cast<uint4*>((r < n_users) ? touch_u + (size_t)r * kTouchWords
+                                                       : touch_i + (size_t)(r - n_users) * kTouchWords);
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < kTouchWords / 4; ++q) {
+        const uint4 v = w[q];
+        c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    if (c) {
+        *cnt += c;
+#pragma unroll
+        for (int q = 0; q < kTouchWords / 4; ++q) w[q] = make_uint4(0, 0, 0, 0);
+    }
+}
+
 }  // namespace tkr
 
+extern "C" int tkr_plan_max_blocks(int32_t batch_size) {
+    return (3 * batch_size + tkr::kTeam - 1) / tkr::kTeam + (3 * batch_size) / (tkr::kLightMax + 1);
+}
+
 extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr,
-                               const int32_t* pos_cols, const int32_t* cols_sorted, int32_t n_items,
-                               uint64_t seed, uint64_t first_triplet, const int64_t* ctl, int32_t n_batches,
-                               int32_t batch_size, int32_t* out_u, int32_t* out_i, int32_t* out_j,
-                               int32_t* task, int32_t* occ, void* stream) {
-    if (n_tr <= 0 || n_items <= 0 || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
+                               const int32_t* pos_cols, const int32_t* cols_sorted, int32_t n_users,
+                               int32_t n_items, uint64_t seed, uint64_t first_triplet, const int64_t* ctl,
+                               int32_t n_batches, int32_t batch_size, int32_t* ucnt, int32_t* icnt,
+                               uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u, int32_t* out_i,
+                               int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr,
+                               void* stream) {
+    if (n_tr <= 0 || n_items <= 0 || n_users <= 0 || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
+    if (n_users >= (1 << 30) || n_items >= (1 << 30)) return TKR_EUNSUPPORTED;   // id bits 30/31 carry flags
     if (batch_size > 8192) return TKR_EUNSUPPORTED;   // 2B 64-bit keys must fit the 160 KiB LDS
+    if (n_batches > 32 * tkr::kTouchWords) return TKR_EUNSUPPORTED;
     if (n_batches == 0) return TKR_OK;
+    if (!ucnt || !icnt || !touch_u || !touch_i || !rec || !hdr) return TKR_EINVAL;
     int npad = 1;
     while (npad < 2 * batch_size) npad <<= 1;
     const size_t lds = (size_t)npad * 8 + (tkr::kPlanThreads + 1) * sizeof(int);
@@ -186,10 +333,19 @@ extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int3
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(tkr::sample_plan_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), lds,
-                       (hipStream_t)stream, tr_users, (uint32_t)n_tr, row_ptr, pos_cols, cols_sorted,
-                       (uint32_t)n_items, seed, first_triplet, ctl, batch_size, npad, out_u, out_i, out_j,
-                       reinterpret_cast<int4*>(task), reinterpret_cast<int2*>(occ));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tkr::sample_plan_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), lds, s, tr_users,
+                       (uint32_t)n_tr, row_ptr, pos_cols, cols_sorted, (uint32_t)n_items, seed, first_triplet, ctl,
+                       batch_size, npad, out_u, out_i, out_j, reinterpret_cast<int4*>(task),
+                       reinterpret_cast<int2*>(occ), touch_u, touch_i);
+    TKR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tkr::resolve_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), 0, s, batch_size,
+                       tkr_plan_max_blocks(batch_size) * tkr::kTeam, reinterpret_cast<int4*>(task),
+                       reinterpret_cast<int2*>(occ), ucnt, icnt, touch_u, touch_i, rec, reinterpret_cast<int4*>(hdr));
+    TKR_LAUNCH_CHECK();
+    const int rows = n_users + n_items;
+    hipLaunchKernelGGL(tkr::commit_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, n_users, n_items, ucnt, icnt,
+                       touch_u, touch_i);
     TKR_LAUNCH_CHECK();
     return TKR_OK;
 }

@@ -50,19 +50,28 @@ __device__ __forceinline__ uint32_t mulhi64(uint32_t lo, uint32_t hi, uint32_t n
     return (uint32_t)__umul64hi(((uint64_t)hi << 32) | lo, (uint64_t)n);
 }
 
-// ---- wave64 reductions ----------------------------------------------------------------
+// ---- wave64 reductions (DPP; fixed tree -> bitwise repeatable) --------------------------------
+// v += dpp(v): lanes whose source is masked off add 0.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false);
+    return v + __int_as_float(moved);
+}
+
+// sum over the 64 lanes, returned to every lane (uniform)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, TKR_WAVE);
-    return v;
+    v = dpp_add<0xb1>(v);              // quad_perm [1,0,3,2]
+    v = dpp_add<0x4e>(v);              // quad_perm [2,3,0,1]
+    v = dpp_add<0x124>(v);             // row_ror:4
+    v = dpp_add<0x128>(v);             // row_ror:8   -> every lane of a 16-lane row holds the row sum
+    v = dpp_add<0x142, 0xa>(v);        // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);        // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ void wave_sum2(float& a, float& b) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        a += __shfl_xor(a, m, TKR_WAVE);
-        b += __shfl_xor(b, m, TKR_WAVE);
-    }
+    a = wave_sum(a);
+    b = wave_sum(b);
 }
 
 __device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }

@@ -10,7 +10,7 @@ import torch
 import tkr_hip
 
 RHO, EPS = 0.9, 1e-10          # tf.train.RMSPropOptimizer defaults (decay, epsilon)
-MAX_PLAN_BATCHES = 4096        # batches planned per K1 launch (84 B of plan per triplet)
+MAX_PLAN_BATCHES = tkr_hip.PLAN_MAX_BATCHES   # batches planned per K1 call
 
 
 def default_device():
@@ -64,7 +64,21 @@ class PlanBuffers:
         self.j = torch.empty(cap * B, **i32)
         self.task = torch.empty(cap * 3 * B * 4, **i32)
         self.occ = torch.empty(cap * 3 * B * 2, **i32)
+        self.rec_stride = tkr_hip.plan_max_blocks(B) * tkr_hip.TEAM * 16
+        self.rec = torch.empty(cap * self.rec_stride, **i32)
+        self.hdr = torch.empty(cap * 4, **i32)
         self.loss = torch.zeros(cap, dtype=torch.float32, device=device)
+
+
+class UpdateCounters:
+    """Per-row update counts (parity = buffer holding the row) + K1's scratch bitmaps."""
+
+    def __init__(self, n_users, n_items, device):
+        i32 = dict(dtype=torch.int32, device=device)
+        self.ucnt = torch.zeros(n_users, **i32)
+        self.icnt = torch.zeros(n_items, **i32)
+        self.touch_u = torch.zeros(n_users * 16, **i32)
+        self.touch_i = torch.zeros(n_items * 16, **i32)
 
 
 class DoubleTable:
@@ -78,8 +92,8 @@ class DoubleTable:
         if init is not None:
             self.p[0].normal_(0.0, init, generator=gen)
 
-    def current(self, stamp):
-        sel = (stamp & 1).long()
+    def current(self, cnt):
+        sel = (cnt & 1).long()
         idx = torch.arange(self.p.shape[1], device=self.p.device)
         return self.p[sel, idx], self.ms[sel, idx]
 
@@ -104,9 +118,7 @@ class BprEngine:
         self.U = DoubleTable(n_users, k, self.device, 0.01, gen)
         self.V = DoubleTable(n_items, k, self.device, 0.01, gen)
         self.b = DoubleTable(n_items, 0, self.device)
-        self.ustamp = torch.zeros(n_users, dtype=torch.int32, device=self.device)
-        self.istamp = torch.zeros(n_items, dtype=torch.int32, device=self.device)
-        self.serial = 0                 # batches applied so far (stamps hold serial<<1|buf)
+        self.cnt = UpdateCounters(n_users, n_items, self.device)
         self.triplets_drawn = 0         # position in the counter-based sample stream
         self.plan = None
         self._state = None
@@ -115,9 +127,9 @@ class BprEngine:
     def state(self):
         hp = self.hp
         st = tkr_hip.BprState()
-        st.U, st.msU, st.ustamp = self.U.p.data_ptr(), self.U.ms.data_ptr(), self.ustamp.data_ptr()
+        st.U, st.msU = self.U.p.data_ptr(), self.U.ms.data_ptr()
         st.V, st.msV = self.V.p.data_ptr(), self.V.ms.data_ptr()
-        st.b, st.msb, st.istamp = self.b.p.data_ptr(), self.b.ms.data_ptr(), self.istamp.data_ptr()
+        st.b, st.msb = self.b.p.data_ptr(), self.b.ms.data_ptr()
         st.n_users, st.n_items, st.k = self.n_users, self.n_items, self.k
         st.mode = 0 if hp['mode'] == 'l2' else 1
         st.lu, st.li, st.lj, st.lb, st.lr = hp['lu'], hp['li'], hp['lj'], hp['lb'], hp['lr']
@@ -126,20 +138,20 @@ class BprEngine:
 
     # ---- parameter access (host <-> current buffers) -----------------------------------------
     def get(self, name):
-        table, stamp = {'U': (self.U, self.ustamp), 'V': (self.V, self.istamp), 'b': (self.b, self.istamp)}[name]
-        return table.current(stamp)
+        table, cnt = {'U': (self.U, self.cnt.ucnt), 'V': (self.V, self.cnt.icnt), 'b': (self.b, self.cnt.icnt)}[name]
+        return table.current(cnt)
 
     def set_users(self, U=None, msU=None):
-        cur, ms = self.U.current(self.ustamp)
+        cur, ms = self.U.current(self.cnt.ucnt)
         self.U.assign(cur if U is None else self._dev(U), ms if msU is None else self._dev(msU))
-        self.ustamp.bitwise_and_(~1)
+        self.cnt.ucnt.zero_()
 
     def set_items(self, V=None, b=None, msV=None, msb=None):
-        cv, mv = self.V.current(self.istamp)
-        cb, mb = self.b.current(self.istamp)
+        cv, mv = self.V.current(self.cnt.icnt)
+        cb, mb = self.b.current(self.cnt.icnt)
         self.V.assign(cv if V is None else self._dev(V), mv if msV is None else self._dev(msV))
         self.b.assign(cb if b is None else self._dev(b).reshape(-1), mb if msb is None else self._dev(msb).reshape(-1))
-        self.istamp.bitwise_and_(~1)
+        self.cnt.icnt.zero_()
 
     def _dev(self, a):
         if isinstance(a, torch.Tensor):
@@ -148,32 +160,23 @@ class BprEngine:
 
     # ---- the loop ------------------------------------------------------------------------------
     def _ensure_plan(self, n_batches, B):
-        cap = min(n_batches, MAX_PLAN_BATCHES)
+        cap = min(n_batches, MAX_PLAN_BATCHES, max(8, (1 << 21) // B))      # <= 2M triplets of plan resident
         if self.plan is None or self.plan.B != B or self.plan.cap < cap:
             self.plan = PlanBuffers(cap, B, self.device)
         return self.plan
-
-    def _renormalise_serial(self):
-        self.ustamp.bitwise_and_(1)
-        self.istamp.bitwise_and_(1)
-        self.serial = 0
 
     def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True):
         """sample + plan + step for n_batches consecutive batches; returns the per-batch
         losses of the LAST chunk as a device tensor (or None)."""
         plan = self._ensure_plan(n_batches, B)
         done, loss = 0, None
+        state = self.state()
         while done < n_batches:
             nb = min(plan.cap, n_batches - done)
-            if self.serial + nb >= (1 << 30) - 1:
-                self._renormalise_serial()
-            tkr_hip.sample_plan(csr.tr_users, csr.row_ptr, csr.pos_cols, csr.cols_sorted, self.n_items,
-                                self.seed, self.triplets_drawn, nb, B, plan.u, plan.i, plan.j, plan.task, plan.occ)
+            tkr_hip.sample_plan(csr, self.n_users, self.n_items, self.seed, self.triplets_drawn, nb, B, self.cnt, plan)
             if want_loss:
                 plan.loss[:nb].zero_()
-            tkr_hip.bpr_run(self.state(), plan.task, plan.occ, B, nb, self.serial + 1,
-                            plan.loss if want_loss else None)
-            self.serial += nb
+            tkr_hip.bpr_run(state, plan, B, nb, plan.loss if want_loss else None)
             self.triplets_drawn += nb * B
             done += nb
             loss = plan.loss[:nb] if want_loss else None

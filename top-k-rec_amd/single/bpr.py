@@ -163,12 +163,11 @@ class BPR(REC):
             self._csr = _engine.TrainingCSR(self.tr_data, self.tr_users, self.n_users, device)
         import tkr_hip
         plan = _engine.PlanBuffers(1, batch_size, device)
+        cnt = _engine.UpdateCounters(self.n_users, self.n_items, device)     # throw-away parities
         seed = int(np.random.SeedSequence().entropy % (2 ** 63)) if self._eng is None else self._eng.seed
         drawn = 0
         while True:
-            tkr_hip.sample_plan(self._csr.tr_users, self._csr.row_ptr, self._csr.pos_cols, self._csr.cols_sorted,
-                                self.n_items, seed ^ 0x5DEECE66D, drawn, 1, batch_size,
-                                plan.u, plan.i, plan.j, plan.task, plan.occ)
+            tkr_hip.sample_plan(self._csr, self.n_users, self.n_items, seed ^ 0x5DEECE66D, drawn, 1, batch_size, cnt, plan)
             drawn += batch_size
             yield plan.u.cpu().numpy().astype(np.int64), plan.i.cpu().numpy(), plan.j.cpu().numpy()
 

@@ -23,9 +23,8 @@ class TkrError(RuntimeError):
 
 class BprState(C.Structure):
     """mirror of tkr_bpr_state (include/tkr.h)"""
-    _fields_ = [('U', C.c_void_p), ('msU', C.c_void_p), ('ustamp', C.c_void_p),
+    _fields_ = [('U', C.c_void_p), ('msU', C.c_void_p),
                 ('V', C.c_void_p), ('msV', C.c_void_p), ('b', C.c_void_p), ('msb', C.c_void_p),
-                ('istamp', C.c_void_p),
                 ('n_users', C.c_int32), ('n_items', C.c_int32), ('k', C.c_int32), ('mode', C.c_int32),
                 ('lu', C.c_float), ('li', C.c_float), ('lj', C.c_float), ('lb', C.c_float),
                 ('lr', C.c_float), ('rho', C.c_float), ('eps', C.c_float)]
@@ -45,7 +44,7 @@ class VbprState(C.Structure):
                 ('lr', C.c_float), ('rho', C.c_float), ('eps', C.c_float)]
 
 
-EXPORTS = ('tkr_version', 'tkr_sample_plan', 'tkr_bpr_step', 'tkr_bpr_run')
+EXPORTS = ('tkr_version', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_bpr_run')
 
 
 def lib():
@@ -82,22 +81,30 @@ def version():
     return lib().tkr_version()
 
 
-def sample_plan(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed, first_triplet, n_batches, B,
-                out_u, out_i, out_j, task, occ, ctl=None):
-    for t in (tr_users, row_ptr, pos_cols, cols_sorted, out_u, out_i, out_j, task, occ):
-        assert t.dtype == torch.int32
-    assert out_u.numel() >= n_batches * B and task.numel() >= n_batches * 3 * B * 4 and occ.numel() >= n_batches * 3 * B * 2
-    _check(lib().tkr_sample_plan(_p(tr_users), C.c_int32(tr_users.numel()), _p(row_ptr), _p(pos_cols),
-                                 _p(cols_sorted), C.c_int32(n_items), C.c_uint64(seed), C.c_uint64(first_triplet),
-                                 _p(ctl), C.c_int32(n_batches), C.c_int32(B), _p(out_u), _p(out_i), _p(out_j),
-                                 _p(task), _p(occ), _stream()), 'tkr_sample_plan')
+PLAN_MAX_BATCHES = 512      # per tkr_sample_plan call (16 bitmap words per row)
+TEAM = 16
 
 
-def bpr_step(state, task, occ, B, serial, loss_out=None):
-    _check(lib().tkr_bpr_step(C.byref(state), _p(task), _p(occ), C.c_int32(B), C.c_int32(serial), _p(loss_out),
-                              _stream()), 'tkr_bpr_step')
+def plan_max_blocks(B):
+    return lib().tkr_plan_max_blocks(C.c_int32(B))
 
 
-def bpr_run(state, task, occ, B, n_batches, first_serial, loss_out=None):
-    _check(lib().tkr_bpr_run(C.byref(state), _p(task), _p(occ), C.c_int32(B), C.c_int32(n_batches),
-                             C.c_int32(first_serial), _p(loss_out), _stream()), 'tkr_bpr_run')
+def sample_plan(csr, n_users, n_items, seed, first_triplet, n_batches, B, cnt, plan, ctl=None):
+    """csr: tensors tr_users,row_ptr,pos_cols,cols_sorted; cnt: ucnt,icnt,touch_u,touch_i;
+    plan: u,i,j,task,occ,rec,hdr (all int32 device tensors)."""
+    assert n_batches <= PLAN_MAX_BATCHES
+    assert plan.u.numel() >= n_batches * B and plan.task.numel() >= n_batches * 3 * B * 4
+    assert plan.rec.numel() >= n_batches * plan_max_blocks(B) * TEAM * 16 and plan.hdr.numel() >= n_batches * 4
+    assert cnt.ucnt.numel() == n_users and cnt.touch_u.numel() == n_users * 16
+    assert cnt.icnt.numel() == n_items and cnt.touch_i.numel() == n_items * 16
+    _check(lib().tkr_sample_plan(_p(csr.tr_users), C.c_int32(csr.tr_users.numel()), _p(csr.row_ptr), _p(csr.pos_cols),
+                                 _p(csr.cols_sorted), C.c_int32(n_users), C.c_int32(n_items), C.c_uint64(seed),
+                                 C.c_uint64(first_triplet), _p(ctl), C.c_int32(n_batches), C.c_int32(B),
+                                 _p(cnt.ucnt), _p(cnt.icnt), _p(cnt.touch_u), _p(cnt.touch_i),
+                                 _p(plan.u), _p(plan.i), _p(plan.j), _p(plan.task), _p(plan.occ), _p(plan.rec),
+                                 _p(plan.hdr), _stream()), 'tkr_sample_plan')
+
+
+def bpr_run(state, plan, B, n_batches, loss_out=None):
+    _check(lib().tkr_bpr_run(C.byref(state), _p(plan.rec), _p(plan.occ), _p(plan.hdr), C.c_int32(B),
+                             C.c_int32(n_batches), _p(loss_out), _stream()), 'tkr_bpr_run')
