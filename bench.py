@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""bench.py -- BPR training triplets/s on synthetic MovieLens-10M-shaped data (BASELINE.json
+configs[1]: ~70k users x ~10k items, k = 128), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one mini-batch: (u,i,j) draw + batch plan (K1) and the
+loss/gradient/RMSProp update (K2), reference semantics (single/bpr.py:136-147), default batch
+256 like the reference's train.py.  Inputs (training CSR, model tables) are resident in HBM
+before the timed region.  N > 1: users are sharded, item tables replicated, one RCCL all-reduce
+of the item-side state per epoch (every (limit//B)//N steps); weak scaling (K steps per rank).
+
+Prints ONE JSON line (rank 0).  Extra objects beside the contract fields:
+  roofline        dominant kernel (K2) against the HBM roofline: algorithmic bytes per launch
+                  (B x (48k+56) B) / average launch duration from HIP events
+  cpu_baseline    the numpy oracle with the reference's cost structure (per-element legacy
+                  np.random sampler + numpy step), bounded sample, rank 0, N = 1 only
+  throughput_mode the same path at batch_size 8192 (a legal train() argument; NOT the headline)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'top-k-rec_amd')]
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_bytes_per_triplet(k):
+    return 48 * k + 56          # 3 rows x (param+slot) x (read+write) + biases + ids
+
+
+def build_problem(shape, k, rank, world, device, seed=42):
+    import synth
+    from single import _engine
+    spec = dict(synth.ML10M if shape == 'ml10m' else synth.NETFLIX)
+    r = synth.make_ratings(seed=seed, **spec)
+    row_ptr, pos, _, tr_users = synth.positives_csr(r)
+    n_users, n_items = r['n_users'], r['n_in'] + r['n_out']
+    import dist as tdist
+    mine = np.asarray(tdist.shard_users(tr_users, rank, world), dtype=np.int32)
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, mine, device)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=1e-4, mode='l2')       # single/bpr.py:20 defaults
+    eng = _engine.BprEngine(n_users, n_items, k, hp, device, seed=1234 + rank)
+    return r, csr, eng, int(row_ptr[-1])
+
+
+def timed_run(eng, csr, B, steps, warmup, sync_every, world):
+    """warmup untimed, then exactly `steps` batches between barriers; returns (wall_s, step_kernel_ms)"""
+    import dist as tdist
+    isync = tdist.ItemSync(eng)
+
+    def run(n):
+        done = 0
+        while done < n:
+            m = min(n - done, sync_every)
+            if world > 1:
+                isync.begin()
+            eng.run_batches(csr, m, B, want_loss=False)
+            if world > 1:
+                isync.end()
+            done += m
+
+    run(warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.step_events = []
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    step_ms = sum(a.elapsed_time(b) for a, b, _ in eng.step_events)
+    launches = sum(n for _, _, n in eng.step_events)
+    eng.step_events = None
+    assert launches == steps
+    return wall, step_ms
+
+
+def cpu_baseline(r, k, B, budget_s=12.0):
+    """the oracle, shaped like the reference: legacy per-element sampler + numpy step, 1 core"""
+    from oracle import ref_np as R
+    keep = r['tr_l'] == 1
+    users, items = r['tr_u'][keep], r['tr_i'][keep]
+    cuts = np.flatnonzero(np.r_[True, users[1:] != users[:-1], True])
+    tr_data = {int(users[a]): items[a:b].tolist() for a, b in zip(cuts[:-1], cuts[1:])}
+    tr_users = list(tr_data.keys())
+    n_users, n_items = r['n_users'], r['n_in'] + r['n_out']
+    st = R.init_bpr_state(n_users, n_items, k, np.random.Generator(np.random.PCG64(0)))
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=1e-4, mode='l2')
+    np.random.seed(0)
+    gen = R.legacy_uniform_user_sampler(tr_users, tr_data, n_items, B)
+    t0 = time.perf_counter()
+    nb = 0
+    while time.perf_counter() - t0 < budget_s:
+        ub, ib, jb = next(gen)
+        R.bpr_step(st, ub, ib, jb, hp)
+        nb += 1
+    dt = time.perf_counter() - t0
+    return dict(value=nb * B / dt, unit='triplets/s', cores=1, kind='port',
+                sample='%d batches of %d triplets (%.1f s): oracle/ref_np legacy np.random sampler + numpy step, '
+                       'ML-10M shape k=%d' % (nb, B, dt, k))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3906 * 2)          # two reference epochs (10^6 // 256 batches each)
+    ap.add_argument('--warmup', type=int, default=512)
+    ap.add_argument('--batch-size', type=int, default=256)          # train.py / single/bpr.py:103 default
+    ap.add_argument('--k', type=int, default=128)
+    ap.add_argument('--shape', default='ml10m', choices=['ml10m', 'netflix'])
+    ap.add_argument('--epoch-sample-limit', type=int, default=10 ** 6)   # train.py:6
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=device)
+
+    B, k = args.batch_size, args.k
+    r, csr, eng, nnz = build_problem(args.shape, k, rank, world, device)
+    sync_every = max(1, (args.epoch_sample_limit // B) // world) if world > 1 else args.steps + args.warmup
+    wall, step_ms = timed_run(eng, csr, B, args.steps, args.warmup, sync_every, world)
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    value = world * args.steps * B / wall
+    launch_us = step_ms * 1e3 / args.steps
+    achieved = B * algorithmic_bytes_per_triplet(k) / (launch_us * 1e-6) / 1e9
+    out = {
+        'metric': 'BPR training triplets/sec (sampler + plan + step), MovieLens-10M shape',
+        'value': value, 'unit': 'triplets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': wall * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BPR %s shape (%d users x %d items, %d train positives), k=%d, batch_size=%d, '
+                               'RMSProp lr=1e-4, reference defaults' % ('MovieLens-10M' if args.shape == 'ml10m' else 'Netflix',
+                                                                        r['n_users'], r['n_in'] + r['n_out'], nnz, k, B),
+                   'batch_size': B, 'k': k, 'sharding': 'users sharded over %d GPU(s), item tables replicated, '
+                                                        'all-reduce every %d steps' % (world, sync_every) if world > 1 else 'single GPU'},
+        'roofline': {'kernel': 'tkr::bpr_step_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'launch_us': launch_us,
+                     'algorithmic_bytes_per_launch': B * algorithmic_bytes_per_triplet(k)},
+    }
+    if rank == 0 and world == 1 and not args.no_extras:
+        # throughput mode: same kernels, batch_size 8192 (fresh tables)
+        from single import _engine
+        B2 = 8192
+        eng2 = _engine.BprEngine(eng.n_users, eng.n_items, k, eng.hp, device, seed=99)
+        w2, s2 = timed_run(eng2, csr, B2, 256, 32, 10 ** 9, 1)
+        a2 = B2 * algorithmic_bytes_per_triplet(k) / (s2 * 1e-3 / 256) / 1e9
+        out['throughput_mode'] = {'batch_size': B2, 'steps': 256, 'value': 256 * B2 / w2, 'unit': 'triplets/s',
+                                  'ms_per_step': w2 * 1e3 / 256,
+                                  'roofline': {'bound': 'hbm', 'achieved': a2, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                               'frac': a2 / HBM_PEAK_GBS, 'launch_us': s2 * 1e3 / 256}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(r, k, B)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -121,7 +121,7 @@ class BprEngine:
         self.cnt = UpdateCounters(n_users, n_items, self.device)
         self.triplets_drawn = 0         # position in the counter-based sample stream
         self.plan = None
-        self._state = None
+        self.step_events = None         # list of (start, end, n_launches) when a bench wants kernel time
 
     # ---- C-ABI state struct ------------------------------------------------------------
     def state(self):
@@ -153,6 +153,10 @@ class BprEngine:
         self.b.assign(cb if b is None else self._dev(b).reshape(-1), mb if msb is None else self._dev(msb).reshape(-1))
         self.cnt.icnt.zero_()
 
+    def set_replicated(self, new):
+        """write back all-reduced item-side tables: {'V': (p, ms), 'b': (p, ms)} (dist.ItemSync)"""
+        self.set_items(V=new['V'][0], b=new['b'][0], msV=new['V'][1], msb=new['b'][1])
+
     def _dev(self, a):
         if isinstance(a, torch.Tensor):
             return a.to(self.device, torch.float32)
@@ -176,7 +180,13 @@ class BprEngine:
             tkr_hip.sample_plan(csr, self.n_users, self.n_items, self.seed, self.triplets_drawn, nb, B, self.cnt, plan)
             if want_loss:
                 plan.loss[:nb].zero_()
+            if self.step_events is not None:          # bench: HIP events around the step launches
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             tkr_hip.bpr_run(state, plan, B, nb, plan.loss if want_loss else None)
+            if self.step_events is not None:
+                e1.record()
+                self.step_events.append((e0, e1, nb))
             self.triplets_drawn += nb * B
             done += nb
             loss = plan.loss[:nb] if want_loss else None
