@@ -79,6 +79,31 @@ typedef struct {
 int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ, const int32_t* hdr,
                 int32_t batch_size, int32_t n_batches, float* loss_out, void* stream);
 
+/* ---- K4: full-catalogue score -> rated mask -> top-K -------------------------------------------
+ * Replaces evaluate.py:78-81 (np.dot + bias + np.argsort over every row) and the rated-item filter
+ * of the rank walk (evaluate.py:96-105).
+ *   U [*, k] user factors; user_idx[n_rows] (nullable) picks the rows to rank (default 0..n_rows-1)
+ *   Vt [n_cols, k], bias[n_cols] (nullable): the scenario's test-item rows, already gathered
+ *     (evaluate.py:75-77; bias gathered per test id -- the reference's broadcast at :79-80 is only
+ *     defined when the scenario's id list equals vid)
+ *   mask [ceil(n_cols/32)][mask_pitch] (nullable): bit (c & 31) of word (c >> 5, row) = column c is
+ *     train-rated by row's user (evaluate.py:98); built by tkr_build_rated_mask into a zeroed buffer
+ *   out_ids [n_rows, K]: the K best unrated columns, descending score, ties -> higher column first;
+ *     -1 where fewer than K unrated columns exist.  out_scores (nullable) alike, -inf padded.
+ * K <= 32, k <= 256. */
+int tkr_build_rated_mask(const int64_t* rated_ptr, const int32_t* rated_cols, int32_t n_rows, int32_t n_cols,
+                         uint32_t* mask, int32_t mask_pitch, void* stream);
+int tkr_score_topk(const float* U, const int32_t* user_idx, int32_t n_rows, const float* Vt, const float* bias,
+                   int32_t n_cols, int32_t k, const uint32_t* mask, int32_t mask_pitch, int32_t K,
+                   int32_t* out_ids, float* out_scores, void* stream);
+
+/* ---- K5: hit counting of the rank walk (evaluate.py:99-103) ------------------------------------
+ * first_bucket[p / step] += 1 (uint64 atomics) for every kept position p < interval*step of row r
+ * whose column is in like_cols[like_ptr[r] .. like_ptr[r+1]) (ascending); hits[q] of the reference
+ * is the running sum over buckets <= q. */
+int tkr_count_hits(const int32_t* ids, int32_t n_rows, int32_t K, const int64_t* like_ptr, const int32_t* like_cols,
+                   int32_t step, int32_t interval, uint64_t* first_bucket, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

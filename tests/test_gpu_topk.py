@@ -1,0 +1,205 @@
+"""GPU parity of K4 (score + rated mask + top-K) and K5 (hit counting), through the C ABI.
+
+Index work: bit-exact.  Ranked id lists are compared
+  * exactly against the golden lists captured from the reference (G4-G7, tie-free by construction),
+  * exactly against the oracle on exact-arithmetic inputs (every partial sum representable ->
+    summation order cannot matter) including deliberate score ties (canonical tie rule),
+  * on generic fp32 inputs wherever the oracle's adjacent score gap exceeds 1e-6 relative."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_np as R
+
+
+@pytest.fixture(scope='module')
+def hip():
+    import tkr_hip
+    assert torch.cuda.is_available()
+    tkr_hip.lib()
+    return tkr_hip
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _oracle_lists(U, V, b, rated_cols, K):
+    s = np.dot(U, V.T)
+    if b is not None:
+        s = s + b.reshape(1, -1)
+    return [R.filtered_topk(s[r], set(rated_cols[r]), K, canonical=True) for r in range(len(U))], s
+
+
+def _gpu_lists(hip, U, V, b, rated_cols, K, user_idx=None, want_scores=False):
+    n_rows = len(rated_cols)
+    ptr = np.zeros(n_rows + 1, np.int64)
+    np.cumsum([len(x) for x in rated_cols], out=ptr[1:])
+    flat = np.array([c for x in rated_cols for c in sorted(x)], dtype=np.int32)
+    mask, pitch = hip.build_rated_mask(_dev(ptr), _dev(flat), n_rows, len(V))
+    out = hip.score_topk(_dev(U), _dev(V), K, bias=None if b is None else _dev(b), mask=mask, mask_pitch=pitch,
+                         user_idx=None if user_idx is None else _dev(user_idx.astype(np.int32)), want_scores=want_scores)
+    torch.cuda.synchronize()
+    return out
+
+
+def _exact(rng, n, k, lim):
+    return rng.integers(-lim, lim + 1, (n, k)).astype(np.float32) / 64.0
+
+
+@pytest.mark.parametrize('n_rows,n_cols,k,K', [(96, 80, 8, 30), (300, 1000, 50, 30), (1000, 333, 128, 32), (70, 2500, 64, 5),
+                                               (33, 40, 100, 1), (257, 95, 200, 30), (5, 17, 3, 30), (1, 1, 16, 4),
+                                               (640, 70000, 16, 30)])
+def test_exact_arithmetic_lists(hip, n_rows, n_cols, k, K):
+    rng = np.random.Generator(np.random.PCG64(n_rows * 7 + n_cols))
+    lim = max(1, int(np.sqrt((1 << 23) / k)) // 2)          # k * (lim/64)^2 * 4096 < 2^24: all partial sums exact
+    U, V = _exact(rng, n_rows, k, min(lim, 512)), _exact(rng, n_cols, k, min(lim, 512))
+    b = (rng.integers(-64, 65, n_cols).astype(np.float32) / 64.0) if n_cols % 2 else None
+    rated = [rng.choice(n_cols, int(rng.integers(0, min(n_cols, 60))), replace=False).tolist() for _ in range(n_rows)]
+    rated[0] = list(range(n_cols))                           # everything rated -> empty list
+    if n_rows > 2:
+        rated[1] = list(range(max(0, n_cols - 3)))           # fewer than K unrated columns
+        rated[2] = []
+    exp, s = _oracle_lists(U, V, b, rated, K)
+    ids, scores = _gpu_lists(hip, U, V, b, rated, K, want_scores=True)
+    ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
+    for r in range(n_rows):
+        got = [int(c) for c in ids[r] if c >= 0]
+        assert got == exp[r], 'row %d' % r
+        assert np.all(ids[r, len(got):] == -1)
+        np.testing.assert_array_equal(scores[r, :len(got)], s[r, got])
+
+
+def test_ties_follow_the_canonical_rule(hip):
+    """equal scores: higher column first (stable ascending argsort read backwards)"""
+    rng = np.random.Generator(np.random.PCG64(5))
+    n_rows, n_cols, k, K = 64, 300, 8, 30
+    U = _exact(rng, n_rows, k, 8)
+    V = _exact(rng, 20, k, 8)[rng.integers(0, 20, n_cols)]   # only 20 distinct item rows -> massive ties
+    V[:, :] = V
+    rated = [rng.choice(n_cols, 25, replace=False).tolist() for _ in range(n_rows)]
+    U[3] = 0                                                 # all scores +0.0 / -0.0
+    exp, _ = _oracle_lists(U, V, None, rated, K)
+    ids = _gpu_lists(hip, U, V, None, rated, K).cpu().numpy()
+    for r in range(n_rows):
+        assert [int(c) for c in ids[r] if c >= 0] == exp[r], 'row %d' % r
+
+
+def test_generic_fp32_lists_match_outside_near_ties(hip):
+    rng = np.random.Generator(np.random.PCG64(11))
+    n_rows, n_cols, k, K = 512, 4000, 128, 30
+    U = (rng.standard_normal((n_rows, k)) * 0.01).astype(np.float32)
+    V = (rng.standard_normal((n_cols, k)) * 0.01).astype(np.float32)
+    b = (rng.standard_normal(n_cols) * 0.001).astype(np.float32)
+    rated = [rng.choice(n_cols, 50, replace=False).tolist() for _ in range(n_rows)]
+    exp, s = _oracle_lists(U, V, b, rated, K)
+    s64 = U.astype(np.float64) @ V.astype(np.float64).T + b
+    ids, scores = _gpu_lists(hip, U, V, b, rated, K, want_scores=True)
+    ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
+    same = 0
+    for r in range(n_rows):
+        np.testing.assert_allclose(scores[r], s64[r, ids[r]], rtol=2e-5, atol=1e-9)   # fp32 dot, K=128
+        assert not (set(ids[r].tolist()) & set(rated[r]))
+        ref = exp[r]
+        # positions whose fp64 score is separated from both neighbours by > 1e-6 relative must agree
+        sref = s64[r, ref]
+        gap_ok = np.ones(K, bool)
+        d = np.abs(np.diff(sref)) > 1e-6 * np.abs(sref[:-1]) + 1e-10
+        gap_ok[:-1] &= d
+        gap_ok[1:] &= d
+        kth_gap = abs(sref[-1] - np.sort(np.delete(s64[r], rated[r]))[-K - 1]) > 1e-6 * abs(sref[-1]) + 1e-10
+        if kth_gap:
+            assert np.all(ids[r][gap_ok] == np.array(ref)[gap_ok]), 'row %d' % r
+        same += int(ids[r].tolist() == ref)
+    assert same > 0.95 * n_rows
+
+
+def test_user_idx_gather(hip):
+    rng = np.random.Generator(np.random.PCG64(2))
+    U, V = _exact(rng, 500, 32, 16), _exact(rng, 700, 32, 16)
+    pick = rng.choice(500, 130, replace=True)                # repeated users allowed (two test lines, one user)
+    rated = [rng.choice(700, 10, replace=False).tolist() for _ in pick]
+    exp, _ = _oracle_lists(U[pick], V, None, rated, 30)
+    ids = _gpu_lists(hip, U, V, None, rated, 30, user_idx=pick).cpu().numpy()
+    for r in range(len(pick)):
+        assert ids[r].tolist() == exp[r]
+
+
+def test_count_hits_matches_rank_walk(hip):
+    rng = np.random.Generator(np.random.PCG64(3))
+    n_rows, n_cols, K = 200, 120, 30
+    ids = np.stack([rng.permutation(n_cols)[:K] for _ in range(n_rows)]).astype(np.int32)
+    ids[5, 7:] = -1
+    likes = [sorted(rng.choice(n_cols, int(rng.integers(1, 20)), replace=False).tolist()) for _ in range(n_rows)]
+    ptr = np.zeros(n_rows + 1, np.int64)
+    np.cumsum([len(x) for x in likes], out=ptr[1:])
+    flat = np.array([c for x in likes for c in x], dtype=np.int32)
+    for step, total in ((5, 30), (3, 10), (1, 4), (7, 30), (40, 30)):
+        interval = total // step
+        got = hip.count_hits(_dev(ids[:, :total].copy()), _dev(ptr), _dev(flat), step, interval).cpu().numpy()
+        exp = np.zeros(interval, np.int64)
+        for r in range(n_rows):
+            kept = [int(c) for c in ids[r, :total] if c >= 0]
+            exp += np.array(R.bucket_hits(kept, set(likes[r]), step, interval), dtype=np.int64)
+        np.testing.assert_array_equal(got, exp)
+
+
+@pytest.mark.parametrize('g,scs', [('g4', ['im', 'om']), ('g5', ['im', 'om']), ('g6', ['all'])])
+def test_cli_matches_reference_stdout_and_lists(hip, golden_dir, g, scs, capsys):
+    import evaluate as E
+    d = os.path.join(golden_dir, g)
+    exp = json.load(open(os.path.join(d, 'expected.json')))
+    data, model = os.path.join(d, 'data'), os.path.join(d, 'model')
+    assert E.main(['-d', data, '-m', model, '-sl'] + scs) == exp['stdout']
+    assert capsys.readouterr().out.strip().split('\n') == exp['stdout']
+    if 'stdout_s3_t10' in exp:
+        assert E.main(['-d', data, '-m', model, '-s', '3', '-t', '10', '-sl', 'om', 'im']) == exp['stdout_s3_t10']
+    uids, vids = E.read_ids(os.path.join(data, 'uid')), E.read_ids(os.path.join(data, 'vid'))
+    rated = E.read_history(os.path.join(data, 'f0tr.txt'))
+    U, V = E.read_matrix(os.path.join(model, 'final-U.dat'), uids), E.read_matrix(os.path.join(model, 'final-V.dat'), vids)
+    bp = os.path.join(model, 'final-B.dat')
+    b = E.read_matrix(bp, vids) if os.path.exists(bp) else None
+    for sc in scs:
+        teids = E.read_ids(os.path.join(data, 'f0te.%s.idl' % sc))
+        tests = E.read_test_lines(os.path.join(data, 'f0te.%s.txt' % sc), teids)
+        ids = E.rank_scenario(_dev(U), V, b, uids, vids, rated, teids, tests, 30, torch.device('cuda')).cpu().numpy()
+        for (uid, _), row in zip(tests, ids):
+            assert [int(c) for c in row if c >= 0] == exp['lists'][sc][uid], (sc, uid)
+
+
+def test_cli_edge_cases_g7(hip, golden_dir):
+    import evaluate as E
+    d = os.path.join(golden_dir, 'g7')
+    exp = json.load(open(os.path.join(d, 'expected.json')))
+    data, model = os.path.join(d, 'data'), os.path.join(d, 'model')
+    for run in exp['runs']:
+        assert E.main(['-d', data, '-m', model, '-s', str(run['step']), '-t', str(run['total']), '-sl', 'sm']) == run['stdout']
+
+
+def test_large_shape_properties(hip):
+    """Netflix-width catalogue (17,770 items, k=128): sampled rows against the oracle, plus size-independent
+    properties on every row: sorted descending, no rated column, no duplicates."""
+    rng = np.random.Generator(np.random.PCG64(8))
+    n_rows, n_cols, k, K = 20000, 17770, 128, 30
+    U = (rng.standard_normal((n_rows, k)) * 0.01).astype(np.float32)
+    V = (rng.standard_normal((n_cols, k)) * 0.01).astype(np.float32)
+    rated = [rng.choice(n_cols, 100, replace=False).tolist() if r % 50 == 0 else [] for r in range(n_rows)]
+    ids, scores = _gpu_lists(hip, U, V, None, rated, K, want_scores=True)
+    ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
+    assert np.all(ids >= 0) and np.all(np.diff(scores, axis=1) <= 0)
+    assert all(len(set(row)) == K for row in ids[::97].tolist())
+    for r in range(0, n_rows, 50):
+        assert not (set(ids[r].tolist()) & set(rated[r]))
+    sample = np.arange(0, n_rows, 400)
+    s64 = U[sample].astype(np.float64) @ V.astype(np.float64).T
+    for q, r in enumerate(sample):
+        s = s64[q].copy()
+        s[rated[r]] = -np.inf
+        top = np.argsort(-s, kind='stable')[:K]
+        np.testing.assert_allclose(scores[r], s[ids[r]], rtol=2e-5, atol=1e-9)
+        assert len(set(top.tolist()) & set(ids[r].tolist())) >= K - 1       # at most one near-tie swap at the cut

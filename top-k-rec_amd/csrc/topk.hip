@@ -1,0 +1,346 @@
+// K4 -- full-catalogue scoring fused with rated-item masking and per-user top-K selection.
+//
+// Replaces evaluate.py:78-81 (scores = np.dot(umat, temat.T) (+ bias); np.argsort over the whole
+// row) and the filtering half of the rank walk (evaluate.py:96-105: skip train-rated items, keep
+// the first `total`).  The [n_users, n_items] score matrix and its int64 argsort never exist:
+// each workgroup keeps W x 32 users' factors in registers, streams 32-item tiles of V through
+// LDS, multiplies with exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) and filters the 32x32 scores
+// of every wave straight out of the accumulators into small per-user candidate lists in LDS.
+//
+// Orientation: MFMA rows = items, columns = users, so a lane owns ONE user (lane & 31) and 16
+// items of the tile: the running K-th best score of its user is one VGPR, the rated-item
+// bitmask of (user, tile) is one 32-bit word.  Candidates (score >= K-th best so far) are
+// appended with an LDS atomic; when a user's list could overflow the wave sorts it
+// (64-lane bitonic network on (score, column) keys), keeps K and raises the threshold.
+//
+// Canonical order: descending score, ties -> higher column first (= a stable
+// ascending argsort read backwards).  -0.0 is canonicalised to +0.0 so it ties with 0.0 like
+// numpy.  Accumulation order of the dot product: k-halves [0,KH) and [KH,2KH) interleaved by
+// the MFMA, k ascending inside a half (one rounding per product; exact whenever all partial
+// sums are representable, which is what the golden G5/G6 fixtures guarantee).
+//
+// Roofline: fp32 MFMA, 2*k*n_items flop per user; HBM traffic per user ~ 4k B factors + 8K B
+// out + 4*n_items/32 B mask words -- three orders of magnitude below the flop ratio.
+#include "tkr_common.h"
+#include "../../include/tkr.h"
+
+namespace tkr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTopkMaxWaves = 10;
+constexpr int kCap = 64;                 // candidate slots per user (= wave width: one entry per lane in a trim)
+constexpr int kMaxK = 32;                // K + 32 (largest per-tile inflow) <= kCap
+
+__device__ __forceinline__ uint32_t ordered_bits(float s) {      // monotone float -> uint
+    const uint32_t f = __float_as_uint(s);
+    return (f & 0x80000000u) ? ~f : (f | 0x80000000u);
+}
+
+// descending bitonic sort of one 64-bit key per lane across the wave
+__device__ __forceinline__ uint64_t wave_sort_desc(uint64_t key, int lane) {
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const uint32_t plo = __shfl_xor((uint32_t)key, stride, 64);
+            const uint32_t phi = __shfl_xor((uint32_t)(key >> 32), stride, 64);
+            const uint64_t other = ((uint64_t)phi << 32) | plo;
+            const bool upper = (lane & stride) != 0;             // I am the higher lane of the pair
+            const bool desc = (lane & size) == 0;                // this block sorts descending
+            const bool take_max = (upper != desc);               // lower lane of a descending block keeps the max
+            const uint64_t mx = key > other ? key : other, mn = key > other ? other : key;
+            key = take_max ? mx : mn;
+        }
+    }
+    return key;
+}
+
+template <typename IdT>
+struct TopkSmem {
+    float* tile;      // [2][32][KP]
+    float* tbias;     // [2][32]
+    int* cnt;         // [users]
+    float* cs;        // [users][kCap]
+    IdT* ci;          // [users][kCap]
+};
+
+// Sort user `uw`'s candidate list, keep the best K, return the new threshold (K-th best, or -inf
+// while fewer than K candidates exist).  Wave-uniform call.
+template <typename IdT>
+__device__ __forceinline__ float trim_user(const TopkSmem<IdT>& sm, int uw, int K, int lane, uint64_t* sorted_out) {
+    const int n = sm.cnt[uw];
+    uint64_t key = 0;                                            // below every real key (real keys have idx+1 > 0)
+    if (lane < n) key = ((uint64_t)ordered_bits(sm.cs[uw * kCap + lane]) << 32) | ((uint32_t)sm.ci[uw * kCap + lane] + 1u);
+    key = wave_sort_desc(key, lane);
+    const int keep = min(n, K);
+    if (lane < keep) {
+        const uint32_t ob = (uint32_t)(key >> 32);
+        const uint32_t f = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+        sm.cs[uw * kCap + lane] = __uint_as_float(f);
+        sm.ci[uw * kCap + lane] = (IdT)((uint32_t)key - 1u);
+    }
+    if (lane == 0) sm.cnt[uw] = keep;
+    if (sorted_out) *sorted_out = key;
+    const uint32_t kb = __builtin_amdgcn_readlane((uint32_t)(key >> 32), K - 1);
+    const uint32_t kf = (kb & 0x80000000u) ? (kb & 0x7fffffffu) : ~kb;
+    return (n >= K) ? __uint_as_float(kf) : -INFINITY;
+}
+
+// wide factor rows (k > 128) keep 100+ operand registers: one wave per SIMD
+template <int KHP>
+constexpr int topk_max_waves() { return KHP > 64 ? 4 : kTopkMaxWaves; }
+
+template <int KHP, typename IdT>
+__global__ __launch_bounds__(topk_max_waves<KHP>() * TKR_WAVE) void score_topk_kernel(
+    const float* __restrict__ U, const int32_t* __restrict__ uidx, int n_rows, const float* __restrict__ Vt,
+    const float* __restrict__ bias, int n_cols, int k, const uint32_t* __restrict__ mask, int mask_pitch, int K,
+    int32_t* __restrict__ out_ids, float* __restrict__ out_scores) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int KP = 2 * KHP + 4;                              // padded LDS row (floats): conflict-free b128 reads
+    const int W = blockDim.x >> 6;
+    const int users = W * 32;
+    TopkSmem<IdT> sm;
+    sm.tile = reinterpret_cast<float*>(smem_raw);
+    sm.tbias = sm.tile + 2 * 32 * KP;
+    sm.cnt = reinterpret_cast<int*>(sm.tbias + 64);
+    sm.cs = reinterpret_cast<float*>(sm.cnt + users);
+    sm.ci = reinterpret_cast<IdT*>(sm.cs + (size_t)users * kCap);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ul = lane & 31, h = lane >> 5;
+    const int uw = wave * 32 + ul;                               // user slot inside the workgroup
+    const int row = blockIdx.x * users + uw;                     // row of the output / index into uidx
+    const bool user_ok = row < n_rows;
+    const int KH = (k + 1) >> 1;                                 // k-range of half h: [h*KH, min(k, (h+1)*KH))
+
+    // ---- B operand: this lane's user, half h of its factor row, resident for the whole kernel
+    float breg[KHP];
+    {
+        const int urow = user_ok ? (uidx ? uidx[row] : row) : 0;
+        const float* up = U + (size_t)urow * k + h * KH;
+#pragma unroll
+        for (int kk = 0; kk < KHP; ++kk) {
+            const int e = h * KH + kk;
+            breg[kk] = (user_ok && kk < KH && e < k) ? up[kk] : 0.f;
+        }
+    }
+    for (int s = tid; s < users; s += blockDim.x) sm.cnt[s] = 0;
+    float thr = -INFINITY;
+    const int n_tiles = (n_cols + 31) >> 5;
+
+    auto stage = [&](int t, int buf) {                           // tile t of V (+ bias) -> LDS buffer `buf`
+        float* dst = sm.tile + buf * 32 * KP;
+        for (int c = tid; c < 32 * 2 * KHP; c += blockDim.x) {
+            const int item = c / (2 * KHP), p = c % (2 * KHP);
+            const int hh = p / KHP, kk = p % KHP;
+            const int e = hh * KH + kk, col = t * 32 + item;
+            float v = 0.f;
+            if (kk < KH && e < k && col < n_cols) v = Vt[(size_t)col * k + e];
+            dst[item * KP + p] = v;
+        }
+        if (tid < 32) {
+            const int col = t * 32 + tid;
+            sm.tbias[buf * 32 + tid] = (bias && col < n_cols) ? bias[col] : 0.f;
+        }
+    };
+
+    stage(0, 0);
+    __syncthreads();
+
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < n_tiles) stage(t + 1, buf ^ 1);              // other buffer: free since the barrier of tile t-1
+        // ---- 32 items x 32 users x k: exact fp32 MFMA ------------------------------------------
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const float* arow = sm.tile + buf * 32 * KP + ul * KP + h * KHP;
+#pragma unroll
+        for (int kk = 0; kk < KHP; kk += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + kk);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, breg[kk + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, breg[kk + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, breg[kk + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, breg[kk + 3], acc, 0, 0, 0);
+        }
+        // ---- epilogue: bias, mask, threshold filter ----------------------------------------------
+        const uint32_t maskw = (mask && user_ok) ? mask[(size_t)t * mask_pitch + row] : 0u;
+        float sc[16];
+        uint32_t ok = 0;                                         // bit r: column exists, user exists, not rated
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ir = (r & 3) + 8 * (r >> 2) + 4 * h;       // item row of accumulator register r
+            sc[r] = (acc[r] + sm.tbias[buf * 32 + ir]) + 0.0f;   // fl(fl(dot)+b); -0.0 -> +0.0
+            const bool good = user_ok && (t * 32 + ir < n_cols) && !((maskw >> ir) & 1u);
+            ok |= (uint32_t)good << r;
+        }
+        for (;;) {
+            uint32_t hits = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hits |= (uint32_t)(sc[r] >= thr) << r;
+            hits &= ok;
+            const int mine = __popc(hits);
+            const int total = mine + __shfl_xor(mine, 32, 64);
+            const bool need = user_ok && total > 0 && (sm.cnt[uw] + total > kCap);
+            uint64_t pending = __ballot(need) & 0xffffffffull;   // one bit per user (lower half lanes)
+            if (pending == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (hits & (1u << r)) {
+                        const int pos = atomicAdd(&sm.cnt[uw], 1);
+                        sm.cs[uw * kCap + pos] = sc[r];
+                        sm.ci[uw * kCap + pos] = (IdT)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                    }
+                }
+                break;
+            }
+            while (pending) {                                    // wave-uniform loop over users that must trim
+                const int u = __ffsll((long long)pending) - 1;
+                pending &= pending - 1;
+                const float nt = trim_user<IdT>(sm, wave * 32 + u, K, lane, nullptr);
+                if (ul == u) thr = nt;
+            }
+        }
+        __syncthreads();                                         // tile t+1 staged; buffer `buf` may be overwritten next
+    }
+
+    // ---- final sort and output --------------------------------------------------------------------
+    for (int u = 0; u < 32; ++u) {
+        const int r = blockIdx.x * users + wave * 32 + u;
+        if (r >= n_rows) break;                                  // wave-uniform
+        uint64_t key;
+        const int n = sm.cnt[wave * 32 + u];
+        trim_user<IdT>(sm, wave * 32 + u, K, lane, &key);
+        if (lane < K) {
+            const bool have = lane < n;
+            const uint32_t ob = (uint32_t)(key >> 32);
+            const uint32_t f = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+            out_ids[(size_t)r * K + lane] = have ? (int32_t)((uint32_t)key - 1u) : -1;
+            if (out_scores) out_scores[(size_t)r * K + lane] = have ? __uint_as_float(f) : -INFINITY;
+        }
+    }
+}
+
+// ---- rated-item bitmask: mask[(col>>5)*pitch + row] bit (col&31) --------------------------------
+__global__ void build_mask_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ cols, int n_rows,
+                                  int n_cols, uint32_t* __restrict__ mask, int pitch) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    for (int64_t p = ptr[row] + lane; p < ptr[row + 1]; p += 64) {
+        const int c = cols[p];
+        if (c >= 0 && c < n_cols) atomicOr(&mask[(size_t)(c >> 5) * pitch + row], 1u << (c & 31));
+    }
+}
+
+// ---- K5: hits per bucket (evaluate.py:99-103) ------------------------------------------------------
+// first_bucket[p / step] += 1 for every kept position p whose column is liked by the row's user;
+// the cumulative sum over buckets (host) gives hits[q] = #liked in positions < (q+1)*step.
+__global__ void count_hits_kernel(const int32_t* __restrict__ ids, int n_rows, int K, const int64_t* __restrict__ like_ptr,
+                                  const int32_t* __restrict__ like_cols, int step, int interval,
+                                  unsigned long long* __restrict__ first_bucket) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_rows * K) return;
+    const int row = g / K, p = g % K;
+    const int c = ids[g];
+    if (c < 0 || p / step >= interval) return;
+    int64_t lo = like_ptr[row], hi = like_ptr[row + 1];
+    const int64_t end = hi;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (like_cols[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    if (lo < end && like_cols[lo] == c) atomicAdd(&first_bucket[p / step], 1ull);
+}
+
+template <int KHP, typename IdT>
+static int launch_topk(int W, const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias,
+                       int n_cols, int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
+                       hipStream_t stream) {
+    constexpr int KP = 2 * KHP + 4;
+    const int users = W * 32;
+    const size_t lds = (size_t)(2 * 32 * KP + 64) * 4 + (size_t)users * 4 + (size_t)users * kCap * (4 + sizeof(IdT));
+    if (lds > 160 * 1024) return TKR_EUNSUPPORTED;
+    auto kern = score_topk_kernel<KHP, IdT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    const int grid = (n_rows + users - 1) / users;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,
+                       out_ids, out_scores);
+    return (int)hipGetLastError();
+}
+
+// waves per workgroup: fill the 256 CUs in whole rounds (every workgroup streams all of V once)
+static int pick_waves(int n_rows, int max_w) {
+    const int tasks = (n_rows + 31) / 32;
+    int best = 4;
+    double best_eff = -1.0;
+    for (int w = 4; w <= max_w; ++w) {
+        const int wgs = (tasks + w - 1) / w;
+        const int rounds = (wgs + 255) / 256;
+        const double eff = (double)tasks / ((double)rounds * 256 * w);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = w; }
+    }
+    return best;
+}
+
+template <typename IdT>
+static int dispatch_topk(const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias, int n_cols,
+                         int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
+                         hipStream_t stream) {
+    const int kh = (k + 1) / 2;
+#define TKR_TOPK_CASE(KHP)                                                                                        \
+    if (kh <= KHP) {                                                                                              \
+        constexpr int KP_ = 2 * KHP + 4;                                                                          \
+        int max_w = topk_max_waves<KHP>();                                                                        \
+        while (max_w > 1 && (size_t)(2 * 32 * KP_ + 64) * 4 + (size_t)max_w * 32 * (4 + kCap * (4 + sizeof(IdT))) > 160 * 1024) \
+            --max_w;                                                                                              \
+        if (max_w < 4) max_w = 4;                                                                                  \
+        return launch_topk<KHP, IdT>(pick_waves(n_rows, max_w), U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, \
+                                     out_ids, out_scores, stream);                                                \
+    }
+    TKR_TOPK_CASE(16)
+    TKR_TOPK_CASE(28)
+    TKR_TOPK_CASE(32)
+    TKR_TOPK_CASE(52)
+    TKR_TOPK_CASE(64)
+    TKR_TOPK_CASE(100)
+    TKR_TOPK_CASE(128)
+#undef TKR_TOPK_CASE
+    return TKR_EUNSUPPORTED;
+}
+
+}  // namespace tkr
+
+extern "C" int tkr_build_rated_mask(const int64_t* rated_ptr, const int32_t* rated_cols, int32_t n_rows, int32_t n_cols,
+                                    uint32_t* mask, int32_t pitch, void* stream) {
+    if (!rated_ptr || !mask || n_rows <= 0 || n_cols <= 0 || pitch < n_rows) return TKR_EINVAL;
+    hipLaunchKernelGGL(tkr::build_mask_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rated_ptr,
+                       rated_cols, n_rows, n_cols, mask, pitch);
+    TKR_LAUNCH_CHECK();
+    return TKR_OK;
+}
+
+extern "C" int tkr_score_topk(const float* U, const int32_t* user_idx, int32_t n_rows, const float* Vt,
+                              const float* bias, int32_t n_cols, int32_t k, const uint32_t* mask, int32_t mask_pitch,
+                              int32_t K, int32_t* out_ids, float* out_scores, void* stream) {
+    if (!U || !Vt || !out_ids || n_rows <= 0 || n_cols <= 0 || k <= 0 || K <= 0) return TKR_EINVAL;
+    if (mask && mask_pitch < n_rows) return TKR_EINVAL;
+    if (K > tkr::kMaxK || k > 256) return TKR_EUNSUPPORTED;
+    if (n_cols <= 65535)
+        return tkr::dispatch_topk<uint16_t>(U, user_idx, n_rows, Vt, bias, n_cols, k, mask, mask_pitch, K, out_ids,
+                                            out_scores, (hipStream_t)stream);
+    return tkr::dispatch_topk<uint32_t>(U, user_idx, n_rows, Vt, bias, n_cols, k, mask, mask_pitch, K, out_ids, out_scores,
+                                        (hipStream_t)stream);
+}
+
+extern "C" int tkr_count_hits(const int32_t* ids, int32_t n_rows, int32_t K, const int64_t* like_ptr,
+                              const int32_t* like_cols, int32_t step, int32_t interval, uint64_t* first_bucket,
+                              void* stream) {
+    if (!ids || !like_ptr || !first_bucket || n_rows <= 0 || K <= 0 || step <= 0 || interval < 0) return TKR_EINVAL;
+    const int n = n_rows * K;
+    hipLaunchKernelGGL(tkr::count_hits_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ids, n_rows, K,
+                       like_ptr, like_cols, step, interval, reinterpret_cast<unsigned long long*>(first_bucket));
+    TKR_LAUNCH_CHECK();
+    return TKR_OK;
+}

@@ -44,7 +44,8 @@ class VbprState(C.Structure):
                 ('lr', C.c_float), ('rho', C.c_float), ('eps', C.c_float)]
 
 
-EXPORTS = ('tkr_version', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_bpr_run')
+EXPORTS = ('tkr_version', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_bpr_run',
+           'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits')
 
 
 def lib():
@@ -108,3 +109,39 @@ def sample_plan(csr, n_users, n_items, seed, first_triplet, n_batches, B, cnt, p
 def bpr_run(state, plan, B, n_batches, loss_out=None):
     _check(lib().tkr_bpr_run(C.byref(state), _p(plan.rec), _p(plan.occ), _p(plan.hdr), C.c_int32(B),
                              C.c_int32(n_batches), _p(loss_out), _stream()), 'tkr_bpr_run')
+
+
+# ---- K4 / K5 -------------------------------------------------------------------------------------
+def build_rated_mask(rated_ptr, rated_cols, n_rows, n_cols):
+    """CSR (int64 ptr, int32 ascending cols; both on device) -> bitmask [ceil(n_cols/32)][pitch] uint32"""
+    assert rated_ptr.dtype == torch.int64 and rated_cols.dtype == torch.int32
+    pitch = (n_rows + 31) // 32 * 32
+    mask = torch.zeros(((n_cols + 31) // 32) * pitch, dtype=torch.int32, device=rated_ptr.device)
+    if rated_cols.numel() == 0:
+        rated_cols = torch.zeros(1, dtype=torch.int32, device=rated_ptr.device)
+    _check(lib().tkr_build_rated_mask(_p(rated_ptr), _p(rated_cols), C.c_int32(n_rows), C.c_int32(n_cols), _p(mask),
+                                      C.c_int32(pitch), _stream()), 'tkr_build_rated_mask')
+    return mask, pitch
+
+
+def score_topk(U, Vt, K, bias=None, user_idx=None, mask=None, mask_pitch=0, want_scores=False):
+    """-> ids int32 [n_rows, K] (and scores fp32 [n_rows, K])"""
+    assert U.dtype == torch.float32 and Vt.dtype == torch.float32 and U.shape[1] == Vt.shape[1]
+    n_rows = int(user_idx.numel()) if user_idx is not None else int(U.shape[0])
+    ids = torch.empty((n_rows, K), dtype=torch.int32, device=U.device)
+    scores = torch.empty((n_rows, K), dtype=torch.float32, device=U.device) if want_scores else None
+    _check(lib().tkr_score_topk(_p(U), _p(user_idx), C.c_int32(n_rows), _p(Vt), _p(bias), C.c_int32(Vt.shape[0]),
+                                C.c_int32(U.shape[1]), _p(mask), C.c_int32(mask_pitch), C.c_int32(K), _p(ids),
+                                _p(scores), _stream()), 'tkr_score_topk')
+    return (ids, scores) if want_scores else ids
+
+
+def count_hits(ids, like_ptr, like_cols, step, interval):
+    """-> int64[interval]: hits per bucket as evaluate.py accumulates them (cumulative over buckets)"""
+    assert ids.dtype == torch.int32 and like_ptr.dtype == torch.int64 and like_cols.dtype == torch.int32
+    first = torch.zeros(max(interval, 1), dtype=torch.int64, device=ids.device)
+    if like_cols.numel() == 0:
+        like_cols = torch.zeros(1, dtype=torch.int32, device=ids.device)
+    _check(lib().tkr_count_hits(_p(ids), C.c_int32(ids.shape[0]), C.c_int32(ids.shape[1]), _p(like_ptr), _p(like_cols),
+                                C.c_int32(step), C.c_int32(interval), _p(first), _stream()), 'tkr_count_hits')
+    return torch.cumsum(first[:interval], 0)
