@@ -17,6 +17,8 @@ Prints ONE JSON line (rank 0).  Extra objects beside the contract fields:
   cpu_baseline    the numpy oracle with the reference's cost structure (per-element legacy
                   np.random sampler + numpy step), bounded sample, rank 0, N = 1 only
   throughput_mode the same path at batch_size 8192 (a legal train() argument; NOT the headline)
+  topk            the other half of BASELINE.json's metric: full-catalogue top-30 scored users/s (K4)
+                  with its own fp32-MFMA roofline and cpu_baseline
 """
 import argparse
 import json
@@ -32,6 +34,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA, dense
 
 
 def algorithmic_bytes_per_triplet(k):
@@ -114,6 +117,85 @@ def cpu_baseline(r, k, B, budget_s=12.0):
                        'ML-10M shape k=%d' % (nb, B, dt, k))
 
 
+def topk_problem(r, k, device, rank, world, seed=7):
+    """scoring inputs: N(0,0.01) factors rounded like the '%f' export, every user's train history as the
+    rated mask, all items as candidates (full catalogue); users block-sharded over ranks."""
+    import synth
+    import tkr_hip
+    n_users, n_items = r['n_users'], r['n_in'] + r['n_out']
+    lo, hi = rank * n_users // world, (rank + 1) * n_users // world
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    U = (torch.randn((n_users, k), device=device, generator=g) * 0.01 * 1e6).round() / 1e6
+    V = (torch.randn((n_items, k), device=device, generator=g) * 0.01 * 1e6).round() / 1e6
+    ptr, cols = synth.rated_csr(r)
+    sub_ptr = torch.from_numpy(ptr[lo:hi + 1] - ptr[lo]).to(device)
+    sub_cols = torch.from_numpy(cols[ptr[lo]:ptr[hi]]).to(device)
+    mask, pitch = tkr_hip.build_rated_mask(sub_ptr, sub_cols, hi - lo, n_items)
+    return U[lo:hi].contiguous(), V, mask, pitch
+
+
+def topk_bench(r, k, device, rank, world, K=30, reps=5):
+    import tkr_hip
+    U, V, mask, pitch = topk_problem(r, k, device, rank, world)
+    tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch)
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    launch_ms = e0.elapsed_time(e1) / reps
+    n_items = V.shape[0]
+    flops = 2.0 * k * n_items * U.shape[0]
+    tf = flops / (launch_ms * 1e-3) / 1e12
+    return {'metric': 'full-catalogue top-%d scored users/sec' % K, 'value': r['n_users'] * reps / wall, 'unit': 'users/s',
+            'config': {'workload': '%d users x %d items, k=%d, top-%d, train history masked' % (r['n_users'], n_items, k, K)},
+            'ms_per_pass': wall * 1e3 / reps,
+            'roofline': {'kernel': 'tkr::score_topk_kernel', 'bound': 'mfma', 'achieved': tf, 'peak': MFMA_F32_PEAK_TF,
+                         'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TF, 'traffic': None, 'launch_ms': launch_ms,
+                         'algorithmic_flops_per_launch': flops}}
+
+
+def topk_cpu_baseline(r, k, K=30, budget_s=12.0, slice_users=2000):
+    """evaluate.py's operations on user slices until the time budget is spent:
+    np.dot -> np.argsort -> python rank walk (oracle restatement of evaluate.py:78-105)"""
+    import synth
+    n_items = r['n_in'] + r['n_out']
+    rng = np.random.Generator(np.random.PCG64(0))
+    V = np.round(rng.standard_normal((n_items, k)) * 0.01, 6).astype(np.float32)
+    ptr, cols = synth.rated_csr(r)
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and done + slice_users <= r['n_users']:
+        U = np.round(rng.standard_normal((slice_users, k)) * 0.01, 6).astype(np.float32)
+        order = np.argsort(np.dot(U, V.T), axis=1)
+        for q in range(slice_users):
+            u = done + q
+            rated = set(cols[ptr[u]:ptr[u + 1]].tolist())
+            kept = 0
+            for c in order[q, ::-1]:
+                if c not in rated:
+                    kept += 1
+                    if kept == K:
+                        break
+        done += slice_users
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit='users/s', cores=os.cpu_count(), kind='port',
+                sample='%d users x %d items (%.1f s): np.dot (BLAS threads = host cores) + np.argsort + python rank walk '
+                       '(single thread), oracle restatement of evaluate.py:78-105' % (done, n_items, dt))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -173,6 +255,11 @@ def main():
                                   'ms_per_step': w2 * 1e3 / 256,
                                   'roofline': {'bound': 'hbm', 'achieved': a2, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                                'frac': a2 / HBM_PEAK_GBS, 'launch_us': s2 * 1e3 / 256}}
+    if not args.no_extras:
+        topk = topk_bench(r, k, device, rank, world)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            topk['cpu_baseline'] = topk_cpu_baseline(r, k)
+        out['topk'] = topk
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(r, k, B)
     if rank == 0:
