@@ -1,0 +1,200 @@
+"""CPU tests of the host side: the reference-API mirror (utils / single.REC / single.BPR loaders and
+text formats) against the golden vectors, the C-ABI library (loads, exports every symbol declared in
+include/tkr.h -- no compute without a GPU), loud failure without a GPU, and the world-size-2 gloo test
+of the multi-GPU exchange rule."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_utils_match_golden(golden_dir, tmp_path):
+    import utils
+    d = os.path.join(golden_dir, 'g1')
+    exp = json.load(open(os.path.join(d, 'expected.json')))
+    uids = utils.get_id_dict_from_file(os.path.join(d, 'uid'))
+    iids = utils.get_id_dict_from_file(os.path.join(d, 'vid'))
+    assert uids == exp['uids'] and iids == exp['iids']
+    assert utils.get_id_dict_from_file(os.path.join(d, 'nope')) == {}
+    data = utils.get_data_from_file(os.path.join(d, 'tr.txt'), uids, iids)
+    assert [list(p) for p in data] == exp['data']
+    g3 = os.path.join(golden_dir, 'g3')
+    e3 = np.load(os.path.join(g3, 'expected.npz'))
+    ids = json.load(open(os.path.join(g3, 'ids.json')))
+    utils.export_embed_to_file(str(tmp_path / 'new' / 'mat.dat'), e3['mat'])
+    utils.export_embed_to_file(str(tmp_path / 'new' / 'bias.dat'), e3['bias'])
+    for name in ('mat.dat', 'bias.dat'):
+        assert open(tmp_path / 'new' / name, 'rb').read() == open(os.path.join(g3, name), 'rb').read()
+    np.testing.assert_array_equal(utils.get_embed_from_file(os.path.join(g3, 'mat.dat')), e3['back_all'])
+    np.testing.assert_array_equal(utils.get_embed_from_file(os.path.join(g3, 'mat.dat'), ids), e3['back_ids'])
+    np.testing.assert_array_equal(utils.get_embed_from_file(os.path.join(g3, 'bias.dat'), ids), e3['back_bias'])
+    assert utils.get_embed_from_file(os.path.join(g3, 'missing')) is None
+
+
+def test_bpr_loader_matches_reference(golden_dir):
+    from single import BPR, REC, VBPR
+    d = os.path.join(golden_dir, 'g1')
+    exp = json.load(open(os.path.join(d, 'expected.json')))
+    m = BPR(k=4)
+    assert isinstance(m, REC) and (m.lu, m.li, m.lj, m.lb, m.lr, m.mode) == (2.5e-3, 2.5e-3, 2.5e-4, 0, 1.0e-4, 'l2')
+    m.load_training_data(os.path.join(d, 'uid'), os.path.join(d, 'vid'), os.path.join(d, 'tr.txt'), data_copy=True)
+    assert m.uids == exp['uids'] and m.iids == exp['iids']
+    assert [list(p) for p in m.data] == exp['data']
+    assert (m.n_users, m.n_items, m.epoch_sample_limit) == (exp['n_users'], exp['n_items'], exp['epoch_sample_limit'])
+    assert {str(k): list(v) for k, v in m.tr_data.items()} == exp['tr_data']
+    assert m.tr_users == exp['tr_users']
+    m2 = BPR(k=4)
+    m2.load_training_data(os.path.join(d, 'uid'), os.path.join(d, 'vid'), os.path.join(d, 'tr.txt'))
+    assert not hasattr(m2, 'data')                               # bpr.py:67-68
+    v = VBPR(k=8, d=5, lambda_e=0.1)
+    assert (v.k, v.d, v.le) == (8, 5, 0.1) and isinstance(v, BPR)
+
+
+def test_out_of_scope_models_raise():
+    import single
+    for name in ('WMF', 'DPM', 'CER', 'ENCODER', 'MLP'):
+        with pytest.raises(NotImplementedError):
+            getattr(single, name)(k=4)
+
+
+def test_train_argument_checks_without_gpu(golden_dir):
+    from single import BPR
+    import tkr_hip
+    d = os.path.join(golden_dir, 'g2')
+    m = BPR(k=4)
+    m.load_training_data(os.path.join(d, 'uid'), os.path.join(d, 'vid'), os.path.join(d, 'f0tr.txt'))
+    with pytest.raises(AssertionError):
+        m.train(epochs=1.5)
+    with pytest.raises(AssertionError):
+        m.train(epoch_sample_limit=10.5)
+    with pytest.raises(ValueError):
+        m.train(sampling='item uniform')
+    with pytest.raises(ValueError):
+        m.train(batch_size=10 ** 6)                              # reference loop would never end
+    if not torch.cuda.is_available():
+        with pytest.raises(tkr_hip.TkrError):                    # loud failure: no CPU fallback
+            m.train(epochs=1, batch_size=16, epoch_sample_limit=10e1)
+
+
+def test_export_import_embeddings_roundtrip(golden_dir, tmp_path):
+    from single import BPR
+    d = os.path.join(golden_dir, 'g2')
+    m = BPR(k=3)
+    m.load_training_data(os.path.join(d, 'uid'), os.path.join(d, 'vid'), os.path.join(d, 'f0tr.txt'))
+    rng = np.random.Generator(np.random.PCG64(0))
+    m.fue = (rng.standard_normal((m.n_users, 3)) * 0.01).astype(np.float32)
+    m.fie = (rng.standard_normal((m.n_items, 3)) * 0.01).astype(np.float32)
+    m.fib = (rng.standard_normal((m.n_items, 1)) * 0.01).astype(np.float32)
+    target = str(tmp_path / 'model')
+    m.export_embeddings(target)                                  # creates the directory (rec.py:48-50)
+    assert sorted(os.listdir(target)) == ['final-B.dat', 'final-U.dat', 'final-V.dat']   # no engine -> no weights file
+    m2 = BPR(k=3)
+    m2.load_training_data(os.path.join(d, 'uid'), os.path.join(d, 'vid'), os.path.join(d, 'f0tr.txt'))
+    m2.import_embeddings(target)
+    for a, b in ((m.fue, m2.fue), (m.fie, m2.fie), (m.fib, m2.fib)):
+        assert b.shape == a.shape and np.max(np.abs(a - b)) <= 5.1e-7        # '%f' keeps 6 decimals (+ fp32 rounding)
+    from oracle import ref_np as R
+    np.testing.assert_array_equal(m2.fue, R.read_embed_text(os.path.join(target, 'final-U.dat'), m.uids))
+
+
+def test_load_content_data(tmp_path, golden_dir):
+    import pickle
+    import scipy.sparse as ss
+    from single import VBPR
+    from oracle import ref_np as R
+    d = os.path.join(golden_dir, 'g2')
+    m = VBPR(k=4, d=6)
+    m.load_training_data(os.path.join(d, 'uid'), os.path.join(d, 'vid'), os.path.join(d, 'f0tr.txt'))
+    fids = list(m.iids.keys())[::-1][:20]                        # features for a subset, in another order
+    open(tmp_path / 'fid', 'w').write(''.join(x + '\n' for x in fids))
+    rng = np.random.Generator(np.random.PCG64(1))
+    dense = rng.random((20, 6)).astype(np.float32)
+    for blob, name in ((dense, 'dense.pkl'), (ss.csr_matrix(dense * (dense > 0.5)), 'sparse.pkl')):
+        pickle.dump(blob, open(tmp_path / name, 'wb'))
+        m.load_content_data(str(tmp_path / name), str(tmp_path / 'fid'))
+        exp = R.load_content(str(tmp_path / name), str(tmp_path / 'fid'), m.iids, m.n_items, 6)
+        np.testing.assert_array_equal(m.feat, exp)
+        assert m.feat.dtype == np.float32 and m.feat.shape == (m.n_items, 6)
+
+
+def test_library_exports_every_declared_symbol():
+    import tkr_hip
+    header = open(os.path.join(ROOT, 'include', 'tkr.h')).read()
+    declared = set(re.findall(r'^int (tkr_\w+)\(', header, flags=re.M))
+    assert declared == set(tkr_hip.EXPORTS), declared ^ set(tkr_hip.EXPORTS)
+    lib = ctypes.CDLL(tkr_hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.tkr_version() == 100
+    assert lib.tkr_plan_max_blocks(256) == 48 + 153
+    # argument validation happens before any device access
+    assert lib.tkr_score_topk(None, None, 0, None, None, 0, 0, None, 0, 0, None, None, None) == -1
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    import tkr_hip
+    monkeypatch.setattr(tkr_hip, '_lib', None)
+    monkeypatch.setattr(tkr_hip, 'LIB_PATH', str(tmp_path / 'libtkr_hip.so'))
+    with pytest.raises(tkr_hip.TkrError):
+        tkr_hip.lib()
+
+
+_GLOO_WORKER = r'''
+import os, sys
+sys.path[:0] = [%(root)r, %(pkg)r]
+import numpy as np, torch, torch.distributed as dist
+import dist as tdist
+rank = int(os.environ['RANK']); world = int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo')
+assert tdist.world() == (rank, world)
+users = list(range(11))
+mine = tdist.shard_users(users, rank, world)
+allu = [None] * world
+dist.all_gather_object(allu, mine)
+assert sorted(sum(allu, [])) == users and len(set(sum(allu, []))) == len(users)
+assert tdist.batches_per_rank(3906, world) == 1953
+
+class Eng:                      # the engine surface ItemSync needs (device-agnostic tensors)
+    def __init__(self):
+        g = torch.Generator().manual_seed(0)
+        self.t = {'V': [torch.randn(6, 4, generator=g), torch.ones(6, 4)], 'b': [torch.zeros(6), torch.ones(6)]}
+    def get(self, n): return self.t[n][0], self.t[n][1]
+    def set_replicated(self, new):
+        for n, (p, ms) in new.items(): self.t[n] = [p.clone(), ms.clone()]
+e = Eng()
+V0 = e.t['V'][0].clone()
+sync = tdist.ItemSync(e)
+sync.begin()
+e.t['V'][0] += (rank + 1) * 0.5          # each replica moves the items by its own delta
+e.t['V'][1] *= (rank + 1)
+e.t['b'][0][rank] = 1.0                  # disjoint bias updates
+sync.end()
+assert torch.allclose(e.t['V'][0], V0 + 0.5 * sum(range(1, world + 1)))        # P0 + sum of deltas
+assert torch.allclose(e.t['V'][1], torch.full((6, 4), sum(range(1, world + 1)) / world))   # slots: mean
+assert torch.allclose(e.t['b'][0][:world], torch.ones(world))
+U0 = torch.zeros(5, 2); U = U0.clone(); U[rank::world] += rank + 1
+out = tdist.combine_user_rows(U, U0)
+exp = torch.zeros(5, 2)
+for r in range(world): exp[r::world] += r + 1
+assert torch.allclose(out, exp)
+dist.barrier(); dist.destroy_process_group()
+print('ok', rank)
+'''
+
+
+def test_item_sync_world_size_2_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_GLOO_WORKER % dict(root=ROOT, pkg=os.path.join(ROOT, 'top-k-rec_amd')))
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+                          '--master-addr', '127.0.0.1', '--master-port', '29631', str(script)],
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count('ok') == 2
