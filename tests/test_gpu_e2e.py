@@ -1,0 +1,106 @@
+"""End-to-end on the GPU through the reference's class API and CLI: BPR.train on text files ->
+export_embeddings -> evaluate.py, against the oracle run on the SAME init and the SAME (u,i,j)
+stream (the device stream is counter-based, so oracle/plan_np reproduces it from the seed).
+
+Stated tolerances: trained embeddings |d| <= 1e-5 + 2e-4*|x| (fp32, a few hundred sequential RMSProp
+steps); accuracy@{5..30} within +-0.001 (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import plan_np as P
+from oracle import ref_np as R
+
+
+def _dataset(tmp_path, seed=3):
+    import synth
+    r = synth.make_ratings(300, 120, 30, seed=seed, mu=3.2, sigma=0.5, min_r=6, max_r=50, om_per_user=4)
+    data = str(tmp_path / 'data')
+    synth.write_dataset(data, r)
+    return data
+
+
+def _oracle_train(m, init, seed, epochs, n_batches, B, hp, ms=None):
+    row_ptr, pos, srt = P.build_csr(m.tr_data, m.n_users)
+    st = dict(U=init[0].copy(), V=init[1].copy(), b=init[2].reshape(-1).copy(),
+              msU=np.ones_like(init[0]), msV=np.ones_like(init[1]), msb=np.ones(len(init[1]), np.float32))
+    if ms is not None:
+        st.update(msU=ms[0].copy(), msV=ms[1].copy(), msb=ms[2].copy())
+    u, i, j = P.sample_triplets(m.tr_users, row_ptr, pos, srt, m.n_items, seed, 0, epochs * n_batches * B)
+    loss = None
+    for s in range(epochs * n_batches):
+        sl = slice(s * B, (s + 1) * B)
+        loss = R.bpr_step(st, u[sl], i[sl], j[sl], hp)
+    return st, loss
+
+
+def test_train_export_evaluate_matches_oracle(tmp_path, capsys):
+    from single import BPR
+    import evaluate as E
+    data = _dataset(tmp_path)
+    k, B, epochs, lr = 16, 64, 3, 0.02
+    m = BPR(k=k, lambda_b=1e-3, lr=lr)
+    m.load_training_data(os.path.join(data, 'uid'), os.path.join(data, 'vid'), os.path.join(data, 'f0tr.txt'))
+    rng = np.random.Generator(np.random.PCG64(0))
+    init = [(rng.standard_normal((m.n_users, k)) * 0.1).astype(np.float32),
+            (rng.standard_normal((m.n_items, k)) * 0.1).astype(np.float32), np.zeros((m.n_items, 1), np.float32)]
+    m.fue, m.fie, m.fib = (a.copy() for a in init)               # warm-start path (bpr.py:127-135) = shared init
+    limit = 64 * 40 + 17                                         # 40 batches per epoch, remainder dropped (F7)
+    m.train(epochs=epochs, batch_size=B, epoch_sample_limit=limit, seed=77, verbose=False)
+    assert m.fue.shape == (m.n_users, k) and m.fie.shape == (m.n_items, k) and m.fib.shape == (m.n_items, 1)
+    hp = dict(lu=m.lu, li=m.li, lj=m.lj, lb=m.lb, lr=lr, mode='l2')
+    st, loss = _oracle_train(m, init, 77, epochs, 40, B, hp)
+    np.testing.assert_allclose(m.fue, st['U'], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(m.fie, st['V'], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(m.fib.ravel(), st['b'], rtol=2e-4, atol=1e-5)
+    assert abs(m.last_epoch_loss - float(loss)) <= 1e-4 * abs(float(loss))
+    # ---- export through the text format, evaluate with the CLI, compare with the oracle pipeline
+    gpu_dir, ref_dir = str(tmp_path / 'gpu_model'), str(tmp_path / 'ref_model')
+    m.export_embeddings(gpu_dir)
+    assert os.path.exists(os.path.join(gpu_dir, 'weights'))
+    os.mkdir(ref_dir)
+    R.write_embed_text(os.path.join(ref_dir, 'final-U.dat'), st['U'])
+    R.write_embed_text(os.path.join(ref_dir, 'final-V.dat'), st['V'])
+    R.write_embed_text(os.path.join(ref_dir, 'final-B.dat'), st['b'].reshape(-1, 1))
+    got = E.main(['-d', data, '-m', gpu_dir, '-sl', 'im', 'om'])
+    exp = R.evaluate_cli(data, ref_dir, scenarios=('im', 'om'))
+    same_model = R.evaluate_cli(data, gpu_dir, scenarios=('im', 'om'))       # oracle scorer on the GPU-trained model
+    for g, e, s in zip(got, exp, same_model):
+        gv, ev, sv = ([float(x) for x in line.split(',')[1:]] for line in (g, e, s))
+        assert g.split(',')[0] == e.split(',')[0]
+        assert max(abs(a - b) for a, b in zip(gv, ev)) <= 1e-3               # north_star: +-0.001
+        assert gv == sv                                                       # same model -> identical metric
+    # the model learned something: train positives outrank sampled negatives
+    assert float(loss) < 0.69 * B
+
+    # ---- resume (bpr.py:120-135): text values override, RMSProp slots come from the checkpoint
+    m2 = BPR(k=k, lambda_b=1e-3, lr=lr)
+    m2.load_training_data(os.path.join(data, 'uid'), os.path.join(data, 'vid'), os.path.join(data, 'f0tr.txt'))
+    m2.train(epochs=1, batch_size=B, epoch_sample_limit=limit, model_path=gpu_dir, seed=5, verbose=False)
+    blob = torch.load(os.path.join(gpu_dir, 'weights'))
+    init2 = [R.read_embed_text(os.path.join(gpu_dir, f), ids) for f, ids in
+             (('final-U.dat', m.uids), ('final-V.dat', m.iids), ('final-B.dat', m.iids))]
+    st2, _ = _oracle_train(m2, init2, 5, 1, 40, B, hp,
+                           ms=[blob['ms_U'].numpy(), blob['ms_V'].numpy(), blob['ms_b'].numpy()])
+    np.testing.assert_allclose(m2.fue, st2['U'], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(m2.fie, st2['V'], rtol=2e-4, atol=1e-5)
+
+
+def test_reference_defaults_and_float_limit(tmp_path):
+    """train.py's literal call: epochs=5, batch_size=256, epoch_sample_limit=10e5 (a float)"""
+    from single import BPR
+    data = _dataset(tmp_path, seed=4)
+    m = BPR(k=50)
+    m.load_training_data(os.path.join(data, 'uid'), os.path.join(data, 'vid'), os.path.join(data, 'f0tr.txt'))
+    m.train(epochs=1, batch_size=256, epoch_sample_limit=10e3, verbose=False)       # 39 batches
+    assert m.epoch_sample_limit == 10000 and np.isfinite(m.fue).all() and np.isfinite(m.fie).all()
+    assert np.any(m.fib != 0) and abs(m.fue).max() < 0.1
+    gen = m._uniform_user_sampling(32)
+    ub, ib, jb = next(gen)
+    assert ub.dtype == np.int64 and ib.dtype == np.int32 and jb.dtype == np.int32 and len(ub) == 32
+    for u, i, j in zip(ub, ib, jb):
+        assert i in m.tr_data[u] and j not in m.tr_data[u]
