@@ -46,6 +46,7 @@ int tkr_version(void);
  *                            bit 30 of every id = parity of that row
  *   rec                      [n_batches][tkr_plan_max_blocks(B)*16][16]  per-wave launch records
  *   hdr                      [n_batches][4]  (workgroups used, light tasks, heavy tasks, tasks)
+ *   occt                     [n_batches][3B] triplet index t of every sorted occurrence (used by K3)
  * batch_size <= 8192, n_batches <= 512, ids < 2^30.  Output is bit-exact against oracle/plan_np.py. */
 int tkr_plan_max_blocks(int32_t batch_size);
 int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,
@@ -53,7 +54,7 @@ int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_pt
                     uint64_t first_triplet, const int64_t* ctl, int32_t n_batches, int32_t batch_size,
                     int32_t* ucnt, int32_t* icnt, uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u,
                     int32_t* out_i, int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr,
-                    void* stream);
+                    int32_t* occt, void* stream);
 
 /* ---- K2: BPR mini-batch step ---------------------------------------------------------------
  * Replaces sess.run([solver, obj]) (single/bpr.py:141) on the graph of single/bpr.py:81-100.
@@ -78,6 +79,39 @@ typedef struct {
  * batch objective (single/bpr.py:93-99) is added to loss_out[b] */
 int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ, const int32_t* hdr,
                 int32_t batch_size, int32_t n_batches, float* loss_out, void* stream);
+
+/* ---- K3: VBPR mini-batch step -------------------------------------------------------------
+ * Replaces sess.run([solver, obj]) of single/vbpr.py:114 on the graph of single/vbpr.py:50-73 and the
+ * per-batch host gather of two dense [B, d] feature slices (vbpr.py:114).  kh = k // 2.
+ *   U, msU      [2][n_users][2*kh]  rows = [ure | uce]  (vbpr.py:37-40), double-buffered like K2
+ *   I, msI      [2][n_items][kh]    ire (vbpr.py:41);   irb, msirb [2][n_items] (vbpr.py:43)
+ *   cem, mscem  [d][kh], icb, msicb [d]: dense variables, updated in place every batch (vbpr.py:45-48,73)
+ *   feat        [n_items][d] dense fp32, resident (REC.load_content_data, rec.py:23-33) */
+typedef struct {
+    float* U;
+    float* msU;
+    float* I;
+    float* msI;
+    float* irb;
+    float* msirb;
+    float* cem;
+    float* mscem;
+    float* icb;
+    float* msicb;
+    const float* feat;
+    int32_t n_users, n_items, kh, d;
+    int32_t mode;                /* 0 = 'l2' (vbpr.py:63-67), 1 = L1 variant (:68-72) */
+    float lu, li, lj, lb, le;    /* lambda_u, lambda_i, lambda_j, lambda_b, lambda_e (vbpr.py:18) */
+    float lr, rho, eps;
+} tkr_vbpr_state;
+
+/* floats of scratch tkr_vbpr_run needs (split-K partials, s_t, P_t, W_t) */
+int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d);
+/* n_batches consecutive batches planned by tkr_sample_plan (tri_i / tri_j = its out_i / out_j);
+ * kh <= 128, batch_size <= 8192; loss_out as in tkr_bpr_run */
+int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* tri_j, const int32_t* rec,
+                 const int32_t* occ, const int32_t* hdr, const int32_t* occt, int32_t batch_size,
+                 int32_t n_batches, float* workspace, float* loss_out, void* stream);
 
 /* ---- K4: full-catalogue score -> rated mask -> top-K -------------------------------------------
  * Replaces evaluate.py:78-81 (np.dot + bias + np.argsort over every row) and the rated-item filter

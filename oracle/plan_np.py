@@ -39,7 +39,9 @@ Launch plan (what the step kernel actually reads; derived from the above):
   records; light tasks fill workgroups 0..nlb-1 in task order, heavy task h is workgroup nlb+h.
   wave record = 16 int32: [0] row|kind<<31 (-1 = idle)  [1] parity | team<<8 | rank<<16
                           [2] occurrences of this wave   [3] index of its first occurrence
-                          [4..11] its first <=4 occurrences (a,b)   [12] task occ_count  [13..15] 0
+                          [4..11] its first <=4 occurrences (a,b)   [12] task occ_count
+                          [13] t0 | t1<<16  [14] t2 | t3<<16  (triplet index of those occurrences)  [15] 0
+  occt[3B]           triplet index t of every sorted occurrence (VBPR reads per-triplet results)
   header per batch = (workgroups used, light tasks, heavy tasks, tasks).
 """
 from __future__ import annotations
@@ -147,8 +149,8 @@ def sample_triplets(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed, fir
     return u.astype(np.int32), i.astype(np.int32), j
 
 
-def plan_batch(u, i, j):
-    """Plan of ONE batch (see module docstring) -> (task int32[3B,4], occ int32[3B,2])."""
+def plan_batch(u, i, j, return_t=False):
+    """Plan of ONE batch (see module docstring) -> (task int32[3B,4], occ int32[3B,2][, occt int32[3B]])."""
     B = len(u)
     task = np.zeros((3 * B, 4), dtype=np.int32)
     task[:, 0] = -1
@@ -158,6 +160,8 @@ def plan_batch(u, i, j):
     su = u[order]
     occ[:B, 0] = i[order]
     occ[:B, 1] = j[order]
+    occt = np.zeros(3 * B, dtype=np.int32)
+    occt[:B] = order
     heads = np.flatnonzero(np.r_[True, su[1:] != su[:-1]])
     ends = np.r_[heads[1:], B]
     nu = len(heads)
@@ -172,6 +176,7 @@ def plan_batch(u, i, j):
     role = (order >= B)
     other = np.where(role, i[t], j[t]).astype(np.int64)
     occ[B:, 0] = u[t]
+    occt[B:] = t
     occ[B:, 1] = (other | (role.astype(np.int64) << 31)).astype(np.uint32).view(np.int32)
     heads = np.flatnonzero(np.r_[True, si[1:] != si[:-1]])
     ends = np.r_[heads[1:], 2 * B]
@@ -179,7 +184,7 @@ def plan_batch(u, i, j):
     task[nu:nu + ni, 0] = (si[heads] | (1 << 31)).astype(np.uint32).view(np.int32)
     task[nu:nu + ni, 1] = B + heads
     task[nu:nu + ni, 2] = ends - heads
-    return task, occ
+    return (task, occ, occt) if return_t else (task, occ)
 
 
 def max_blocks(B):
@@ -207,8 +212,14 @@ def resolve_parity(task, occ, B, ucnt, icnt):
     icnt[rows[is_item]] += 1
 
 
-def launch_plan(task, occ, B):
+def _pack_t(ts):
+    ts = [int(x) for x in ts] + [0] * (4 - len(ts))
+    return ts[0] | (ts[1] << 16), ts[2] | (ts[3] << 16)
+
+
+def launch_plan(task, occ, B, occt=None):
     """wave records + header of one batch (see module docstring)."""
+    occt = np.zeros(3 * B, dtype=np.int32) if occt is None else occt
     nblk = max_blocks(B)
     rec = np.zeros((nblk * TEAM, 16), dtype=np.int32)
     live = np.flatnonzero(task[:, 0] != -1)
@@ -221,6 +232,7 @@ def launch_plan(task, occ, B):
         rec[slot, 0:4] = (rowk, par | (1 << 8), cnt, start)
         rec[slot, 4:4 + 2 * cnt] = occ[start:start + cnt].reshape(-1)
         rec[slot, 12] = cnt
+        rec[slot, 13:15] = _pack_t(occt[start:start + cnt])
     for h, t in enumerate(heavy):
         rowk, start, cnt, par = task[t]
         for w in range(TEAM):
@@ -230,6 +242,7 @@ def launch_plan(task, occ, B):
             first = occ[mine[:4]].reshape(-1)
             r[4:4 + len(first)] = first
             r[12] = cnt
+            r[13:15] = _pack_t(occt[mine[:4]])
     hdr = np.array([nlb + len(heavy), len(light), len(heavy), len(live)], dtype=np.int32)
     return rec, hdr
 
@@ -238,7 +251,7 @@ def sample_and_plan(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed, fir
                     n_batches, B, ucnt=None, icnt=None, n_users=None):
     """What ``tkr_sample_plan`` produces for n_batches batches: (u,i,j)[n_batches*B],
     task[n_batches,3B,4], occ[n_batches,3B,2], rec[n_batches, max_blocks*TEAM, 16],
-    hdr[n_batches,4]; ucnt/icnt (int32 update counters) are advanced in place."""
+    hdr[n_batches,4], occt[n_batches,3B]; ucnt/icnt (int32 update counters) are advanced in place."""
     n_users = n_users if n_users is not None else len(row_ptr) - 1
     ucnt = np.zeros(n_users, dtype=np.int32) if ucnt is None else ucnt
     icnt = np.zeros(n_items, dtype=np.int32) if icnt is None else icnt
@@ -248,9 +261,10 @@ def sample_and_plan(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed, fir
     occs = np.zeros((n_batches, 3 * B, 2), dtype=np.int32)
     recs = np.zeros((n_batches, max_blocks(B) * TEAM, 16), dtype=np.int32)
     hdrs = np.zeros((n_batches, 4), dtype=np.int32)
+    occts = np.zeros((n_batches, 3 * B), dtype=np.int32)
     for b in range(n_batches):
         sl = slice(b * B, (b + 1) * B)
-        tasks[b], occs[b] = plan_batch(u[sl], i[sl], j[sl])
+        tasks[b], occs[b], occts[b] = plan_batch(u[sl], i[sl], j[sl], return_t=True)
         resolve_parity(tasks[b], occs[b], B, ucnt, icnt)
-        recs[b], hdrs[b] = launch_plan(tasks[b], occs[b], B)
-    return u, i, j, tasks, occs, recs, hdrs
+        recs[b], hdrs[b] = launch_plan(tasks[b], occs[b], B, occts[b])
+    return u, i, j, tasks, occs, recs, hdrs, occts

@@ -54,7 +54,8 @@ def _run_plan(hip, tr, tr_users, n_users, n_items, seed, first, nb, B, chunks=1)
     torch.cuda.synchronize()
     got = [plan.u.cpu().numpy(), plan.i.cpu().numpy(), plan.j.cpu().numpy(),
            plan.task.cpu().numpy().reshape(nb, 3 * B, 4), plan.occ.cpu().numpy().reshape(nb, 3 * B, 2),
-           plan.rec.cpu().numpy().reshape(nb, -1, 16), plan.hdr.cpu().numpy().reshape(nb, 4)]
+           plan.rec.cpu().numpy().reshape(nb, -1, 16), plan.hdr.cpu().numpy().reshape(nb, 4),
+           plan.occt.cpu().numpy().reshape(nb, 3 * B)]
     np.testing.assert_array_equal(cnt.ucnt.cpu().numpy(), ucnt)
     np.testing.assert_array_equal(cnt.icnt.cpu().numpy(), icnt)
     assert int(cnt.touch_u.abs().sum()) == 0 and int(cnt.touch_i.abs().sum()) == 0
@@ -68,7 +69,7 @@ def test_sample_plan_bit_exact(hip, n_users, n_items, B, nb, chunks):
     tr, tr_users = _toy(n_users, n_items, seed=n_users + B)
     got, exp, _ = _run_plan(hip, tr, tr_users, n_users, n_items, seed=0x1234567890ABCDEF, first=(1 << 33) + 17, nb=nb,
                             B=B, chunks=chunks)
-    for name, g, e in zip(('u', 'i', 'j', 'task', 'occ', 'rec', 'hdr'), got, exp):
+    for name, g, e in zip(('u', 'i', 'j', 'task', 'occ', 'rec', 'hdr', 'occt'), got, exp):
         if name == 'rec':                       # only the used workgroups are defined
             for b in range(nb):
                 used = exp[6][b, 0] * 16
@@ -173,6 +174,6 @@ def test_abi_rejects_bad_arguments(hip):
     st = hip.BprState()
     assert hip.lib().tkr_bpr_run(C.byref(st), None, None, None, 256, 1, None, None) == -1
     args = [None] * 24
-    assert hip.lib().tkr_sample_plan(None, 0, None, None, None, 5, 10, 0, 0, None, 1, 256, *([None] * 11), None) == -1
-    assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 1, 16384, *([None] * 11), None) == -2
-    assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 513, 256, *([None] * 11), None) == -2
+    assert hip.lib().tkr_sample_plan(None, 0, None, None, None, 5, 10, 0, 0, None, 1, 256, *([None] * 12), None) == -1
+    assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 1, 16384, *([None] * 12), None) == -2
+    assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 513, 256, *([None] * 12), None) == -2

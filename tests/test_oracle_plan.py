@@ -79,7 +79,7 @@ def test_plan_layout():
     csr = P.build_csr(tr, 60)
     B = 32
     ucnt, icnt = np.zeros(60, np.int32), np.zeros(n_items, np.int32)
-    u, i, j, tasks, occs, recs, hdrs = P.sample_and_plan(tr_users, *csr, n_items, 11, 0, 3, B, ucnt, icnt)
+    u, i, j, tasks, occs, recs, hdrs, occts = P.sample_and_plan(tr_users, *csr, n_items, 11, 0, 3, B, ucnt, icnt)
     seen_u, seen_i = np.zeros(60, np.int32), np.zeros(n_items, np.int32)
     for b in range(3):
         ub, ib, jb = (x[b * B:(b + 1) * B] for x in (u, i, j))
@@ -108,6 +108,8 @@ def test_plan_layout():
             got = [(int(a & M), int(o & M), int((o >> 31) & 1)) for a, o in occ[start:start + cnt]]
             assert got == exp
             assert [int((a >> 30) & 1) for a, _ in occ[start:start + cnt]] == [int(seen_u[e[0]] & 1) for e in exp]
+        assert occts[b][:B].tolist() == np.argsort(ub, kind='stable').tolist()
+        assert (occts[b][B:] == np.argsort(np.concatenate([ib, jb]), kind='stable') % B).all()
         # launch plan: every task appears once; heavy tasks are split over a team of 16 waves
         rec, hdr = recs[b], hdrs[b]
         assert hdr[3] == len(live) and hdr[1] + hdr[2] == hdr[3]

@@ -121,8 +121,8 @@ __global__ __launch_bounds__(kPlanThreads) void sample_plan_kernel(
     const int32_t* __restrict__ pos_cols, const int32_t* __restrict__ cols_sorted, uint32_t n_items,
     uint64_t seed, uint64_t first_triplet, const int64_t* __restrict__ ctl, int B, int npad_items,
     int32_t* __restrict__ out_u, int32_t* __restrict__ out_i, int32_t* __restrict__ out_j,
-    int4* __restrict__ task_all, int2* __restrict__ occ_all, uint32_t* __restrict__ touch_u,
-    uint32_t* __restrict__ touch_i) {
+    int4* __restrict__ task_all, int2* __restrict__ occ_all, int32_t* __restrict__ occt_all,
+    uint32_t* __restrict__ touch_u, uint32_t* __restrict__ touch_i) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                       // [npad_items]
     int* scan = reinterpret_cast<int*>(smem + (size_t)npad_items * 8);        // [kPlanThreads+1]
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(kPlanThreads) void sample_plan_kernel(
     int32_t* bj = out_j + (size_t)b * B;
     int4* task = task_all + (size_t)b * 3 * B;
     int2* occ = occ_all + (size_t)b * 3 * B;
+    int32_t* occt = occt_all + (size_t)b * 3 * B;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 
     // ---- draw; item keys go to LDS, triplets to HBM ---------------------------------
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(kPlanThreads) void sample_plan_kernel(
     for (int p = threadIdx.x; p < B; p += kPlanThreads) {
         const int t = (int)(uint32_t)keys[p];
         occ[p] = make_int2(bi[t], bj[t]);
+        occt[p] = t;
     }
     __syncthreads();
 
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(kPlanThreads) void sample_plan_kernel(
         const int t = role ? o - B : o;
         const uint32_t other = (uint32_t)(role ? bi[t] : bj[t]);
         occ[B + p] = make_int2(bu[t], (int)(other | ((uint32_t)role << 31)));
+        occt[B + p] = t;
     }
     for (int s = n_uq + n_iq + threadIdx.x; s < 3 * B; s += kPlanThreads) task[s] = make_int4(-1, 0, 0, 0);
 }
@@ -208,12 +211,14 @@ __device__ __forceinline__ int block_exclusive_scan2(int a, int b, int* scan /*L
 
 __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
     int B, int rec_stride /*records per batch*/, int4* __restrict__ task_all, int2* __restrict__ occ_all,
+    const int32_t* __restrict__ occt_all,
     const int32_t* __restrict__ ucnt, const int32_t* __restrict__ icnt, const uint32_t* __restrict__ touch_u,
     const uint32_t* __restrict__ touch_i, int32_t* __restrict__ rec_all, int4* __restrict__ hdr_all) {
     __shared__ int scan[2 * (kPlanThreads + 1)];
     const int b = blockIdx.x;
     int4* task = task_all + (size_t)b * 3 * B;
     int2* occ = occ_all + (size_t)b * 3 * B;
+    const int32_t* occt = occt_all + (size_t)b * 3 * B;
     int32_t* rec = rec_all + (size_t)b * rec_stride * 16;
 
     for (int s = threadIdx.x; s < 3 * B; s += kPlanThreads) {
@@ -256,22 +261,26 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
         if (t.z <= kLightMax) {
             int32_t* r = rec + (size_t)li * 16;
             r[0] = t.x; r[1] = t.w | (1 << 8); r[2] = t.z; r[3] = t.y;
+            int tt[4];
             for (int q = 0; q < kLightMax; ++q) {
                 const int2 o = (q < t.z) ? occ[t.y + q] : make_int2(0, 0);
                 r[4 + 2 * q] = o.x; r[5 + 2 * q] = o.y;
+                tt[q] = (q < t.z) ? occt[t.y + q] : 0;
             }
-            r[12] = t.z; r[13] = 0; r[14] = 0; r[15] = 0;
+            r[12] = t.z; r[13] = tt[0] | (tt[1] << 16); r[14] = tt[2] | (tt[3] << 16); r[15] = 0;
             ++li;
         } else {
             for (int w = 0; w < kTeam; ++w) {
                 int32_t* r = rec + ((size_t)(nlb + hi) * kTeam + w) * 16;
                 const int mine = (t.z > w) ? (t.z - w + kTeam - 1) / kTeam : 0;
                 r[0] = t.x; r[1] = t.w | (kTeam << 8) | (w << 16); r[2] = mine; r[3] = t.y + w;
+                int tt[4];
                 for (int q = 0; q < 4; ++q) {
                     const int2 o = (q < mine) ? occ[t.y + w + q * kTeam] : make_int2(0, 0);
                     r[4 + 2 * q] = o.x; r[5 + 2 * q] = o.y;
+                    tt[q] = (q < mine) ? occt[t.y + w + q * kTeam] : 0;
                 }
-                r[12] = t.z; r[13] = 0; r[14] = 0; r[15] = 0;
+                r[12] = t.z; r[13] = tt[0] | (tt[1] << 16); r[14] = tt[2] | (tt[3] << 16); r[15] = 0;
             }
             ++hi;
         }
@@ -317,13 +326,13 @@ extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int3
                                int32_t n_batches, int32_t batch_size, int32_t* ucnt, int32_t* icnt,
                                uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u, int32_t* out_i,
                                int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr,
-                               void* stream) {
+                               int32_t* occt, void* stream) {
     if (n_tr <= 0 || n_items <= 0 || n_users <= 0 || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
     if (n_users >= (1 << 30) || n_items >= (1 << 30)) return TKR_EUNSUPPORTED;   // id bits 30/31 carry flags
     if (batch_size > 8192) return TKR_EUNSUPPORTED;   // 2B 64-bit keys must fit the 160 KiB LDS
     if (n_batches > 32 * tkr::kTouchWords) return TKR_EUNSUPPORTED;
     if (n_batches == 0) return TKR_OK;
-    if (!ucnt || !icnt || !touch_u || !touch_i || !rec || !hdr) return TKR_EINVAL;
+    if (!ucnt || !icnt || !touch_u || !touch_i || !rec || !hdr || !occt) return TKR_EINVAL;
     int npad = 1;
     while (npad < 2 * batch_size) npad <<= 1;
     const size_t lds = (size_t)npad * 8 + (tkr::kPlanThreads + 1) * sizeof(int);
@@ -337,11 +346,12 @@ extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int3
     hipLaunchKernelGGL(tkr::sample_plan_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), lds, s, tr_users,
                        (uint32_t)n_tr, row_ptr, pos_cols, cols_sorted, (uint32_t)n_items, seed, first_triplet, ctl,
                        batch_size, npad, out_u, out_i, out_j, reinterpret_cast<int4*>(task),
-                       reinterpret_cast<int2*>(occ), touch_u, touch_i);
+                       reinterpret_cast<int2*>(occ), occt, touch_u, touch_i);
     TKR_LAUNCH_CHECK();
     hipLaunchKernelGGL(tkr::resolve_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), 0, s, batch_size,
                        tkr_plan_max_blocks(batch_size) * tkr::kTeam, reinterpret_cast<int4*>(task),
-                       reinterpret_cast<int2*>(occ), ucnt, icnt, touch_u, touch_i, rec, reinterpret_cast<int4*>(hdr));
+                       reinterpret_cast<int2*>(occ), occt, ucnt, icnt, touch_u, touch_i, rec,
+                       reinterpret_cast<int4*>(hdr));
     TKR_LAUNCH_CHECK();
     const int rows = n_users + n_items;
     hipLaunchKernelGGL(tkr::commit_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, n_users, n_items, ucnt, icnt,

@@ -1,0 +1,500 @@
+// K3 -- one VBPR mini-batch (content-aware BPR).
+//
+// Replaces sess.run([solver, obj]) of single/vbpr.py:114 on the graph of single/vbpr.py:50-73, and
+// the per-batch host gather + H2D feed of two dense [B, d] feature slices (vbpr.py:114): the
+// feature matrix stays resident in HBM and rows are gathered by the kernels.
+//
+//   x_t = irb_i - irb_j + <ure_u, ire_i - ire_j> + <uce_u, (f_i - f_j).cem> + (f_i - f_j).icb
+//
+// iceb/jceb enter the reference only through x_ui - x_uj and are not regularised, so projecting the
+// DIFFERENCE once is exact in real arithmetic and halves the contraction.
+//
+// Four launches per batch, all on pre-step values:
+//   V1  project   P_t = (f_i - f_j).cem, q_t = (f_i - f_j).icb      fp32 MFMA, split over d (K)
+//   V1b occur     per user occurrence: reduce the split-K partials, x_t, s_t = sigma(-x_t),
+//                 W_t = -s_t * uce_u, loss                          (plan of K1: parities inline)
+//   V2  rows      sparse RMSProp on [ure|uce] rows, ire rows, irb   (same launch records as K2,
+//                 gradients use the stored s_t, P_t -- nothing is recomputed)
+//   V3  dense     G_cem = D^T.W + le*cem, G_icb = D^T.(-s) + lb*icb  fp32 MFMA over the batch,
+//                 with TF's DENSE ApplyRMSProp fused into the epilogue (every element of cem/icb is
+//                 updated every batch; vbpr.py:65,67,73)
+//
+// Roofline (dense features, d = 20,000, kh = 64, B = 256): 4*d*kh = 5.12 MFLOP per triplet on the
+// fp32 MFMA (V1 + V3) against 2*4d B = 160 KB of feature rows per triplet read twice from HBM/MALL
+// and 16*d*kh B = 20 MB of dense optimizer traffic per batch: MFMA and HBM ceilings are within 10 %
+// of each other, both reported by bench.
+#include "tkr_common.h"
+#include "../../include/tkr.h"
+
+namespace tkr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kVTeam = 16;                       // waves per workgroup of the record-driven kernels
+constexpr int kSlice = 256;                      // d-columns per split-K slice of V1
+constexpr int kIdMaskV = 0x3fffffff;
+
+__host__ __device__ inline int vbpr_slices(int d) { return (d + kSlice - 1) / kSlice; }
+
+// ------------------------------------------------------------------------------------------------
+// V1: Ppart[s][t][0..kh) = sum_{c in slice s} (f_i[c]-f_j[c]) * cem[c][.],  Ppart[s][t][kh] = same with icb
+// one wave per (slice, 32 triplets); MFMA rows = triplets, columns = kh, K = slice columns
+template <int NT>
+__global__ __launch_bounds__(64) void vbpr_project_kernel(tkr_vbpr_state st, const int32_t* __restrict__ ti,
+                                                         const int32_t* __restrict__ tj, int B,
+                                                         float* __restrict__ ppart) {
+    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
+    const int s = blockIdx.x, t = blockIdx.y * 32 + m;
+    const int d = st.d, kh = st.kh, NP = kh + 1;
+    const bool tv = t < B;
+    const float* fi = st.feat + (size_t)(tv ? ti[t] : 0) * d;
+    const float* fj = st.feat + (size_t)(tv ? tj[t] : 0) * d;
+    const int base = s * kSlice + h * (kSlice / 2);
+    const bool vec = (d & 3) == 0;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float q = 0.f;
+    for (int kk = 0; kk < kSlice / 2; kk += 4) {
+        const int c = base + kk;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (tv) {
+            if (vec && c + 3 < d) {
+                const float4 x = *reinterpret_cast<const float4*>(fi + c);
+                const float4 y = *reinterpret_cast<const float4*>(fj + c);
+                a[0] = x.x - y.x; a[1] = x.y - y.y; a[2] = x.z - y.z; a[3] = x.w - y.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < d) a[e] = fi[c + e] - fj[c + e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ce = c + e;
+            const bool cv = ce < d;
+            q = fmaf(a[e], cv ? st.icb[ce] : 0.f, q);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = nt * 32 + m;
+                const float b = (cv && n < kh) ? st.cem[(size_t)ce * kh + n] : 0.f;
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b, acc[nt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int to = blockIdx.y * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n = nt * 32 + m;
+            if (to < B && n < kh) ppart[((size_t)s * B + to) * NP + n] = acc[nt][r];
+        }
+    }
+    q += __shfl_xor(q, 32, 64);
+    if (h == 0 && tv) ppart[((size_t)s * B + t) * NP + kh] = q;
+}
+
+// ------------------------------------------------------------------------------------------------
+// record access shared by V1b and V2 (64-byte wave records of K1, see oracle/plan_np.py)
+struct WaveRec {
+    int rowk, par, team, n_occ, first;
+    int oa[4], ob[4], ot[4];
+};
+
+__device__ __forceinline__ WaveRec read_rec(const int32_t* __restrict__ rec_all, int blk, int wave, int lane) {
+    const int word = (lane < 16) ? rec_all[((size_t)blk * kVTeam + wave) * 16 + lane] : 0;
+    WaveRec r;
+    r.rowk = bcast_i(word, 0);
+    const int meta = bcast_i(word, 1);
+    r.par = meta & 1;
+    r.team = (meta >> 8) & 0xff;
+    r.n_occ = bcast_i(word, 2);
+    r.first = bcast_i(word, 3);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { r.oa[q] = bcast_i(word, 4 + 2 * q); r.ob[q] = bcast_i(word, 5 + 2 * q); }
+    const int t01 = bcast_i(word, 13), t23 = bcast_i(word, 14);
+    r.ot[0] = t01 & 0xffff; r.ot[1] = (t01 >> 16) & 0xffff; r.ot[2] = t23 & 0xffff; r.ot[3] = (t23 >> 16) & 0xffff;
+    return r;
+}
+
+// occurrences [done, done+4) of a wave: inline for done == 0, else fetched from occ/occt
+__device__ __forceinline__ void next_occ(const WaveRec& r, int done, int n, int lane, const int2* __restrict__ occ,
+                                         const int32_t* __restrict__ occt, int (&oa)[4], int (&ob)[4], int (&ot)[4]) {
+    if (done == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { oa[q] = r.oa[q]; ob[q] = r.ob[q]; ot[q] = r.ot[q]; }
+    } else {
+        int2 o = make_int2(0, 0);
+        int t = 0;
+        if (lane < n) { o = occ[r.first + (done + lane) * r.team]; t = occt[r.first + (done + lane) * r.team]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { oa[q] = bcast_i(o.x, q); ob[q] = bcast_i(o.y, q); ot[q] = bcast_i(t, q); }
+    }
+}
+
+// V1b: user occurrences -> s_t, P_t, W_t, loss.   NH = ceil(kh / 64)
+template <int NH>
+__global__ __launch_bounds__(kVTeam * TKR_WAVE) void vbpr_occur_kernel(
+    tkr_vbpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
+    const int32_t* __restrict__ occt, const int4* __restrict__ hdr, int B, const float* __restrict__ ppart,
+    float* __restrict__ s_out, float* __restrict__ P, float* __restrict__ Wm, float* __restrict__ loss_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_blocks = __builtin_amdgcn_readfirstlane((*hdr).x);
+    const int kh = st.kh, k2 = 2 * kh, NP = kh + 1, S = vbpr_slices(st.d);
+    const size_t ustride = (size_t)st.n_users * k2, istride = (size_t)st.n_items * kh;
+    const bool l2 = st.mode == 0;
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const WaveRec r = read_rec(rec_all, blk, wave, lane);
+        if (r.rowk < 0) continue;                       // item task or idle wave (-1): nothing to do here
+        const int u = r.rowk;
+        const float* urow = st.U + r.par * ustride + (size_t)u * k2;
+        float ure[NH], uce[NH];
+#pragma unroll
+        for (int e = 0; e < NH; ++e) {
+            const int c = lane + e * 64;
+            ure[e] = c < kh ? urow[c] : 0.f;
+            uce[e] = c < kh ? urow[kh + c] : 0.f;
+        }
+        float loss = 0.f, loss_lane = 0.f;
+        for (int done = 0; done < r.n_occ; done += 4) {
+            const int n = min(4, r.n_occ - done);
+            int oa[4], ob[4], ot[4];
+            next_occ(r, done, n, lane, occ, occt, oa, ob, ot);
+            for (int q = 0; q < n; ++q) {
+                const int i = oa[q] & kIdMaskV, pi = (oa[q] >> 30) & 1;
+                const int j = ob[q] & kIdMaskV, pj = (ob[q] >> 30) & 1;
+                const int t = ot[q];
+                float p[NH], vi[NH], vj[NH];
+                float qsum = 0.f;
+#pragma unroll
+                for (int e = 0; e < NH; ++e) p[e] = 0.f;
+                for (int s = 0; s < S; ++s) {                      // reduce the split-K partials in slice order
+                    const float* pp = ppart + ((size_t)s * B + t) * NP;
+#pragma unroll
+                    for (int e = 0; e < NH; ++e) {
+                        const int c = lane + e * 64;
+                        if (c < kh) p[e] += pp[c];
+                    }
+                    qsum += pp[kh];
+                }
+                const float* ri = st.I + pi * istride + (size_t)i * kh;
+                const float* rj = st.I + pj * istride + (size_t)j * kh;
+                float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < NH; ++e) {
+                    const int c = lane + e * 64;
+                    vi[e] = c < kh ? ri[c] : 0.f;
+                    vj[e] = c < kh ? rj[c] : 0.f;
+                    d1 = fmaf(ure[e], vi[e] - vj[e], d1);
+                    d2 = fmaf(uce[e], p[e], d2);
+                }
+                const float bi = st.irb[(size_t)pi * st.n_items + i], bj = st.irb[(size_t)pj * st.n_items + j];
+                const float x = bi - bj + wave_sum(d1) + wave_sum(d2) + qsum;
+                const float sg = sigmoid_neg(x);
+                loss += softplus_neg(x);
+                if (l2) {
+                    loss += 0.5f * (bi * bi + bj * bj) * st.lb;
+#pragma unroll
+                    for (int e = 0; e < NH; ++e)
+                        loss_lane += 0.5f * ((ure[e] * ure[e] + uce[e] * uce[e]) * st.lu + vi[e] * vi[e] * st.li + vj[e] * vj[e] * st.lj);
+                } else {
+                    loss += (fabsf(bi) + fabsf(bj)) * st.lb;
+#pragma unroll
+                    for (int e = 0; e < NH; ++e)
+                        loss_lane += (fabsf(ure[e]) + fabsf(uce[e])) * st.lu + fabsf(vi[e]) * st.li + fabsf(vj[e]) * st.lj;
+                }
+#pragma unroll
+                for (int e = 0; e < NH; ++e) {
+                    const int c = lane + e * 64;
+                    if (c < kh) { P[(size_t)t * kh + c] = p[e]; Wm[(size_t)t * kh + c] = -sg * uce[e]; }
+                }
+                if (lane == 0) s_out[t] = sg;
+            }
+        }
+        if (loss_out) {
+            const float tot = wave_sum(loss_lane) + loss;
+            if (lane == 0) atomicAdd(loss_out, tot);
+        }
+    }
+}
+
+// V2: sparse RMSProp on the touched [ure|uce] rows (users) and ire rows + irb (items).  NE = ceil(2kh/64)
+template <int NE>
+__global__ __launch_bounds__(kVTeam * TKR_WAVE) void vbpr_rows_kernel(
+    tkr_vbpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
+    const int32_t* __restrict__ occt, const int4* __restrict__ hdr, const float* __restrict__ s_in,
+    const float* __restrict__ P) {
+    __shared__ float red[kVTeam][NE * TKR_WAVE + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int4 h4 = *hdr;
+    const int n_blocks = __builtin_amdgcn_readfirstlane(h4.x);
+    const int nlb = (__builtin_amdgcn_readfirstlane(h4.y) + kVTeam - 1) / kVTeam;
+    const int kh = st.kh, k2 = 2 * kh;
+    const size_t ustride = (size_t)st.n_users * k2, istride = (size_t)st.n_items * kh;
+    const bool l2 = st.mode == 0;
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const bool heavy = blk >= nlb;
+        const WaveRec r = read_rec(rec_all, blk, wave, lane);
+        if (r.rowk == -1) continue;
+        const bool is_item = r.rowk < 0;
+        const int row = r.rowk & 0x7fffffff, par = r.par;
+        const int width = is_item ? kh : k2;
+        const float* src = is_item ? st.I + par * istride + (size_t)row * kh : st.U + par * ustride + (size_t)row * k2;
+        float own[NE], g[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int c = lane + e * 64;
+            own[e] = c < width ? src[c] : 0.f;
+            g[e] = 0.f;
+        }
+        const float br = is_item ? st.irb[(size_t)par * st.n_items + row] : 0.f;
+        float gb = 0.f;
+        for (int done = 0; done < r.n_occ; done += 4) {
+            const int n = min(4, r.n_occ - done);
+            int oa[4], ob[4], ot[4];
+            next_occ(r, done, n, lane, occ, occt, oa, ob, ot);
+            for (int q = 0; q < n; ++q) {
+                const float sg = s_in[ot[q]];
+                if (is_item) {
+                    const int u = oa[q] & kIdMaskV, pu = (oa[q] >> 30) & 1;
+                    const bool role_j = ob[q] < 0;
+                    const float sgn_s = role_j ? sg : -sg;
+                    const float lam = role_j ? st.lj : st.li;
+                    const float* ur = st.U + pu * ustride + (size_t)u * k2;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        const int c = lane + e * 64;
+                        if (c < kh) g[e] += sgn_s * ur[c] + lam * (l2 ? own[e] : sgn(own[e]));
+                    }
+                    gb += sgn_s + st.lb * (l2 ? br : sgn(br));
+                } else {
+                    const int i = oa[q] & kIdMaskV, pi = (oa[q] >> 30) & 1;
+                    const int j = ob[q] & kIdMaskV, pj = (ob[q] >> 30) & 1;
+                    const float* ri = st.I + pi * istride + (size_t)i * kh;
+                    const float* rj = st.I + pj * istride + (size_t)j * kh;
+                    const float* pt = P + (size_t)ot[q] * kh;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        const int c = lane + e * 64;
+                        if (c < k2) {
+                            const float partner = c < kh ? (ri[c] - rj[c]) : pt[c - kh];
+                            g[e] += -sg * partner + st.lu * (l2 ? own[e] : sgn(own[e]));
+                        }
+                    }
+                }
+            }
+        }
+        if (heavy) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) red[wave][lane + e * 64] = g[e];
+            if (lane == 0) red[wave][NE * 64] = gb;
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    float a = 0.f;
+                    for (int w = 0; w < kVTeam; ++w) a += red[w][lane + e * 64];
+                    g[e] = a;
+                }
+                float a = 0.f;
+                for (int w = 0; w < kVTeam; ++w) a += red[w][NE * 64];
+                gb = a;
+            }
+            __syncthreads();
+            if (wave != 0) continue;
+        }
+        const float* msrc = is_item ? st.msI + par * istride + (size_t)row * kh : st.msU + par * ustride + (size_t)row * k2;
+        float* po = is_item ? st.I + (par ^ 1) * istride + (size_t)row * kh : st.U + (par ^ 1) * ustride + (size_t)row * k2;
+        float* mo = is_item ? st.msI + (par ^ 1) * istride + (size_t)row * kh : st.msU + (par ^ 1) * ustride + (size_t)row * k2;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int c = lane + e * 64;
+            if (c < width) {
+                const float m2 = st.rho * msrc[c] + (1.f - st.rho) * g[e] * g[e];
+                mo[c] = m2;
+                po[c] = own[e] - st.lr * g[e] / sqrtf(m2 + st.eps);
+            }
+        }
+        if (is_item && lane == 0) {
+            const float m2 = st.rho * st.msirb[(size_t)par * st.n_items + row] + (1.f - st.rho) * gb * gb;
+            st.msirb[(size_t)(par ^ 1) * st.n_items + row] = m2;
+            st.irb[(size_t)(par ^ 1) * st.n_items + row] = br - st.lr * gb / sqrtf(m2 + st.eps);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// V3: 64 rows of cem/icb per workgroup; 4 waves split the batch (K of the contraction); MFMA rows =
+// feature columns c (two interleaved m-tiles fed by one float2 load), columns = kh, K = triplets.
+template <int NT>
+__global__ __launch_bounds__(256) void vbpr_dense_kernel(tkr_vbpr_state st, const int32_t* __restrict__ ti,
+                                                        const int32_t* __restrict__ tj, int B,
+                                                        const float* __restrict__ s_in, const float* __restrict__ Wm,
+                                                        float* __restrict__ loss_out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int NW = 4, LD = NT * 32 + 1;
+    float* red = sm;                                   // [NW][64][LD]
+    float* redi = sm + NW * 64 * LD;                   // [NW][2][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
+    const int d = st.d, kh = st.kh;
+    const int c0 = blockIdx.x * 64, cA = c0 + 2 * m;
+    const int TB = (((B + NW - 1) / NW) + 1) & ~1, TH = TB / 2;
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[q][nt] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float gi0 = 0.f, gi1 = 0.f;
+    const bool pair = ((d & 1) == 0) && (cA + 1 < d);
+    for (int kk = 0; kk < TH; ++kk) {
+        const int t = wave * TB + h * TH + kk;
+        float a0 = 0.f, a1 = 0.f, sg = 0.f;
+        const bool tv = t < B;
+        if (tv) {
+            const float* fi = st.feat + (size_t)ti[t] * d;
+            const float* fj = st.feat + (size_t)tj[t] * d;
+            if (pair) {
+                const float2 x = *reinterpret_cast<const float2*>(fi + cA);
+                const float2 y = *reinterpret_cast<const float2*>(fj + cA);
+                a0 = x.x - y.x; a1 = x.y - y.y;
+            } else {
+                if (cA < d) a0 = fi[cA] - fj[cA];
+                if (cA + 1 < d) a1 = fi[cA + 1] - fj[cA + 1];
+            }
+            sg = s_in[t];
+        }
+        gi0 = fmaf(-sg, a0, gi0);
+        gi1 = fmaf(-sg, a1, gi1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 32 + m;
+            const float b = (tv && n < kh) ? Wm[(size_t)t * kh + n] : 0.f;
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][nt], 0, 0, 0);
+            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][nt], 0, 0, 0);
+        }
+    }
+    // C layout: column = lane&31 (n), row = (r&3)+8*(r>>2)+4*h = m-index -> feature column c0 + 2*row + q
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mi = (r & 3) + 8 * (r >> 2) + 4 * h;
+                red[(wave * 64 + 2 * mi + q) * LD + nt * 32 + m] = acc[q][nt][r];
+            }
+    redi[(wave * 2 + h) * 64 + 2 * m] = gi0;
+    redi[(wave * 2 + h) * 64 + 2 * m + 1] = gi1;
+    __syncthreads();
+    const bool l2 = st.mode == 0;
+    float lpart = 0.f;
+    for (int idx = tid; idx < 64 * kh; idx += 256) {
+        const int cr = idx / kh, n = idx % kh, c = c0 + cr;
+        if (c >= d) continue;
+        float g = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) g += red[(w * 64 + cr) * LD + n];
+        const size_t o = (size_t)c * kh + n;
+        const float v = st.cem[o];
+        g += st.le * (l2 ? v : sgn(v));
+        lpart += l2 ? 0.5f * st.le * v * v : st.le * fabsf(v);
+        float ms = st.mscem[o];
+        ms += (g * g - ms) * (1.f - st.rho);                 // TF dense ApplyRMSProp
+        st.mscem[o] = ms;
+        st.cem[o] = v - st.lr * g / sqrtf(ms + st.eps);
+    }
+    if (tid < 64 && c0 + tid < d) {
+        const int c = c0 + tid;
+        float g = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW * 2; ++w) g += redi[w * 64 + tid];
+        const float v = st.icb[c];
+        g += st.lb * (l2 ? v : sgn(v));
+        lpart += l2 ? 0.5f * st.lb * v * v : st.lb * fabsf(v);
+        float ms = st.msicb[c];
+        ms += (g * g - ms) * (1.f - st.rho);
+        st.msicb[c] = ms;
+        st.icb[c] = v - st.lr * g / sqrtf(ms + st.eps);
+    }
+    if (loss_out) {
+        lpart = wave_sum(lpart);
+        if (lane == 0 && lpart != 0.f) atomicAdd(loss_out, lpart);
+    }
+}
+
+static int vbpr_grid(int B) {
+    int grid = (3 * B + kVTeam - 1) / kVTeam + 16;
+    return grid > 2048 ? 2048 : grid;
+}
+
+template <int NT>
+static int launch_vbpr(const tkr_vbpr_state& st, const int32_t* ti, const int32_t* tj, const int32_t* rec,
+                       const int32_t* occ, const int32_t* hdr, const int32_t* occt, int B, float* ws, float* loss,
+                       hipStream_t stream) {
+    const int kh = st.kh, S = vbpr_slices(st.d);
+    float* ppart = ws;
+    float* s_buf = ppart + (size_t)S * B * (kh + 1);
+    float* P = s_buf + B;
+    float* Wm = P + (size_t)B * kh;
+    const int2* occ2 = reinterpret_cast<const int2*>(occ);
+    const int4* hdr4 = reinterpret_cast<const int4*>(hdr);
+    hipLaunchKernelGGL(vbpr_project_kernel<NT>, dim3(S, (B + 31) / 32), dim3(64), 0, stream, st, ti, tj, B, ppart);
+    const int NH = (kh + 63) / 64, NE = (2 * kh + 63) / 64;
+    if (NH == 1) hipLaunchKernelGGL(vbpr_occur_kernel<1>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, B, ppart, s_buf, P, Wm, loss);
+    else hipLaunchKernelGGL(vbpr_occur_kernel<2>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, B, ppart, s_buf, P, Wm, loss);
+    switch (NE) {
+        case 1: hipLaunchKernelGGL(vbpr_rows_kernel<1>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
+        case 2: hipLaunchKernelGGL(vbpr_rows_kernel<2>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
+        case 3: hipLaunchKernelGGL(vbpr_rows_kernel<3>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
+        default: hipLaunchKernelGGL(vbpr_rows_kernel<4>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
+    }
+    const size_t lds = (size_t)(4 * 64 * (NT * 32 + 1) + 4 * 2 * 64) * sizeof(float);
+    auto dense = vbpr_dense_kernel<NT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dense), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(dense, dim3((st.d + 63) / 64), dim3(256), lds, stream, st, ti, tj, B, s_buf, Wm, loss);
+    return (int)hipGetLastError();
+}
+
+}  // namespace tkr
+
+extern "C" int tkr_plan_max_blocks(int32_t batch_size);
+
+extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d) {
+    const int64_t S = tkr::vbpr_slices(d);
+    return S * batch_size * (kh + 1) + batch_size + 2ll * batch_size * kh;
+}
+
+extern "C" int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* tri_j, const int32_t* rec,
+                            const int32_t* occ, const int32_t* hdr, const int32_t* occt, int32_t batch_size,
+                            int32_t n_batches, float* workspace, float* loss_out, void* stream) {
+    if (!st || !st->U || !st->msU || !st->I || !st->msI || !st->irb || !st->msirb || !st->cem || !st->mscem ||
+        !st->icb || !st->msicb || !st->feat)
+        return TKR_EINVAL;
+    if (st->n_users <= 0 || st->n_items <= 0 || st->kh <= 0 || st->d <= 0) return TKR_EINVAL;
+    if (!tri_i || !tri_j || !rec || !occ || !hdr || !occt || !workspace || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
+    if (st->kh > 128 || batch_size > 8192) return TKR_EUNSUPPORTED;
+    const size_t stride_r = (size_t)tkr_plan_max_blocks(batch_size) * tkr::kVTeam * 16;
+    const size_t stride_o = (size_t)3 * batch_size;
+    const int NT = (st->kh + 31) / 32;
+    for (int b = 0; b < n_batches; ++b) {
+        const int32_t* ti = tri_i + (size_t)b * batch_size;
+        const int32_t* tj = tri_j + (size_t)b * batch_size;
+        const int32_t* r = rec + b * stride_r;
+        const int32_t* o = occ + b * stride_o * 2;
+        const int32_t* h = hdr + (size_t)b * 4;
+        const int32_t* ot = occt + b * stride_o;
+        float* l = loss_out ? loss_out + b : nullptr;
+        int rc;
+        switch (NT) {
+            case 1: rc = tkr::launch_vbpr<1>(*st, ti, tj, r, o, h, ot, batch_size, workspace, l, (hipStream_t)stream); break;
+            case 2: rc = tkr::launch_vbpr<2>(*st, ti, tj, r, o, h, ot, batch_size, workspace, l, (hipStream_t)stream); break;
+            case 3: rc = tkr::launch_vbpr<3>(*st, ti, tj, r, o, h, ot, batch_size, workspace, l, (hipStream_t)stream); break;
+            default: rc = tkr::launch_vbpr<4>(*st, ti, tj, r, o, h, ot, batch_size, workspace, l, (hipStream_t)stream); break;
+        }
+        if (rc != 0) return rc;
+    }
+    return TKR_OK;
+}

@@ -49,8 +49,9 @@ class ItemSync:
     ``names`` are engine table names updated by every rank (BPR: V, b; VBPR adds the dense
     content tables).  ``begin()`` snapshots, ``end()`` all-reduces and writes back."""
 
-    def __init__(self, engine, names=('V', 'b')):
-        self.eng, self.names = engine, names
+    def __init__(self, engine, names=None):
+        self.eng = engine
+        self.names = names or getattr(engine, 'replicated_names', ('V', 'b'))
         self.start = None
 
     def begin(self):

@@ -67,6 +67,7 @@ class PlanBuffers:
         self.rec_stride = tkr_hip.plan_max_blocks(B) * tkr_hip.TEAM * 16
         self.rec = torch.empty(cap * self.rec_stride, **i32)
         self.hdr = torch.empty(cap * 4, **i32)
+        self.occt = torch.empty(cap * 3 * B, **i32)
         self.loss = torch.zeros(cap, dtype=torch.float32, device=device)
 
 
@@ -153,6 +154,8 @@ class BprEngine:
         self.b.assign(cb if b is None else self._dev(b).reshape(-1), mb if msb is None else self._dev(msb).reshape(-1))
         self.cnt.icnt.zero_()
 
+    replicated_names = ('V', 'b')
+
     def set_replicated(self, new):
         """write back all-reduced item-side tables: {'V': (p, ms), 'b': (p, ms)} (dist.ItemSync)"""
         self.set_items(V=new['V'][0], b=new['b'][0], msV=new['V'][1], msb=new['b'][1])
@@ -184,6 +187,109 @@ class BprEngine:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             tkr_hip.bpr_run(state, plan, B, nb, plan.loss if want_loss else None)
+            if self.step_events is not None:
+                e1.record()
+                self.step_events.append((e0, e1, nb))
+            self.triplets_drawn += nb * B
+            done += nb
+            loss = plan.loss[:nb] if want_loss else None
+        return loss
+
+
+class VbprEngine:
+    """Tables + sampler + step loop of one VBPR model on one GPU (single/vbpr.py:29-74).
+
+    User rows hold [ure | uce] (width 2*kh, the layout of the exported ``fue``); item rows hold ire;
+    cem / icb are dense and single-buffered (their update is its own launch, after every read)."""
+
+    def __init__(self, n_users, n_items, k, d, feat, hp, device=None, seed=None):
+        self.device = device or default_device()
+        self.n_users, self.n_items, self.k, self.kh, self.d = n_users, n_items, k, k // 2, d
+        self.hp = hp
+        self.seed = int(seed if seed is not None else np.random.SeedSequence().entropy % (2 ** 63))
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(self.seed & 0x7FFFFFFFFFFFFFFF)
+        kh = self.kh
+        self.U = DoubleTable(n_users, 2 * kh, self.device, 0.01, gen)          # vbpr.py:37-40
+        self.I = DoubleTable(n_items, kh, self.device, 0.01, gen)              # vbpr.py:41
+        self.irb = DoubleTable(n_items, 0, self.device)                        # vbpr.py:43
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.cem = torch.full((d, kh), 2.0 / (d * k), **f32)                   # vbpr.py:45-46
+        self.mscem = torch.ones((d, kh), **f32)
+        self.icb = torch.zeros(d, **f32)                                       # vbpr.py:47-48
+        self.msicb = torch.ones(d, **f32)
+        self.feat = feat if isinstance(feat, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(feat, dtype=np.float32))
+        self.feat = self.feat.to(self.device).contiguous()
+        assert self.feat.shape == (n_items, d)
+        self.cnt = UpdateCounters(n_users, n_items, self.device)
+        self.triplets_drawn = 0
+        self.plan = None
+        self.ws = None
+        self.step_events = None
+
+    def state(self):
+        hp = self.hp
+        st = tkr_hip.VbprState()
+        st.U, st.msU, st.I, st.msI = self.U.p.data_ptr(), self.U.ms.data_ptr(), self.I.p.data_ptr(), self.I.ms.data_ptr()
+        st.irb, st.msirb = self.irb.p.data_ptr(), self.irb.ms.data_ptr()
+        st.cem, st.mscem, st.icb, st.msicb = self.cem.data_ptr(), self.mscem.data_ptr(), self.icb.data_ptr(), self.msicb.data_ptr()
+        st.feat = self.feat.data_ptr()
+        st.n_users, st.n_items, st.kh, st.d = self.n_users, self.n_items, self.kh, self.d
+        st.mode = 0 if hp['mode'] == 'l2' else 1
+        st.lu, st.li, st.lj, st.lb, st.le, st.lr = hp['lu'], hp['li'], hp['lj'], hp['lb'], hp['le'], hp['lr']
+        st.rho, st.eps = RHO, EPS
+        return st
+
+    def get(self, name):
+        if name == 'U':
+            return self.U.current(self.cnt.ucnt)
+        if name == 'I':
+            return self.I.current(self.cnt.icnt)
+        if name == 'irb':
+            return self.irb.current(self.cnt.icnt)
+        return {'cem': (self.cem, self.mscem), 'icb': (self.icb, self.msicb)}[name]
+
+    _dev = BprEngine._dev
+
+    def set_users(self, U=None, msU=None):
+        cur, ms = self.U.current(self.cnt.ucnt)
+        self.U.assign(cur if U is None else self._dev(U), ms if msU is None else self._dev(msU))
+        self.cnt.ucnt.zero_()
+
+    def set_items(self, I=None, irb=None, msI=None, msirb=None):
+        ci, mi = self.I.current(self.cnt.icnt)
+        cb, mb = self.irb.current(self.cnt.icnt)
+        self.I.assign(ci if I is None else self._dev(I), mi if msI is None else self._dev(msI))
+        self.irb.assign(cb if irb is None else self._dev(irb).reshape(-1), mb if msirb is None else self._dev(msirb).reshape(-1))
+        self.cnt.icnt.zero_()
+
+    def set_dense(self, cem=None, icb=None, mscem=None, msicb=None):
+        for dst, src in ((self.cem, cem), (self.icb, icb), (self.mscem, mscem), (self.msicb, msicb)):
+            if src is not None:
+                dst.copy_(self._dev(src).reshape(dst.shape))
+
+    def set_replicated(self, new):
+        self.set_items(I=new['I'][0], irb=new['irb'][0], msI=new['I'][1], msirb=new['irb'][1])
+        self.set_dense(cem=new['cem'][0], icb=new['icb'][0], mscem=new['cem'][1], msicb=new['icb'][1])
+
+    replicated_names = ('I', 'irb', 'cem', 'icb')
+
+    def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True):
+        cap = min(n_batches, MAX_PLAN_BATCHES, max(8, (1 << 21) // B))
+        if self.plan is None or self.plan.B != B or self.plan.cap < cap:
+            self.plan = PlanBuffers(cap, B, self.device)
+            self.ws = torch.empty(tkr_hip.vbpr_workspace_floats(B, self.kh, self.d), dtype=torch.float32, device=self.device)
+        plan, done, loss = self.plan, 0, None
+        state = self.state()
+        while done < n_batches:
+            nb = min(plan.cap, n_batches - done)
+            tkr_hip.sample_plan(csr, self.n_users, self.n_items, self.seed, self.triplets_drawn, nb, B, self.cnt, plan)
+            if want_loss:
+                plan.loss[:nb].zero_()
+            if self.step_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            tkr_hip.vbpr_run(state, plan, B, nb, self.ws, plan.loss if want_loss else None)
             if self.step_events is not None:
                 e1.record()
                 self.step_events.append((e0, e1, nb))

@@ -32,20 +32,14 @@ class BprState(C.Structure):
 
 class VbprState(C.Structure):
     """mirror of tkr_vbpr_state (include/tkr.h)"""
-    _fields_ = [('ure', C.c_void_p), ('ms_ure', C.c_void_p), ('uce', C.c_void_p), ('ms_uce', C.c_void_p),
-                ('ustamp', C.c_void_p),
-                ('ire', C.c_void_p), ('ms_ire', C.c_void_p), ('irb', C.c_void_p), ('ms_irb', C.c_void_p),
-                ('istamp', C.c_void_p),
-                ('cem', C.c_void_p), ('ms_cem', C.c_void_p), ('icb', C.c_void_p), ('ms_icb', C.c_void_p),
-                ('feat', C.c_void_p),
-                ('n_users', C.c_int32), ('n_items', C.c_int32), ('kh', C.c_int32), ('d', C.c_int32),
-                ('mode', C.c_int32),
-                ('lu', C.c_float), ('li', C.c_float), ('lj', C.c_float), ('lb', C.c_float), ('le', C.c_float),
-                ('lr', C.c_float), ('rho', C.c_float), ('eps', C.c_float)]
+    _fields_ = [(n, C.c_void_p) for n in ('U', 'msU', 'I', 'msI', 'irb', 'msirb', 'cem', 'mscem', 'icb', 'msicb', 'feat')] + \
+               [(n, C.c_int32) for n in ('n_users', 'n_items', 'kh', 'd', 'mode')] + \
+               [(n, C.c_float) for n in ('lu', 'li', 'lj', 'lb', 'le', 'lr', 'rho', 'eps')]
 
 
 EXPORTS = ('tkr_version', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_bpr_run',
-           'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits')
+           'tkr_vbpr_run', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits')
+EXPORTS_I64 = ('tkr_vbpr_workspace_floats',)
 
 
 def lib():
@@ -58,6 +52,8 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         for name in EXPORTS:
             getattr(_lib, name).restype = C.c_int
+        for name in EXPORTS_I64:
+            getattr(_lib, name).restype = C.c_int64
     return _lib
 
 
@@ -103,12 +99,22 @@ def sample_plan(csr, n_users, n_items, seed, first_triplet, n_batches, B, cnt, p
                                  C.c_uint64(first_triplet), _p(ctl), C.c_int32(n_batches), C.c_int32(B),
                                  _p(cnt.ucnt), _p(cnt.icnt), _p(cnt.touch_u), _p(cnt.touch_i),
                                  _p(plan.u), _p(plan.i), _p(plan.j), _p(plan.task), _p(plan.occ), _p(plan.rec),
-                                 _p(plan.hdr), _stream()), 'tkr_sample_plan')
+                                 _p(plan.hdr), _p(plan.occt), _stream()), 'tkr_sample_plan')
 
 
 def bpr_run(state, plan, B, n_batches, loss_out=None):
     _check(lib().tkr_bpr_run(C.byref(state), _p(plan.rec), _p(plan.occ), _p(plan.hdr), C.c_int32(B),
                              C.c_int32(n_batches), _p(loss_out), _stream()), 'tkr_bpr_run')
+
+
+def vbpr_workspace_floats(B, kh, d):
+    return int(lib().tkr_vbpr_workspace_floats(C.c_int32(B), C.c_int32(kh), C.c_int32(d)))
+
+
+def vbpr_run(state, plan, B, n_batches, workspace, loss_out=None):
+    _check(lib().tkr_vbpr_run(C.byref(state), _p(plan.i), _p(plan.j), _p(plan.rec), _p(plan.occ), _p(plan.hdr),
+                              _p(plan.occt), C.c_int32(B), C.c_int32(n_batches), _p(workspace), _p(loss_out),
+                              _stream()), 'tkr_vbpr_run')
 
 
 # ---- K4 / K5 -------------------------------------------------------------------------------------
