@@ -137,9 +137,24 @@ class BPR(REC):
         tprint('Learning rate is %.6f, regularization mode is %s' % (self.lr, self.mode))
         tprint('Training for %d epochs of %d batches using %s sampler' % (epochs, batch_limit, sampling))
         self._warm_start()
+        # one process per GPU (torch.distributed initialised by the launcher): users sharded, item-side
+        # tables replicated and reconciled once per epoch (dist.py; the reference is single-process)
+        import dist as tdist
+        rank, world = tdist.world()
+        if world > 1:
+            shard = tdist.shard_users(self.tr_users, rank, world)
+            self._csr = _engine.TrainingCSR(self.tr_data, shard, self.n_users, self._eng.device)
+            n_batches = tdist.batches_per_rank(n_batches, world)
+            self._eng.triplets_drawn = rank * epochs * n_batches * batch_size      # disjoint stream positions
+            sync = tdist.ItemSync(self._eng)
+            users_start = self._eng.get('U')[0].clone()
         for eid in range(epochs):
             t0 = time.time()
+            if world > 1:
+                sync.begin()
             loss = self._run_epoch(n_batches, batch_size)
+            if world > 1:
+                sync.end()
             torch.cuda.synchronize(self._eng.device)
             spent = time.time() - t0
             self.last_epoch_loss = loss
@@ -148,6 +163,10 @@ class BPR(REC):
                 sys.stderr.write(' ... total time collapse %8.4fs' % spent)
                 sys.stderr.flush()
                 print()
+        if world > 1:
+            p, ms = self._eng.get('U')
+            self._eng.set_users(U=tdist.combine_user_rows(p, users_start), msU=ms)
+            self._csr = None                     # the sharded CSR is not the model's full training set
         self._collect()
 
     def _run_epoch(self, n_batches, batch_size):
