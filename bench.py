@@ -37,6 +37,19 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA, dense
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch measured with rocprofv3 PMC counters in an earlier profiled run of this
+    same command (profiles/rNN_pmc_traffic.json, newest round); None if that run does not exist"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1])).get(key, {}).get('hbm_bytes_per_launch_corrected')
+    except (OSError, ValueError):
+        return None
+
+
 def algorithmic_bytes_per_triplet(k):
     return 48 * k + 56          # SURVEY.md §8d: 3 rows x (param+slot) x (read+write) + biases + ids
 
@@ -164,7 +177,9 @@ def topk_bench(r, k, device, rank, world, K=30, reps=5):
             'config': {'workload': '%d users x %d items, k=%d, top-%d, train history masked' % (r['n_users'], n_items, k, K)},
             'ms_per_pass': wall * 1e3 / reps,
             'roofline': {'kernel': 'tkr::score_topk_kernel', 'bound': 'mfma', 'achieved': tf, 'peak': MFMA_F32_PEAK_TF,
-                         'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TF, 'traffic': None, 'launch_ms': launch_ms,
+                         'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TF,
+                         'traffic': pmc_traffic('score_topk_ml10m_k128') if (k == 128 and n_items == 10380 and world == 1) else None,
+                         'launch_ms': launch_ms,
                          'algorithmic_flops_per_launch': flops}}
 
 
@@ -241,7 +256,8 @@ def main():
                    'batch_size': B, 'k': k, 'sharding': 'users sharded over %d GPU(s), item tables replicated, '
                                                         'all-reduce every %d steps' % (world, sync_every) if world > 1 else 'single GPU'},
         'roofline': {'kernel': 'tkr::bpr_step_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'launch_us': launch_us,
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic('bpr_step_B%d' % B) if (k == 128 and args.shape == 'ml10m') else None,
+                     'launch_us': launch_us,
                      'algorithmic_bytes_per_launch': B * algorithmic_bytes_per_triplet(k)},
     }
     if rank == 0 and world == 1 and not args.no_extras:
@@ -254,7 +270,8 @@ def main():
         out['throughput_mode'] = {'batch_size': B2, 'steps': 256, 'value': 256 * B2 / w2, 'unit': 'triplets/s',
                                   'ms_per_step': w2 * 1e3 / 256,
                                   'roofline': {'bound': 'hbm', 'achieved': a2, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                               'frac': a2 / HBM_PEAK_GBS, 'launch_us': s2 * 1e3 / 256}}
+                                               'frac': a2 / HBM_PEAK_GBS, 'launch_us': s2 * 1e3 / 256,
+                                               'traffic': pmc_traffic('bpr_step_B8192') if (k == 128 and args.shape == 'ml10m') else None}}
     if not args.no_extras:
         topk = topk_bench(r, k, device, rank, world)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:

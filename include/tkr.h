@@ -138,6 +138,10 @@ int tkr_score_topk(const float* U, const int32_t* user_idx, int32_t n_rows, cons
 int tkr_count_hits(const int32_t* ids, int32_t n_rows, int32_t K, const int64_t* like_ptr, const int32_t* like_cols,
                    int32_t step, int32_t interval, uint64_t* first_bucket, void* stream);
 
+/* ---- profiling aid: dst[r] = src[r] + 1 for the n listed rows of a [*, k] table, with the step
+ * kernels' access pattern; used by scripts/pmc_calibrate.py to calibrate rocprofv3 byte counters */
+int tkr_calib_rowcopy(const float* src, float* dst, const int32_t* rows, int32_t n, int32_t k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,7 +38,7 @@ class VbprState(C.Structure):
 
 
 EXPORTS = ('tkr_version', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_bpr_run',
-           'tkr_vbpr_run', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits')
+           'tkr_vbpr_run', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy')
 EXPORTS_I64 = ('tkr_vbpr_workspace_floats',)
 
 
