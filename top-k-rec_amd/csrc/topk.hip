@@ -37,23 +37,44 @@ __device__ __forceinline__ uint32_t ordered_bits(float s) {      // monotone flo
     return (f & 0x80000000u) ? ~f : (f | 0x80000000u);
 }
 
-// descending bitonic sort of one 64-bit key per lane across the wave
+// value of lane (lane ^ STRIDE).  Strides 1..8 stay in the VALU (DPP), 16 uses the LDS crossbar without
+// an address (ds_swizzle), only 32 needs a bpermute.
+template <int STRIDE>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    if constexpr (STRIDE == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    else if constexpr (STRIDE == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // [2,3,0,1]
+    else if constexpr (STRIDE == 4) {   // half_mirror (i ^ 7) then quad reverse (i ^ 3)
+        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xf, 0xf, true);
+    } else if constexpr (STRIDE == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);   // row_ror:8
+    else if constexpr (STRIDE == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);   // xor 16 inside each 32 lanes
+    else return (uint32_t)__shfl_xor((int)v, 32, 64);
+}
+
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void cmpx(uint32_t& hi, uint32_t& lo, int lane) {
+    const uint32_t ohi = lane_xor<STRIDE>(hi), olo = lane_xor<STRIDE>(lo);
+    const bool other_gt = (ohi > hi) || (ohi == hi && olo > lo);
+    const bool upper = (lane & STRIDE) != 0;                 // I am the higher lane of the pair
+    const bool desc = (lane & SIZE) == 0;                    // this block sorts descending
+    const bool take_max = (upper != desc);                   // lower lane of a descending block keeps the max
+    const bool take_other = (take_max == other_gt);
+    hi = take_other ? ohi : hi;
+    lo = take_other ? olo : lo;
+}
+
+// descending bitonic sort of one 64-bit key per lane across the wave (keys are distinct)
 __device__ __forceinline__ uint64_t wave_sort_desc(uint64_t key, int lane) {
-#pragma unroll
-    for (int size = 2; size <= 64; size <<= 1) {
-#pragma unroll
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const uint32_t plo = __shfl_xor((uint32_t)key, stride, 64);
-            const uint32_t phi = __shfl_xor((uint32_t)(key >> 32), stride, 64);
-            const uint64_t other = ((uint64_t)phi << 32) | plo;
-            const bool upper = (lane & stride) != 0;             // I am the higher lane of the pair
-            const bool desc = (lane & size) == 0;                // this block sorts descending
-            const bool take_max = (upper != desc);               // lower lane of a descending block keeps the max
-            const uint64_t mx = key > other ? key : other, mn = key > other ? other : key;
-            key = take_max ? mx : mn;
-        }
-    }
-    return key;
+    uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+    cmpx<2, 1>(hi, lo, lane);
+    cmpx<4, 2>(hi, lo, lane); cmpx<4, 1>(hi, lo, lane);
+    cmpx<8, 4>(hi, lo, lane); cmpx<8, 2>(hi, lo, lane); cmpx<8, 1>(hi, lo, lane);
+    cmpx<16, 8>(hi, lo, lane); cmpx<16, 4>(hi, lo, lane); cmpx<16, 2>(hi, lo, lane); cmpx<16, 1>(hi, lo, lane);
+    cmpx<32, 16>(hi, lo, lane); cmpx<32, 8>(hi, lo, lane); cmpx<32, 4>(hi, lo, lane); cmpx<32, 2>(hi, lo, lane);
+    cmpx<32, 1>(hi, lo, lane);
+    cmpx<64, 32>(hi, lo, lane); cmpx<64, 16>(hi, lo, lane); cmpx<64, 8>(hi, lo, lane); cmpx<64, 4>(hi, lo, lane);
+    cmpx<64, 2>(hi, lo, lane); cmpx<64, 1>(hi, lo, lane);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 template <typename IdT>
@@ -129,28 +150,70 @@ __global__ __launch_bounds__(topk_max_waves<KHP>() * TKR_WAVE) void score_topk_k
     float thr = -INFINITY;
     const int n_tiles = (n_cols + 31) >> 5;
 
-    auto stage = [&](int t, int buf) {                           // tile t of V (+ bias) -> LDS buffer `buf`
-        float* dst = sm.tile + buf * 32 * KP;
-        for (int c = tid; c < 32 * 2 * KHP; c += blockDim.x) {
-            const int item = c / (2 * KHP), p = c % (2 * KHP);
-            const int hh = p / KHP, kk = p % KHP;
-            const int e = hh * KH + kk, col = t * 32 + item;
-            float v = 0.f;
-            if (kk < KH && e < k && col < n_cols) v = Vt[(size_t)col * k + e];
-            dst[item * KP + p] = v;
+    // ---- tile staging: global -> registers (issued early) -> LDS (written after the MFMA chain) ------
+    // float4 path when every k-half starts 16-B aligned (k % 8 == 0); scalar path otherwise.
+    constexpr int NC = (32 * 2 * KHP / 4 + 255) / 256;            // float4 chunks per thread at >= 4 waves
+    const bool vec = (k & 7) == 0;                                // then KH % 4 == 0: no chunk straddles the halves
+    const int nthreads = blockDim.x;
+    const int k4 = k >> 2;
+    int src_off[NC], dst_off[NC], item_of[NC];                    // per-chunk offsets, fixed for the whole kernel
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const int c = tid + q * nthreads;
+        const int item = vec ? c / k4 : 0, e = vec ? (c % k4) * 4 : 0;
+        const bool live = vec && c < 32 * k4;
+        src_off[q] = live ? item * k + e : -1;
+        dst_off[q] = item * KP + (e / KH) * KHP + (e % KH);
+        item_of[q] = item;
+    }
+    float4 stg[NC];
+    float stg_bias = 0.f;
+    auto stage_load = [&](int t) {                                // tile t -> registers
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                stg[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (src_off[q] >= 0 && t * 32 + item_of[q] < n_cols)
+                    stg[q] = *reinterpret_cast<const float4*>(Vt + (size_t)t * 32 * k + src_off[q]);
+            }
         }
         if (tid < 32) {
             const int col = t * 32 + tid;
-            sm.tbias[buf * 32 + tid] = (bias && col < n_cols) ? bias[col] : 0.f;
+            stg_bias = (bias && col < n_cols) ? bias[col] : 0.f;
         }
     };
-
-    stage(0, 0);
+    auto stage_store = [&](int t, int buf) {                      // registers (or, scalar path, global) -> LDS
+        float* dst = sm.tile + buf * 32 * KP;
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q)
+                if (src_off[q] >= 0) *reinterpret_cast<float4*>(dst + dst_off[q]) = stg[q];
+        } else {
+            for (int c = tid; c < 32 * 2 * KHP; c += nthreads) {
+                const int item = c / (2 * KHP), p = c % (2 * KHP);
+                const int hh = p / KHP, kk = p % KHP;
+                const int e = hh * KH + kk, col = t * 32 + item;
+                float v = 0.f;
+                if (kk < KH && e < k && col < n_cols) v = Vt[(size_t)col * k + e];
+                dst[item * KP + p] = v;
+            }
+        }
+        if (tid < 32) sm.tbias[buf * 32 + tid] = stg_bias;
+    };
+    if (vec) {                                                    // zero the LDS padding the vector path never writes
+        for (int c = tid; c < 2 * 32 * KP; c += nthreads) sm.tile[c] = 0.f;
+        __syncthreads();
+    }
+    stage_load(0);
+    stage_store(0, 0);
     __syncthreads();
+    if (n_tiles > 1) stage_load(1);
 
+    const uint32_t tail_mask = (n_cols & 31) ? (0xffffffffu << (n_cols & 31)) : 0u;
     for (int t = 0; t < n_tiles; ++t) {
         const int buf = t & 1;
-        if (t + 1 < n_tiles) stage(t + 1, buf ^ 1);              // other buffer: free since the barrier of tile t-1
+        // rated / non-existent columns of this (user, tile) as one word; issued before the MFMA chain
+        uint32_t maskw = (mask && user_ok) ? mask[(size_t)t * mask_pitch + row] : 0u;
         // ---- 32 items x 32 users x k: exact fp32 MFMA ------------------------------------------
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const float* arow = sm.tile + buf * 32 * KP + ul * KP + h * KHP;
@@ -162,17 +225,25 @@ __global__ __launch_bounds__(topk_max_waves<KHP>() * TKR_WAVE) void score_topk_k
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, breg[kk + 2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, breg[kk + 3], acc, 0, 0, 0);
         }
+        // tile t+1: registers -> the other LDS buffer (free since the barrier of tile t-1); tile t+2 -> registers
+        if (t + 1 < n_tiles) stage_store(t + 1, buf ^ 1);
+        if (t + 2 < n_tiles) stage_load(t + 2);
         // ---- epilogue: bias, mask, threshold filter ----------------------------------------------
-        const uint32_t maskw = (mask && user_ok) ? mask[(size_t)t * mask_pitch + row] : 0u;
+        if (!user_ok) maskw = 0xffffffffu;
+        if (t == n_tiles - 1) maskw |= tail_mask;
+        const uint32_t mh = maskw >> (4 * h);                    // bit (r&3)+8*(r>>2) <-> accumulator register r
         float sc[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                            // rows 8g+4h .. 8g+4h+3 are registers 4g..4g+3
+            const float4 bq = *reinterpret_cast<const float4*>(sm.tbias + buf * 32 + 8 * g + 4 * h);
+            sc[4 * g + 0] = (acc[4 * g + 0] + bq.x) + 0.0f;      // fl(fl(dot)+b); -0.0 -> +0.0
+            sc[4 * g + 1] = (acc[4 * g + 1] + bq.y) + 0.0f;
+            sc[4 * g + 2] = (acc[4 * g + 2] + bq.z) + 0.0f;
+            sc[4 * g + 3] = (acc[4 * g + 3] + bq.w) + 0.0f;
+        }
         uint32_t ok = 0;                                         // bit r: column exists, user exists, not rated
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ir = (r & 3) + 8 * (r >> 2) + 4 * h;       // item row of accumulator register r
-            sc[r] = (acc[r] + sm.tbias[buf * 32 + ir]) + 0.0f;   // fl(fl(dot)+b); -0.0 -> +0.0
-            const bool good = user_ok && (t * 32 + ir < n_cols) && !((maskw >> ir) & 1u);
-            ok |= (uint32_t)good << r;
-        }
+        for (int r = 0; r < 16; ++r) ok |= ((~mh >> ((r & 3) + 8 * (r >> 2))) & 1u) << r;
         for (;;) {
             uint32_t hits = 0;
 #pragma unroll
@@ -180,7 +251,7 @@ __global__ __launch_bounds__(topk_max_waves<KHP>() * TKR_WAVE) void score_topk_k
             hits &= ok;
             const int mine = __popc(hits);
             const int total = mine + __shfl_xor(mine, 32, 64);
-            const bool need = user_ok && total > 0 && (sm.cnt[uw] + total > kCap);
+            const bool need = total > 0 && (sm.cnt[uw] + total > kCap);
             uint64_t pending = __ballot(need) & 0xffffffffull;   // one bit per user (lower half lanes)
             if (pending == 0) {
 #pragma unroll
@@ -270,16 +341,18 @@ static int launch_topk(int W, const float* U, const int32_t* uidx, int n_rows, c
     return (int)hipGetLastError();
 }
 
-// waves per workgroup: fill the 256 CUs in whole rounds (every workgroup streams all of V once)
+// waves per workgroup.  Every workgroup streams all of V and its waves run in lockstep (one barrier per
+// tile), so the time of a launch ~ rounds x ceil(W / 4) tile-times; prefer >= 2 waves per SIMD so that one
+// wave's filter/trim overlaps the other's MFMA chain.
 static int pick_waves(int n_rows, int max_w) {
     const int tasks = (n_rows + 31) / 32;
-    int best = 4;
-    double best_eff = -1.0;
-    for (int w = 4; w <= max_w; ++w) {
+    int best = max_w < 8 ? max_w : 8;
+    double best_cost = 1e30;
+    for (int w = (max_w < 8 ? 4 : 8); w <= max_w; ++w) {
         const int wgs = (tasks + w - 1) / w;
         const int rounds = (wgs + 255) / 256;
-        const double eff = (double)tasks / ((double)rounds * 256 * w);
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = w; }
+        const double cost = (double)rounds * ((w + 3) / 4);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = w; }
     }
     return best;
 }
