@@ -28,7 +28,7 @@ namespace tkr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTopkMaxWaves = 10;
+constexpr int kTopkMaxWaves = 8;
 constexpr int kCap = 64;                 // candidate slots per user (= wave width: one entry per lane in a trim)
 constexpr int kMaxK = 32;                // K + 32 (largest per-tile inflow) <= kCap
 
@@ -82,8 +82,9 @@ struct TopkSmem {
     float* tile;      // [2][32][KP]
     float* tbias;     // [2][32]
     int* cnt;         // [users]
-    float* cs;        // [users][kCap]
-    IdT* ci;          // [users][kCap]
+    float* cs;        // [kCap][users]   entry-major: the 32 users of a wave scan their lists conflict-free
+    IdT* ci;          // [kCap][users]
+    int users;
 };
 
 // Sort user `uw`'s candidate list, keep the best K, return the new threshold (K-th best, or -inf
@@ -92,14 +93,14 @@ template <typename IdT>
 __device__ __forceinline__ float trim_user(const TopkSmem<IdT>& sm, int uw, int K, int lane, uint64_t* sorted_out) {
     const int n = sm.cnt[uw];
     uint64_t key = 0;                                            // below every real key (real keys have idx+1 > 0)
-    if (lane < n) key = ((uint64_t)ordered_bits(sm.cs[uw * kCap + lane]) << 32) | ((uint32_t)sm.ci[uw * kCap + lane] + 1u);
+    if (lane < n) key = ((uint64_t)ordered_bits(sm.cs[lane * sm.users + uw]) << 32) | ((uint32_t)sm.ci[lane * sm.users + uw] + 1u);
     key = wave_sort_desc(key, lane);
     const int keep = min(n, K);
     if (lane < keep) {
         const uint32_t ob = (uint32_t)(key >> 32);
         const uint32_t f = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
-        sm.cs[uw * kCap + lane] = __uint_as_float(f);
-        sm.ci[uw * kCap + lane] = (IdT)((uint32_t)key - 1u);
+        sm.cs[lane * sm.users + uw] = __uint_as_float(f);
+        sm.ci[lane * sm.users + uw] = (IdT)((uint32_t)key - 1u);
     }
     if (lane == 0) sm.cnt[uw] = keep;
     if (sorted_out) *sorted_out = key;
@@ -108,12 +109,66 @@ __device__ __forceinline__ float trim_user(const TopkSmem<IdT>& sm, int uw, int 
     return (n >= K) ? __uint_as_float(kf) : -INFINITY;
 }
 
+// Scheduled trim of ALL 32 users of a wave at once, one user per lane pair (half h scans entries
+// [32h, 32h+32)): bitwise search for the K-th largest score, then in-place compaction of the entries
+// >= that score.  No cross-lane traffic except one xor-32 exchange per step.  Entries tied with the
+// K-th score are all kept (the exact order among them is settled by the final sort); a list that
+// does not shrink enough is caught by the on-demand exact trim.
+template <typename IdT>
+__device__ __forceinline__ float trim_all_users(const TopkSmem<IdT>& sm, int uw, int h, int K, float thr) {
+    const int n = sm.cnt[uw];
+    uint32_t key[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        const int p = 32 * h + e;
+        key[e] = (p < n) ? ordered_bits(sm.cs[p * sm.users + uw]) : 0u;       // 0 < every real key
+    }
+    uint32_t prefix = 0;
+#pragma unroll 1
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t cand = prefix | (1u << b);
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) c += (key[e] >= cand);
+        c += __shfl_xor(c, 32, 64);
+        if (c >= K) prefix = cand;
+    }
+    const bool active = n >= K;                              // fewer than K candidates: keep all, threshold unchanged
+    int mine = 0;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) mine += (key[e] >= prefix);
+    const int other = __shfl_xor(mine, 32, 64);
+    // in-place compaction, half 0 first (writes at or below what it reads), then half 1 behind it
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+        if (active && h == phase) {
+            int pos = h ? other : 0;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                if (key[e] >= prefix) {
+                    const IdT id = sm.ci[(32 * h + e) * sm.users + uw];
+                    const uint32_t f = (key[e] & 0x80000000u) ? (key[e] & 0x7fffffffu) : ~key[e];
+                    sm.cs[pos * sm.users + uw] = __uint_as_float(f);
+                    sm.ci[pos * sm.users + uw] = id;
+                    ++pos;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (active && h == 0) sm.cnt[uw] = mine + other;
+    const uint32_t f = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
+    return active ? __uint_as_float(f) : thr;
+}
+
 // wide factor rows (k > 128) keep 100+ operand registers: one wave per SIMD
-template <int KHP>
-constexpr int topk_max_waves() { return KHP > 64 ? 4 : kTopkMaxWaves; }
+// waves per workgroup of an instantiation: 8 (two per SIMD: one wave's filter overlaps the other's MFMA
+// chain); 6 when candidate ids need 32 bits (LDS); 4 for wide factor rows (100+ operand registers)
+template <int KHP, typename IdT>
+constexpr int topk_waves() { return KHP > 64 ? 4 : (sizeof(IdT) == 2 ? kTopkMaxWaves : 6); }
 
 template <int KHP, typename IdT>
-__global__ __launch_bounds__(topk_max_waves<KHP>() * TKR_WAVE) void score_topk_kernel(
+__global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_topk_kernel(
     const float* __restrict__ U, const int32_t* __restrict__ uidx, int n_rows, const float* __restrict__ Vt,
     const float* __restrict__ bias, int n_cols, int k, const uint32_t* __restrict__ mask, int mask_pitch, int K,
     int32_t* __restrict__ out_ids, float* __restrict__ out_scores) {
@@ -127,6 +182,7 @@ __global__ __launch_bounds__(topk_max_waves<KHP>() * TKR_WAVE) void score_topk_k
     sm.cnt = reinterpret_cast<int*>(sm.tbias + 64);
     sm.cs = reinterpret_cast<float*>(sm.cnt + users);
     sm.ci = reinterpret_cast<IdT*>(sm.cs + (size_t)users * kCap);
+    sm.users = users;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ul = lane & 31, h = lane >> 5;
@@ -152,7 +208,8 @@ __global__ __launch_bounds__(topk_max_waves<KHP>() * TKR_WAVE) void score_topk_k
 
     // ---- tile staging: global -> registers (issued early) -> LDS (written after the MFMA chain) ------
     // float4 path when every k-half starts 16-B aligned (k % 8 == 0); scalar path otherwise.
-    constexpr int NC = (32 * 2 * KHP / 4 + 255) / 256;            // float4 chunks per thread at >= 4 waves
+    constexpr int NT_ = topk_waves<KHP, IdT>() * 64;
+    constexpr int NC = (32 * 2 * KHP / 4 + NT_ - 1) / NT_;         // float4 chunks per thread
     const bool vec = (k & 7) == 0;                                // then KH % 4 == 0: no chunk straddles the halves
     const int nthreads = blockDim.x;
     const int k4 = k >> 2;
@@ -210,6 +267,7 @@ __global__ __launch_bounds__(topk_max_waves<KHP>() * TKR_WAVE) void score_topk_k
     if (n_tiles > 1) stage_load(1);
 
     const uint32_t tail_mask = (n_cols & 31) ? (0xffffffffu << (n_cols & 31)) : 0u;
+    int next_sched = 2;                                          // scheduled trims at tiles 2, 3, 5, 8, 12, ... (x1.5)
     for (int t = 0; t < n_tiles; ++t) {
         const int buf = t & 1;
         // rated / non-existent columns of this (user, tile) as one word; issued before the MFMA chain
@@ -241,6 +299,10 @@ __global__ __launch_bounds__(topk_max_waves<KHP>() * TKR_WAVE) void score_topk_k
             sc[4 * g + 2] = (acc[4 * g + 2] + bq.z) + 0.0f;
             sc[4 * g + 3] = (acc[4 * g + 3] + bq.w) + 0.0f;
         }
+        if (t == next_sched) {                                   // workgroup-uniform: every wave trims all its users now
+            thr = trim_all_users<IdT>(sm, uw, h, K, thr);
+            next_sched = t + ((t + 1) >> 1);
+        }
         uint32_t ok = 0;                                         // bit r: column exists, user exists, not rated
 #pragma unroll
         for (int r = 0; r < 16; ++r) ok |= ((~mh >> ((r & 3) + 8 * (r >> 2))) & 1u) << r;
@@ -258,8 +320,8 @@ __global__ __launch_bounds__(topk_max_waves<KHP>() * TKR_WAVE) void score_topk_k
                 for (int r = 0; r < 16; ++r) {
                     if (hits & (1u << r)) {
                         const int pos = atomicAdd(&sm.cnt[uw], 1);
-                        sm.cs[uw * kCap + pos] = sc[r];
-                        sm.ci[uw * kCap + pos] = (IdT)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                        sm.cs[pos * users + uw] = sc[r];
+                        sm.ci[pos * users + uw] = (IdT)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
                     }
                 }
                 break;
@@ -341,37 +403,15 @@ static int launch_topk(int W, const float* U, const int32_t* uidx, int n_rows, c
     return (int)hipGetLastError();
 }
 
-// waves per workgroup.  Every workgroup streams all of V and its waves run in lockstep (one barrier per
-// tile), so the time of a launch ~ rounds x ceil(W / 4) tile-times; prefer >= 2 waves per SIMD so that one
-// wave's filter/trim overlaps the other's MFMA chain.
-static int pick_waves(int n_rows, int max_w) {
-    const int tasks = (n_rows + 31) / 32;
-    int best = max_w < 8 ? max_w : 8;
-    double best_cost = 1e30;
-    for (int w = (max_w < 8 ? 4 : 8); w <= max_w; ++w) {
-        const int wgs = (tasks + w - 1) / w;
-        const int rounds = (wgs + 255) / 256;
-        const double cost = (double)rounds * ((w + 3) / 4);
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = w; }
-    }
-    return best;
-}
-
 template <typename IdT>
 static int dispatch_topk(const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias, int n_cols,
                          int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
                          hipStream_t stream) {
     const int kh = (k + 1) / 2;
-#define TKR_TOPK_CASE(KHP)                                                                                        \
-    if (kh <= KHP) {                                                                                              \
-        constexpr int KP_ = 2 * KHP + 4;                                                                          \
-        int max_w = topk_max_waves<KHP>();                                                                        \
-        while (max_w > 1 && (size_t)(2 * 32 * KP_ + 64) * 4 + (size_t)max_w * 32 * (4 + kCap * (4 + sizeof(IdT))) > 160 * 1024) \
-            --max_w;                                                                                              \
-        if (max_w < 4) max_w = 4;                                                                                  \
-        return launch_topk<KHP, IdT>(pick_waves(n_rows, max_w), U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, \
-                                     out_ids, out_scores, stream);                                                \
-    }
+#define TKR_TOPK_CASE(KHP)                                                                                   \
+    if (kh <= KHP)                                                                                           \
+        return launch_topk<KHP, IdT>(topk_waves<KHP, IdT>(), U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, \
+                                     out_ids, out_scores, stream);
     TKR_TOPK_CASE(16)
     TKR_TOPK_CASE(28)
     TKR_TOPK_CASE(32)
