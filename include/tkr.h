@@ -124,12 +124,16 @@ int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* 
  *     train-rated by row's user (evaluate.py:98); built by tkr_build_rated_mask into a zeroed buffer
  *   out_ids [n_rows, K]: the K best unrated columns, descending score, ties -> higher column first;
  *     -1 where fewer than K unrated columns exist.  out_scores (nullable) alike, -inf padded.
+ *   workspace (nullable, device, workspace_bytes): scratch for per-item-range partial lists; with
+ *     tkr_topk_workspace_bytes(n_rows, K) bytes the launch splits the catalogue so that the grid fills
+ *     the 256 CUs in whole rounds (results are identical with or without it)
  * K <= 32, k <= 256. */
+int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K);
 int tkr_build_rated_mask(const int64_t* rated_ptr, const int32_t* rated_cols, int32_t n_rows, int32_t n_cols,
                          uint32_t* mask, int32_t mask_pitch, void* stream);
 int tkr_score_topk(const float* U, const int32_t* user_idx, int32_t n_rows, const float* Vt, const float* bias,
                    int32_t n_cols, int32_t k, const uint32_t* mask, int32_t mask_pitch, int32_t K,
-                   int32_t* out_ids, float* out_scores, void* stream);
+                   int32_t* out_ids, float* out_scores, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- K5: hit counting of the rank walk (evaluate.py:99-103) ------------------------------------
  * first_bucket[p / step] += 1 (uint64 atomics) for every kept position p < interval*step of row r

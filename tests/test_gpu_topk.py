@@ -119,6 +119,22 @@ def test_generic_fp32_lists_match_outside_near_ties(hip):
     assert same > 0.95 * n_rows
 
 
+def test_item_range_split_is_invisible(hip):
+    """the launch may split the catalogue into item ranges and merge: identical ids and scores either way"""
+    rng = np.random.Generator(np.random.PCG64(21))
+    for n_rows, n_cols, k in ((3000, 5000, 64), (70000, 2100, 16), (700, 20000, 128)):
+        U = (rng.standard_normal((n_rows, k)) * 0.01).astype(np.float32)
+        V = (rng.standard_normal((n_cols, k)) * 0.01).astype(np.float32)
+        V[::7] = V[1]                                        # exact ties across item ranges
+        ptr = np.arange(0, (n_rows + 1) * 20, 20, dtype=np.int64)
+        cols = rng.integers(0, n_cols, n_rows * 20).astype(np.int32)
+        mask, pitch = hip.build_rated_mask(_dev(ptr), _dev(cols), n_rows, n_cols)
+        a = hip.score_topk(_dev(U), _dev(V), 30, mask=mask, mask_pitch=pitch, want_scores=True, split=True)
+        b = hip.score_topk(_dev(U), _dev(V), 30, mask=mask, mask_pitch=pitch, want_scores=True, split=False)
+        torch.cuda.synchronize()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_user_idx_gather(hip):
     rng = np.random.Generator(np.random.PCG64(2))
     U, V = _exact(rng, 500, 32, 16), _exact(rng, 700, 32, 16)

@@ -137,7 +137,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.tkr_version() == 100
     assert lib.tkr_plan_max_blocks(256) == 48 + 153
     # argument validation happens before any device access
-    assert lib.tkr_score_topk(None, None, 0, None, None, 0, 0, None, 0, 0, None, None, None) == -1
+    assert lib.tkr_score_topk(None, None, 0, None, None, 0, 0, None, 0, 0, None, None, None, 0, None) == -1
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

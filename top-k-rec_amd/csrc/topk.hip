@@ -21,6 +21,8 @@
 //
 // Roofline: fp32 MFMA, 2*k*n_items flop per user; HBM traffic per user ~ 4k B factors + 8K B
 // out + 4*n_items/32 B mask words -- three orders of magnitude below the flop ratio.
+#include <algorithm>
+
 #include "tkr_common.h"
 #include "../../include/tkr.h"
 
@@ -171,7 +173,8 @@ template <int KHP, typename IdT>
 __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_topk_kernel(
     const float* __restrict__ U, const int32_t* __restrict__ uidx, int n_rows, const float* __restrict__ Vt,
     const float* __restrict__ bias, int n_cols, int k, const uint32_t* __restrict__ mask, int mask_pitch, int K,
-    int32_t* __restrict__ out_ids, float* __restrict__ out_scores) {
+    int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int tiles_per_split,
+    uint64_t* __restrict__ part /*[n_rows][gridDim.y][K] sorted keys, when gridDim.y > 1*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int KP = 2 * KHP + 4;                              // padded LDS row (floats): conflict-free b128 reads
     const int W = blockDim.x >> 6;
@@ -204,7 +207,9 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
     }
     for (int s = tid; s < users; s += blockDim.x) sm.cnt[s] = 0;
     float thr = -INFINITY;
-    const int n_tiles = (n_cols + 31) >> 5;
+    const int n_tiles_all = (n_cols + 31) >> 5;
+    const int t_begin = blockIdx.y * tiles_per_split;           // this workgroup ranks items of tiles [t_begin, n_tiles)
+    const int n_tiles = min(n_tiles_all, t_begin + tiles_per_split);
 
     // ---- tile staging: global -> registers (issued early) -> LDS (written after the MFMA chain) ------
     // float4 path when every k-half starts 16-B aligned (k % 8 == 0); scalar path otherwise.
@@ -261,14 +266,14 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
         for (int c = tid; c < 2 * 32 * KP; c += nthreads) sm.tile[c] = 0.f;
         __syncthreads();
     }
-    stage_load(0);
-    stage_store(0, 0);
+    stage_load(t_begin);
+    stage_store(t_begin, t_begin & 1);
     __syncthreads();
-    if (n_tiles > 1) stage_load(1);
+    if (t_begin + 1 < n_tiles) stage_load(t_begin + 1);
 
     const uint32_t tail_mask = (n_cols & 31) ? (0xffffffffu << (n_cols & 31)) : 0u;
-    int next_sched = 2;                                          // scheduled trims at tiles 2, 3, 5, 8, 12, ... (x1.5)
-    for (int t = 0; t < n_tiles; ++t) {
+    int next_sched = t_begin + 2;                                // scheduled trims after 2, 3, 5, 8, 12, ... tiles (x1.5)
+    for (int t = t_begin; t < n_tiles; ++t) {
         const int buf = t & 1;
         // rated / non-existent columns of this (user, tile) as one word; issued before the MFMA chain
         uint32_t maskw = (mask && user_ok) ? mask[(size_t)t * mask_pitch + row] : 0u;
@@ -288,7 +293,7 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
         if (t + 2 < n_tiles) stage_load(t + 2);
         // ---- epilogue: bias, mask, threshold filter ----------------------------------------------
         if (!user_ok) maskw = 0xffffffffu;
-        if (t == n_tiles - 1) maskw |= tail_mask;
+        if (t == n_tiles_all - 1) maskw |= tail_mask;
         const uint32_t mh = maskw >> (4 * h);                    // bit (r&3)+8*(r>>2) <-> accumulator register r
         float sc[16];
 #pragma unroll
@@ -301,7 +306,7 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
         }
         if (t == next_sched) {                                   // workgroup-uniform: every wave trims all its users now
             thr = trim_all_users<IdT>(sm, uw, h, K, thr);
-            next_sched = t + ((t + 1) >> 1);
+            next_sched = t + ((t - t_begin + 1) >> 1);
         }
         uint32_t ok = 0;                                         // bit r: column exists, user exists, not rated
 #pragma unroll
@@ -343,6 +348,10 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
         uint64_t key;
         const int n = sm.cnt[wave * 32 + u];
         trim_user<IdT>(sm, wave * 32 + u, K, lane, &key);
+        if (gridDim.y > 1) {                                     // partial list of this item range; merged later
+            if (lane < K) part[((size_t)r * gridDim.y + blockIdx.y) * K + lane] = (lane < n) ? key : 0ull;
+            continue;
+        }
         if (lane < K) {
             const bool have = lane < n;
             const uint32_t ob = (uint32_t)(key >> 32);
@@ -351,6 +360,44 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
             if (out_scores) out_scores[(size_t)r * K + lane] = have ? __uint_as_float(f) : -INFINITY;
         }
     }
+}
+
+// ---- merge of the per-item-range partial lists: one wave per row ----------------------------------
+__global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t* __restrict__ part, int n_rows, int S, int K,
+                                                        int32_t* __restrict__ out_ids, float* __restrict__ out_scores) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const uint64_t* p = part + (size_t)r * S * K;
+    uint64_t key = (lane < K) ? p[lane] : 0ull;                  // best K so far in lanes 0..K-1 (K <= 32)
+    for (int s = 1; s < S; ++s) {
+        const uint64_t in = (lane >= 32 && lane - 32 < K) ? p[(size_t)s * K + lane - 32] : 0ull;
+        key = wave_sort_desc(lane < 32 ? (lane < K ? key : 0ull) : in, lane);
+    }
+    if (lane < K) {
+        const bool have = key != 0ull;
+        const uint32_t ob = (uint32_t)(key >> 32);
+        const uint32_t f = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+        out_ids[(size_t)r * K + lane] = have ? (int32_t)((uint32_t)key - 1u) : -1;
+        if (out_scores) out_scores[(size_t)r * K + lane] = have ? __uint_as_float(f) : -INFINITY;
+    }
+}
+
+// item-range splits: fill the CUs in whole rounds.  cost ~ rounds x (tiles per split + fixed per-workgroup work);
+// the fixed part is large (measured ~40 tile-times: every split re-pays the low-threshold early phase), so a
+// split only pays when it removes a mostly-empty last round
+static int pick_splits(int n_rows, int users_per_wg, int n_tiles, int max_splits) {
+    const int wgs = (n_rows + users_per_wg - 1) / users_per_wg;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= max_splits && s <= n_tiles; ++s) {
+        const int tps = (n_tiles + s - 1) / s;
+        const int used = (n_tiles + tps - 1) / tps;              // splits that actually get tiles
+        const double rounds = (double)(((size_t)wgs * used + 255) / 256);
+        const double cost = rounds * (tps + 40.0) * (used > 1 ? 1.03 : 1.0);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = used; }
+    }
+    return best;
 }
 
 // ---- rated-item bitmask: mask[(col>>5)*pitch + row] bit (col&31) --------------------------------
@@ -388,7 +435,7 @@ __global__ void count_hits_kernel(const int32_t* __restrict__ ids, int n_rows, i
 template <int KHP, typename IdT>
 static int launch_topk(int W, const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias,
                        int n_cols, int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
-                       hipStream_t stream) {
+                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
     constexpr int KP = 2 * KHP + 4;
     const int users = W * 32;
     const size_t lds = (size_t)(2 * 32 * KP + 64) * 4 + (size_t)users * 4 + (size_t)users * kCap * (4 + sizeof(IdT));
@@ -398,20 +445,29 @@ static int launch_topk(int W, const float* U, const int32_t* uidx, int n_rows, c
                                        160 * 1024);
     if (e != hipSuccess) return (int)e;
     const int grid = (n_rows + users - 1) / users;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,
-                       out_ids, out_scores);
+    const int n_tiles = (n_cols + 31) / 32;
+    const size_t per_split = (size_t)n_rows * K * sizeof(uint64_t);
+    const int max_splits = workspace ? (int)std::min<size_t>(16, workspace_bytes / (per_split ? per_split : 1)) : 1;
+    int S = pick_splits(n_rows, users, n_tiles, max_splits < 1 ? 1 : max_splits);
+    const int tps = (n_tiles + S - 1) / S;
+    S = (n_tiles + tps - 1) / tps;
+    hipLaunchKernelGGL(kern, dim3(grid, S), dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,
+                       out_ids, out_scores, tps, reinterpret_cast<uint64_t*>(workspace));
+    if (S > 1)
+        hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream,
+                           reinterpret_cast<const uint64_t*>(workspace), n_rows, S, K, out_ids, out_scores);
     return (int)hipGetLastError();
 }
 
 template <typename IdT>
 static int dispatch_topk(const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias, int n_cols,
                          int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
-                         hipStream_t stream) {
+                         void* workspace, size_t workspace_bytes, hipStream_t stream) {
     const int kh = (k + 1) / 2;
 #define TKR_TOPK_CASE(KHP)                                                                                   \
     if (kh <= KHP)                                                                                           \
         return launch_topk<KHP, IdT>(topk_waves<KHP, IdT>(), U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, \
-                                     out_ids, out_scores, stream);
+                                     out_ids, out_scores, workspace, workspace_bytes, stream);
     TKR_TOPK_CASE(16)
     TKR_TOPK_CASE(28)
     TKR_TOPK_CASE(32)
@@ -434,17 +490,23 @@ extern "C" int tkr_build_rated_mask(const int64_t* rated_ptr, const int32_t* rat
     return TKR_OK;
 }
 
+extern "C" int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K) {
+    return (int64_t)16 * n_rows * K * (int64_t)sizeof(uint64_t);      // up to 16 item-range splits
+}
+
 extern "C" int tkr_score_topk(const float* U, const int32_t* user_idx, int32_t n_rows, const float* Vt,
                               const float* bias, int32_t n_cols, int32_t k, const uint32_t* mask, int32_t mask_pitch,
-                              int32_t K, int32_t* out_ids, float* out_scores, void* stream) {
+                              int32_t K, int32_t* out_ids, float* out_scores, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
     if (!U || !Vt || !out_ids || n_rows <= 0 || n_cols <= 0 || k <= 0 || K <= 0) return TKR_EINVAL;
     if (mask && mask_pitch < n_rows) return TKR_EINVAL;
     if (K > tkr::kMaxK || k > 256) return TKR_EUNSUPPORTED;
     if (n_cols <= 65535)
         return tkr::dispatch_topk<uint16_t>(U, user_idx, n_rows, Vt, bias, n_cols, k, mask, mask_pitch, K, out_ids,
-                                            out_scores, (hipStream_t)stream);
+                                            out_scores, workspace, (size_t)(workspace_bytes > 0 ? workspace_bytes : 0),
+                                            (hipStream_t)stream);
     return tkr::dispatch_topk<uint32_t>(U, user_idx, n_rows, Vt, bias, n_cols, k, mask, mask_pitch, K, out_ids, out_scores,
-                                        (hipStream_t)stream);
+                                        workspace, (size_t)(workspace_bytes > 0 ? workspace_bytes : 0), (hipStream_t)stream);
 }
 
 extern "C" int tkr_count_hits(const int32_t* ids, int32_t n_rows, int32_t K, const int64_t* like_ptr,

@@ -39,7 +39,7 @@ class VbprState(C.Structure):
 
 EXPORTS = ('tkr_version', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_bpr_run',
            'tkr_vbpr_run', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy')
-EXPORTS_I64 = ('tkr_vbpr_workspace_floats',)
+EXPORTS_I64 = ('tkr_vbpr_workspace_floats', 'tkr_topk_workspace_bytes')
 
 
 def lib():
@@ -130,15 +130,29 @@ def build_rated_mask(rated_ptr, rated_cols, n_rows, n_cols):
     return mask, pitch
 
 
-def score_topk(U, Vt, K, bias=None, user_idx=None, mask=None, mask_pitch=0, want_scores=False):
+_topk_ws = {}
+
+
+def _topk_workspace(n_rows, K, device):
+    """cached scratch for the item-range split (grows on demand, per device)"""
+    need = int(lib().tkr_topk_workspace_bytes(C.c_int32(n_rows), C.c_int32(K)))
+    ws = _topk_ws.get(device)
+    if ws is None or ws.numel() < need:
+        ws = _topk_ws[device] = torch.empty(need, dtype=torch.uint8, device=device)
+    return ws
+
+
+def score_topk(U, Vt, K, bias=None, user_idx=None, mask=None, mask_pitch=0, want_scores=False, split=True):
     """-> ids int32 [n_rows, K] (and scores fp32 [n_rows, K])"""
     assert U.dtype == torch.float32 and Vt.dtype == torch.float32 and U.shape[1] == Vt.shape[1]
     n_rows = int(user_idx.numel()) if user_idx is not None else int(U.shape[0])
     ids = torch.empty((n_rows, K), dtype=torch.int32, device=U.device)
     scores = torch.empty((n_rows, K), dtype=torch.float32, device=U.device) if want_scores else None
+    ws = _topk_workspace(n_rows, K, U.device) if split else None
     _check(lib().tkr_score_topk(_p(U), _p(user_idx), C.c_int32(n_rows), _p(Vt), _p(bias), C.c_int32(Vt.shape[0]),
                                 C.c_int32(U.shape[1]), _p(mask), C.c_int32(mask_pitch), C.c_int32(K), _p(ids),
-                                _p(scores), _stream()), 'tkr_score_topk')
+                                _p(scores), _p(ws), C.c_int64(ws.numel() if ws is not None else 0), _stream()),
+           'tkr_score_topk')
     return (ids, scores) if want_scores else ids
 
 
