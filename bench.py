@@ -69,10 +69,10 @@ def build_problem(shape, k, rank, world, device, seed=42):
     return r, csr, eng, int(row_ptr[-1])
 
 
-def timed_run(eng, csr, B, steps, warmup, sync_every, world):
+def timed_run(eng, csr, B, steps, warmup, sync_every, world, names=None):
     """warmup untimed, then exactly `steps` batches between barriers; returns (wall_s, step_kernel_ms)"""
     import dist as tdist
-    isync = tdist.ItemSync(eng)
+    isync = tdist.ItemSync(eng, names)
 
     def run(n):
         done = 0
@@ -183,6 +183,63 @@ def topk_bench(r, k, device, rank, world, K=30, reps=5):
                          'algorithmic_flops_per_launch': flops}}
 
 
+def topk_bench_netflix(k, device, K=30, reps=3):
+    """BASELINE.json configs[4] shape on ONE GPU: 480,189 users x 17,770 items, every user with 150 random
+    train-rated items masked (the synthetic Netflix-size rating file is not generated for this leg)"""
+    import tkr_hip
+    n_users, n_items, deg = 480189, 17770, 150
+    g = torch.Generator(device=device)
+    g.manual_seed(11)
+    U = (torch.randn((n_users, k), device=device, generator=g) * 0.01 * 1e6).round() / 1e6
+    V = (torch.randn((n_items, k), device=device, generator=g) * 0.01 * 1e6).round() / 1e6
+    ptr = torch.arange(0, (n_users + 1) * deg, deg, dtype=torch.int64, device=device)
+    cols = torch.randint(0, n_items, (n_users * deg,), device=device, generator=g, dtype=torch.int32)
+    mask, pitch = tkr_hip.build_rated_mask(ptr, cols, n_users, n_items)
+    tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * k * n_items * n_users
+    tf = flops / (ms * 1e-3) / 1e12
+    return {'value': n_users * reps / wall, 'unit': 'users/s', 'ms_per_pass': wall * 1e3 / reps,
+            'config': {'workload': '%d users x %d items, k=%d, top-%d, %d rated items per user masked' % (n_users, n_items, k, K, deg)},
+            'roofline': {'kernel': 'tkr::score_topk_kernel', 'bound': 'mfma', 'achieved': tf, 'peak': MFMA_F32_PEAK_TF,
+                         'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TF, 'launch_ms': ms}}
+
+
+def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
+    """BASELINE.json configs[2]: VBPR, ML-10M shape, dense content features d=20,000 (train.py:11), ~100 nnz/row"""
+    import synth
+    from single import _engine
+    n_users, n_items = r['n_users'], r['n_in'] + r['n_out']
+    g = torch.Generator(device=device)
+    g.manual_seed(7)
+    feat = torch.zeros((n_items, d), device=device)                      # tf-idf-like: ~100 positive entries per row, L2-normalised
+    cols = torch.randint(0, d, (n_items, 100), device=device, generator=g)
+    feat.scatter_(1, cols, torch.rand((n_items, 100), device=device, generator=g) + 0.1)
+    feat /= feat.norm(dim=1, keepdim=True)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, le=0.0, lr=1e-4, mode='l2')
+    eng = _engine.VbprEngine(n_users, n_items, k, d, feat, hp, device, seed=3)
+    wall, step_ms = timed_run(eng, csr, B, steps, warmup, 10 ** 9, 1, names=eng.replicated_names)
+    kh = k // 2
+    flops = 4.0 * d * kh * B                                               # SURVEY §8d: project the difference once, fwd + dense gradient
+    tf = flops / (step_ms * 1e-3 / steps) / 1e12
+    bytes_ = B * 2 * 4 * d * 2 + 16.0 * d * kh                             # feature rows (V1 + V3) + dense optimizer traffic
+    gbs = bytes_ / (step_ms * 1e-3 / steps) / 1e9
+    return {'value': steps * B / wall, 'unit': 'triplets/s', 'steps': steps, 'ms_per_step': wall * 1e3 / steps,
+            'config': {'workload': 'VBPR ML-10M shape, k=%d (kh=%d), dense features d=%d, batch_size=%d' % (k, kh, d, B)},
+            'roofline': {'kernels': 'tkr::vbpr_project/occur/rows/dense (4 launches per batch)', 'bound': 'mfma', 'achieved': tf,
+                         'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TF,
+                         'hbm_GBps_algorithmic': gbs, 'hbm_frac': gbs / HBM_PEAK_GBS, 'step_us': step_ms * 1e3 / steps}}
+
+
 def topk_cpu_baseline(r, k, K=30, budget_s=12.0, slice_users=2000):
     """evaluate.py's operations on user slices until the time budget is spent:
     np.dot -> np.argsort -> python rank walk (oracle restatement of evaluate.py:78-105)"""
@@ -277,6 +334,9 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             topk['cpu_baseline'] = topk_cpu_baseline(r, k)
         out['topk'] = topk
+        if rank == 0 and world == 1:
+            out['topk_netflix_shape'] = topk_bench_netflix(k, device)
+            out['vbpr'] = vbpr_bench(r, csr, k, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(r, k, B)
     if rank == 0:

@@ -1,0 +1,25 @@
+"""dev probe: K3 (VBPR) per-kernel timing at ML-10M shape, dense d=20000."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'top-k-rec_amd')]
+import numpy as np, torch, synth, tkr_hip
+from single import _engine
+k, d, B, nb = 128, int(os.environ.get('D', 20000)), int(os.environ.get('B', 256)), 64
+r = synth.make_ratings(**synth.ML10M, seed=42)
+row_ptr, pos, srt, tr_users = synth.positives_csr(r)
+dev = torch.device('cuda', 0)
+n_users, n_items = r['n_users'], r['n_in'] + r['n_out']
+csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, tr_users, dev)
+g = torch.Generator(device=dev); g.manual_seed(7)
+feat = torch.zeros((n_items, d), device=dev)
+cols = torch.randint(0, d, (n_items, 100), device=dev, generator=g)
+feat.scatter_(1, cols, torch.rand((n_items, 100), device=dev, generator=g) + 0.1)
+feat /= feat.norm(dim=1, keepdim=True)
+hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, le=0.0, lr=1e-4, mode='l2')
+eng = _engine.VbprEngine(n_users, n_items, k, d, feat, hp, dev, seed=3)
+eng.run_batches(csr, nb, B, want_loss=False)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+eng.run_batches(csr, nb, B, want_loss=False)
+torch.cuda.synchronize()
+print('B=%d d=%d: %.1f us/batch' % (B, d, (time.perf_counter() - t0) / nb * 1e6))
