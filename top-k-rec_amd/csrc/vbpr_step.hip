@@ -9,10 +9,11 @@
 // iceb/jceb enter the reference only through x_ui - x_uj and are not regularised, so projecting the
 // DIFFERENCE once is exact in real arithmetic and halves the contraction.
 //
-// Four launches per batch, all on pre-step values:
+// Five launches per batch, all on pre-step values:
 //   V1  project   P_t = (f_i - f_j).cem, q_t = (f_i - f_j).icb      fp32 MFMA, split over d (K)
-//   V1b occur     per user occurrence: reduce the split-K partials, x_t, s_t = sigma(-x_t),
-//                 W_t = -s_t * uce_u, loss                          (plan of K1: parities inline)
+//   V1r reduce    P_t, q_t = sum of the split-K partials (slice-parallel, fixed order)
+//   V1b occur     per user occurrence: x_t, s_t = sigma(-x_t), W_t = -s_t * uce_u, loss
+//                                                                   (plan of K1: parities inline)
 //   V2  rows      sparse RMSProp on [ure|uce] rows, ire rows, irb   (same launch records as K2,
 //                 gradients use the stored s_t, P_t -- nothing is recomputed)
 //   V3  dense     G_cem = D^T.W + le*cem, G_icb = D^T.(-s) + lb*icb  fp32 MFMA over the batch,
@@ -31,7 +32,7 @@ namespace tkr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kVTeam = 16;                       // waves per workgroup of the record-driven kernels
-constexpr int kSlice = 256;                      // d-columns per split-K slice of V1
+constexpr int kSlice = 128;                      // d-columns per split-K slice of V1 (64 per MFMA k-slot)
 constexpr int kIdMaskV = 0x3fffffff;
 
 __host__ __device__ inline int vbpr_slices(int d) { return (d + kSlice - 1) / kSlice; }
@@ -55,31 +56,43 @@ __global__ __launch_bounds__(64) void vbpr_project_kernel(tkr_vbpr_state st, con
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float q = 0.f;
-    for (int kk = 0; kk < kSlice / 2; kk += 4) {
+    constexpr int CH = 16;                                       // columns per batch: all loads first, then the MFMAs
+    for (int kk = 0; kk < kSlice / 2; kk += CH) {
         const int c = base + kk;
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        float a[CH], w[CH], bop[CH][NT];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) a[e] = 0.f;
         if (tv) {
-            if (vec && c + 3 < d) {
-                const float4 x = *reinterpret_cast<const float4*>(fi + c);
-                const float4 y = *reinterpret_cast<const float4*>(fj + c);
-                a[0] = x.x - y.x; a[1] = x.y - y.y; a[2] = x.z - y.z; a[3] = x.w - y.w;
+            if (vec && c + CH - 1 < d) {
+#pragma unroll
+                for (int g = 0; g < CH / 4; ++g) {
+                    const float4 x = *reinterpret_cast<const float4*>(fi + c + 4 * g);
+                    const float4 y = *reinterpret_cast<const float4*>(fj + c + 4 * g);
+                    a[4 * g + 0] = x.x - y.x; a[4 * g + 1] = x.y - y.y; a[4 * g + 2] = x.z - y.z; a[4 * g + 3] = x.w - y.w;
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < CH; ++e)
                     if (c + e < d) a[e] = fi[c + e] - fj[c + e];
             }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < CH; ++e) {
             const int ce = c + e;
             const bool cv = ce < d;
-            q = fmaf(a[e], cv ? st.icb[ce] : 0.f, q);
+            w[e] = cv ? st.icb[ce] : 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = nt * 32 + m;
-                const float b = (cv && n < kh) ? st.cem[(size_t)ce * kh + n] : 0.f;
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b, acc[nt], 0, 0, 0);
+                bop[e][nt] = (cv && n < kh) ? st.cem[(size_t)ce * kh + n] : 0.f;
             }
+        }
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            q = fmaf(a[e], w[e], q);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], bop[e][nt], acc[nt], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -92,6 +105,31 @@ __global__ __launch_bounds__(64) void vbpr_project_kernel(tkr_vbpr_state st, con
     }
     q += __shfl_xor(q, 32, 64);
     if (h == 0 && tv) ppart[((size_t)s * B + t) * NP + kh] = q;
+}
+
+// ------------------------------------------------------------------------------------------------
+// V1r: P[t][n] = sum_s Ppart[s][t][n] (n < kh), Q[t] = sum_s Ppart[s][t][kh].  One workgroup per triplet:
+// 4 slice groups x 64 columns, every thread sums its slices in ascending order, groups combined in order.
+__global__ __launch_bounds__(256) void vbpr_reduce_kernel(const float* __restrict__ ppart, int S, int B, int kh,
+                                                         float* __restrict__ P, float* __restrict__ Q) {
+    __shared__ float red[4][129];
+    const int t = blockIdx.x, sg = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int NP = kh + 1;
+    for (int n0 = 0; n0 < NP; n0 += 64) {
+        const int n = n0 + ln;
+        float a = 0.f;
+        if (n < NP) {
+#pragma unroll 8
+            for (int s = sg; s < S; s += 4) a += ppart[((size_t)s * B + t) * NP + n];
+        }
+        red[sg][ln] = a;
+        __syncthreads();
+        if (sg == 0 && n < NP) {
+            const float v = ((red[0][ln] + red[1][ln]) + red[2][ln]) + red[3][ln];
+            if (n < kh) P[(size_t)t * kh + n] = v; else Q[t] = v;
+        }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -136,11 +174,11 @@ __device__ __forceinline__ void next_occ(const WaveRec& r, int done, int n, int 
 template <int NH>
 __global__ __launch_bounds__(kVTeam * TKR_WAVE) void vbpr_occur_kernel(
     tkr_vbpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
-    const int32_t* __restrict__ occt, const int4* __restrict__ hdr, int B, const float* __restrict__ ppart,
-    float* __restrict__ s_out, float* __restrict__ P, float* __restrict__ Wm, float* __restrict__ loss_out) {
+    const int32_t* __restrict__ occt, const int4* __restrict__ hdr, int B, const float* __restrict__ Q,
+    float* __restrict__ s_out, const float* __restrict__ P, float* __restrict__ Wm, float* __restrict__ loss_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_blocks = __builtin_amdgcn_readfirstlane((*hdr).x);
-    const int kh = st.kh, k2 = 2 * kh, NP = kh + 1, S = vbpr_slices(st.d);
+    const int kh = st.kh, k2 = 2 * kh;
     const size_t ustride = (size_t)st.n_users * k2, istride = (size_t)st.n_items * kh;
     const bool l2 = st.mode == 0;
     for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
@@ -165,17 +203,11 @@ __global__ __launch_bounds__(kVTeam * TKR_WAVE) void vbpr_occur_kernel(
                 const int j = ob[q] & kIdMaskV, pj = (ob[q] >> 30) & 1;
                 const int t = ot[q];
                 float p[NH], vi[NH], vj[NH];
-                float qsum = 0.f;
+                const float qsum = Q[t];
 #pragma unroll
-                for (int e = 0; e < NH; ++e) p[e] = 0.f;
-                for (int s = 0; s < S; ++s) {                      // reduce the split-K partials in slice order
-                    const float* pp = ppart + ((size_t)s * B + t) * NP;
-#pragma unroll
-                    for (int e = 0; e < NH; ++e) {
-                        const int c = lane + e * 64;
-                        if (c < kh) p[e] += pp[c];
-                    }
-                    qsum += pp[kh];
+                for (int e = 0; e < NH; ++e) {
+                    const int c = lane + e * 64;
+                    p[e] = c < kh ? P[(size_t)t * kh + c] : 0.f;
                 }
                 const float* ri = st.I + pi * istride + (size_t)i * kh;
                 const float* rj = st.I + pj * istride + (size_t)j * kh;
@@ -206,7 +238,7 @@ __global__ __launch_bounds__(kVTeam * TKR_WAVE) void vbpr_occur_kernel(
 #pragma unroll
                 for (int e = 0; e < NH; ++e) {
                     const int c = lane + e * 64;
-                    if (c < kh) { P[(size_t)t * kh + c] = p[e]; Wm[(size_t)t * kh + c] = -sg * uce[e]; }
+                    if (c < kh) Wm[(size_t)t * kh + c] = -sg * uce[e];
                 }
                 if (lane == 0) s_out[t] = sg;
             }
@@ -346,31 +378,54 @@ __global__ __launch_bounds__(256) void vbpr_dense_kernel(tkr_vbpr_state st, cons
         for (int nt = 0; nt < NT; ++nt) acc[q][nt] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float gi0 = 0.f, gi1 = 0.f;
     const bool pair = ((d & 1) == 0) && (cA + 1 < d);
-    for (int kk = 0; kk < TH; ++kk) {
-        const int t = wave * TB + h * TH + kk;
-        float a0 = 0.f, a1 = 0.f, sg = 0.f;
-        const bool tv = t < B;
-        if (tv) {
-            const float* fi = st.feat + (size_t)ti[t] * d;
-            const float* fj = st.feat + (size_t)tj[t] * d;
-            if (pair) {
-                const float2 x = *reinterpret_cast<const float2*>(fi + cA);
-                const float2 y = *reinterpret_cast<const float2*>(fj + cA);
-                a0 = x.x - y.x; a1 = x.y - y.y;
-            } else {
-                if (cA < d) a0 = fi[cA] - fj[cA];
-                if (cA + 1 < d) a1 = fi[cA + 1] - fj[cA + 1];
-            }
-            sg = s_in[t];
-        }
-        gi0 = fmaf(-sg, a0, gi0);
-        gi1 = fmaf(-sg, a1, gi1);
+    constexpr int UN = 8;                                        // triplets per batch of loads
+    for (int k0 = 0; k0 < TH; k0 += 32) {
+        // this half's next 32 triplet ids / s_t, one per lane, then broadcast inside the half
+        const int tl = wave * TB + h * TH + k0 + m;
+        const bool lv = (k0 + m < TH) && (tl < B);
+        const int my_i = lv ? ti[tl] : 0, my_j = lv ? tj[tl] : 0;
+        const float my_s = lv ? s_in[tl] : 0.f;
+        const int lim = min(32, TH - k0);
+        for (int kb = 0; kb < lim; kb += UN) {
+            float a0[UN], a1[UN], sg[UN], bw[UN][NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = nt * 32 + m;
-            const float b = (tv && n < kh) ? Wm[(size_t)t * kh + n] : 0.f;
-            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][nt], 0, 0, 0);
-            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][nt], 0, 0, 0);
+            for (int e = 0; e < UN; ++e) {
+                const int src = (lane & 32) | ((kb + e) & 31);
+                const int it = __shfl(my_i, src, 64), jt = __shfl(my_j, src, 64);
+                sg[e] = __shfl(my_s, src, 64);
+                const int t = wave * TB + h * TH + k0 + kb + e;
+                const bool tv = (kb + e < lim) && (t < B);
+                a0[e] = 0.f; a1[e] = 0.f;
+                if (tv) {
+                    const float* fi = st.feat + (size_t)it * d;
+                    const float* fj = st.feat + (size_t)jt * d;
+                    if (pair) {
+                        const float2 x = *reinterpret_cast<const float2*>(fi + cA);
+                        const float2 y = *reinterpret_cast<const float2*>(fj + cA);
+                        a0[e] = x.x - y.x; a1[e] = x.y - y.y;
+                    } else {
+                        if (cA < d) a0[e] = fi[cA] - fj[cA];
+                        if (cA + 1 < d) a1[e] = fi[cA + 1] - fj[cA + 1];
+                    }
+                } else {
+                    sg[e] = 0.f;
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = nt * 32 + m;
+                    bw[e][nt] = (tv && n < kh) ? Wm[(size_t)t * kh + n] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < UN; ++e) {
+                gi0 = fmaf(-sg[e], a0[e], gi0);
+                gi1 = fmaf(-sg[e], a1[e], gi1);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bw[e][nt], acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bw[e][nt], acc[1][nt], 0, 0, 0);
+                }
+            }
         }
     }
     // C layout: column = lane&31 (n), row = (r&3)+8*(r>>2)+4*h = m-index -> feature column c0 + 2*row + q
@@ -436,12 +491,14 @@ static int launch_vbpr(const tkr_vbpr_state& st, const int32_t* ti, const int32_
     float* s_buf = ppart + (size_t)S * B * (kh + 1);
     float* P = s_buf + B;
     float* Wm = P + (size_t)B * kh;
+    float* Q = Wm + (size_t)B * kh;
     const int2* occ2 = reinterpret_cast<const int2*>(occ);
     const int4* hdr4 = reinterpret_cast<const int4*>(hdr);
     hipLaunchKernelGGL(vbpr_project_kernel<NT>, dim3(S, (B + 31) / 32), dim3(64), 0, stream, st, ti, tj, B, ppart);
+    hipLaunchKernelGGL(vbpr_reduce_kernel, dim3(B), dim3(256), 0, stream, ppart, S, B, kh, P, Q);
     const int NH = (kh + 63) / 64, NE = (2 * kh + 63) / 64;
-    if (NH == 1) hipLaunchKernelGGL(vbpr_occur_kernel<1>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, B, ppart, s_buf, P, Wm, loss);
-    else hipLaunchKernelGGL(vbpr_occur_kernel<2>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, B, ppart, s_buf, P, Wm, loss);
+    if (NH == 1) hipLaunchKernelGGL(vbpr_occur_kernel<1>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
+    else hipLaunchKernelGGL(vbpr_occur_kernel<2>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
     switch (NE) {
         case 1: hipLaunchKernelGGL(vbpr_rows_kernel<1>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
         case 2: hipLaunchKernelGGL(vbpr_rows_kernel<2>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
@@ -464,7 +521,7 @@ extern "C" int tkr_plan_max_blocks(int32_t batch_size);
 
 extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d) {
     const int64_t S = tkr::vbpr_slices(d);
-    return S * batch_size * (kh + 1) + batch_size + 2ll * batch_size * kh;
+    return S * batch_size * (kh + 1) + 2ll * batch_size + 2ll * batch_size * kh;
 }
 
 extern "C" int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* tri_j, const int32_t* rec,
