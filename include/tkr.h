@@ -44,11 +44,12 @@ int tkr_version(void);
  *   task                     [n_batches][3B][4]  (row | kind<<31, occ_start, occ_count, parity); -1 = unused
  *   occ                      [n_batches][3B][2]  user occurrence: (i, j); item occurrence: (u, other|role<<31);
  *                            bit 30 of every id = parity of that row
- *   rec                      [n_batches][tkr_plan_max_blocks(B)*16][16]  per-wave launch records
- *   hdr                      [n_batches][4]  (workgroups used, light tasks, heavy tasks, tasks)
+ *   rec                      [n_batches][tkr_plan_max_blocks(B)*tkr_plan_team(B)][16]  per-wave launch records
+ *   hdr                      [n_batches][4]  (workgroups used, light workgroups, heavy tasks, tasks)
  *   occt                     [n_batches][3B] triplet index t of every sorted occurrence (used by K3)
  * batch_size <= 8192, n_batches <= 512, ids < 2^30.  Output is bit-exact against oracle/plan_np.py. */
-int tkr_plan_max_blocks(int32_t batch_size);
+int tkr_plan_team(int32_t batch_size);        /* waves per step workgroup / heavy-row team: 4 (B <= 1024) or 16 */
+int tkr_plan_max_blocks(int32_t batch_size);  /* workgroups a batch can need */
 int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,
                     const int32_t* cols_sorted, int32_t n_users, int32_t n_items, uint64_t seed,
                     uint64_t first_triplet, const int64_t* ctl, int32_t n_batches, int32_t batch_size,

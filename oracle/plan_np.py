@@ -35,14 +35,16 @@ Plan definition (per batch of B triplets, consumed by the step kernels):
                      task's own row and in bit 30 of every occ id for the partner rows.
 Launch plan (what the step kernel actually reads; derived from the above):
   a task with <= LIGHT_MAX occurrences is LIGHT (one wave), otherwise HEAVY (a team of TEAM
-  waves = one workgroup, wave w takes occurrences w, w+TEAM, ...).  Workgroups hold TEAM wave
+  waves = one workgroup, wave w takes occurrences w, w+TEAM, ...; TEAM = team_for(B): 4 up to
+  B = 1024, 16 above).  Workgroups hold TEAM wave
   records; light tasks fill workgroups 0..nlb-1 in task order, heavy task h is workgroup nlb+h.
   wave record = 16 int32: [0] row|kind<<31 (-1 = idle)  [1] parity | team<<8 | rank<<16
                           [2] occurrences of this wave   [3] index of its first occurrence
                           [4..11] its first <=4 occurrences (a,b)   [12] task occ_count
                           [13] t0 | t1<<16  [14] t2 | t3<<16  (triplet index of those occurrences)  [15] 0
   occt[3B]           triplet index t of every sorted occurrence (VBPR reads per-triplet results)
-  header per batch = (workgroups used, light tasks, heavy tasks, tasks).
+  header per batch = (workgroups used, light workgroups, heavy tasks, tasks); light workgroups hold
+  light_per_block(B) tasks each, remaining wave slots are idle (-1).
 """
 from __future__ import annotations
 
@@ -52,7 +54,19 @@ U32 = np.uint32
 U64 = np.uint64
 MAX_ROUNDS = 64
 LIGHT_MAX = 4          # occurrences a single wave handles (csrc/sampler.hip kLightMax)
-TEAM = 16              # waves per workgroup / per heavy task (csrc/bpr_step.hip)
+TEAM = 16              # waves per workgroup / per heavy task for batches > TEAM_SMALL_MAX_B
+TEAM_SMALL = 4         # ... and for small batches: 4-wave workgroups spread a 256-batch over ~180 CUs
+TEAM_SMALL_MAX_B = 1024
+
+
+def light_per_block(B):
+    """light tasks packed into one workgroup (= every wave slot; half-filled groups were measured slower)"""
+    return team_for(B)
+
+
+def team_for(B):
+    """tkr_plan_team: waves per workgroup (= per heavy-row team) of the step kernels"""
+    return TEAM_SMALL if B <= TEAM_SMALL_MAX_B else TEAM
 PAR_BIT = 1 << 30
 
 _M0, _M1 = U64(0xD2511F53), U64(0xCD9E8D57)
@@ -189,7 +203,8 @@ def plan_batch(u, i, j, return_t=False):
 
 def max_blocks(B):
     """workgroups a batch can need: light tasks 16 per group + heavy tasks (>= 5 occurrences each)"""
-    return (3 * B + TEAM - 1) // TEAM + (3 * B) // (LIGHT_MAX + 1)
+    lpb = light_per_block(B)
+    return (3 * B + lpb - 1) // lpb + (3 * B) // (LIGHT_MAX + 1)
 
 
 def resolve_parity(task, occ, B, ucnt, icnt):
@@ -220,14 +235,17 @@ def _pack_t(ts):
 def launch_plan(task, occ, B, occt=None):
     """wave records + header of one batch (see module docstring)."""
     occt = np.zeros(3 * B, dtype=np.int32) if occt is None else occt
+    TEAM = team_for(B)
     nblk = max_blocks(B)
     rec = np.zeros((nblk * TEAM, 16), dtype=np.int32)
     live = np.flatnonzero(task[:, 0] != -1)
     light = [t for t in live if task[t, 2] <= LIGHT_MAX]
     heavy = [t for t in live if task[t, 2] > LIGHT_MAX]
-    nlb = (len(light) + TEAM - 1) // TEAM
+    LPB = light_per_block(B)
+    nlb = (len(light) + LPB - 1) // LPB
     rec[: nlb * TEAM, 0] = -1
-    for slot, t in enumerate(light):
+    for li, t in enumerate(light):
+        slot = (li // LPB) * TEAM + li % LPB
         rowk, start, cnt, par = task[t]
         rec[slot, 0:4] = (rowk, par | (1 << 8), cnt, start)
         rec[slot, 4:4 + 2 * cnt] = occ[start:start + cnt].reshape(-1)
@@ -243,7 +261,7 @@ def launch_plan(task, occ, B, occt=None):
             r[4:4 + len(first)] = first
             r[12] = cnt
             r[13:15] = _pack_t(occt[mine[:4]])
-    hdr = np.array([nlb + len(heavy), len(light), len(heavy), len(live)], dtype=np.int32)
+    hdr = np.array([nlb + len(heavy), nlb, len(heavy), len(live)], dtype=np.int32)
     return rec, hdr
 
 
@@ -259,7 +277,7 @@ def sample_and_plan(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed, fir
                               first_triplet, n_batches * B)
     tasks = np.zeros((n_batches, 3 * B, 4), dtype=np.int32)
     occs = np.zeros((n_batches, 3 * B, 2), dtype=np.int32)
-    recs = np.zeros((n_batches, max_blocks(B) * TEAM, 16), dtype=np.int32)
+    recs = np.zeros((n_batches, max_blocks(B) * team_for(B), 16), dtype=np.int32)
     hdrs = np.zeros((n_batches, 4), dtype=np.int32)
     occts = np.zeros((n_batches, 3 * B), dtype=np.int32)
     for b in range(n_batches):

@@ -17,25 +17,16 @@ csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, tr_users, dev)
 hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=1e-4, mode='l2')
 for B in [int(x) for x in os.environ.get('BS', '256,2048,8192').split(',')]:
     eng = _engine.BprEngine(n_users, n_items, k, hp, dev, seed=1)
-    nb = max(8, min(3906, (1 << 20) // B))
-    plan = eng._ensure_plan(nb, B)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    nb = min(nb, plan.cap)
-    st = eng.state()
-    for rep in range(3):
-        ev[0].record()
-        tkr_hip.sample_plan(csr, n_users, n_items, 1, rep * nb * B, nb, B, eng.cnt, plan)
-        ev[1].record()
-        t1 = time.time()
-        tkr_hip.bpr_run(st, plan, B, nb, None)
-        t2 = time.time()
-        ev[2].record()
-        torch.cuda.synchronize()
-        tp, ts = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
-    ntask = int((plan.task.view(nb, 3 * B, 4)[:, :, 0] != -1).sum()) / nb
-    maxocc = int(plan.task.view(nb, 3 * B, 4)[:, :, 2].max())
-    hd = plan.hdr.view(-1, 4)[:nb].float().mean(0).tolist()
-    print('hdr mean (blocks, light, heavy, tasks):', hd)
-    print('B=%5d nb=%4d plan %.3f ms (%.2f us/batch) | step %.3f ms = %.2f us/batch host-issue %.2f us/batch -> %.1f M triplets/s, '
-          '%.1f GB/s algorithmic | tasks/batch %.0f max_occ %d' % (B, nb, tp, tp / nb * 1e3, ts, ts / nb * 1e3, (t2 - t1) / nb * 1e6,
-          nb * B / ((tp + ts) * 1e-3) / 1e6, nb * B * (48 * k + 56) / (ts * 1e-3) / 1e9, ntask, maxocc), flush=True)
+    nb = max(8, min(3906, (1 << 21) // B))
+    eng.run_batches(csr, nb, B, want_loss=False)            # warm-up
+    torch.cuda.synchronize()
+    eng.step_events = []
+    t0 = time.perf_counter()
+    eng.run_batches(csr, nb, B, want_loss=False)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ts = sum(a.elapsed_time(b) for a, b, _ in eng.step_events)
+    eng.step_events = None
+    hd = eng.plan.hdr.view(-1, 4)[:8].float().mean(0).tolist()
+    print('B=%5d nb=%4d wall %.2f us/batch | step launches %.2f us/batch -> %.1f M triplets/s, %.1f GB/s algorithmic | hdr mean %s'
+          % (B, nb, wall / nb * 1e6, ts / nb * 1e3, nb * B / wall / 1e6, nb * B * (48 * k + 56) / (ts * 1e-3) / 1e9, hd), flush=True)

@@ -72,7 +72,7 @@ def test_sample_plan_bit_exact(hip, n_users, n_items, B, nb, chunks):
     for name, g, e in zip(('u', 'i', 'j', 'task', 'occ', 'rec', 'hdr', 'occt'), got, exp):
         if name == 'rec':                       # only the used workgroups are defined
             for b in range(nb):
-                used = exp[6][b, 0] * 16
+                used = exp[6][b, 0] * P.team_for(B)
                 np.testing.assert_array_equal(g[b, :used], e[b, :used], err_msg='rec batch %d' % b)
         else:
             np.testing.assert_array_equal(g, e, err_msg=name)

@@ -23,21 +23,59 @@
 // Roofline: HBM / cache-bandwidth bound gather-scatter.  Algorithmic bytes per triplet
 // (no credit for in-batch duplicates): 3 rows x (param+ms) x (read+write)
 // = 48k B + 32 B biases + 24 B ids  ->  6,200 B at k = 128.
+#include <stdlib.h>
+#include <string.h>
+
 #include "tkr_common.h"
 #include "../../include/tkr.h"
 
+extern "C" int tkr_plan_team(int32_t batch_size);
+
 namespace tkr {
 
-constexpr int kTeam = 16;                          // waves per workgroup (oracle/plan_np.py TEAM)
-constexpr int kStepThreads = kTeam * TKR_WAVE;     // 1024
+// waves per workgroup = per heavy-row team: 4 for B <= 1024, 16 above (oracle/plan_np.py team_for).  A CU
+// pulls only ~10 B/clk from the fabric, so a small batch must be spread over many CUs: 4-wave workgroups put
+// a 256-batch on ~180 CUs instead of ~47 (measured: the row-gather level drops from 3.4 us to ~1 us).
 constexpr int kIdMask = 0x3fffffff;
 
-template <int NE>
+// Row access: lane l owns the NE = ceil(k/64) CONTIGUOUS elements [l*NE, l*NE+NE) of a row.  VEC (chosen on
+// the host) means FULL rows, k == 64*NE: one unpredicated 4/8/16-byte access per lane (256 B / 512 B / 1 KiB
+// per wave-instruction), nothing between the load and its first real use.  Otherwise loads come from
+// clamped (always valid) addresses and are zeroed by a select: a predicated load would compile to an
+// exec-branch whose join forces s_waitcnt vmcnt(0) and serialises the row loads of a wave.
+template <int NE, bool VEC>
 __device__ __forceinline__ void load_row(const float* __restrict__ base, int k, int lane, float (&r)[NE]) {
+    const int e0 = lane * NE;
+    if constexpr (VEC && NE == 1) {
+        r[0] = base[e0];
+    } else if constexpr (VEC && NE == 2) {
+        const float2 v = *reinterpret_cast<const float2*>(base + e0);
+        r[0] = v.x; r[1] = v.y;
+    } else if constexpr (VEC && NE == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(base + e0);
+        r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+    } else {
 #pragma unroll
-    for (int q = 0; q < NE; ++q) {
-        const int e = lane + q * TKR_WAVE;
-        r[q] = (e < k) ? base[e] : 0.f;
+        for (int q = 0; q < NE; ++q) {
+            const float v = base[min(e0 + q, k - 1)];
+            r[q] = (e0 + q < k) ? v : 0.f;
+        }
+    }
+}
+
+template <int NE, bool VEC>
+__device__ __forceinline__ void store_row(float* __restrict__ base, int k, int lane, const float (&r)[NE]) {
+    const int e0 = lane * NE;
+    if constexpr (VEC && NE == 1) {
+        base[e0] = r[0];
+    } else if constexpr (VEC && NE == 2) {
+        *reinterpret_cast<float2*>(base + e0) = make_float2(r[0], r[1]);
+    } else if constexpr (VEC && NE == 4) {
+        *reinterpret_cast<float4*>(base + e0) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < NE; ++q)
+            if (e0 + q < k) base[e0 + q] = r[q];
     }
 }
 
@@ -64,9 +102,9 @@ struct Acc {            // per-wave accumulators besides the row gradient
 };
 
 // G occurrences of a USER row: oa = i | par<<30, ob = j | par<<30
-template <int NE, int G>
+template <int NE, bool VEC, int G>
 __device__ __forceinline__ void user_group(const tkr_bpr_state& st, int lane, const int (&oa)[4], const int (&ob)[4],
-                                           const float (&ur)[NE], float (&g)[NE], Acc& acc) {
+                                           const float (&ur_in)[NE], float (&g)[NE], Acc& acc, bool want_loss) {
     const int k = st.k;
     const size_t istride = (size_t)st.n_items * k;
     float vi[G][NE], vj[G][NE], bi[G], bj[G];
@@ -74,11 +112,17 @@ __device__ __forceinline__ void user_group(const tkr_bpr_state& st, int lane, co
     for (int q = 0; q < G; ++q) {
         const int i = oa[q] & kIdMask, pi = (oa[q] >> 30) & 1;
         const int j = ob[q] & kIdMask, pj = (ob[q] >> 30) & 1;
-        load_row<NE>(st.V + pi * istride + (size_t)i * k, k, lane, vi[q]);
-        load_row<NE>(st.V + pj * istride + (size_t)j * k, k, lane, vj[q]);
+        load_row<NE, VEC>(st.V + pi * istride + (size_t)i * k, k, lane, vi[q]);
+        load_row<NE, VEC>(st.V + pj * istride + (size_t)j * k, k, lane, vj[q]);
         bi[q] = st.b[(size_t)pi * st.n_items + i];
         bj[q] = st.b[(size_t)pj * st.n_items + j];
     }
+    // First use of the owned row sits HERE, behind the issue of every partner load: without this register
+    // barrier the compiler hoists the loop-invariant regulariser terms (lambda*own, sgn(own), own^2) above the
+    // loads and has to wait for the own row first -- two memory levels instead of one.
+    float ur[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { ur[e] = ur_in[e]; asm volatile("" : "+v"(ur[e])); }
     const bool l2 = (st.mode == 0);
 #pragma unroll
     for (int q = 0; q < G; ++q) {
@@ -86,29 +130,29 @@ __device__ __forceinline__ void user_group(const tkr_bpr_state& st, int lane, co
         dot2<NE>(ur, vi[q], vj[q], xui, xuj);
         const float x = bi[q] - bj[q] + xui - xuj;
         const float s = sigmoid_neg(x);
-        acc.loss_x += softplus_neg(x);
+        if (want_loss) acc.loss_x += softplus_neg(x);
         if (l2) {
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 g[e] += -s * (vi[q][e] - vj[q][e]) + st.lu * ur[e];
-                acc.loss_lane += 0.5f * (ur[e] * ur[e] * st.lu + vi[q][e] * vi[q][e] * st.li + vj[q][e] * vj[q][e] * st.lj);
+                if (want_loss) acc.loss_lane += 0.5f * (ur[e] * ur[e] * st.lu + vi[q][e] * vi[q][e] * st.li + vj[q][e] * vj[q][e] * st.lj);
             }
-            acc.loss_x += 0.5f * (bi[q] * bi[q] + bj[q] * bj[q]) * st.lb;
+            if (want_loss) acc.loss_x += 0.5f * (bi[q] * bi[q] + bj[q] * bj[q]) * st.lb;
         } else {
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 g[e] += -s * (vi[q][e] - vj[q][e]) + st.lu * sgn(ur[e]);
-                acc.loss_lane += fabsf(ur[e]) * st.lu + fabsf(vi[q][e]) * st.li + fabsf(vj[q][e]) * st.lj;
+                if (want_loss) acc.loss_lane += fabsf(ur[e]) * st.lu + fabsf(vi[q][e]) * st.li + fabsf(vj[q][e]) * st.lj;
             }
-            acc.loss_x += (fabsf(bi[q]) + fabsf(bj[q])) * st.lb;
+            if (want_loss) acc.loss_x += (fabsf(bi[q]) + fabsf(bj[q])) * st.lb;
         }
     }
 }
 
 // G occurrences of an ITEM row: oa = u | par<<30, ob = other | par<<30 | role<<31
-template <int NE, int G>
+template <int NE, bool VEC, int G>
 __device__ __forceinline__ void item_group(const tkr_bpr_state& st, int lane, const int (&oa)[4], const int (&ob)[4],
-                                           const float (&vr)[NE], float br, float (&g)[NE], Acc& acc) {
+                                           const float (&vr_in)[NE], float br_in, float (&g)[NE], Acc& acc) {
     const int k = st.k;
     const size_t ustride = (size_t)st.n_users * k, istride = (size_t)st.n_items * k;
     float uu[G][NE], vo[G][NE], bo[G];
@@ -116,10 +160,15 @@ __device__ __forceinline__ void item_group(const tkr_bpr_state& st, int lane, co
     for (int q = 0; q < G; ++q) {
         const int u = oa[q] & kIdMask, pu = (oa[q] >> 30) & 1;
         const int o = ob[q] & kIdMask, po = (ob[q] >> 30) & 1;
-        load_row<NE>(st.U + pu * ustride + (size_t)u * k, k, lane, uu[q]);
-        load_row<NE>(st.V + po * istride + (size_t)o * k, k, lane, vo[q]);
+        load_row<NE, VEC>(st.U + pu * ustride + (size_t)u * k, k, lane, uu[q]);
+        load_row<NE, VEC>(st.V + po * istride + (size_t)o * k, k, lane, vo[q]);
         bo[q] = st.b[(size_t)po * st.n_items + o];
     }
+    float vr[NE];                                     // see user_group: first use of the owned row after the loads
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { vr[e] = vr_in[e]; asm volatile("" : "+v"(vr[e])); }
+    float br = br_in;
+    asm volatile("" : "+v"(br));
     const bool l2 = (st.mode == 0);
 #pragma unroll
     for (int q = 0; q < G; ++q) {
@@ -144,37 +193,37 @@ __device__ __forceinline__ void item_group(const tkr_bpr_state& st, int lane, co
     }
 }
 
-template <int NE, bool ITEM>
+template <int NE, bool VEC, bool ITEM>
 __device__ __forceinline__ void run_group(const tkr_bpr_state& st, int lane, int n, const int (&oa)[4],
                                           const int (&ob)[4], const float (&row)[NE], float br, float (&g)[NE],
-                                          Acc& acc) {
+                                          Acc& acc, bool want_loss) {
     if constexpr (ITEM) {
         switch (n) {
-            case 1: item_group<NE, 1>(st, lane, oa, ob, row, br, g, acc); break;
-            case 2: item_group<NE, 2>(st, lane, oa, ob, row, br, g, acc); break;
-            case 3: item_group<NE, 3>(st, lane, oa, ob, row, br, g, acc); break;
-            default: item_group<NE, 4>(st, lane, oa, ob, row, br, g, acc); break;
+            case 1: item_group<NE, VEC, 1>(st, lane, oa, ob, row, br, g, acc); break;
+            case 2: item_group<NE, VEC, 2>(st, lane, oa, ob, row, br, g, acc); break;
+            case 3: item_group<NE, VEC, 3>(st, lane, oa, ob, row, br, g, acc); break;
+            default: item_group<NE, VEC, 4>(st, lane, oa, ob, row, br, g, acc); break;
         }
     } else {
         switch (n) {
-            case 1: user_group<NE, 1>(st, lane, oa, ob, row, g, acc); break;
-            case 2: user_group<NE, 2>(st, lane, oa, ob, row, g, acc); break;
-            case 3: user_group<NE, 3>(st, lane, oa, ob, row, g, acc); break;
-            default: user_group<NE, 4>(st, lane, oa, ob, row, g, acc); break;
+            case 1: user_group<NE, VEC, 1>(st, lane, oa, ob, row, g, acc, want_loss); break;
+            case 2: user_group<NE, VEC, 2>(st, lane, oa, ob, row, g, acc, want_loss); break;
+            case 3: user_group<NE, VEC, 3>(st, lane, oa, ob, row, g, acc, want_loss); break;
+            default: user_group<NE, VEC, 4>(st, lane, oa, ob, row, g, acc, want_loss); break;
         }
     }
 }
 
-template <int NE>
-__global__ __launch_bounds__(kStepThreads) void bpr_step_kernel(
+template <int NE, bool VEC, int kTeam>
+__global__ __launch_bounds__((kTeam * TKR_WAVE)) void bpr_step_kernel(
     tkr_bpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
     const int4* __restrict__ hdr, float* __restrict__ loss_out) {
     __shared__ float red[kTeam][NE * TKR_WAVE + 1];
     const int lane = threadIdx.x & (TKR_WAVE - 1);
     const int wave = threadIdx.x >> 6;
-    const int4 h = *hdr;                         // (workgroups used, light tasks, heavy tasks, tasks)
+    const int4 h = *hdr;                         // (workgroups used, light workgroups, heavy tasks, tasks)
     const int n_blocks = __builtin_amdgcn_readfirstlane(h.x);
-    const int nlb = (__builtin_amdgcn_readfirstlane(h.y) + kTeam - 1) / kTeam;
+    const int nlb = __builtin_amdgcn_readfirstlane(h.y);
     const int k = st.k;
     const size_t ustride = (size_t)st.n_users * k, istride = (size_t)st.n_items * k;
 
@@ -194,9 +243,13 @@ __global__ __launch_bounds__(kStepThreads) void bpr_step_kernel(
 #pragma unroll
         for (int e = 0; e < NE; ++e) g[e] = 0.f;
         Acc acc = {0.f, 0.f, 0.f};
-        const float* src = is_item ? st.V + par * istride + (size_t)row * k : st.U + par * ustride + (size_t)row * k;
-        load_row<NE>(src, k, lane, own);
-        const float br = is_item ? st.b[(size_t)par * st.n_items + row] : 0.f;
+        const size_t roff = (is_item ? par * istride : par * ustride) + (size_t)row * k;
+        load_row<NE, VEC>((is_item ? st.V : st.U) + roff, k, lane, own);
+        float ms[NE];                                    // RMSProp slot of the owned row: same memory level as the row
+        load_row<NE, VEC>((is_item ? st.msV : st.msU) + roff, k, lane, ms);
+        const size_t boff = is_item ? (size_t)par * st.n_items + row : 0;     // valid either way: no branch
+        const float br_raw = st.b[boff], msb_raw = st.msb[boff];
+        const float br = is_item ? br_raw : 0.f, msb = is_item ? msb_raw : 0.f;
 
         for (int done = 0; done < n_occ; done += 4) {
             const int n = min(4, n_occ - done);
@@ -210,8 +263,8 @@ __global__ __launch_bounds__(kStepThreads) void bpr_step_kernel(
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { oa[q] = bcast_i(o.x, q); ob[q] = bcast_i(o.y, q); }
             }
-            if (is_item) run_group<NE, true>(st, lane, n, oa, ob, own, br, g, acc);
-            else run_group<NE, false>(st, lane, n, oa, ob, own, 0.f, g, acc);
+            if (is_item) run_group<NE, VEC, true>(st, lane, n, oa, ob, own, br, g, acc, false);
+            else run_group<NE, VEC, false>(st, lane, n, oa, ob, own, 0.f, g, acc, loss_out != nullptr);
         }
 
         if (!is_item && loss_out) {
@@ -240,22 +293,16 @@ __global__ __launch_bounds__(kStepThreads) void bpr_step_kernel(
         }
 
         // ---- RMSProp on the owned row (TF SparseApplyRMSProp, momentum 0), written to buffer par^1
-        float ms[NE];
-        const float* msrc = is_item ? st.msV + par * istride + (size_t)row * k : st.msU + par * ustride + (size_t)row * k;
-        load_row<NE>(msrc, k, lane, ms);
-        float* po = is_item ? st.V + (par ^ 1) * istride + (size_t)row * k : st.U + (par ^ 1) * ustride + (size_t)row * k;
-        float* mo = is_item ? st.msV + (par ^ 1) * istride + (size_t)row * k : st.msU + (par ^ 1) * ustride + (size_t)row * k;
+        const size_t woff = (is_item ? (par ^ 1) * istride : (par ^ 1) * ustride) + (size_t)row * k;
+        float pn[NE], mn[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            const int c = lane + e * TKR_WAVE;
-            if (c < k) {
-                const float m2 = st.rho * ms[e] + (1.f - st.rho) * g[e] * g[e];
-                mo[c] = m2;
-                po[c] = own[e] - st.lr * g[e] / sqrtf(m2 + st.eps);
-            }
+            mn[e] = st.rho * ms[e] + (1.f - st.rho) * g[e] * g[e];
+            pn[e] = own[e] - st.lr * g[e] / sqrtf(mn[e] + st.eps);
         }
+        store_row<NE, VEC>((is_item ? st.msV : st.msU) + woff, k, lane, mn);
+        store_row<NE, VEC>((is_item ? st.V : st.U) + woff, k, lane, pn);
         if (is_item && lane == 0) {
-            const float msb = st.msb[(size_t)par * st.n_items + row];
             const float m2 = st.rho * msb + (1.f - st.rho) * acc.gb * acc.gb;
             st.msb[(size_t)(par ^ 1) * st.n_items + row] = m2;
             st.b[(size_t)(par ^ 1) * st.n_items + row] = br - st.lr * acc.gb / sqrtf(m2 + st.eps);
@@ -263,29 +310,42 @@ __global__ __launch_bounds__(kStepThreads) void bpr_step_kernel(
     }
 }
 
-static int step_grid(int B) {
+static int step_grid(int B, int team) {
     // enough workgroups for every light task plus a handful of teams; the kernel grid-strides
-    const int light = (3 * B + kTeam - 1) / kTeam;
+    const int lpb = team;                            // oracle/plan_np.py light_per_block
+    const int light = (3 * B + lpb - 1) / lpb;
     int grid = light + 16;
     if (grid > 2048) grid = 2048;
     return grid;
 }
 
-template <int NE>
-static int launch_step(const tkr_bpr_state& st, const int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
+template <int NE, bool VEC, int TEAM>
+static int launch_step_t(const tkr_bpr_state& st, const int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
                        float* loss_out, hipStream_t stream) {
-    hipLaunchKernelGGL(bpr_step_kernel<NE>, dim3(step_grid(B)), dim3(kStepThreads), 0, stream, st, rec,
+    hipLaunchKernelGGL((bpr_step_kernel<NE, VEC, TEAM>), dim3(step_grid(B, TEAM)), dim3(TEAM * TKR_WAVE), 0, stream, st, rec,
                        reinterpret_cast<const int2*>(occ), reinterpret_cast<const int4*>(hdr), loss_out);
     return (int)hipGetLastError();
 }
 
+template <int NE, bool VEC>
+static int launch_step(const tkr_bpr_state& st, const int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
+                       float* loss_out, hipStream_t stream) {
+    return tkr_plan_team(B) == 4 ? launch_step_t<NE, VEC, 4>(st, rec, occ, hdr, B, loss_out, stream)
+                                 : launch_step_t<NE, VEC, 16>(st, rec, occ, hdr, B, loss_out, stream);
+}
+
 static int dispatch_step(const tkr_bpr_state& st, const int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
                          float* loss_out, hipStream_t stream) {
-    switch ((st.k + TKR_WAVE - 1) / TKR_WAVE) {
-        case 1: return launch_step<1>(st, rec, occ, hdr, B, loss_out, stream);
-        case 2: return launch_step<2>(st, rec, occ, hdr, B, loss_out, stream);
-        case 3: return launch_step<3>(st, rec, occ, hdr, B, loss_out, stream);
-        case 4: return launch_step<4>(st, rec, occ, hdr, B, loss_out, stream);
+    const int ne = (st.k + TKR_WAVE - 1) / TKR_WAVE;
+    const bool full = (st.k == ne * TKR_WAVE) && ne != 3;           // k = 64, 128, 256: unpredicated vector rows
+    switch (ne) {
+        case 1: return full ? launch_step<1, true>(st, rec, occ, hdr, B, loss_out, stream)
+                            : launch_step<1, false>(st, rec, occ, hdr, B, loss_out, stream);
+        case 2: return full ? launch_step<2, true>(st, rec, occ, hdr, B, loss_out, stream)
+                            : launch_step<2, false>(st, rec, occ, hdr, B, loss_out, stream);
+        case 3: return launch_step<3, false>(st, rec, occ, hdr, B, loss_out, stream);
+        case 4: return full ? launch_step<4, true>(st, rec, occ, hdr, B, loss_out, stream)
+                            : launch_step<4, false>(st, rec, occ, hdr, B, loss_out, stream);
         default: return TKR_EUNSUPPORTED;       // k > 256
     }
 }
@@ -301,17 +361,90 @@ static int check_state(const tkr_bpr_state* st) {
     return TKR_OK;
 }
 
+// ---- launch path -------------------------------------------------------------------------------------
+// The n_batches launches of a chunk have the same arguments every time a plan buffer is reused (K1 only
+// rewrites the buffer contents), so the chain is captured once into a hipGraph and replayed: one host call
+// per chunk instead of one per batch.  TKR_GRAPH=0 disables it.
+namespace {
+struct GraphKey {
+    tkr_bpr_state st;
+    const int32_t *rec, *occ, *hdr;
+    float* loss;
+    int B, nb;
+    hipStream_t stream;
+};
+struct GraphEntry {
+    GraphKey key;
+    hipGraphExec_t exec;
+    hipGraph_t graph;
+    uint64_t used;
+};
+constexpr int kGraphCache = 8;
+GraphEntry g_cache[kGraphCache];
+int g_cache_n = 0;
+uint64_t g_tick = 0;
+
+bool graphs_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("TKR_GRAPH");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on == 1;
+}
+
+int launch_chain(const tkr_bpr_state& st, const int32_t* rec, const int32_t* occ, const int32_t* hdr, int B, int nb,
+                 float* loss_out, hipStream_t stream) {
+    const size_t stride_r = (size_t)tkr_plan_max_blocks(B) * tkr_plan_team(B) * 16;
+    const size_t stride_o = (size_t)3 * B * 2;
+    for (int b = 0; b < nb; ++b) {
+        const int r = tkr::dispatch_step(st, rec + b * stride_r, occ + b * stride_o, hdr + (size_t)b * 4, B,
+                                         loss_out ? loss_out + b : nullptr, stream);
+        if (r != 0) return r;
+    }
+    return TKR_OK;
+}
+}  // namespace
+
 extern "C" int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ, const int32_t* hdr,
                            int32_t batch_size, int32_t n_batches, float* loss_out, void* stream) {
     const int rc = check_state(st);
     if (rc != TKR_OK) return rc;
     if (!rec || !occ || !hdr || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
-    const size_t stride_r = (size_t)tkr_plan_max_blocks(batch_size) * tkr::kTeam * 16;
-    const size_t stride_o = (size_t)3 * batch_size * 2;
-    for (int b = 0; b < n_batches; ++b) {
-        const int r = tkr::dispatch_step(*st, rec + b * stride_r, occ + b * stride_o, hdr + (size_t)b * 4, batch_size,
-                                         loss_out ? loss_out + b : nullptr, (hipStream_t)stream);
-        if (r != 0) return r;
+    hipStream_t s = (hipStream_t)stream;
+    if (!graphs_enabled() || n_batches < 8) return launch_chain(*st, rec, occ, hdr, batch_size, n_batches, loss_out, s);
+
+    GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.st = *st; key.rec = rec; key.occ = occ; key.hdr = hdr; key.loss = loss_out;
+    key.B = batch_size; key.nb = n_batches; key.stream = nullptr;
+    ++g_tick;
+    for (int i = 0; i < g_cache_n; ++i)
+        if (memcmp(&g_cache[i].key, &key, sizeof(key)) == 0) {
+            g_cache[i].used = g_tick;
+            return (int)hipGraphLaunch(g_cache[i].exec, s);
+        }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    static hipStream_t cap = nullptr;               // the caller's stream may be the (uncapturable) default stream
+    if (!cap) TKR_CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+    TKR_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed));
+    const int lr = launch_chain(*st, rec, occ, hdr, batch_size, n_batches, loss_out, cap);
+    const hipError_t ee = hipStreamEndCapture(cap, &graph);
+    if (lr != 0) { if (graph) (void)hipGraphDestroy(graph); return lr; }
+    if (ee != hipSuccess) return (int)ee;
+    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (ie != hipSuccess) { (void)hipGraphDestroy(graph); return (int)ie; }
+    int slot = g_cache_n;
+    if (g_cache_n < kGraphCache) {
+        ++g_cache_n;
+    } else {
+        slot = 0;
+        for (int i = 1; i < kGraphCache; ++i)
+            if (g_cache[i].used < g_cache[slot].used) slot = i;
+        (void)hipGraphExecDestroy(g_cache[slot].exec);
+        (void)hipGraphDestroy(g_cache[slot].graph);
     }
-    return TKR_OK;
+    g_cache[slot].key = key; g_cache[slot].exec = exec; g_cache[slot].graph = graph; g_cache[slot].used = g_tick;
+    return (int)hipGraphLaunch(exec, s);
 }

@@ -24,10 +24,15 @@
 
 namespace tkr {
 
-constexpr int kPlanThreads = 256;
+constexpr int kPlanThreads = 256;      // resolve/commit kernels, and sample_plan for B <= 1024
+constexpr int kPlanThreadsBig = 1024;  // sample_plan for larger batches (the LDS sort dominates there)
 constexpr int kMaxRounds = 64;   // oracle/plan_np.py MAX_ROUNDS
 constexpr int kLightMax = 4;     // oracle/plan_np.py LIGHT_MAX: occurrences one wave handles
-constexpr int kTeam = 16;        // oracle/plan_np.py TEAM: waves per workgroup / heavy task
+constexpr int kTeamBig = 16;     // oracle/plan_np.py TEAM: waves per workgroup / heavy task, B > 1024
+constexpr int kTeamSmall = 4;    // ... TEAM_SMALL for B <= 1024 (spreads a small batch over many CUs)
+__host__ __device__ inline int team_for(int B) { return B <= 1024 ? kTeamSmall : kTeamBig; }
+// light tasks per workgroup (oracle light_per_block): every wave slot (half-filled groups measured slower)
+__host__ __device__ inline int light_per_block(int B) { return team_for(B); }
 constexpr int kTouchWords = 16;  // bitmap words per row -> at most 512 batches per call
 
 __device__ __forceinline__ bool is_member(const int32_t* __restrict__ cols_sorted, int lo, int hi, int item) {
@@ -66,11 +71,12 @@ __device__ __forceinline__ void draw_triplet(const int32_t* __restrict__ tr_user
 }
 
 // In-LDS bitonic sort of n (power of two) 64-bit keys, ascending.
+template <int T>
 __device__ __forceinline__ void bitonic_sort(uint64_t* keys, int n) {
     for (int size = 2; size <= n; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
-            for (int p = threadIdx.x; p < (n >> 1); p += kPlanThreads) {
+            for (int p = threadIdx.x; p < (n >> 1); p += T) {
                 const int lo = ((p & ~(stride - 1)) << 1) | (p & (stride - 1));
                 const int hi = lo | stride;
                 const bool asc = ((lo & size) == 0);
@@ -85,10 +91,11 @@ __device__ __forceinline__ void bitonic_sort(uint64_t* keys, int n) {
 // Turn sorted keys[0..n) (row<<32 | occurrence) into task heads + counts.  Returns the
 // number of groups (uniform across the block).  `slot0` = first task slot to fill,
 // `occ0` = occ offset of sorted position 0, `kind` = 0 users / 1 items.
+template <int T>
 __device__ __forceinline__ int emit_tasks(const uint64_t* keys, int n, int4* task, int slot0, int occ0,
-                                          int kind, int* scan /*LDS [kPlanThreads+1]*/,
+                                          int kind, int* scan /*LDS [T+1]*/,
                                           uint32_t* __restrict__ touch, int batch) {
-    const int per = (n + kPlanThreads - 1) / kPlanThreads;
+    const int per = (n + T - 1) / T;
     const int beg = min((int)threadIdx.x * per, n), end = min(beg + per, n);
     int cnt = 0;
     for (int p = beg; p < end; ++p)
@@ -97,10 +104,10 @@ __device__ __forceinline__ int emit_tasks(const uint64_t* keys, int n, int4* tas
     if (threadIdx.x == 0) scan[0] = 0;
     __syncthreads();
     if (threadIdx.x == 0)
-        for (int t = 1; t <= kPlanThreads; ++t) scan[t] += scan[t - 1];
+        for (int t = 1; t <= T; ++t) scan[t] += scan[t - 1];
     __syncthreads();
     int s = scan[threadIdx.x];
-    const int total = scan[kPlanThreads];
+    const int total = scan[T];
     for (int p = beg; p < end; ++p) {
         const uint32_t row = (uint32_t)(keys[p] >> 32);
         if ((p == 0) || (row != (uint32_t)(keys[p - 1] >> 32))) {
@@ -116,7 +123,8 @@ __device__ __forceinline__ int emit_tasks(const uint64_t* keys, int n, int4* tas
     return total;
 }
 
-__global__ __launch_bounds__(kPlanThreads) void sample_plan_kernel(
+template <int T>
+__global__ __launch_bounds__(T) void sample_plan_kernel(
     const int32_t* __restrict__ tr_users, uint32_t n_tr, const int32_t* __restrict__ row_ptr,
     const int32_t* __restrict__ pos_cols, const int32_t* __restrict__ cols_sorted, uint32_t n_items,
     uint64_t seed, uint64_t first_triplet, const int64_t* __restrict__ ctl, int B, int npad_items,
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(kPlanThreads) void sample_plan_kernel(
     uint32_t* __restrict__ touch_u, uint32_t* __restrict__ touch_i) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                       // [npad_items]
-    int* scan = reinterpret_cast<int*>(smem + (size_t)npad_items * 8);        // [kPlanThreads+1]
+    int* scan = reinterpret_cast<int*>(smem + (size_t)npad_items * 8);        // [T+1]
 
     const int b = blockIdx.x;
     const uint64_t batch0 = ctl ? (uint64_t)ctl[0] : 0ull;                    // device-side chunk base
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(kPlanThreads) void sample_plan_kernel(
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 
     // ---- draw; item keys go to LDS, triplets to HBM ---------------------------------
-    for (int t = threadIdx.x; t < B; t += kPlanThreads) {
+    for (int t = threadIdx.x; t < B; t += T) {
         int u, i, j;
         draw_triplet(tr_users, n_tr, row_ptr, pos_cols, cols_sorted, n_items, k0, k1, g0 + t, u, i, j);
         bu[t] = u; bi[t] = i; bj[t] = j;
@@ -150,11 +158,11 @@ __global__ __launch_bounds__(kPlanThreads) void sample_plan_kernel(
     // ---- users: sort (u<<32 | t) ----------------------------------------------------------
     int npad_u = 1;
     while (npad_u < B) npad_u <<= 1;
-    for (int t = threadIdx.x; t < npad_u; t += kPlanThreads)
+    for (int t = threadIdx.x; t < npad_u; t += T)
         keys[t] = (t < B) ? (((uint64_t)(uint32_t)bu[t] << 32) | (uint32_t)t) : ~0ull;
-    bitonic_sort(keys, npad_u);
-    const int n_uq = emit_tasks(keys, B, task, 0, 0, 0, scan, touch_u, b);
-    for (int p = threadIdx.x; p < B; p += kPlanThreads) {
+    bitonic_sort<T>(keys, npad_u);
+    const int n_uq = emit_tasks<T>(keys, B, task, 0, 0, 0, scan, touch_u, b);
+    for (int p = threadIdx.x; p < B; p += T) {
         const int t = (int)(uint32_t)keys[p];
         occ[p] = make_int2(bi[t], bj[t]);
         occt[p] = t;
@@ -162,15 +170,15 @@ __global__ __launch_bounds__(kPlanThreads) void sample_plan_kernel(
     __syncthreads();
 
     // ---- items: sort (item<<32 | o), o<B: i-role of triplet o, else j-role of o-B ---------
-    for (int o = threadIdx.x; o < npad_items; o += kPlanThreads) {
+    for (int o = threadIdx.x; o < npad_items; o += T) {
         uint64_t key = ~0ull;
         if (o < B) key = ((uint64_t)(uint32_t)bi[o] << 32) | (uint32_t)o;
         else if (o < 2 * B) key = ((uint64_t)(uint32_t)bj[o - B] << 32) | (uint32_t)o;
         keys[o] = key;
     }
-    bitonic_sort(keys, npad_items);
-    const int n_iq = emit_tasks(keys, 2 * B, task, n_uq, B, 1, scan, touch_i, b);
-    for (int p = threadIdx.x; p < 2 * B; p += kPlanThreads) {
+    bitonic_sort<T>(keys, npad_items);
+    const int n_iq = emit_tasks<T>(keys, 2 * B, task, n_uq, B, 1, scan, touch_i, b);
+    for (int p = threadIdx.x; p < 2 * B; p += T) {
         const int o = (int)(uint32_t)keys[p];
         const bool role = o >= B;
         const int t = role ? o - B : o;
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(kPlanThreads) void sample_plan_kernel(
         occ[B + p] = make_int2(bu[t], (int)(other | ((uint32_t)role << 31)));
         occt[B + p] = t;
     }
-    for (int s = n_uq + n_iq + threadIdx.x; s < 3 * B; s += kPlanThreads) task[s] = make_int4(-1, 0, 0, 0);
+    for (int s = n_uq + n_iq + threadIdx.x; s < 3 * B; s += T) task[s] = make_int4(-1, 0, 0, 0);
 }
 
 // ---- K1b: parities + per-wave launch records ------------------------------------------------
@@ -215,6 +223,7 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
     const int32_t* __restrict__ ucnt, const int32_t* __restrict__ icnt, const uint32_t* __restrict__ touch_u,
     const uint32_t* __restrict__ touch_i, int32_t* __restrict__ rec_all, int4* __restrict__ hdr_all) {
     __shared__ int scan[2 * (kPlanThreads + 1)];
+    const int kTeam = team_for(B);
     const int b = blockIdx.x;
     int4* task = task_all + (size_t)b * 3 * B;
     int2* occ = occ_all + (size_t)b * 3 * B;
@@ -254,12 +263,13 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
     }
     int tot_l, tot_h, hi;
     int li = block_exclusive_scan2(nl, nh, scan, tot_l, tot_h, hi);
-    const int nlb = (tot_l + kTeam - 1) / kTeam;
+    const int lpb = light_per_block(B);
+    const int nlb = (tot_l + lpb - 1) / lpb;
     for (int s = beg; s < end; ++s) {
         const int4 t = task[s];
         if (t.x == -1) continue;
         if (t.z <= kLightMax) {
-            int32_t* r = rec + (size_t)li * 16;
+            int32_t* r = rec + ((size_t)(li / lpb) * kTeam + li % lpb) * 16;
             r[0] = t.x; r[1] = t.w | (1 << 8); r[2] = t.z; r[3] = t.y;
             int tt[4];
             for (int q = 0; q < kLightMax; ++q) {
@@ -285,12 +295,15 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
             ++hi;
         }
     }
-    for (int s = tot_l + threadIdx.x; s < nlb * kTeam; s += kPlanThreads) {      // idle waves of the last light group
-        int32_t* r = rec + (size_t)s * 16;
-        r[0] = -1;
-        for (int q = 1; q < 16; ++q) r[q] = 0;
+    for (int s = threadIdx.x; s < nlb * kTeam; s += kPlanThreads) {      // idle wave slots of the light groups
+        const int li_of = (s / kTeam) * lpb + (s % kTeam);
+        if ((s % kTeam) >= lpb || li_of >= tot_l) {
+            int32_t* r = rec + (size_t)s * 16;
+            r[0] = -1;
+            for (int q = 1; q < 16; ++q) r[q] = 0;
+        }
     }
-    if (threadIdx.x == 0) hdr_all[b] = make_int4(nlb + tot_h, tot_l, tot_h, tot_l + tot_h);
+    if (threadIdx.x == 0) hdr_all[b] = make_int4(nlb + tot_h, nlb, tot_h, tot_l + tot_h);
 }
 
 // ---- K1c: fold the chunk's touch bitmap into the update counters and clear it --------------
@@ -316,8 +329,11 @@ __global__ void commit_kernel(int n_users, int n_items, int32_t* __restrict__ uc
 
 }  // namespace tkr
 
+extern "C" int tkr_plan_team(int32_t batch_size) { return tkr::team_for(batch_size); }
+
 extern "C" int tkr_plan_max_blocks(int32_t batch_size) {
-    return (3 * batch_size + tkr::kTeam - 1) / tkr::kTeam + (3 * batch_size) / (tkr::kLightMax + 1);
+    const int lpb = tkr::light_per_block(batch_size);
+    return (3 * batch_size + lpb - 1) / lpb + (3 * batch_size) / (tkr::kLightMax + 1);
 }
 
 extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr,
@@ -335,21 +351,29 @@ extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int3
     if (!ucnt || !icnt || !touch_u || !touch_i || !rec || !hdr || !occt) return TKR_EINVAL;
     int npad = 1;
     while (npad < 2 * batch_size) npad <<= 1;
-    const size_t lds = (size_t)npad * 8 + (tkr::kPlanThreads + 1) * sizeof(int);
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        TKR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tkr::sample_plan_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(tkr::sample_plan_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), lds, s, tr_users,
-                       (uint32_t)n_tr, row_ptr, pos_cols, cols_sorted, (uint32_t)n_items, seed, first_triplet, ctl,
-                       batch_size, npad, out_u, out_i, out_j, reinterpret_cast<int4*>(task),
-                       reinterpret_cast<int2*>(occ), occt, touch_u, touch_i);
+    if (batch_size <= 1024) {
+        const size_t lds = (size_t)npad * 8 + (tkr::kPlanThreads + 1) * sizeof(int);
+        hipLaunchKernelGGL(tkr::sample_plan_kernel<tkr::kPlanThreads>, dim3(n_batches), dim3(tkr::kPlanThreads), lds, s,
+                           tr_users, (uint32_t)n_tr, row_ptr, pos_cols, cols_sorted, (uint32_t)n_items, seed,
+                           first_triplet, ctl, batch_size, npad, out_u, out_i, out_j, reinterpret_cast<int4*>(task),
+                           reinterpret_cast<int2*>(occ), occt, touch_u, touch_i);
+    } else {
+        const size_t lds = (size_t)npad * 8 + (tkr::kPlanThreadsBig + 1) * sizeof(int);
+        static bool attr_set = false;
+        if (lds > 64 * 1024 && !attr_set) {
+            TKR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tkr::sample_plan_kernel<tkr::kPlanThreadsBig>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(tkr::sample_plan_kernel<tkr::kPlanThreadsBig>, dim3(n_batches), dim3(tkr::kPlanThreadsBig), lds,
+                           s, tr_users, (uint32_t)n_tr, row_ptr, pos_cols, cols_sorted, (uint32_t)n_items, seed,
+                           first_triplet, ctl, batch_size, npad, out_u, out_i, out_j, reinterpret_cast<int4*>(task),
+                           reinterpret_cast<int2*>(occ), occt, touch_u, touch_i);
+    }
     TKR_LAUNCH_CHECK();
     hipLaunchKernelGGL(tkr::resolve_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), 0, s, batch_size,
-                       tkr_plan_max_blocks(batch_size) * tkr::kTeam, reinterpret_cast<int4*>(task),
+                       tkr_plan_max_blocks(batch_size) * tkr::team_for(batch_size), reinterpret_cast<int4*>(task),
                        reinterpret_cast<int2*>(occ), occt, ucnt, icnt, touch_u, touch_i, rec,
                        reinterpret_cast<int4*>(hdr));
     TKR_LAUNCH_CHECK();

@@ -27,11 +27,12 @@
 #include "tkr_common.h"
 #include "../../include/tkr.h"
 
+extern "C" int tkr_plan_team(int32_t batch_size);
+
 namespace tkr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kVTeam = 16;                       // waves per workgroup of the record-driven kernels
 constexpr int kSlice = 128;                      // d-columns per split-K slice of V1 (64 per MFMA k-slot)
 constexpr int kIdMaskV = 0x3fffffff;
 
@@ -139,8 +140,8 @@ struct WaveRec {
     int oa[4], ob[4], ot[4];
 };
 
-__device__ __forceinline__ WaveRec read_rec(const int32_t* __restrict__ rec_all, int blk, int wave, int lane) {
-    const int word = (lane < 16) ? rec_all[((size_t)blk * kVTeam + wave) * 16 + lane] : 0;
+__device__ __forceinline__ WaveRec read_rec(const int32_t* __restrict__ rec_all, int team, int blk, int wave, int lane) {
+    const int word = (lane < 16) ? rec_all[((size_t)blk * team + wave) * 16 + lane] : 0;
     WaveRec r;
     r.rowk = bcast_i(word, 0);
     const int meta = bcast_i(word, 1);
@@ -171,8 +172,8 @@ __device__ __forceinline__ void next_occ(const WaveRec& r, int done, int n, int 
 }
 
 // V1b: user occurrences -> s_t, P_t, W_t, loss.   NH = ceil(kh / 64)
-template <int NH>
-__global__ __launch_bounds__(kVTeam * TKR_WAVE) void vbpr_occur_kernel(
+template <int NH, int kVTeam>
+__global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_occur_kernel(
     tkr_vbpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
     const int32_t* __restrict__ occt, const int4* __restrict__ hdr, int B, const float* __restrict__ Q,
     float* __restrict__ s_out, const float* __restrict__ P, float* __restrict__ Wm, float* __restrict__ loss_out) {
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(kVTeam * TKR_WAVE) void vbpr_occur_kernel(
     const size_t ustride = (size_t)st.n_users * k2, istride = (size_t)st.n_items * kh;
     const bool l2 = st.mode == 0;
     for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const WaveRec r = read_rec(rec_all, blk, wave, lane);
+        const WaveRec r = read_rec(rec_all, kVTeam, blk, wave, lane);
         if (r.rowk < 0) continue;                       // item task or idle wave (-1): nothing to do here
         const int u = r.rowk;
         const float* urow = st.U + r.par * ustride + (size_t)u * k2;
@@ -251,8 +252,8 @@ __global__ __launch_bounds__(kVTeam * TKR_WAVE) void vbpr_occur_kernel(
 }
 
 // V2: sparse RMSProp on the touched [ure|uce] rows (users) and ire rows + irb (items).  NE = ceil(2kh/64)
-template <int NE>
-__global__ __launch_bounds__(kVTeam * TKR_WAVE) void vbpr_rows_kernel(
+template <int NE, int kVTeam>
+__global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_rows_kernel(
     tkr_vbpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
     const int32_t* __restrict__ occt, const int4* __restrict__ hdr, const float* __restrict__ s_in,
     const float* __restrict__ P) {
@@ -260,13 +261,13 @@ __global__ __launch_bounds__(kVTeam * TKR_WAVE) void vbpr_rows_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int4 h4 = *hdr;
     const int n_blocks = __builtin_amdgcn_readfirstlane(h4.x);
-    const int nlb = (__builtin_amdgcn_readfirstlane(h4.y) + kVTeam - 1) / kVTeam;
+    const int nlb = __builtin_amdgcn_readfirstlane(h4.y);
     const int kh = st.kh, k2 = 2 * kh;
     const size_t ustride = (size_t)st.n_users * k2, istride = (size_t)st.n_items * kh;
     const bool l2 = st.mode == 0;
     for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         const bool heavy = blk >= nlb;
-        const WaveRec r = read_rec(rec_all, blk, wave, lane);
+        const WaveRec r = read_rec(rec_all, kVTeam, blk, wave, lane);
         if (r.rowk == -1) continue;
         const bool is_item = r.rowk < 0;
         const int row = r.rowk & 0x7fffffff, par = r.par;
@@ -477,15 +478,16 @@ __global__ __launch_bounds__(256) void vbpr_dense_kernel(tkr_vbpr_state st, cons
     }
 }
 
-static int vbpr_grid(int B) {
-    int grid = (3 * B + kVTeam - 1) / kVTeam + 16;
+static int vbpr_grid(int B, int team) {
+    const int lpb = team;                                // oracle/plan_np.py light_per_block
+    int grid = (3 * B + lpb - 1) / lpb + 16;
     return grid > 2048 ? 2048 : grid;
 }
 
-template <int NT>
-static int launch_vbpr(const tkr_vbpr_state& st, const int32_t* ti, const int32_t* tj, const int32_t* rec,
-                       const int32_t* occ, const int32_t* hdr, const int32_t* occt, int B, float* ws, float* loss,
-                       hipStream_t stream) {
+template <int NT, int TEAM>
+static int launch_vbpr_t(const tkr_vbpr_state& st, const int32_t* ti, const int32_t* tj, const int32_t* rec,
+                         const int32_t* occ, const int32_t* hdr, const int32_t* occt, int B, float* ws, float* loss,
+                         hipStream_t stream) {
     const int kh = st.kh, S = vbpr_slices(st.d);
     float* ppart = ws;
     float* s_buf = ppart + (size_t)S * B * (kh + 1);
@@ -494,16 +496,17 @@ static int launch_vbpr(const tkr_vbpr_state& st, const int32_t* ti, const int32_
     float* Q = Wm + (size_t)B * kh;
     const int2* occ2 = reinterpret_cast<const int2*>(occ);
     const int4* hdr4 = reinterpret_cast<const int4*>(hdr);
+    const dim3 rgrid(vbpr_grid(B, TEAM)), rblock(TEAM * 64);
     hipLaunchKernelGGL(vbpr_project_kernel<NT>, dim3(S, (B + 31) / 32), dim3(64), 0, stream, st, ti, tj, B, ppart);
     hipLaunchKernelGGL(vbpr_reduce_kernel, dim3(B), dim3(256), 0, stream, ppart, S, B, kh, P, Q);
     const int NH = (kh + 63) / 64, NE = (2 * kh + 63) / 64;
-    if (NH == 1) hipLaunchKernelGGL(vbpr_occur_kernel<1>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
-    else hipLaunchKernelGGL(vbpr_occur_kernel<2>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
+    if (NH == 1) hipLaunchKernelGGL((vbpr_occur_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
+    else hipLaunchKernelGGL((vbpr_occur_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
     switch (NE) {
-        case 1: hipLaunchKernelGGL(vbpr_rows_kernel<1>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
-        case 2: hipLaunchKernelGGL(vbpr_rows_kernel<2>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
-        case 3: hipLaunchKernelGGL(vbpr_rows_kernel<3>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
-        default: hipLaunchKernelGGL(vbpr_rows_kernel<4>, dim3(vbpr_grid(B)), dim3(kVTeam * 64), 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
+        case 1: hipLaunchKernelGGL((vbpr_rows_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
+        case 2: hipLaunchKernelGGL((vbpr_rows_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
+        case 3: hipLaunchKernelGGL((vbpr_rows_kernel<3, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
+        default: hipLaunchKernelGGL((vbpr_rows_kernel<4, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
     }
     const size_t lds = (size_t)(4 * 64 * (NT * 32 + 1) + 4 * 2 * 64) * sizeof(float);
     auto dense = vbpr_dense_kernel<NT>;
@@ -513,6 +516,14 @@ static int launch_vbpr(const tkr_vbpr_state& st, const int32_t* ti, const int32_
     }
     hipLaunchKernelGGL(dense, dim3((st.d + 63) / 64), dim3(256), lds, stream, st, ti, tj, B, s_buf, Wm, loss);
     return (int)hipGetLastError();
+}
+
+template <int NT>
+static int launch_vbpr(const tkr_vbpr_state& st, const int32_t* ti, const int32_t* tj, const int32_t* rec,
+                       const int32_t* occ, const int32_t* hdr, const int32_t* occt, int B, float* ws, float* loss,
+                       hipStream_t stream) {
+    return tkr_plan_team(B) == 4 ? launch_vbpr_t<NT, 4>(st, ti, tj, rec, occ, hdr, occt, B, ws, loss, stream)
+                                 : launch_vbpr_t<NT, 16>(st, ti, tj, rec, occ, hdr, occt, B, ws, loss, stream);
 }
 
 }  // namespace tkr
@@ -533,7 +544,7 @@ extern "C" int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, cons
     if (st->n_users <= 0 || st->n_items <= 0 || st->kh <= 0 || st->d <= 0) return TKR_EINVAL;
     if (!tri_i || !tri_j || !rec || !occ || !hdr || !occt || !workspace || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
     if (st->kh > 128 || batch_size > 8192) return TKR_EUNSUPPORTED;
-    const size_t stride_r = (size_t)tkr_plan_max_blocks(batch_size) * tkr::kVTeam * 16;
+    const size_t stride_r = (size_t)tkr_plan_max_blocks(batch_size) * tkr_plan_team(batch_size) * 16;
     const size_t stride_o = (size_t)3 * batch_size;
     const int NT = (st->kh + 31) / 32;
     for (int b = 0; b < n_batches; ++b) {

@@ -37,7 +37,7 @@ class VbprState(C.Structure):
                [(n, C.c_float) for n in ('lu', 'li', 'lj', 'lb', 'le', 'lr', 'rho', 'eps')]
 
 
-EXPORTS = ('tkr_version', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_bpr_run',
+EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_bpr_run',
            'tkr_vbpr_run', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy')
 EXPORTS_I64 = ('tkr_vbpr_workspace_floats', 'tkr_topk_workspace_bytes')
 
@@ -79,7 +79,10 @@ def version():
 
 
 PLAN_MAX_BATCHES = 512      # per tkr_sample_plan call (16 bitmap words per row)
-TEAM = 16
+
+
+def plan_team(B):
+    return lib().tkr_plan_team(C.c_int32(B))
 
 
 def plan_max_blocks(B):
@@ -91,7 +94,7 @@ def sample_plan(csr, n_users, n_items, seed, first_triplet, n_batches, B, cnt, p
     plan: u,i,j,task,occ,rec,hdr (all int32 device tensors)."""
     assert n_batches <= PLAN_MAX_BATCHES
     assert plan.u.numel() >= n_batches * B and plan.task.numel() >= n_batches * 3 * B * 4
-    assert plan.rec.numel() >= n_batches * plan_max_blocks(B) * TEAM * 16 and plan.hdr.numel() >= n_batches * 4
+    assert plan.rec.numel() >= n_batches * plan_max_blocks(B) * plan_team(B) * 16 and plan.hdr.numel() >= n_batches * 4
     assert cnt.ucnt.numel() == n_users and cnt.touch_u.numel() == n_users * 16
     assert cnt.icnt.numel() == n_items and cnt.touch_i.numel() == n_items * 16
     _check(lib().tkr_sample_plan(_p(csr.tr_users), C.c_int32(csr.tr_users.numel()), _p(csr.row_ptr), _p(csr.pos_cols),
