@@ -128,7 +128,8 @@ int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* 
  *   workspace (nullable, device, workspace_bytes): scratch for per-item-range partial lists; with
  *     tkr_topk_workspace_bytes(n_rows, K) bytes the launch splits the catalogue so that the grid fills
  *     the 256 CUs in whole rounds (results are identical with or without it)
- * K <= 32, k <= 256. */
+ * K <= 32 per launch (larger K: rank 32, add the found columns to the mask with tkr_build_rated_mask, rank
+ * again -- top-k-rec_amd/tkr_hip.py score_topk does this), k <= 256. */
 int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K);
 int tkr_build_rated_mask(const int64_t* rated_ptr, const int32_t* rated_cols, int32_t n_rows, int32_t n_cols,
                          uint32_t* mask, int32_t mask_pitch, void* stream);

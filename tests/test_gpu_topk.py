@@ -135,6 +135,24 @@ def test_item_range_split_is_invisible(hip):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
+@pytest.mark.parametrize('K', [33, 50, 64, 100])
+def test_large_k_multi_pass(hip, K):
+    """evaluate.py -t above 32: exact through repeated launches"""
+    rng = np.random.Generator(np.random.PCG64(K))
+    n_rows, n_cols, k = 200, 400, 16
+    U, V = _exact(rng, n_rows, k, 32), _exact(rng, n_cols, k, 32)
+    rated = [rng.choice(n_cols, int(rng.integers(0, 40)), replace=False).tolist() for _ in range(n_rows)]
+    rated[0] = list(range(n_cols - 40))                     # fewer than K unrated columns
+    exp, s = _oracle_lists(U, V, None, rated, K)
+    ids, scores = _gpu_lists(hip, U, V, None, rated, K, want_scores=True)
+    ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
+    assert ids.shape == (n_rows, K)
+    for r in range(n_rows):
+        got = [int(c) for c in ids[r] if c >= 0]
+        assert got == exp[r], 'row %d' % r
+        np.testing.assert_array_equal(scores[r, :len(got)], s[r, got])
+
+
 def test_user_idx_gather(hip):
     rng = np.random.Generator(np.random.PCG64(2))
     U, V = _exact(rng, 500, 32, 16), _exact(rng, 700, 32, 16)
@@ -186,6 +204,15 @@ def test_cli_matches_reference_stdout_and_lists(hip, golden_dir, g, scs, capsys)
         ids = E.rank_scenario(_dev(U), V, b, uids, vids, rated, teids, tests, 30, torch.device('cuda')).cpu().numpy()
         for (uid, _), row in zip(tests, ids):
             assert [int(c) for c in row if c >= 0] == exp['lists'][sc][uid], (sc, uid)
+
+
+def test_cli_total_above_32_matches_oracle(hip, golden_dir):
+    import evaluate as E
+    d = os.path.join(golden_dir, 'g4')
+    data, model = os.path.join(d, 'data'), os.path.join(d, 'model')
+    for step, total in ((10, 50), (7, 64)):
+        assert E.main(['-d', data, '-m', model, '-s', str(step), '-t', str(total), '-sl', 'im', 'om']) == \
+            R.evaluate_cli(data, model, step=step, total=total, scenarios=('im', 'om'))
 
 
 def test_cli_edge_cases_g7(hip, golden_dir):

@@ -145,9 +145,10 @@ def _topk_workspace(n_rows, K, device):
     return ws
 
 
-def score_topk(U, Vt, K, bias=None, user_idx=None, mask=None, mask_pitch=0, want_scores=False, split=True):
-    """-> ids int32 [n_rows, K] (and scores fp32 [n_rows, K])"""
-    assert U.dtype == torch.float32 and Vt.dtype == torch.float32 and U.shape[1] == Vt.shape[1]
+TOPK_MAX_K = 32      # one launch of K4 ranks at most this many columns per row
+
+
+def _score_topk_once(U, Vt, K, bias, user_idx, mask, mask_pitch, want_scores, split):
     n_rows = int(user_idx.numel()) if user_idx is not None else int(U.shape[0])
     ids = torch.empty((n_rows, K), dtype=torch.int32, device=U.device)
     scores = torch.empty((n_rows, K), dtype=torch.float32, device=U.device) if want_scores else None
@@ -156,7 +157,36 @@ def score_topk(U, Vt, K, bias=None, user_idx=None, mask=None, mask_pitch=0, want
                                 C.c_int32(U.shape[1]), _p(mask), C.c_int32(mask_pitch), C.c_int32(K), _p(ids),
                                 _p(scores), _p(ws), C.c_int64(ws.numel() if ws is not None else 0), _stream()),
            'tkr_score_topk')
-    return (ids, scores) if want_scores else ids
+    return ids, scores
+
+
+def score_topk(U, Vt, K, bias=None, user_idx=None, mask=None, mask_pitch=0, want_scores=False, split=True):
+    """-> ids int32 [n_rows, K] (and scores fp32 [n_rows, K]).
+
+    K > 32 (evaluate.py -t above 32) is served exactly by several launches: the best 32, then the best 32
+    of what is left (the columns already found are added to a copy of the rated mask), and so on."""
+    assert U.dtype == torch.float32 and Vt.dtype == torch.float32 and U.shape[1] == Vt.shape[1]
+    if K <= TOPK_MAX_K:
+        ids, scores = _score_topk_once(U, Vt, K, bias, user_idx, mask, mask_pitch, want_scores, split)
+        return (ids, scores) if want_scores else ids
+    n_rows = int(user_idx.numel()) if user_idx is not None else int(U.shape[0])
+    n_cols = int(Vt.shape[0])
+    pitch = mask_pitch if mask is not None else (n_rows + 31) // 32 * 32
+    work = mask.clone() if mask is not None else torch.zeros(((n_cols + 31) // 32) * pitch, dtype=torch.int32, device=U.device)
+    ptr = torch.arange(0, (n_rows + 1) * TOPK_MAX_K, TOPK_MAX_K, dtype=torch.int64, device=U.device)
+    parts_i, parts_s, left = [], [], K
+    while left > 0:
+        ids, scores = _score_topk_once(U, Vt, TOPK_MAX_K, bias, user_idx, work, pitch, want_scores, split)
+        take = min(left, TOPK_MAX_K)
+        parts_i.append(ids[:, :take])
+        if want_scores:
+            parts_s.append(scores[:, :take])
+        left -= take
+        if left > 0:      # found columns join the mask (negative ids = padding are skipped by the kernel)
+            _check(lib().tkr_build_rated_mask(_p(ptr), _p(ids.reshape(-1)), C.c_int32(n_rows), C.c_int32(n_cols), _p(work),
+                                              C.c_int32(pitch), _stream()), 'tkr_build_rated_mask')
+    ids = torch.cat(parts_i, dim=1).contiguous()
+    return (ids, torch.cat(parts_s, dim=1).contiguous()) if want_scores else ids
 
 
 def count_hits(ids, like_ptr, like_cols, step, interval):
