@@ -299,18 +299,19 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                            // rows 8g+4h .. 8g+4h+3 are registers 4g..4g+3
             const float4 bq = *reinterpret_cast<const float4*>(sm.tbias + buf * 32 + 8 * g + 4 * h);
-            sc[4 * g + 0] = (acc[4 * g + 0] + bq.x) + 0.0f;      // fl(fl(dot)+b); -0.0 -> +0.0
-            sc[4 * g + 1] = (acc[4 * g + 1] + bq.y) + 0.0f;
-            sc[4 * g + 2] = (acc[4 * g + 2] + bq.z) + 0.0f;
-            sc[4 * g + 3] = (acc[4 * g + 3] + bq.w) + 0.0f;
+            sc[4 * g + 0] = acc[4 * g + 0] + bq.x;               // fl(fl(dot)+b)
+            sc[4 * g + 1] = acc[4 * g + 1] + bq.y;
+            sc[4 * g + 2] = acc[4 * g + 2] + bq.z;
+            sc[4 * g + 3] = acc[4 * g + 3] + bq.w;
         }
         if (t == next_sched) {                                   // workgroup-uniform: every wave trims all its users now
             thr = trim_all_users<IdT>(sm, uw, h, K, thr);
             next_sched = t + ((t - t_begin + 1) >> 1);
         }
-        uint32_t ok = 0;                                         // bit r: column exists, user exists, not rated
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ok |= ((~mh >> ((r & 3) + 8 * (r >> 2))) & 1u) << r;
+        // bit r of ok: column exists, user exists, not rated.  Register r <-> mask bit (r&3) + 8*(r>>2):
+        // gather the four nibbles at bits 0, 8, 16, 24 of ~mh
+        const uint32_t nm = ~mh;
+        const uint32_t ok = (nm & 0xfu) | ((nm >> 4) & 0xf0u) | ((nm >> 8) & 0xf00u) | ((nm >> 12) & 0xf000u);
         for (;;) {
             uint32_t hits = 0;
 #pragma unroll
@@ -325,7 +326,7 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
                 for (int r = 0; r < 16; ++r) {
                     if (hits & (1u << r)) {
                         const int pos = atomicAdd(&sm.cnt[uw], 1);
-                        sm.cs[pos * users + uw] = sc[r];
+                        sm.cs[pos * users + uw] = sc[r] + 0.0f;         // -0.0 -> +0.0: ties with 0.0 like numpy
                         sm.ci[pos * users + uw] = (IdT)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
                     }
                 }
