@@ -285,11 +285,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if os.environ.get('TKR_BENCH_SINGLE_DEVICE') == '1':        # test hook: several ranks share GPU 0 (with gloo)
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=device)
+        backend = os.environ.get('TKR_BENCH_BACKEND', 'nccl')       # 'nccl' = RCCL over xGMI
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     B, k = args.batch_size, args.k
     r, csr, eng, nnz = build_problem(args.shape, k, rank, world, device)
