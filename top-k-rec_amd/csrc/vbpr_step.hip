@@ -110,23 +110,26 @@ __global__ __launch_bounds__(64) void vbpr_project_kernel(tkr_vbpr_state st, con
 
 // ------------------------------------------------------------------------------------------------
 // V1r: P[t][n] = sum_s Ppart[s][t][n] (n < kh), Q[t] = sum_s Ppart[s][t][kh].  One workgroup per triplet:
-// 4 slice groups x 64 columns, every thread sums its slices in ascending order, groups combined in order.
-__global__ __launch_bounds__(256) void vbpr_reduce_kernel(const float* __restrict__ ppart, int S, int B, int kh,
-                                                         float* __restrict__ P, float* __restrict__ Q) {
-    __shared__ float red[4][129];
+// 16 slice groups x 64 columns, every thread sums its slices in ascending order, groups combined in order.
+__global__ __launch_bounds__(1024) void vbpr_reduce_kernel(const float* __restrict__ ppart, int S, int B, int kh,
+                                                          float* __restrict__ P, float* __restrict__ Q) {
+    constexpr int SG = 16;                                       // slice groups: thread (sg, ln) sums slices sg, sg+16, ...
+    __shared__ float red[SG][65];
     const int t = blockIdx.x, sg = threadIdx.x >> 6, ln = threadIdx.x & 63;
     const int NP = kh + 1;
     for (int n0 = 0; n0 < NP; n0 += 64) {
         const int n = n0 + ln;
         float a = 0.f;
         if (n < NP) {
-#pragma unroll 8
-            for (int s = sg; s < S; s += 4) a += ppart[((size_t)s * B + t) * NP + n];
+#pragma unroll 10
+            for (int s = sg; s < S; s += SG) a += ppart[((size_t)s * B + t) * NP + n];
         }
         red[sg][ln] = a;
         __syncthreads();
         if (sg == 0 && n < NP) {
-            const float v = ((red[0][ln] + red[1][ln]) + red[2][ln]) + red[3][ln];
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < SG; ++g) v += red[g][ln];        // fixed order
             if (n < kh) P[(size_t)t * kh + n] = v; else Q[t] = v;
         }
         __syncthreads();
@@ -498,7 +501,7 @@ static int launch_vbpr_t(const tkr_vbpr_state& st, const int32_t* ti, const int3
     const int4* hdr4 = reinterpret_cast<const int4*>(hdr);
     const dim3 rgrid(vbpr_grid(B, TEAM)), rblock(TEAM * 64);
     hipLaunchKernelGGL(vbpr_project_kernel<NT>, dim3(S, (B + 31) / 32), dim3(64), 0, stream, st, ti, tj, B, ppart);
-    hipLaunchKernelGGL(vbpr_reduce_kernel, dim3(B), dim3(256), 0, stream, ppart, S, B, kh, P, Q);
+    hipLaunchKernelGGL(vbpr_reduce_kernel, dim3(B), dim3(1024), 0, stream, ppart, S, B, kh, P, Q);
     const int NH = (kh + 63) / 64, NE = (2 * kh + 63) / 64;
     if (NH == 1) hipLaunchKernelGGL((vbpr_occur_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
     else hipLaunchKernelGGL((vbpr_occur_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
