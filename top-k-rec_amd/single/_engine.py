@@ -198,8 +198,9 @@ def _run_pipelined(eng, csr, n_batches, B, want_loss, step_fn):
 
 
 class DoubleTable:
-    """A parameter table + its RMSProp slot, double-buffered for K2 ([2][n][k], see
-    csrc/bpr_step.hip).  ``stamp`` is shared by tables updated together."""
+    """A parameter table + its RMSProp slot, double-buffered for K2 ([2][n][k], see csrc/bpr_step.hip).
+    Which buffer holds row r is the parity of the row's update counter (UpdateCounters), shared by the
+    tables that are updated together (V and b; ire and irb)."""
 
     def __init__(self, n, k, device, init=None, gen=None):
         shape = (2, n, k) if k else (2, n)
@@ -213,9 +214,9 @@ class DoubleTable:
         idx = torch.arange(self.p.shape[1], device=self.p.device)
         return self.p[sel, idx], self.ms[sel, idx]
 
-    def assign(self, stamp_zeroed_values, ms=None):
-        """write values into buffer 0 (caller resets the stamp's buffer bit to 0)"""
-        self.p[0].copy_(stamp_zeroed_values)
+    def assign(self, values, ms=None):
+        """write values into buffer 0 (the caller zeroes the update counters so that buffer 0 is current)"""
+        self.p[0].copy_(values)
         if ms is not None:
             self.ms[0].copy_(ms)
 
