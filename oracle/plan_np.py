@@ -34,7 +34,7 @@ Plan definition (per batch of B triplets, consumed by the step kernels):
                      running per-row update counters ucnt / icnt.  Stored in task[.,3] for the
                      task's own row and in bit 30 of every occ id for the partner rows.
 Launch plan (what the step kernel actually reads; derived from the above):
-  a task with <= LIGHT_MAX occurrences is LIGHT (one wave), otherwise HEAVY (a team of TEAM
+  a task with <= light_max(B) occurrences (4 for B <= 4096, else 16) is LIGHT (one wave), otherwise HEAVY (a team of TEAM
   waves = one workgroup, wave w takes occurrences w, w+TEAM, ...; TEAM = team_for(B): 4 up to
   B = 1024, 16 above).  Workgroups hold TEAM wave
   records; light tasks fill workgroups 0..nlb-1 in task order, heavy task h is workgroup nlb+h.
@@ -53,7 +53,8 @@ import numpy as np
 U32 = np.uint32
 U64 = np.uint64
 MAX_ROUNDS = 64
-LIGHT_MAX = 4          # occurrences a single wave handles (csrc/sampler.hip kLightMax)
+LIGHT_MAX = 4          # occurrences a single wave handles for B <= 4096 (csrc/sampler.hip)
+LIGHT_MAX_BIG = 16     # ... and for larger batches (fewer, fuller 16-wave teams: dispatching them dominates)
 TEAM = 16              # waves per workgroup / per heavy task for batches > TEAM_SMALL_MAX_B
 TEAM_SMALL = 4         # ... and for small batches: 4-wave workgroups spread a 256-batch over ~180 CUs
 TEAM_SMALL_MAX_B = 1024
@@ -62,6 +63,13 @@ TEAM_SMALL_MAX_B = 1024
 def light_per_block(B):
     """light tasks packed into one workgroup (= every wave slot; half-filled groups were measured slower)"""
     return team_for(B)
+
+
+LIGHT_BIG_MIN_B = 4096  # batches above this use LIGHT_MAX_BIG
+
+
+def light_max(B):
+    return LIGHT_MAX if B <= LIGHT_BIG_MIN_B else LIGHT_MAX_BIG
 
 
 def team_for(B):
@@ -204,7 +212,7 @@ def plan_batch(u, i, j, return_t=False):
 def max_blocks(B):
     """workgroups a batch can need: light tasks 16 per group + heavy tasks (>= 5 occurrences each)"""
     lpb = light_per_block(B)
-    return (3 * B + lpb - 1) // lpb + (3 * B) // (LIGHT_MAX + 1)
+    return (3 * B + lpb - 1) // lpb + (3 * B) // (light_max(B) + 1)
 
 
 def resolve_parity(task, occ, B, ucnt, icnt):
@@ -239,8 +247,8 @@ def launch_plan(task, occ, B, occt=None):
     nblk = max_blocks(B)
     rec = np.zeros((nblk * TEAM, 16), dtype=np.int32)
     live = np.flatnonzero(task[:, 0] != -1)
-    light = [t for t in live if task[t, 2] <= LIGHT_MAX]
-    heavy = [t for t in live if task[t, 2] > LIGHT_MAX]
+    light = [t for t in live if task[t, 2] <= light_max(B)]
+    heavy = [t for t in live if task[t, 2] > light_max(B)]
     LPB = light_per_block(B)
     nlb = (len(light) + LPB - 1) // LPB
     rec[: nlb * TEAM, 0] = -1
@@ -248,9 +256,10 @@ def launch_plan(task, occ, B, occt=None):
         slot = (li // LPB) * TEAM + li % LPB
         rowk, start, cnt, par = task[t]
         rec[slot, 0:4] = (rowk, par | (1 << 8), cnt, start)
-        rec[slot, 4:4 + 2 * cnt] = occ[start:start + cnt].reshape(-1)
+        inl = min(cnt, 4)
+        rec[slot, 4:4 + 2 * inl] = occ[start:start + inl].reshape(-1)
         rec[slot, 12] = cnt
-        rec[slot, 13:15] = _pack_t(occt[start:start + cnt])
+        rec[slot, 13:15] = _pack_t(occt[start:start + inl])
     for h, t in enumerate(heavy):
         rowk, start, cnt, par = task[t]
         for w in range(TEAM):

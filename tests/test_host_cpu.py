@@ -136,7 +136,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name)
     assert lib.tkr_version() == 100
     assert lib.tkr_plan_team(256) == 4 and lib.tkr_plan_team(8192) == 16
-    assert lib.tkr_plan_max_blocks(256) == 192 + 153 and lib.tkr_plan_max_blocks(2048) == 384 + 1228
+    assert lib.tkr_plan_max_blocks(256) == 192 + 153 and lib.tkr_plan_max_blocks(2048) == 384 + 1228 and lib.tkr_plan_max_blocks(8192) == 1536 + 1445
     # argument validation happens before any device access
     assert lib.tkr_score_topk(None, None, 0, None, None, 0, 0, None, 0, 0, None, None, None, 0, None) == -1
 

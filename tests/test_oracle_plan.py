@@ -113,14 +113,14 @@ def test_plan_layout():
         # launch plan: every task appears once; heavy tasks are split over a team of 16 waves
         rec, hdr = recs[b], hdrs[b]
         TEAM = P.team_for(B)
-        n_light = sum(1 for t in live if t[2] <= P.LIGHT_MAX)
+        n_light = sum(1 for t in live if t[2] <= P.light_max(B))
         nlb = hdr[1]
         assert hdr[3] == len(live) and n_light + hdr[2] == hdr[3] and hdr[0] == nlb + hdr[2]
         assert nlb == (n_light + P.light_per_block(B) - 1) // P.light_per_block(B)
         used = rec[: hdr[0] * TEAM]
         lightrec = used[: nlb * TEAM]
-        assert [r for r in lightrec[:, 0] if r != -1] == [t[0] for t in live if t[2] <= P.LIGHT_MAX]
-        for h, t in enumerate([t for t in live if t[2] > P.LIGHT_MAX]):
+        assert [r for r in lightrec[:, 0] if r != -1] == [t[0] for t in live if t[2] <= P.light_max(B)]
+        for h, t in enumerate([t for t in live if t[2] > P.light_max(B)]):
             team = used[(nlb + h) * TEAM:(nlb + h + 1) * TEAM]
             assert np.all(team[:, 0] == t[0]) and team[:, 2].sum() == t[2] and np.all(team[:, 12] == t[2])
             assert ((team[:, 1] >> 16) & 0xff).tolist() == list(range(TEAM))

@@ -27,7 +27,9 @@ namespace tkr {
 constexpr int kPlanThreads = 256;      // resolve/commit kernels, and sample_plan for B <= 1024
 constexpr int kPlanThreadsBig = 1024;  // sample_plan for larger batches (the LDS sort dominates there)
 constexpr int kMaxRounds = 64;   // oracle/plan_np.py MAX_ROUNDS
-constexpr int kLightMax = 4;     // oracle/plan_np.py LIGHT_MAX: occurrences one wave handles
+constexpr int kLightMax = 4;     // oracle/plan_np.py LIGHT_MAX: occurrences one wave handles, B <= 4096
+constexpr int kLightMaxBig = 16; // ... LIGHT_MAX_BIG for larger batches
+__host__ __device__ inline int light_max(int B) { return B <= 4096 ? kLightMax : kLightMaxBig; }
 constexpr int kTeamBig = 16;     // oracle/plan_np.py TEAM: waves per workgroup / heavy task, B > 1024
 constexpr int kTeamSmall = 4;    // ... TEAM_SMALL for B <= 1024 (spreads a small batch over many CUs)
 __host__ __device__ inline int team_for(int B) { return B <= 1024 ? kTeamSmall : kTeamBig; }
@@ -224,6 +226,7 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
     const uint32_t* __restrict__ touch_i, int32_t* __restrict__ rec_all, int4* __restrict__ hdr_all) {
     __shared__ int scan[2 * (kPlanThreads + 1)];
     const int kTeam = team_for(B);
+    const int lmax = light_max(B);
     const int b = blockIdx.x;
     int4* task = task_all + (size_t)b * 3 * B;
     int2* occ = occ_all + (size_t)b * 3 * B;
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
     int nl = 0, nh = 0;
     for (int s = beg; s < end; ++s) {
         const int4 t = task[s];
-        if (t.x != -1) { if (t.z <= kLightMax) ++nl; else ++nh; }
+        if (t.x != -1) { if (t.z <= lmax) ++nl; else ++nh; }
     }
     int tot_l, tot_h, hi;
     int li = block_exclusive_scan2(nl, nh, scan, tot_l, tot_h, hi);
@@ -268,11 +271,11 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
     for (int s = beg; s < end; ++s) {
         const int4 t = task[s];
         if (t.x == -1) continue;
-        if (t.z <= kLightMax) {
+        if (t.z <= lmax) {
             int32_t* r = rec + ((size_t)(li / lpb) * kTeam + li % lpb) * 16;
             r[0] = t.x; r[1] = t.w | (1 << 8); r[2] = t.z; r[3] = t.y;
             int tt[4];
-            for (int q = 0; q < kLightMax; ++q) {
+            for (int q = 0; q < 4; ++q) {
                 const int2 o = (q < t.z) ? occ[t.y + q] : make_int2(0, 0);
                 r[4 + 2 * q] = o.x; r[5 + 2 * q] = o.y;
                 tt[q] = (q < t.z) ? occt[t.y + q] : 0;
@@ -333,7 +336,7 @@ extern "C" int tkr_plan_team(int32_t batch_size) { return tkr::team_for(batch_si
 
 extern "C" int tkr_plan_max_blocks(int32_t batch_size) {
     const int lpb = tkr::light_per_block(batch_size);
-    return (3 * batch_size + lpb - 1) / lpb + (3 * batch_size) / (tkr::kLightMax + 1);
+    return (3 * batch_size + lpb - 1) / lpb + (3 * batch_size) / (tkr::light_max(batch_size) + 1);
 }
 
 extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr,
