@@ -112,33 +112,36 @@ __device__ __forceinline__ float trim_user(const TopkSmem<IdT>& sm, int uw, int 
 }
 
 // Scheduled trim of ALL 32 users of a wave at once, one user per lane pair (half h scans entries
-// [32h, 32h+32)): bitwise search for the K-th largest score, then in-place compaction of the entries
-// >= that score.  No cross-lane traffic except one xor-32 exchange per step.  Entries tied with the
-// K-th score are all kept (the exact order among them is settled by the final sort); a list that
-// does not shrink enough is caught by the on-demand exact trim.
+// [32h, 32h+32)).  The filter only needs a LOWER BOUND of the K-th best score (a superset of the top K may
+// stay; order and exact cut come from the final sort), so the search runs on the upper 16 bits of the ordered
+// score: 16 bitwise steps over 32 keys packed two per register, then in-place compaction of the entries whose
+// 16-bit key reaches the bound.  A list that does not shrink enough is caught by the on-demand exact trim.
 template <typename IdT>
 __device__ __forceinline__ float trim_all_users(const TopkSmem<IdT>& sm, int uw, int h, int K, float thr) {
     const int n = sm.cnt[uw];
-    uint32_t key[32];
+    uint32_t kp[16];                                         // entries 2e (low half) and 2e+1 (high half); 0 = absent
 #pragma unroll
-    for (int e = 0; e < 32; ++e) {
-        const int p = 32 * h + e;
-        key[e] = (p < n) ? ordered_bits(sm.cs[p * sm.users + uw]) : 0u;       // 0 < every real key
+    for (int e = 0; e < 16; ++e) {
+        const int p0 = 32 * h + 2 * e;
+        const float v0 = sm.cs[p0 * sm.users + uw], v1 = sm.cs[(p0 + 1) * sm.users + uw];   // slots exist; masked below
+        const uint32_t k0 = (p0 < n) ? (ordered_bits(v0) >> 16) : 0u;
+        const uint32_t k1 = (p0 + 1 < n) ? (ordered_bits(v1) >> 16) : 0u;
+        kp[e] = k0 | (k1 << 16);
     }
     uint32_t prefix = 0;
 #pragma unroll 1
-    for (int b = 31; b >= 0; --b) {
+    for (int b = 15; b >= 0; --b) {
         const uint32_t cand = prefix | (1u << b);
         int c = 0;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) c += (key[e] >= cand);
+        for (int e = 0; e < 16; ++e) c += ((kp[e] & 0xffffu) >= cand) + ((kp[e] >> 16) >= cand);
         c += __shfl_xor(c, 32, 64);
         if (c >= K) prefix = cand;
     }
-    const bool active = n >= K;                              // fewer than K candidates: keep all, threshold unchanged
+    const bool active = n >= K && prefix != 0;               // fewer than K candidates: keep all, threshold unchanged
     int mine = 0;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) mine += (key[e] >= prefix);
+    for (int e = 0; e < 16; ++e) mine += ((kp[e] & 0xffffu) >= prefix) + ((kp[e] >> 16) >= prefix);
     const int other = __shfl_xor(mine, 32, 64);
     // in-place compaction, half 0 first (writes at or below what it reads), then half 1 behind it
 #pragma unroll 1
@@ -147,10 +150,11 @@ __device__ __forceinline__ float trim_all_users(const TopkSmem<IdT>& sm, int uw,
             int pos = h ? other : 0;
 #pragma unroll
             for (int e = 0; e < 32; ++e) {
-                if (key[e] >= prefix) {
+                const uint32_t k16 = (e & 1) ? (kp[e >> 1] >> 16) : (kp[e >> 1] & 0xffffu);
+                if (k16 >= prefix) {
+                    const float v = sm.cs[(32 * h + e) * sm.users + uw];
                     const IdT id = sm.ci[(32 * h + e) * sm.users + uw];
-                    const uint32_t f = (key[e] & 0x80000000u) ? (key[e] & 0x7fffffffu) : ~key[e];
-                    sm.cs[pos * sm.users + uw] = __uint_as_float(f);
+                    sm.cs[pos * sm.users + uw] = v;
                     sm.ci[pos * sm.users + uw] = id;
                     ++pos;
                 }
@@ -159,11 +163,11 @@ __device__ __forceinline__ float trim_all_users(const TopkSmem<IdT>& sm, int uw,
         __builtin_amdgcn_wave_barrier();
     }
     if (active && h == 0) sm.cnt[uw] = mine + other;
-    const uint32_t f = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
-    return active ? __uint_as_float(f) : thr;
+    const uint32_t ob = prefix << 16;                        // smallest ordered score with this 16-bit key
+    const uint32_t f = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+    return active ? fmaxf(thr, __uint_as_float(f)) : thr;
 }
 
-// wide factor rows (k > 128) keep 100+ operand registers: one wave per SIMD
 // waves per workgroup of an instantiation: 8 (two per SIMD: one wave's filter overlaps the other's MFMA
 // chain); 6 when candidate ids need 32 bits (LDS); 4 for wide factor rows (100+ operand registers)
 template <int KHP, typename IdT>
