@@ -18,10 +18,13 @@ import numpy as np
 
 ML10M = dict(n_users=69878, n_in=8305, n_out=2075, mu=4.2, sigma=1.0)        # data/uid, vid, f0t*.idl sizes
 NETFLIX = dict(n_users=480189, n_in=14216, n_out=3554, mu=4.84, sigma=1.0)   # 17,770 items, 80/20 in/out
+# ML-10M shape with selection bias and a flatter popularity curve: the preset on which a trained BPR model beats
+# the popularity-only ranking (acc@30 0.066 vs 0.057, scripts/acceptance_ml10m.py) -- use it for accuracy studies
+ML10M_SIGNAL = dict(ML10M, alpha=0.6, gain=2.0, select=4.0)
 
 
 def make_ratings(n_users, n_in, n_out=0, seed=42, mu=4.2, sigma=1.0, alpha=0.9, gain=1.5,
-                 min_r=5, max_r=3000, om_per_user=8, rank=16):
+                 min_r=5, max_r=3000, om_per_user=8, rank=16, select=0.0):
     """-> dict of flat arrays.  ``tr_*``/``im_*``: (user, item, like) triples of the train
     file and the in-matrix test file (items 0..n_in-1); ``om_*``: the out-of-matrix test
     file (items n_in..n_in+n_out-1).  Item numbers here are *positions in the vid list*."""
@@ -32,8 +35,13 @@ def make_ratings(n_users, n_in, n_out=0, seed=42, mu=4.2, sigma=1.0, alpha=0.9, 
     cdf = np.cumsum(pop / pop.sum())
     perm = rng.permutation(n_in)                       # popularity rank -> item position
     cnt = np.clip(rng.lognormal(mu, sigma, n_users), min_r, min(max_r, n_in // 2)).astype(np.int64)
-    users = np.repeat(np.arange(n_users, dtype=np.int64), cnt)
+    over = 4 if select > 0 else 1
+    users = np.repeat(np.arange(n_users, dtype=np.int64), cnt * over)
     items = perm[np.minimum(np.searchsorted(cdf, rng.random(len(users))), n_in - 1)]
+    if select > 0:
+        aff = np.einsum('ij,ij->i', P[users], Q[items]) * (select / 4.0)
+        keep = rng.random(len(users)) < 1.0 / (1.0 + np.exp(-aff))
+        users, items = users[keep], items[keep]
     key = np.unique(users * n_in + items)              # drop repeated (user,item) draws
     users, items = key // n_in, key % n_in
     shuffle = rng.permutation(len(users))              # file order inside a user's line is arbitrary
