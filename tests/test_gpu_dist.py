@@ -71,3 +71,57 @@ def test_two_rank_sharded_training_matches_oracle(tmp_path):
                          capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count('ok') == 2
+
+
+_ACC_WORKER = r'''
+import os, sys, json
+sys.path[:0] = [%(root)r, %(pkg)r]
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group('gloo')
+from single import BPR
+m = BPR(k=16, lr=1e-2)
+m.load_training_data(%(data)r + '/uid', %(data)r + '/vid', %(data)r + '/f0tr.txt')
+m.train(epochs=12, batch_size=256, seed=21, verbose=False)
+if dist.get_rank() == 0:
+    m.export_embeddings(%(out)r)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_sharded_accuracy_tracks_single_stream(tmp_path):
+    """SURVEY H4: 4 user shards + per-epoch sum-of-deltas exchange vs the single-stream run, same data and
+    hyper-parameters (different sample streams): accuracy@k must agree within the seed-noise band (0.01 here,
+    measured differences are a few 1e-3) and both must clearly beat an untrained model."""
+    sys.path.insert(0, os.path.join(ROOT, 'top-k-rec_amd'))
+    import synth
+    import evaluate as E
+    from single import BPR
+    r = synth.make_ratings(3000, 700, 0, seed=5, mu=3.6, sigma=0.6, min_r=8, max_r=150, alpha=0.6, gain=2.0, select=4.0)
+    data = str(tmp_path / 'data')
+    synth.write_dataset(data, r)
+    single = BPR(k=16, lr=1e-2)
+    single.load_training_data(data + '/uid', data + '/vid', data + '/f0tr.txt')
+    single.train(epochs=12, batch_size=256, seed=7, verbose=False)
+    single.export_embeddings(str(tmp_path / 'single'))
+    script = tmp_path / 'acc_worker.py'
+    script.write_text(_ACC_WORKER % dict(root=ROOT, pkg=os.path.join(ROOT, 'top-k-rec_amd'), data=data, out=str(tmp_path / 'sharded')))
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=4',
+                          '--master-addr', '127.0.0.1', '--master-port', '29643', str(script)],
+                         capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    acc = {}
+    for name in ('single', 'sharded'):
+        line = E.main(['-d', data, '-m', str(tmp_path / name), '-sl', 'im'])[0]
+        acc[name] = np.array([float(x) for x in line.split(',')[1:]])
+    untrained = BPR(k=16)
+    untrained.load_training_data(data + '/uid', data + '/vid', data + '/f0tr.txt')
+    rng = np.random.Generator(np.random.PCG64(1))
+    untrained.fue = (rng.standard_normal((3000, 16)) * 0.01).astype(np.float32)
+    untrained.fie = (rng.standard_normal((700, 16)) * 0.01).astype(np.float32)
+    untrained.fib = np.zeros((700, 1), np.float32)
+    untrained.export_embeddings(str(tmp_path / 'untrained'))
+    base = np.array([float(x) for x in E.main(['-d', data, '-m', str(tmp_path / 'untrained'), '-sl', 'im'])[0].split(',')[1:]])
+    print('acc single', acc['single'], 'sharded', acc['sharded'], 'untrained', base)
+    assert np.max(np.abs(acc['single'] - acc['sharded'])) <= 0.01
+    assert acc['single'][-1] > 2 * base[-1] and acc['sharded'][-1] > 2 * base[-1]
