@@ -17,6 +17,7 @@ Prints ONE JSON line (rank 0).  Extra objects beside the contract fields:
   cpu_baseline    the numpy oracle with the reference's cost structure (per-element legacy
                   np.random sampler + numpy step), bounded sample, rank 0, N = 1 only
   throughput_mode the same path at batch_size 8192 (a legal train() argument; NOT the headline)
+  streams_mode    opt-in train(streams=4): four user shards on four HIP streams of the one GPU (extra, not headline)
   topk            the other half of BASELINE.json's metric: full-catalogue top-30 scored users/s (K4)
                   with its own fp32-MFMA roofline and cpu_baseline
 """
@@ -240,6 +241,37 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
                          'hbm_GBps_algorithmic': gbs, 'hbm_frac': gbs / HBM_PEAK_GBS, 'step_us': step_ms * 1e3 / steps}}
 
 
+def streams_bench(r, k, device, B=256, S=4, steps=2048, warmup=512):
+    """opt-in train(streams=S): S user shards with replicated item tables on S HIP streams of ONE GPU (per-epoch
+    exchange as in the multi-GPU layout; the exchange itself is outside this timed region like in the N>1 bench
+    it happens every (limit//B)//S steps).  Aggregate triplets/s over the S streams."""
+    import synth
+    import dist as tdist
+    from single import _engine
+    row_ptr, pos, _, tr_users = synth.positives_csr(r)
+    n_users, n_items = r['n_users'], r['n_in'] + r['n_out']
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=1e-4, mode='l2')
+    engs = [_engine.BprEngine(n_users, n_items, k, hp, device, seed=50) for _ in range(S)]
+    csrs = [_engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tdist.shard_users(tr_users, i, S), dtype=np.int32), device)
+            for i in range(S)]
+    hs = [torch.cuda.Stream(device=device) for _ in range(S)]
+
+    def run(n):
+        for e, c, st in zip(engs, csrs, hs):
+            with torch.cuda.stream(st):
+                e.run_batches(c, n, B, want_loss=False)
+    run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return {'streams': S, 'batch_size': B, 'steps_per_stream': steps, 'value': S * steps * B / wall, 'unit': 'triplets/s',
+            'us_per_batch_per_stream': wall / steps * 1e6,
+            'semantics': 'user-sharded data parallel inside one GPU (same per-epoch sum-of-deltas exchange as multi-GPU); '
+                         'NOT the single-stream reference semantics of the headline value'}
+
+
 def topk_cpu_baseline(r, k, K=30, budget_s=12.0, slice_users=2000):
     """evaluate.py's operations on user slices until the time budget is spent:
     np.dot -> np.argsort -> python rank walk (oracle restatement of evaluate.py:78-105)"""
@@ -343,6 +375,7 @@ def main():
         if rank == 0 and world == 1:
             out['topk_netflix_shape'] = topk_bench_netflix(k, device)
             out['vbpr'] = vbpr_bench(r, csr, k, device)
+            out['streams_mode'] = streams_bench(r, k, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(r, k, B)
     if rank == 0:

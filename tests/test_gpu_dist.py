@@ -125,3 +125,46 @@ def test_sharded_accuracy_tracks_single_stream(tmp_path):
     print('acc single', acc['single'], 'sharded', acc['sharded'], 'untrained', base)
     assert np.max(np.abs(acc['single'] - acc['sharded'])) <= 0.01
     assert acc['single'][-1] > 2 * base[-1] and acc['sharded'][-1] > 2 * base[-1]
+
+
+def test_streams_mode_matches_oracle_simulation(tmp_path):
+    """train(streams=3): three user shards on three HIP streams of one GPU == oracle simulation of three shards
+    with the per-epoch sum-of-deltas exchange (the multi-GPU rule applied inside one GPU)."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'top-k-rec_amd')]
+    import synth
+    import dist as tdist
+    from single import BPR
+    from oracle import plan_np as P, ref_np as R
+    r = synth.make_ratings(150, 60, 0, seed=17, mu=2.6, sigma=0.4, min_r=4, max_r=25)
+    data = str(tmp_path / 'data')
+    synth.write_dataset(data, r)
+    k, B, epochs, limit, lr, S = 16, 32, 2, 32 * 13, 0.02, 3
+    m = BPR(k=k, lr=lr, lambda_b=1e-3)
+    m.load_training_data(data + '/uid', data + '/vid', data + '/f0tr.txt')
+    rng = np.random.Generator(np.random.PCG64(0))
+    init = [(rng.standard_normal((m.n_users, k)) * 0.1).astype(np.float32), (rng.standard_normal((m.n_items, k)) * 0.1).astype(np.float32),
+            np.zeros((m.n_items, 1), np.float32)]
+    m.fue, m.fie, m.fib = (a.copy() for a in init)
+    m.train(epochs=epochs, batch_size=B, epoch_sample_limit=limit, seed=11, verbose=False, streams=S)
+    hp = dict(lu=m.lu, li=m.li, lj=m.lj, lb=m.lb, lr=lr, mode='l2')
+    nb = (limit // B) // S
+    row_ptr, pos, srt = P.build_csr(m.tr_data, m.n_users)
+    st = [dict(U=init[0].copy(), V=init[1].copy(), b=init[2].ravel().copy(), msU=np.ones_like(init[0]), msV=np.ones_like(init[1]),
+               msb=np.ones(m.n_items, np.float32)) for _ in range(S)]
+    drawn = [q * epochs * nb * B for q in range(S)]
+    for e in range(epochs):
+        V0, b0 = st[0]['V'].copy(), st[0]['b'].copy()
+        for q in range(S):
+            users = tdist.shard_users(m.tr_users, q, S)
+            u, i, j = P.sample_triplets(users, row_ptr, pos, srt, m.n_items, 11, drawn[q], nb * B)
+            drawn[q] += nb * B
+            for t in range(nb):
+                R.bpr_step(st[q], u[t * B:(t + 1) * B], i[t * B:(t + 1) * B], j[t * B:(t + 1) * B], hp)
+        V = V0 + sum(x['V'] - V0 for x in st); b = b0 + sum(x['b'] - b0 for x in st)
+        msV = sum(x['msV'] for x in st) / S; msb = sum(x['msb'] for x in st) / S
+        for x in st:
+            x['V'], x['b'], x['msV'], x['msb'] = V.copy(), b.copy(), msV.copy(), msb.copy()
+    U = init[0] + sum(x['U'] - init[0] for x in st)
+    np.testing.assert_allclose(m.fie, st[0]['V'], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(m.fib.ravel(), st[0]['b'], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(m.fue, U, rtol=2e-4, atol=1e-5)

@@ -273,6 +273,12 @@ class BprEngine:
 
     replicated_names = ('V', 'b')
 
+    def copy_model_from(self, other):
+        """start from another engine's current parameters and slots (shards of one model)"""
+        p, ms = other.get('U')
+        self.set_users(U=p, msU=ms)
+        self.set_replicated({n: other.get(n) for n in self.replicated_names})
+
     def set_replicated(self, new):
         """write back all-reduced item-side tables: {'V': (p, ms), 'b': (p, ms)} (dist.ItemSync)"""
         self.set_items(V=new['V'][0], b=new['b'][0], msV=new['V'][1], msb=new['b'][1])
@@ -369,6 +375,7 @@ class VbprEngine:
         self.set_dense(cem=new['cem'][0], icb=new['icb'][0], mscem=new['cem'][1], msicb=new['icb'][1])
 
     replicated_names = ('I', 'irb', 'cem', 'icb')
+    copy_model_from = BprEngine.copy_model_from
 
     def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True):
         need = tkr_hip.vbpr_workspace_floats(B, self.kh, self.d)

@@ -115,7 +115,7 @@ class BPR(REC):
 
     def train(self, sampling: str = 'user uniform', epochs: int = 5, batch_size: int = 256,
               epoch_sample_limit: int = None, model_path: str = None, *, seed=None, device=None,
-              verbose: bool = True):
+              verbose: bool = True, streams: int = 1):
         assert isinstance(sampling, str)
         assert isinstance(epochs, int)
         assert isinstance(batch_size, int)
@@ -141,6 +141,15 @@ class BPR(REC):
         # tables replicated and reconciled once per epoch (dist.py; the reference is single-process)
         import dist as tdist
         rank, world = tdist.world()
+        if streams > 1:
+            # opt-in: the multi-GPU layout inside ONE GPU -- `streams` user shards with replicated item tables run
+            # concurrently on separate HIP streams and are reconciled once per epoch by the same rule (dist.py).
+            # One sequential 256-batch stream leaves most of the chip idle (it is launch-latency bound); ~4 streams
+            # triple the aggregate rate.  Not the reference's single-stream semantics: off by default.
+            assert world == 1, 'streams > 1 and torch.distributed sharding are not combined'
+            self._train_streams(epochs, n_batches, batch_size, streams, verbose)
+            self._collect()
+            return
         if world > 1:
             shard = tdist.shard_users(self.tr_users, rank, world)
             self._csr = _engine.TrainingCSR(self.tr_data, shard, self.n_users, self._eng.device)
@@ -168,6 +177,47 @@ class BPR(REC):
             self._eng.set_users(U=tdist.combine_user_rows(p, users_start), msU=ms)
             self._csr = None                     # the sharded CSR is not the model's full training set
         self._collect()
+
+    def _train_streams(self, epochs, n_batches, batch_size, S, verbose):
+        import dist as tdist
+        dev = self._eng.device
+        names = self._eng.replicated_names
+        engines = [self._eng] + [self._make_engine(dev, self._eng.seed) for _ in range(S - 1)]
+        lead = engines[0]
+        for e in engines[1:]:                              # every shard starts from the same (possibly warm-started) model
+            e.copy_model_from(lead)
+        nb = tdist.batches_per_rank(n_batches, S)
+        csrs, hip_streams = [], []
+        for i, e in enumerate(engines):
+            csrs.append(_engine.TrainingCSR(self.tr_data, tdist.shard_users(self.tr_users, i, S), self.n_users, dev))
+            e.triplets_drawn = i * epochs * nb * batch_size                      # disjoint stream positions, one key
+            hip_streams.append(torch.cuda.Stream(device=dev))
+        users_start = lead.get('U')[0].clone()
+        for eid in range(epochs):
+            t0 = time.time()
+            start = {n: lead.get(n)[0].clone() for n in names}
+            torch.cuda.synchronize(dev)
+            losses = []
+            for e, csr, st in zip(engines, csrs, hip_streams):
+                with torch.cuda.stream(st):
+                    losses.append(e.run_batches(csr, nb, batch_size, want_loss=True))
+            torch.cuda.synchronize(dev)
+            new = {}
+            for n in names:                                # P <- P0 + sum of deltas, slots <- mean (dist.py)
+                ps = [e.get(n) for e in engines]
+                new[n] = (start[n] + sum(p - start[n] for p, _ in ps), sum(ms for _, ms in ps) / S)
+            for e in engines:
+                e.set_replicated(new)
+            torch.cuda.synchronize(dev)
+            spent = time.time() - t0
+            self.last_epoch_loss = float(losses[0][-1])
+            if verbose:
+                sys.stderr.write('\rEpoch=%3d, batch=%6d, loss=%8.4f, time=%4.4fs' % (eid + 1, nb * S, self.last_epoch_loss, spent / (nb * S)))
+                sys.stderr.write(' ... total time collapse %8.4fs' % spent)
+                sys.stderr.flush()
+                print()
+        parts = [e.get('U') for e in engines]               # every user row was changed by at most one shard
+        lead.set_users(U=users_start + sum(p - users_start for p, _ in parts), msU=sum(ms - 1.0 for _, ms in parts) + 1.0)
 
     def _run_epoch(self, n_batches, batch_size):
         losses = self._eng.run_batches(self._csr, n_batches, batch_size, want_loss=True)
