@@ -241,7 +241,7 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
                          'hbm_GBps_algorithmic': gbs, 'hbm_frac': gbs / HBM_PEAK_GBS, 'step_us': step_ms * 1e3 / steps}}
 
 
-def streams_bench(r, k, device, B=256, S=4, steps=2048, warmup=512):
+def streams_bench(r, k, device, B=256, S=4, steps=2048, warmup=2048):   # warm-up = run: plan buffers and graphs cached
     """opt-in train(streams=S): S user shards with replicated item tables on S HIP streams of ONE GPU (per-epoch
     exchange as in the multi-GPU layout; the exchange itself is outside this timed region like in the N>1 bench
     it happens every (limit//B)//S steps).  Aggregate triplets/s over the S streams."""
@@ -256,10 +256,21 @@ def streams_bench(r, k, device, B=256, S=4, steps=2048, warmup=512):
             for i in range(S)]
     hs = [torch.cuda.Stream(device=device) for _ in range(S)]
 
-    def run(n):
-        for e, c, st in zip(engs, csrs, hs):
-            with torch.cuda.stream(st):
-                e.run_batches(c, n, B, want_loss=False)
+    phase = {}
+
+    def run(n):                                  # as BPR._train_streams: plan all shards first, then step concurrently
+        t_a = time.perf_counter()
+        planned = [_engine.plan_ahead(e, c, n, B) for e, c in zip(engs, csrs)]
+        torch.cuda.synchronize()
+        t_b = time.perf_counter()
+        fns = [e.step_fn(B) for e in engs]
+        for chunk in range(max(len(pl) for pl in planned)):            # round-robin over streams, one chunk each
+            for e, pl, st, fn in zip(engs, planned, hs, fns):
+                if chunk < len(pl):
+                    with torch.cuda.stream(st):
+                        _engine.run_planned(e, pl[chunk:chunk + 1], B, False, fn)
+        torch.cuda.synchronize()
+        phase['plan_ms'], phase['step_ms'] = (t_b - t_a) * 1e3, (time.perf_counter() - t_b) * 1e3
     run(warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -267,7 +278,7 @@ def streams_bench(r, k, device, B=256, S=4, steps=2048, warmup=512):
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     return {'streams': S, 'batch_size': B, 'steps_per_stream': steps, 'value': S * steps * B / wall, 'unit': 'triplets/s',
-            'us_per_batch_per_stream': wall / steps * 1e6,
+            'us_per_batch_per_stream': wall / steps * 1e6, 'plan_ms': phase['plan_ms'], 'step_ms': phase['step_ms'],
             'semantics': 'user-sharded data parallel inside one GPU (same per-epoch sum-of-deltas exchange as multi-GPU); '
                          'NOT the single-stream reference semantics of the headline value'}
 

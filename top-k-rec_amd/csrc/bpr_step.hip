@@ -379,7 +379,7 @@ struct GraphEntry {
     hipGraph_t graph;
     uint64_t used;
 };
-constexpr int kGraphCache = 8;
+constexpr int kGraphCache = 64;      // (state, plan buffer, n_batches) combinations kept instantiated
 GraphEntry g_cache[kGraphCache];
 int g_cache_n = 0;
 uint64_t g_tick = 0;

@@ -197,6 +197,43 @@ def _run_pipelined(eng, csr, n_batches, B, want_loss, step_fn):
     return loss
 
 
+def plan_ahead(eng, csr, n_batches, B):
+    """K1 for n_batches batches into freshly held buffers (no stepping): -> [(PlanBuffers, nb), ...].
+    Used by the multi-stream mode, where planner launches would disturb the other streams' step chains."""
+    cap = _chunk_cap(n_batches, B)
+    planned, left = [], n_batches
+    pool = getattr(eng, '_plan_pool', [])
+    idx = 0
+    while left:
+        nb = min(cap, left)
+        if idx >= len(pool) or pool[idx].B != B or pool[idx].cap < nb:
+            buf = PlanBuffers(cap, B, eng.device)
+            if idx < len(pool):
+                pool[idx] = buf
+            else:
+                pool.append(buf)
+        buf = pool[idx]
+        tkr_hip.sample_plan(csr, eng.n_users, eng.n_items, eng.seed, eng.triplets_drawn, nb, B, eng.cnt, buf)
+        eng.triplets_drawn += nb * B
+        planned.append((buf, nb))
+        left -= nb
+        idx += 1
+    eng._plan_pool = pool
+    return planned
+
+
+def run_planned(eng, planned, B, want_loss, step_fn):
+    """step kernels of batches planned by plan_ahead, on the current stream"""
+    loss = None
+    for plan, nb in planned:
+        if want_loss:
+            plan.loss[:nb].zero_()
+        step_fn(plan, nb, plan.loss if want_loss else None)
+        loss = plan.loss[:nb] if want_loss else None
+        eng.plan = plan
+    return loss
+
+
 class DoubleTable:
     """A parameter table + its RMSProp slot, double-buffered for K2 ([2][n][k], see csrc/bpr_step.hip).
     Which buffer holds row r is the parity of the row's update counter (UpdateCounters), shared by the
@@ -296,6 +333,10 @@ class BprEngine:
         return _run_pipelined(self, csr, n_batches, B, want_loss,
                               lambda plan, nb, loss: tkr_hip.bpr_run(state, plan, B, nb, loss))
 
+    def step_fn(self, B):
+        state = self.state()
+        return lambda plan, nb, loss: tkr_hip.bpr_run(state, plan, B, nb, loss)
+
 
 class VbprEngine:
     """Tables + sampler + step loop of one VBPR model on one GPU (single/vbpr.py:29-74).
@@ -384,3 +425,10 @@ class VbprEngine:
         state = self.state()
         return _run_pipelined(self, csr, n_batches, B, want_loss,
                               lambda plan, nb, loss: tkr_hip.vbpr_run(state, plan, B, nb, self.ws, loss))
+
+    def step_fn(self, B):
+        need = tkr_hip.vbpr_workspace_floats(B, self.kh, self.d)
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        state = self.state()
+        return lambda plan, nb, loss: tkr_hip.vbpr_run(state, plan, B, nb, self.ws, loss)

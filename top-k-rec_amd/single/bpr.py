@@ -144,8 +144,9 @@ class BPR(REC):
         if streams > 1:
             # opt-in: the multi-GPU layout inside ONE GPU -- `streams` user shards with replicated item tables run
             # concurrently on separate HIP streams and are reconciled once per epoch by the same rule (dist.py).
-            # One sequential 256-batch stream leaves most of the chip idle (it is launch-latency bound); ~4 streams
-            # triple the aggregate rate.  Not the reference's single-stream semantics: off by default.
+            # One sequential 256-batch stream leaves most of the chip idle (it is launch-latency bound); 4 streams
+            # give ~1.7x the aggregate rate (bench.py streams_mode).  Not the reference's single-stream semantics:
+            # off by default.
             assert world == 1, 'streams > 1 and torch.distributed sharding are not combined'
             self._train_streams(epochs, n_batches, batch_size, streams, verbose)
             self._collect()
@@ -197,10 +198,13 @@ class BPR(REC):
             t0 = time.time()
             start = {n: lead.get(n)[0].clone() for n in names}
             torch.cuda.synchronize(dev)
+            # plan every shard's epoch first (planner launches would disturb the other streams' step chains) ...
+            planned = [_engine.plan_ahead(e, csr, nb, batch_size) for e, csr in zip(engines, csrs)]
+            torch.cuda.synchronize(dev)
             losses = []
-            for e, csr, st in zip(engines, csrs, hip_streams):
+            for e, pl, st in zip(engines, planned, hip_streams):      # ... then only step chains run concurrently
                 with torch.cuda.stream(st):
-                    losses.append(e.run_batches(csr, nb, batch_size, want_loss=True))
+                    losses.append(_engine.run_planned(e, pl, batch_size, True, e.step_fn(batch_size)))
             torch.cuda.synchronize(dev)
             new = {}
             for n in names:                                # P <- P0 + sum of deltas, slots <- mean (dist.py)
