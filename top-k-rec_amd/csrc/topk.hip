@@ -93,7 +93,7 @@ struct TopkSmem {
 // while fewer than K candidates exist).  Wave-uniform call.
 template <typename IdT>
 __device__ __forceinline__ float trim_user(const TopkSmem<IdT>& sm, int uw, int K, int lane, uint64_t* sorted_out) {
-    const int n = sm.cnt[uw];
+    const int n = min(sm.cnt[uw], kCap);                         // a reservation past the capacity wrote nothing
     uint64_t key = 0;                                            // below every real key (real keys have idx+1 > 0)
     if (lane < n) key = ((uint64_t)ordered_bits(sm.cs[lane * sm.users + uw]) << 32) | ((uint32_t)sm.ci[lane * sm.users + uw] + 1u);
     key = wave_sort_desc(key, lane);
@@ -312,35 +312,56 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
             thr = trim_all_users<IdT>(sm, uw, h, K, thr);
             next_sched = t + ((t - t_begin + 1) >> 1);
         }
-        // bit r of ok: column exists, user exists, not rated.  Register r <-> mask bit (r&3) + 8*(r>>2):
-        // gather the four nibbles at bits 0, 8, 16, 24 of ~mh
-        const uint32_t nm = ~mh;
-        const uint32_t ok = (nm & 0xfu) | ((nm >> 4) & 0xf0u) | ((nm >> 8) & 0xf00u) | ((nm >> 12) & 0xf000u);
-        for (;;) {
-            uint32_t hits = 0;
+        // ---- filter.  fp32 MFMA and VALU time add up on a SIMD (measured: nothing hides in the MFMA shadow, from
+        // the same wave or the other one), so the common path is kept to one compare per score: hr[r] is the
+        // wave's lane mask of "score r reaches my user's threshold" and lives in SGPRs; registers without a
+        // single candidate are skipped by a scalar branch, the rated/tail/no-user bits are consulted only for
+        // lanes that have one.
+        uint64_t hr[16], any = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hits |= (uint32_t)(sc[r] >= thr) << r;
-            hits &= ok;
-            const int mine = __popc(hits);
-            const int total = mine + __shfl_xor(mine, 32, 64);
-            const bool need = total > 0 && (sm.cnt[uw] + total > kCap);
-            uint64_t pending = __ballot(need) & 0xffffffffull;   // one bit per user (lower half lanes)
-            if (pending == 0) {
+        for (int r = 0; r < 16; ++r) { hr[r] = __ballot(sc[r] >= thr); any |= hr[r]; }
+        if (any) {
+            uint32_t hits = 0;                                   // bit r: register r of this lane is a candidate
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; ++r) hits |= (sc[r] >= thr) ? (1u << r) : 0u;
+            // register r <-> mask bit (r&3) + 8*(r>>2): gather the four nibbles at bits 0, 8, 16, 24 of ~mh
+            const uint32_t nm = ~mh;
+            hits &= (nm & 0xfu) | ((nm >> 4) & 0xf0u) | ((nm >> 8) & 0xf00u) | ((nm >> 12) & 0xf000u);
+            uint32_t unplaced = 0;
+            int pos = 0;
+            if (hits) pos = atomicAdd(&sm.cnt[uw], __popc(hits));   // one LDS atomic per lane reserves all its slots
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (hr[r]) {                                     // scalar branch: most registers hold no candidate
+                    asm volatile("" ::: "memory");               // (keeps the branch: the body must not be if-converted)
                     if (hits & (1u << r)) {
-                        const int pos = atomicAdd(&sm.cnt[uw], 1);
-                        sm.cs[pos * users + uw] = sc[r] + 0.0f;         // -0.0 -> +0.0: ties with 0.0 like numpy
-                        sm.ci[pos * users + uw] = (IdT)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                        if (pos < kCap) {
+                            sm.cs[pos * users + uw] = sc[r] + 0.0f;          // -0.0 -> +0.0: ties with 0.0 like numpy
+                            sm.ci[pos * users + uw] = (IdT)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                        } else {
+                            unplaced |= 1u << r;                 // list full: trimmed below, then appended
+                        }
+                        ++pos;
                     }
                 }
-                break;
-            }
-            while (pending) {                                    // wave-uniform loop over users that must trim
-                const int u = __ffsll((long long)pending) - 1;
-                pending &= pending - 1;
+            // rare: some user's list overflowed.  Exact trim of that user (keeps K, raises the threshold), then
+            // its lanes append what still qualifies: at most 32 per user and tile, K + 32 <= kCap.
+            uint64_t ov = __ballot(unplaced != 0);
+            while (ov) {
+                const int u = (__ffsll((long long)ov) - 1) & 31;
                 const float nt = trim_user<IdT>(sm, wave * 32 + u, K, lane, nullptr);
-                if (ul == u) thr = nt;
+                if (ul == u) {
+                    thr = nt;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((unplaced & (1u << r)) && sc[r] >= thr) {
+                            const int pos = atomicAdd(&sm.cnt[uw], 1);
+                            sm.cs[pos * users + uw] = sc[r] + 0.0f;
+                            sm.ci[pos * users + uw] = (IdT)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                        }
+                    unplaced = 0;
+                }
+                ov = __ballot(unplaced != 0);
             }
         }
         __syncthreads();                                         // tile t+1 staged; buffer `buf` may be overwritten next
