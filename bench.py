@@ -17,6 +17,7 @@ Prints ONE JSON line (rank 0).  Extra objects beside the contract fields:
   cpu_baseline    the numpy oracle with the reference's cost structure (per-element legacy
                   np.random sampler + numpy step), bounded sample, rank 0, N = 1 only
   throughput_mode the same path at batch_size 8192 (a legal train() argument; NOT the headline)
+  sgd_mode / sgd_throughput_mode  the legacy plain-SGD optimiser (old/methods/bpr.py:57-61) at batch 256 / 8192
   streams_mode    opt-in train(streams=4): four user shards on four HIP streams of the one GPU (extra, not headline)
   topk            the other half of BASELINE.json's metric: full-catalogue top-30 scored users/s (K4)
                   with its own fp32-MFMA roofline and cpu_baseline
@@ -378,6 +379,16 @@ def main():
                                   'roofline': {'bound': 'hbm', 'achieved': a2, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                                'frac': a2 / HBM_PEAK_GBS, 'launch_us': s2 * 1e3 / 256,
                                                'traffic': pmc_traffic('bpr_step_B8192') if (k == 128 and args.shape == 'ml10m') else None}}
+        # legacy plain-SGD optimiser (old/methods/bpr.py:57-61): same path, no RMSProp slot traffic
+        for Bs, key, steps_s in ((B, 'sgd_mode', 2048), (B2, 'sgd_throughput_mode', 256)):
+            eng3 = _engine.BprEngine(eng.n_users, eng.n_items, k, dict(eng.hp, opt='sgd'), device, seed=77)
+            w3, s3 = timed_run(eng3, csr, Bs, steps_s, steps_s, 10 ** 9, 1)
+            a3 = Bs * (24 * k + 40) / (s3 * 1e-3 / steps_s) / 1e9        # 3 rows x (read+write) + biases + ids
+            out[key] = {'batch_size': Bs, 'steps': steps_s, 'value': steps_s * Bs / w3, 'unit': 'triplets/s',
+                        'ms_per_step': w3 * 1e3 / steps_s,
+                        'roofline': {'bound': 'hbm', 'achieved': a3, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a3 / HBM_PEAK_GBS,
+                                     'launch_us': s3 * 1e3 / steps_s, 'algorithmic_bytes_per_triplet': 24 * k + 40, 'traffic': None}}
+            del eng3
     if not args.no_extras:
         topk = topk_bench(r, k, device, rank, world)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:

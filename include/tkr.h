@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TKR_VERSION 100 /* 0.1.0 */
+#define TKR_VERSION 101 /* 0.1.1: tkr_bpr_state.opt */
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
 
@@ -60,7 +60,10 @@ int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_pt
 /* ---- K2: BPR mini-batch step ---------------------------------------------------------------
  * Replaces sess.run([solver, obj]) (single/bpr.py:141) on the graph of single/bpr.py:81-100.
  * Double-buffered tables: U, msU are [2][n_users][k]; V, msV [2][n_items][k]; b, msb [2][n_items];
- * the buffer holding row r is (ucnt[r] & 1) resp. (icnt[r] & 1) -- see K1. */
+ * the buffer holding row r is (ucnt[r] & 1) resp. (icnt[r] & 1) -- see K1.
+ * opt = 1 selects the legacy plain-SGD update P -= lr * g of old/methods/bpr.py:57-61: the
+ * objective and gradients are the same as mode 0 (old/methods/bpr.py:43-51), the ms* tables are neither read
+ * nor written and may be NULL. */
 typedef struct {
     float* U;
     float* msU;
@@ -73,6 +76,7 @@ typedef struct {
     float lu, li, lj, lb;    /* lambda_u, lambda_i, lambda_j, lambda_b (single/bpr.py:20) */
     float lr;                /* RMSPropOptimizer(lr) (single/bpr.py:100) */
     float rho, eps;          /* TF defaults 0.9, 1e-10 */
+    int32_t opt;             /* 0 = sparse RMSProp (single/bpr.py:100), 1 = plain SGD (old/methods/bpr.py:57-61) */
 } tkr_bpr_state;
 
 /* n_batches consecutive batches of a plan (the inner loop of single/bpr.py:139-147), one launch

@@ -208,10 +208,45 @@ def bpr_step(state, ub, ib, jb, hp):
     items = np.concatenate([ib, jb])
     rows_v, sum_v = _segment_sum(items, np.concatenate([gVi, gVj]))
     rows_b, sum_b = _segment_sum(items, np.concatenate([gbi, gbj]))
+    if hp.get('opt', 'rmsprop') == 'sgd':
+        # legacy optimiser, old/methods/bpr.py:57-61: P <- P - lr * dcost/dP.  Theano's dense
+        # gradient of the gathered rows is the same per-row sum (zero on untouched rows); L2 objective only
+        # (old/methods/bpr.py:43-51 == single/bpr.py:92-95).  PARITY UNPINNED (Theano absent), checked
+        # against torch autograd in tests/test_oracle_step.py.
+        lr = F32(hp['lr'])
+        U[rows_u] = (U[rows_u] - lr * sum_u).astype(F32)
+        V[rows_v] = (V[rows_v] - lr * sum_v).astype(F32)
+        b[rows_b] = (b[rows_b] - lr * sum_b).astype(F32)
+        return F32(loss)
     _rmsprop_rows(U, state['msU'], rows_u, sum_u, hp['lr'])
     _rmsprop_rows(V, state['msV'], rows_v, sum_v, hp['lr'])
     _rmsprop_rows(b, state['msb'], rows_b, sum_b, hp['lr'])
     return F32(loss)
+
+
+def legacy_pregenerated_sampler(train_dict, n_items, n_samples):
+    """old/methods/bpr.py:88-99 (_uniform_user_sampling): ALL users first with one vectorised
+    ``np.random.randint(len(train_dict), size=n)`` over ``list(train_dict.keys())``, then per
+    sample one positive (``randint(len(pos))``) and rejection-sampled negative
+    (``randint(n_items)`` until not in the user's positives).  Uses the legacy global
+    ``np.random`` stream like the reference (pinned by golden G8).  Returns three int64 arrays."""
+    keys = np.array(list(train_dict.keys()))
+    users = keys[np.random.randint(len(train_dict), size=n_samples)]
+    pos, neg = [], []
+    for u in users:
+        items = train_dict[u]
+        pos.append(items[np.random.randint(len(items))])
+        j = np.random.randint(n_items)
+        while j in items:
+            j = np.random.randint(n_items)
+        neg.append(j)
+    return users.astype(np.int64), np.asarray(pos, dtype=np.int64), np.asarray(neg, dtype=np.int64)
+
+
+def legacy_batches(n_samples, batch_size):
+    """old/methods/bpr.py:72-77: ``while (z+1)*batch_size < n_sgd_samples`` -- strict, so a final batch
+    that would end exactly at n_samples is dropped as well."""
+    return max(0, (n_samples - 1) // batch_size) if n_samples > 0 else 0
 
 
 def init_bpr_state(n_users, n_items, k, rng):

@@ -1,4 +1,4 @@
-"""Generate the golden fixtures G1-G7 by running the REFERENCE's own importable code.
+"""Generate the golden fixtures G1-G9 by running the REFERENCE's own importable code.
 
 Run in the build container only (``/root/reference`` does not exist on the GPU box):
 
@@ -12,6 +12,8 @@ What runs from the reference (never copied into this repo, only executed):
   * ``evaluate.py``         the CLI itself through a subprocess (stdout is the fixture) and
                             its helper functions get_ids/get_ivt/get_mat/get_history for the
                             per-user list extraction                                (G4-G7)
+  * ``old/methods/bpr.py``  _data_to_dict / _uniform_user_sampling with ``theano`` stubbed       (G8)
+  * ``utils.py``            get_history_from_file / get_score / evaluate                      (G9)
 The TF train step cannot run (TensorFlow 1.15 absent): no fixture pins it.
 Inputs are produced by ``top-k-rec_amd/synth.py`` (this repo) and committed next to the
 expected outputs, so the tests never need the generator to stay frozen.
@@ -252,6 +254,66 @@ def g7():
     json.dump(out, open(os.path.join(d, 'expected.json'), 'w'))
 
 
+# ---------------------------------------------------------------- G8 legacy pre-generated sampler
+def g8():
+    """old/methods/bpr.py:88-99 run with ``theano`` stubbed (the sampler and _data_to_dict are pure numpy)."""
+    import importlib.util
+    for name in ('theano', 'theano.tensor'):
+        sys.modules[name] = mock.MagicMock()
+    spec = importlib.util.spec_from_file_location('legacy_bpr', os.path.join(REF, 'old', 'methods', 'bpr.py'))
+    legacy = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(legacy)
+    d = fresh(os.path.join(HERE, 'g8'))
+    users = {100 + 7 * x: x for x in range(12)}                  # raw id -> index, as bpr_train.py:23-40 builds them
+    items = {5000 + 3 * x: x for x in range(20)}
+    rng = np.random.Generator(np.random.PCG64(81))
+    data = []
+    for uid in users:
+        if uid == 100 + 7 * 5:
+            continue                                             # a user without positives never enters train_dict
+        for iid in rng.choice(list(items), int(rng.integers(1, 9)), replace=False):
+            data.append((int(uid), int(iid)))
+    m = legacy.BPR(4, users, items)
+    m._train_dict = m._data_to_dict(data, users, items)
+    np.random.seed(321)
+    su, sp, sn = m._uniform_user_sampling(64)
+    json.dump(dict(users={str(k): v for k, v in users.items()}, items={str(k): v for k, v in items.items()}, data=data,
+                   train_dict={str(k): [int(x) for x in v] for k, v in m._train_dict.items()},
+                   su=[int(x) for x in su], sp=[int(x) for x in sp], sn=[int(x) for x in sn]),
+              open(os.path.join(d, 'expected.json'), 'w'))
+
+
+# ---------------------------------------------------------------- G9 utils.get_score / utils.evaluate (SURVEY §8f n3)
+def g9():
+    """utils.py:92-127 on the G4 data and model: dense score matrix, raw-rank buckets, reciprocal-rank sums."""
+    d = fresh(os.path.join(HERE, 'g9'))
+    src = os.path.join(HERE, 'g4')
+    data, model = os.path.join(src, 'data'), os.path.join(src, 'model')
+    uids = ref_utils.get_id_dict_from_file(os.path.join(data, 'uid'))
+    vids = ref_utils.get_id_dict_from_file(os.path.join(data, 'vid'))
+    U = ref_utils.get_embed_from_file(os.path.join(model, 'final-U.dat'), uids)
+    V = ref_utils.get_embed_from_file(os.path.join(model, 'final-V.dat'), vids)
+    rated, counter = ref_utils.get_history_from_file(os.path.join(data, 'f0tr.txt'))
+    out = dict(counter=counter, runs=[])
+    for sc in ('im', 'om'):
+        te_iids = ref_utils.get_id_dict_from_file(os.path.join(data, 'f0te.%s.idl' % sc))
+        te_ivt = {v: k for k, v in te_iids.items()}
+        likes = {}
+        for line in open(os.path.join(data, 'f0te.%s.txt' % sc)):
+            terms = line.strip().split(',')
+            likes[terms[0]] = set(t.split(':')[0] for t in terms[1:] if t.split(':')[1] == '1')
+        score = ref_utils.get_score(U, V, vids, te_iids)
+        for step, total in ((5, 30), (3, 10)):
+            interval = total // step
+            hits, trrs, count = ref_utils.evaluate(score, rated, likes, uids, te_iids, te_ivt, step, total, interval)
+            out['runs'].append(dict(scenario=sc, step=step, total=total, hits=hits, trrs=trrs, count=count))
+        if sc == 'im':
+            np.save(os.path.join(d, 'score_im.npy'), score)
+    json.dump(out, open(os.path.join(d, 'expected.json'), 'w'))
+
+
 if __name__ == '__main__':
-    g1(); g2(); g3(); g4(); g5(); g6(); g7()
-    print('golden fixtures written under', HERE)
+    todo = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
+    for name in todo:
+        globals()[name]()
+    print('golden fixtures written under', HERE, todo)

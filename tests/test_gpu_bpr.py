@@ -102,6 +102,7 @@ def _state_struct(hip, T, n_users, n_items, k, hp):
     st.mode = 0 if hp['mode'] == 'l2' else 1
     st.lu, st.li, st.lj, st.lb, st.lr = hp['lu'], hp['li'], hp['lj'], hp['lb'], hp['lr']
     st.rho, st.eps = 0.9, 1e-10
+    st.opt = 1 if hp.get('opt') == 'sgd' else 0
     return st
 
 
@@ -177,3 +178,77 @@ def test_abi_rejects_bad_arguments(hip):
     assert hip.lib().tkr_sample_plan(None, 0, None, None, None, 5, 10, 0, 0, None, 1, 256, *([None] * 12), None) == -1
     assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 1, 16384, *([None] * 12), None) == -2
     assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 513, 256, *([None] * 12), None) == -2
+
+
+@pytest.mark.parametrize('k,B,nb', [(16, 64, 12), (128, 256, 10), (50, 512, 5), (128, 2048, 3)])
+def test_sgd_step_parity(hip, k, B, nb):
+    """tkr_bpr_state.opt = 1: the legacy update P -= lr*g (old/methods/bpr.py:57-61), no slot traffic at all --
+    the ms pointers are NULL"""
+    n_users, n_items = 400, 120
+    tr, tr_users = _toy(n_users, n_items, seed=k + B + 1, all_but_one=False)
+    rng = np.random.Generator(np.random.PCG64(k + 1))
+    ref = R.init_bpr_state(n_users, n_items, k, rng)
+    ref['b'][:] = (rng.standard_normal(n_items) * 0.01).astype(np.float32)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.05, mode='l2', opt='sgd')
+    T = _tables(ref, n_users, n_items, k)
+    _, exp, plan = _run_plan(hip, tr, tr_users, n_users, n_items, seed=43, first=0, nb=nb, B=B)
+    st = _state_struct(hip, T, n_users, n_items, k, hp)
+    st.msU = st.msV = st.msb = None
+    loss = torch.zeros(nb, device='cuda')
+    hip.bpr_run(st, plan, B, nb, loss)
+    torch.cuda.synchronize()
+    u, i, j = exp[0], exp[1], exp[2]
+    ucnt, icnt = np.zeros(n_users, np.int32), np.zeros(n_items, np.int32)
+    ref_loss = []
+    for b in range(nb):
+        sl = slice(b * B, (b + 1) * B)
+        ref_loss.append(R.bpr_step(ref, u[sl], i[sl], j[sl], hp))
+        ucnt[np.unique(u[sl])] += 1
+        icnt[np.unique(np.concatenate([i[sl], j[sl]]))] += 1
+    for name, cnt in (('U', ucnt), ('V', icnt), ('b', icnt)):
+        np.testing.assert_allclose(_current(T, name, cnt), ref[name], rtol=2e-4, atol=1e-5, err_msg=name)
+        assert torch.all(T['ms' + name] == 1.0)                       # never written
+    np.testing.assert_allclose(loss.cpu().numpy(), np.array(ref_loss), rtol=1e-4)
+    # an RMSProp state without slots is rejected, an unknown optimiser too
+    st.opt = 0
+    assert hip.lib().tkr_bpr_run(C.byref(st), plan.rec.data_ptr(), plan.occ.data_ptr(), plan.hdr.data_ptr(), B, 1, None, None) == -1
+    st.opt = 7
+    assert hip.lib().tkr_bpr_run(C.byref(st), plan.rec.data_ptr(), plan.occ.data_ptr(), plan.hdr.data_ptr(), B, 1, None, None) == -1
+
+
+def test_legacy_bpr_api(hip, capfd):
+    """old/methods/bpr.py surface: BPR(K, users, items, ...).train(data, epochs, batch_size); W/H/B.get_value()"""
+    from old.methods.bpr import BPR as LegacyBPR
+    rng = np.random.Generator(np.random.PCG64(5))
+    users = {1000 + 3 * x: x for x in range(300)}
+    items = {50 + x: x for x in range(90)}
+    P, Q = rng.standard_normal((300, 4)), rng.standard_normal((90, 4))
+    data = []
+    for uid, ux in users.items():
+        top = np.argsort(-(P[ux] @ Q.T))[:8]
+        data += [(uid, 50 + int(t)) for t in top]
+    m = LegacyBPR(16, users, items, learning_rate=0.05, seed=11)
+    W0, H0 = m.W.get_value().copy(), m.H.get_value().copy()
+    assert W0.shape == (300, 16) and H0.shape == (90, 16) and np.all(m.B.get_value() == 0)
+    assert abs(W0.std() - 0.01) < 2e-3
+    m.train(data, epochs=20, batch_size=256)
+    err = capfd.readouterr().err
+    assert 'Generating 48000 random training samples' in err and 'Total training time' in err
+    n_batches = (len(data) * 20 - 1) // 256                           # old/methods/bpr.py:72
+    assert m._engine.triplets_drawn == n_batches * 256 and m.losses is not None
+    W, H, B = m.W.get_value(), m.H.get_value(), m.B.get_value()
+    assert np.isfinite(W).all() and np.isfinite(H).all() and not np.array_equal(W, W0)
+    # the model learned the planted preferences: positives outrank the rest for most users
+    s = W @ H.T + B
+    auc = []
+    for uid, ux in users.items():
+        pos = sorted({items[i] for u, i in data if u == uid})
+        neg = np.setdiff1d(np.arange(90), pos)
+        auc.append((s[ux][pos][:, None] > s[ux][neg][None, :]).mean())
+    assert np.mean(auc) > 0.8
+    # small data: batch size clipped with the reference's warning (old/methods/bpr.py:64-66)
+    m2 = LegacyBPR(8, users, items, seed=1)
+    m2.train(data[:40], epochs=3, batch_size=256)
+    assert 'switching to a batch size of 40' in capfd.readouterr().err
+    m2.W.set_value(np.ones((300, 8), np.float32))
+    assert np.all(m2.W.get_value() == 1.0)

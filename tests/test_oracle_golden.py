@@ -95,3 +95,23 @@ def test_batches_per_epoch_f7():
     assert R.batches_per_epoch(10**6, 256) == 3906
     assert R.batches_per_epoch(10e5, 256) == 3906
     assert R.batches_per_epoch(512, 256) == 2
+
+
+def test_g8_legacy_pregenerated_sampler(golden_dir):
+    """old/methods/bpr.py:88-99 + :101-105, bit-exact under np.random.seed(321)"""
+    from collections import defaultdict
+    exp = json.load(open(os.path.join(golden_dir, 'g8', 'expected.json')))
+    users = {int(k): v for k, v in exp['users'].items()}
+    items = {int(k): v for k, v in exp['items'].items()}
+    train_dict = defaultdict(list)
+    for uid, iid in exp['data']:
+        train_dict[users[uid]].append(items[iid])
+    assert {str(k): v for k, v in train_dict.items()} == exp['train_dict']
+    assert list(train_dict.keys()) == [int(k) for k in exp['train_dict'].keys()]        # insertion order feeds keys()
+    np.random.seed(321)
+    su, sp, sn = R.legacy_pregenerated_sampler(train_dict, len(items), 64)
+    assert su.tolist() == exp['su'] and sp.tolist() == exp['sp'] and sn.tolist() == exp['sn']
+    for u, i, j in zip(su, sp, sn):
+        assert i in train_dict[u] and j not in train_dict[u]
+    # old/methods/bpr.py:72: while (z+1)*B < n  -- the batch that would end exactly at n is dropped too
+    assert [R.legacy_batches(n, 4) for n in (0, 1, 4, 5, 8, 9)] == [0, 0, 0, 1, 1, 2]

@@ -124,3 +124,29 @@ def test_vbpr_step_matches_autograd(mode):
     xui = (st['ure'][ub] * st['ire'][ib]).sum(1) + (st['uce'][ub] * (feat[ib] @ st['cem'])).sum(1) \
         + st['irb'][ib] + feat[ib] @ st['icb']
     np.testing.assert_allclose((fue[ub] * fie[ib]).sum(1) + fib[ib, 0], xui, rtol=1e-4, atol=1e-6)
+
+
+def test_sgd_step_matches_autograd():
+    """legacy optimiser (old/methods/bpr.py:43-61): P' = P - lr * dcost/dP, exactly the autograd gradient"""
+    rng = np.random.Generator(np.random.PCG64(4))
+    n_users, n_items, k, B = 40, 25, 12, 64
+    st = R.init_bpr_state(n_users, n_items, k, rng)
+    st['b'][:] = (rng.standard_normal(n_items) * 0.01).astype(np.float32)
+    ub, ib, jb = _batch(rng, n_users, n_items, B)
+    hp = dict(HP, mode='l2', opt='sgd')
+    U = torch.tensor(st['U'], dtype=torch.float64, requires_grad=True)
+    V = torch.tensor(st['V'], dtype=torch.float64, requires_grad=True)
+    b = torch.tensor(st['b'], dtype=torch.float64, requires_grad=True)
+    tu, ti, tj = (torch.tensor(x) for x in (ub, ib, jb))
+    x = b[ti] - b[tj] + (U[tu] * V[ti]).sum(1) - (U[tu] * V[tj]).sum(1)
+    # the literal legacy objective: -(sum log sigmoid(x) - regularisers)
+    cost = -(torch.log(torch.sigmoid(x)).sum() - hp['lu'] * 0.5 * (U[tu] ** 2).sum() - hp['li'] * 0.5 * (V[ti] ** 2).sum()
+             - hp['lj'] * 0.5 * (V[tj] ** 2).sum() - hp['lb'] * 0.5 * (b[ti] ** 2 + b[tj] ** 2).sum())
+    cost.backward()
+    before = {n: st[n].copy() for n in ('U', 'V', 'b', 'msU', 'msV', 'msb')}
+    loss = R.bpr_step(st, ub, ib, jb, hp)
+    assert abs(float(loss) - float(cost.detach())) < 2e-4 * max(1.0, abs(float(cost.detach())))
+    for name, grad in (('U', U.grad), ('V', V.grad), ('b', b.grad)):
+        want = before[name].astype(np.float64) - hp['lr'] * grad.numpy()
+        np.testing.assert_allclose(st[name], want, rtol=1e-5, atol=2e-7)
+        np.testing.assert_array_equal(st['ms' + name], before['ms' + name])       # no slot in this mode

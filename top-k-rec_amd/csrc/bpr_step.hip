@@ -214,7 +214,7 @@ __device__ __forceinline__ void run_group(const tkr_bpr_state& st, int lane, int
     }
 }
 
-template <int NE, bool VEC, int kTeam>
+template <int NE, bool VEC, int kTeam, bool SGD>
 __global__ __launch_bounds__((kTeam * TKR_WAVE)) void bpr_step_kernel(
     tkr_bpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
     const int4* __restrict__ hdr, float* __restrict__ loss_out) {
@@ -246,9 +246,11 @@ __global__ __launch_bounds__((kTeam * TKR_WAVE)) void bpr_step_kernel(
         const size_t roff = (is_item ? par * istride : par * ustride) + (size_t)row * k;
         load_row<NE, VEC>((is_item ? st.V : st.U) + roff, k, lane, own);
         float ms[NE];                                    // RMSProp slot of the owned row: same memory level as the row
-        load_row<NE, VEC>((is_item ? st.msV : st.msU) + roff, k, lane, ms);
+        if constexpr (!SGD) load_row<NE, VEC>((is_item ? st.msV : st.msU) + roff, k, lane, ms);
         const size_t boff = is_item ? (size_t)par * st.n_items + row : 0;     // valid either way: no branch
-        const float br_raw = st.b[boff], msb_raw = st.msb[boff];
+        const float br_raw = st.b[boff];
+        float msb_raw = 0.f;
+        if constexpr (!SGD) msb_raw = st.msb[boff];
         const float br = is_item ? br_raw : 0.f, msb = is_item ? msb_raw : 0.f;
 
         for (int done = 0; done < n_occ; done += 4) {
@@ -294,18 +296,26 @@ __global__ __launch_bounds__((kTeam * TKR_WAVE)) void bpr_step_kernel(
 
         // ---- RMSProp on the owned row (TF SparseApplyRMSProp, momentum 0), written to buffer par^1
         const size_t woff = (is_item ? (par ^ 1) * istride : (par ^ 1) * ustride) + (size_t)row * k;
-        float pn[NE], mn[NE];
+        float pn[NE];
+        if constexpr (SGD) {                       // old/methods/bpr.py:57-61: P <- P - lr * dcost/dP
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            mn[e] = st.rho * ms[e] + (1.f - st.rho) * g[e] * g[e];
-            pn[e] = own[e] - st.lr * g[e] / sqrtf(mn[e] + st.eps);
-        }
-        store_row<NE, VEC>((is_item ? st.msV : st.msU) + woff, k, lane, mn);
-        store_row<NE, VEC>((is_item ? st.V : st.U) + woff, k, lane, pn);
-        if (is_item && lane == 0) {
-            const float m2 = st.rho * msb + (1.f - st.rho) * acc.gb * acc.gb;
-            st.msb[(size_t)(par ^ 1) * st.n_items + row] = m2;
-            st.b[(size_t)(par ^ 1) * st.n_items + row] = br - st.lr * acc.gb / sqrtf(m2 + st.eps);
+            for (int e = 0; e < NE; ++e) pn[e] = own[e] - st.lr * g[e];
+            store_row<NE, VEC>((is_item ? st.V : st.U) + woff, k, lane, pn);
+            if (is_item && lane == 0) st.b[(size_t)(par ^ 1) * st.n_items + row] = br - st.lr * acc.gb;
+        } else {
+            float mn[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                mn[e] = st.rho * ms[e] + (1.f - st.rho) * g[e] * g[e];
+                pn[e] = own[e] - st.lr * g[e] / sqrtf(mn[e] + st.eps);
+            }
+            store_row<NE, VEC>((is_item ? st.msV : st.msU) + woff, k, lane, mn);
+            store_row<NE, VEC>((is_item ? st.V : st.U) + woff, k, lane, pn);
+            if (is_item && lane == 0) {
+                const float m2 = st.rho * msb + (1.f - st.rho) * acc.gb * acc.gb;
+                st.msb[(size_t)(par ^ 1) * st.n_items + row] = m2;
+                st.b[(size_t)(par ^ 1) * st.n_items + row] = br - st.lr * acc.gb / sqrtf(m2 + st.eps);
+            }
         }
     }
 }
@@ -322,8 +332,12 @@ static int step_grid(int B, int team) {
 template <int NE, bool VEC, int TEAM>
 static int launch_step_t(const tkr_bpr_state& st, const int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
                        float* loss_out, hipStream_t stream) {
-    hipLaunchKernelGGL((bpr_step_kernel<NE, VEC, TEAM>), dim3(step_grid(B, TEAM)), dim3(TEAM * TKR_WAVE), 0, stream, st, rec,
-                       reinterpret_cast<const int2*>(occ), reinterpret_cast<const int4*>(hdr), loss_out);
+    if (st.opt == 1)
+        hipLaunchKernelGGL((bpr_step_kernel<NE, VEC, TEAM, true>), dim3(step_grid(B, TEAM)), dim3(TEAM * TKR_WAVE), 0, stream,
+                           st, rec, reinterpret_cast<const int2*>(occ), reinterpret_cast<const int4*>(hdr), loss_out);
+    else
+        hipLaunchKernelGGL((bpr_step_kernel<NE, VEC, TEAM, false>), dim3(step_grid(B, TEAM)), dim3(TEAM * TKR_WAVE), 0, stream,
+                           st, rec, reinterpret_cast<const int2*>(occ), reinterpret_cast<const int4*>(hdr), loss_out);
     return (int)hipGetLastError();
 }
 
@@ -355,7 +369,9 @@ static int dispatch_step(const tkr_bpr_state& st, const int32_t* rec, const int3
 extern "C" int tkr_plan_max_blocks(int32_t batch_size);
 
 static int check_state(const tkr_bpr_state* st) {
-    if (!st || !st->U || !st->msU || !st->V || !st->msV || !st->b || !st->msb) return TKR_EINVAL;
+    if (!st || !st->U || !st->V || !st->b) return TKR_EINVAL;
+    if (st->opt != 0 && st->opt != 1) return TKR_EINVAL;
+    if (st->opt == 0 && (!st->msU || !st->msV || !st->msb)) return TKR_EINVAL;
     if (st->n_users <= 0 || st->n_items <= 0 || st->k <= 0) return TKR_EINVAL;
     if (st->k > 256) return TKR_EUNSUPPORTED;
     return TKR_OK;

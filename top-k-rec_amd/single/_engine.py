@@ -289,6 +289,7 @@ class BprEngine:
         st.mode = 0 if hp['mode'] == 'l2' else 1
         st.lu, st.li, st.lj, st.lb, st.lr = hp['lu'], hp['li'], hp['lj'], hp['lb'], hp['lr']
         st.rho, st.eps = RHO, EPS
+        st.opt = 1 if hp.get('opt', 'rmsprop') == 'sgd' else 0       # 'sgd': old/methods/bpr.py:57-61
         return st
 
     # ---- parameter access (host <-> current buffers) -----------------------------------------

@@ -27,7 +27,7 @@ class BprState(C.Structure):
                 ('V', C.c_void_p), ('msV', C.c_void_p), ('b', C.c_void_p), ('msb', C.c_void_p),
                 ('n_users', C.c_int32), ('n_items', C.c_int32), ('k', C.c_int32), ('mode', C.c_int32),
                 ('lu', C.c_float), ('li', C.c_float), ('lj', C.c_float), ('lb', C.c_float),
-                ('lr', C.c_float), ('rho', C.c_float), ('eps', C.c_float)]
+                ('lr', C.c_float), ('rho', C.c_float), ('eps', C.c_float), ('opt', C.c_int32)]
 
 
 class VbprState(C.Structure):
