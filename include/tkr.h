@@ -23,8 +23,11 @@ extern "C" {
 #endif
 
 #define TKR_VERSION 101 /* 0.1.1: tkr_bpr_state.opt */
+#define TKR_OK 0
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
+#define TKR_E_IO (-3)          /* host text I/O: file cannot be opened / written */
+#define TKR_E_PARSE (-4)       /* host text I/O: malformed line (where the reference raises) */
 
 int tkr_version(void);
 
@@ -151,6 +154,35 @@ int tkr_count_hits(const int32_t* ids, int32_t n_rows, int32_t K, const int64_t*
 /* ---- profiling aid: dst[r] = src[r] + 1 for the n listed rows of a [*, k] table, with the step
  * kernels' access pattern; used by scripts/pmc_calibrate.py to calibrate rocprofv3 byte counters */
 int tkr_calib_rowcopy(const float* src, float* dst, const int32_t* rows, int32_t n, int32_t k, void* stream);
+
+/* ---- host-side text I/O of the reference's data formats (no GPU work) ------------
+ * The reference parses its inputs with per-element Python loops (utils.py:58-70 get_data_from_file,
+ * evaluate.py:30-45 get_history and :84-93 the test file, utils.py:28-44 / evaluate.py:19-28 the '%f ' matrices,
+ * utils.py:47-55 the writer); these do the same in one pass and return flat arrays.
+ *
+ * id map: token -> index, built from the n '\n'-separated tokens of `blob` (no trailing newline) and their
+ *   indices (the host passes the reference's own dict, duplicate-line quirk of utils.py:10-16 included).
+ * ratings ("uid,iid:like,iid:like,..." per line): one record per line -- line_user[l] = index of the uid or -1,
+ *   entries [line_ptr[l], line_ptr[l+1]) in field order with item[e] = index of the iid or -1 and like[e] = the
+ *   integer after the first ':' (a field without ':' or with a non-integer like -> TKR_E_PARSE, where the
+ *   reference raises IndexError / ValueError).  Which entries count (known user, known item, like == 1, last line
+ *   of a user wins, ...) is the caller's rule, as it differs between utils.py:58-70, evaluate.py:30-45 and :84-93.
+ * matrix: every line parsed as ' '-separated decimal numbers (strtod, narrowed to fp32: the two roundings of
+ *   np.float32(str)); ragged rows -> TKR_E_PARSE.  tkr_matrix_write emits "%f " per element and '\n' per row,
+ *   byte-identical to utils.py:47-55.
+ * Handles are created by *_create / *_parse / *_read and released by *_destroy. */
+int tkr_idmap_create(const char* blob, int64_t blob_len, const int32_t* index, int64_t n, void** out_map);
+int tkr_idmap_destroy(void* map);
+int tkr_ratings_parse(const char* path, const void* user_map, const void* item_map, void** out_ratings);
+int tkr_ratings_sizes(const void* ratings, int64_t* n_lines, int64_t* n_entries);
+int tkr_ratings_copy(const void* ratings, int32_t* line_user, int64_t* line_ptr /*[n_lines+1]*/, int32_t* item,
+                     int32_t* like);
+int tkr_ratings_destroy(void* ratings);
+int tkr_matrix_read(const char* path, void** out_matrix);
+int tkr_matrix_sizes(const void* matrix, int64_t* rows, int64_t* cols);
+int tkr_matrix_copy(const void* matrix, float* dst /*[rows*cols]*/);
+int tkr_matrix_destroy(void* matrix);
+int tkr_matrix_write(const char* path, const float* data, int64_t rows, int64_t cols);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+os.environ.setdefault('TKR_NO_CACHE', '1')      # no .npy copies beside the committed fixtures; cache tests re-enable it
 
 
 def pytest_configure(config):

@@ -194,16 +194,16 @@ def test_cli_matches_reference_stdout_and_lists(hip, golden_dir, g, scs, capsys)
     if 'stdout_s3_t10' in exp:
         assert E.main(['-d', data, '-m', model, '-s', '3', '-t', '10', '-sl', 'om', 'im']) == exp['stdout_s3_t10']
     uids, vids = E.read_ids(os.path.join(data, 'uid')), E.read_ids(os.path.join(data, 'vid'))
-    rated = E.read_history(os.path.join(data, 'f0tr.txt'))
     U, V = E.read_matrix(os.path.join(model, 'final-U.dat'), uids), E.read_matrix(os.path.join(model, 'final-V.dat'), vids)
     bp = os.path.join(model, 'final-B.dat')
     b = E.read_matrix(bp, vids) if os.path.exists(bp) else None
+    token = {v: t for t, v in uids.items()}
     for sc in scs:
-        teids = E.read_ids(os.path.join(data, 'f0te.%s.idl' % sc))
-        tests = E.read_test_lines(os.path.join(data, 'f0te.%s.txt' % sc), teids)
-        ids = E.rank_scenario(_dev(U), V, b, uids, vids, rated, teids, tests, 30, torch.device('cuda')).cpu().numpy()
-        for (uid, _), row in zip(tests, ids):
-            assert [int(c) for c in row if c >= 0] == exp['lists'][sc][uid], (sc, uid)
+        scen = E.load_scenario(data, 0, sc, uids)
+        ids = E.rank_scenario(_dev(U), V, b, vids, scen, 30, torch.device('cuda')).cpu().numpy()
+        assert len(scen.users) == len(exp['lists'][sc])
+        for u, row in zip(scen.users, ids):
+            assert [int(c) for c in row if c >= 0] == exp['lists'][sc][token[int(u)]], (sc, token[int(u)])
 
 
 def test_cli_total_above_32_matches_oracle(hip, golden_dir):

@@ -200,3 +200,96 @@ def test_item_sync_world_size_2_gloo(tmp_path):
                          capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count('ok') == 2
+
+
+# ---------------------------------------------------------------- native text I/O (csrc/textio.hip)
+def _py_ratings(path, users, items):
+    """per-field restatement of the three reference parsers' common core"""
+    line_user, line_ptr, item, like = [], [0], [], []
+    for line in open(path):
+        terms = line.strip().split(',')
+        line_user.append(users.get(terms[0], -1))
+        for t in terms[1:]:
+            item.append(items.get(t.split(':')[0], -1))
+            like.append(int(t.split(':')[1]))
+        line_ptr.append(len(item))
+    return line_user, line_ptr, item, like
+
+
+def test_native_ratings_parser_matches_python(golden_dir, tmp_path):
+    import textio
+    from oracle import ref_np as R
+    cases = [(os.path.join(golden_dir, 'g1', 'tr.txt'), os.path.join(golden_dir, 'g1', 'uid'), os.path.join(golden_dir, 'g1', 'vid')),
+             (os.path.join(golden_dir, 'g4', 'data', 'f0tr.txt'), os.path.join(golden_dir, 'g4', 'data', 'uid'),
+              os.path.join(golden_dir, 'g4', 'data', 'f0te.om.idl')),
+             (os.path.join(golden_dir, 'g7', 'data', 'f0te.sm.txt'), os.path.join(golden_dir, 'g7', 'data', 'uid'),
+              os.path.join(golden_dir, 'g7', 'data', 'f0te.sm.idl'))]
+    odd = tmp_path / 'odd.txt'                      # CRLF, blank line, spaces, no trailing newline, like with sign, extra ':' part
+    odd.write_bytes(b'u1,a:1,b:0\r\n\n  u2,c: 1 ,a:+1:zz,\tq:-3\nu3\nzz,a:1\n u1 ,b:01')
+    (tmp_path / 'u').write_text('u1\nu2\nu3\n')
+    (tmp_path / 'v').write_text('a\nb\nc\n')
+    cases.append((str(odd), str(tmp_path / 'u'), str(tmp_path / 'v')))
+    for path, upath, vpath in cases:
+        users, items = R.read_id_list(upath), R.read_id_list(vpath)
+        got = textio.parse_ratings(path, users, items)
+        lu, lp, it, lk = _py_ratings(path, users, items)
+        assert got.line_user.tolist() == lu and got.line_ptr.tolist() == lp
+        assert got.item.tolist() == it and got.like.tolist() == lk
+        assert got.entry_user.tolist() == [lu[l] for l in range(len(lu)) for _ in range(lp[l + 1] - lp[l])]
+    # where the reference raises, so does the parser
+    bad = tmp_path / 'bad.txt'
+    bad.write_text('u1,a\n')
+    with pytest.raises(textio.TextFormatError):
+        textio.parse_ratings(str(bad), {'u1': 0}, {'a': 0})
+    bad.write_text('u1,a:x\n')
+    with pytest.raises(textio.TextFormatError):
+        textio.parse_ratings(str(bad), {'u1': 0}, {'a': 0})
+    with pytest.raises(OSError):
+        textio.parse_ratings(str(tmp_path / 'missing.txt'), {'u1': 0}, {'a': 0})
+    empty = tmp_path / 'empty.txt'
+    empty.write_text('')
+    got = textio.parse_ratings(str(empty), {'u1': 0}, {'a': 0})
+    assert len(got.line_user) == 0 and got.line_ptr.tolist() == [0]
+
+
+def test_native_matrix_io_matches_reference_bytes(golden_dir, tmp_path, monkeypatch):
+    import textio
+    d = os.path.join(golden_dir, 'g3')
+    exp = np.load(os.path.join(d, 'expected.npz'))
+    for name in ('mat', 'bias'):
+        out = tmp_path / (name + '.dat')
+        textio.write_matrix(str(out), exp[name])
+        assert out.read_bytes() == open(os.path.join(d, name + '.dat'), 'rb').read()      # reference export_embed_to_file
+        assert not os.path.exists(str(out) + '.npy')                                      # TKR_NO_CACHE=1 in the test env
+    np.testing.assert_array_equal(textio.read_matrix(os.path.join(d, 'mat.dat')), exp['back_all'])
+    # random values incl. specials: same bytes as Python's '%f', same values back as np.float32(str)
+    rng = np.random.Generator(np.random.PCG64(9))
+    m = np.concatenate([rng.standard_normal(4000) * 10.0 ** rng.integers(-8, 6, 4000),
+                        [0.0, -0.0, np.inf, -np.inf, np.nan, 3.4e38, -3.4e38, 1e-45, 0.0000005, 0.00000049999]]).astype(np.float32)
+    m = m[:4008].reshape(-1, 8)
+    path = tmp_path / 'r.dat'
+    textio.write_matrix(str(path), m)
+    text = ''.join(''.join('%f ' % v for v in row) + '\n' for row in m)
+    assert path.read_text() == text
+    back = textio.read_matrix(str(path))
+    want = np.array([[np.float32(t) for t in line.strip().split(' ')] for line in text.strip('\n').split('\n')], dtype=np.float32)
+    np.testing.assert_array_equal(back, want)
+    # ragged rows and junk raise like numpy would
+    path.write_text('1.0 2.0 \n3.0 \n')
+    with pytest.raises(textio.TextFormatError):
+        textio.read_matrix(str(path))
+    path.write_text('1.0 x \n')
+    with pytest.raises(textio.TextFormatError):
+        textio.read_matrix(str(path))
+    # n1: the binary copy is what the TEXT says (6 decimals), is used while newer than the text, and goes stale with it
+    monkeypatch.setenv('TKR_NO_CACHE', '0')
+    textio.write_matrix(str(path), m[:3])
+    cached = np.load(str(path) + '.npy')
+    np.testing.assert_array_equal(cached, want[:3])
+    np.save(str(path) + '.npy', np.full((3, 8), 7, np.float32))                            # a newer cache wins ...
+    os.utime(str(path) + '.npy', (os.path.getmtime(str(path)) + 5,) * 2)
+    assert np.all(textio.read_matrix(str(path)) == 7)
+    path.write_text('1.5 2.5 \n')                                                           # ... until the text changes
+    os.utime(str(path), (os.path.getmtime(str(path) + '.npy') + 5,) * 2)
+    np.testing.assert_array_equal(textio.read_matrix(str(path)), np.array([[1.5, 2.5]], np.float32))
+    np.testing.assert_array_equal(np.load(str(path) + '.npy'), np.array([[1.5, 2.5]], np.float32))

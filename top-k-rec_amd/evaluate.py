@@ -8,8 +8,10 @@ scenario ``S,%.6f,...`` :113-117):
 Same inputs: ``DATA/uid``, ``DATA/vid``, ``DATA/f{fold}tr.txt``, ``MODEL/final-U.dat``,
 ``final-V.dat``, optional ``final-B.dat``, ``DATA/f{fold}te.{S}.idl`` and ``.txt``.
 
-What runs where: text parsing on the host; the scores, the rated-item filter, the top-``total``
-selection (K4) and the hit counting (K5) on the GPU through libtkr_hip.so -- the
+What runs where: the text files are parsed by the native host parsers of libtkr_hip.so
+(textio.py; one pass per file, flat arrays instead of dicts of sets -- SURVEY.md §8f n2; the
+'%f ' matrices keep a binary ``.npy`` copy beside them, n1); the scores, the rated-item filter,
+the top-``total`` selection (K4) and the hit counting (K5) run on the GPU -- the
 [n_users, n_items] score matrix and its argsort (evaluate.py:78-81) are never materialised.
 
 Stated differences from the reference:
@@ -20,6 +22,9 @@ Stated differences from the reference:
     inherits numpy's unspecified unstable order.
   * only users that appear in the scenario's test file with at least one like are ranked
     (the reference scores every user and then reads only those rows).
+  * ids are resolved to indices while parsing, so the rated set of a user is keyed by the uid's
+    index and a test column by its index in the id list; the reference keys both by token.  The
+    two differ only if an id file repeats a token (the re-pointing quirk of evaluate.py:5-10).
 """
 from __future__ import annotations
 
@@ -29,6 +34,7 @@ import os
 import numpy as np
 import torch
 
+import textio
 import tkr_hip
 
 
@@ -43,79 +49,93 @@ def read_ids(path):
 
 def read_matrix(path, ids):
     """'%f ' text matrix rows addressed through ``ids`` (evaluate.py:19-28) -> fp32 [len(ids), k]"""
-    with open(path) as fh:
-        rows = fh.readlines()
-    out = None
-    for r in sorted(set(ids.values())):
-        vals = np.array(rows[r].split(), dtype=np.float32)
-        if out is None:
-            out = np.zeros((len(ids), vals.shape[0]), dtype=np.float32)
-        out[r] = vals
+    every = textio.read_matrix(path)
+    rows = np.unique(np.fromiter(ids.values(), dtype=np.int64, count=len(ids)))
+    out = np.zeros((len(ids), every.shape[1]), dtype=np.float32)
+    out[rows] = every[rows]
     return out
 
 
-def read_history(path):
-    """uid -> list of every vid on the user's train line, like 0 or 1 (evaluate.py:30-45)"""
-    rated = {}
-    with open(path) as fh:
-        for line in fh:
-            head, *fields = line.strip().split(',')
-            rated[head] = [f.split(':')[0] for f in fields]
-    return rated
+class Scenario:
+    """One test scenario as flat arrays.  ``users`` [n] = uid index of every test line with >= 1 like (file order),
+    ``like_ptr``/``like_cols``: its liked test columns, ascending (evaluate.py:84-95); ``rated_ptr``/``rated_cols``:
+    the test columns on the user's train line, like 0 or 1 (evaluate.py:30-45,98); ``tcount`` = sum of |likes|."""
+
+    def __init__(self, teids, users, like_ptr, like_cols, rated_ptr, rated_cols):
+        self.teids, self.users = teids, users
+        self.like_ptr, self.like_cols, self.rated_ptr, self.rated_cols = like_ptr, like_cols, rated_ptr, rated_cols
+        self.tcount = int(like_ptr[-1])
 
 
-def read_test_lines(path, teids):
-    """per test line with >= 1 like: (uid, sorted liked test columns) (evaluate.py:84-95)"""
-    out = []
-    with open(path) as fh:
-        for line in fh:
-            head, *fields = line.strip().split(',')
-            liked = set()
-            for f in fields:
-                vid, like = f.split(':')[0], int(f.split(':')[1])
-                if like == 1:
-                    liked.add(teids[vid])
-            if liked:
-                out.append((head, sorted(liked)))
-    return out
+def _group(rows, cols, n_rows, n_cols):
+    """unique (row, col) pairs -> CSR over rows with ascending cols"""
+    key = np.unique(rows.astype(np.int64) * n_cols + cols)
+    ptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(key // n_cols, minlength=n_rows), out=ptr[1:])
+    return ptr, (key % n_cols).astype(np.int32)
 
 
-def _csr(lists, device):
-    ptr = np.zeros(len(lists) + 1, dtype=np.int64)
-    np.cumsum([len(x) for x in lists], out=ptr[1:])
-    flat = np.fromiter((c for x in lists for c in x), dtype=np.int32, count=int(ptr[-1]))
-    return torch.from_numpy(ptr).to(device), torch.from_numpy(flat).to(device)
+def load_scenario(data_dir, fold, scenario, uids, umap=None):
+    umap = umap or textio.IdMap(uids)
+    teids = read_ids(os.path.join(data_dir, 'f%dte.%s.idl' % (fold, scenario)))
+    temap = textio.IdMap(teids)
+    n_te = max(len(teids), 1)
+    te_path = os.path.join(data_dir, 'f%dte.%s.txt' % (fold, scenario))
+    T = textio.parse_ratings(te_path, umap, temap)
+    liked = T.like == 1
+    if np.any(liked & (T.item < 0)):
+        raise KeyError('%s likes an id that is not in the scenario id list' % te_path)        # teids[vid], :93
+    lptr_all, lcols = _group(T.entry_line[liked], T.item[liked], len(T.line_user), n_te)
+    lines = np.flatnonzero(np.diff(lptr_all) > 0)                                           # len(likes) != 0, :95
+    users = T.line_user[lines].astype(np.int64)
+    if np.any(users < 0):
+        raise KeyError('%s: test user missing from the uid list' % te_path)                   # uids[uid], :98
+    like_ptr = np.zeros(len(lines) + 1, dtype=np.int64)
+    np.cumsum(np.diff(lptr_all)[lines], out=like_ptr[1:])
+    # history: the LAST train line of a user is its rated set (rated[uid] = set() per line, :34)
+    hist_path = os.path.join(data_dir, 'f%dtr.txt' % fold)
+    H = textio.parse_ratings(hist_path, umap, temap)
+    n_users = max(int(max(uids.values())) + 1 if uids else 0, 1)
+    last = np.full(n_users, -1, dtype=np.int64)
+    known = np.flatnonzero(H.line_user >= 0)
+    np.maximum.at(last, H.line_user[known], known)
+    hl = last[users]
+    if np.any(hl < 0):
+        raise KeyError('%s: test user without a line in %s' % (te_path, hist_path))           # rated[uid], :98
+    seg = H.line_ptr[hl + 1] - H.line_ptr[hl]
+    row = np.repeat(np.arange(len(lines), dtype=np.int64), seg)
+    pos = np.arange(int(seg.sum()), dtype=np.int64) - np.repeat(np.cumsum(seg) - seg, seg) + np.repeat(H.line_ptr[hl], seg)
+    item = H.item[pos]
+    keep = item >= 0                                                                         # only test columns matter
+    rated_ptr, rated_cols = _group(row[keep], item[keep], len(lines), n_te)
+    return Scenario(teids, users, like_ptr, lcols, rated_ptr, rated_cols)
 
 
-def rank_scenario(umat_dev, vmat, bmat, uids, vids, rated, teids, tests, total, device, want_scores=False):
+def rank_scenario(umat_dev, vmat, bmat, vids, sc, total, device, want_scores=False):
     """filtered top-`total` test columns of every test line -> int32 [n_lines, total] (device)"""
-    te_rows = np.zeros(len(teids), dtype=np.int64)
-    for vid, col in teids.items():
+    te_rows = np.zeros(len(sc.teids), dtype=np.int64)
+    for vid, col in sc.teids.items():
         te_rows[col] = vids[vid]                                     # evaluate.py:75-77
     Vt = torch.from_numpy(np.ascontiguousarray(vmat[te_rows])).to(device)
     bias = None
     if bmat is not None:
         bias = torch.from_numpy(np.ascontiguousarray(bmat.reshape(-1)[te_rows])).to(device)
-    user_idx = torch.tensor([uids[uid] for uid, _ in tests], dtype=torch.int32, device=device)
-    rated_cols = [sorted({teids[v] for v in rated[uid] if v in teids}) for uid, _ in tests]   # evaluate.py:98
-    rptr, rcols = _csr(rated_cols, device)
-    mask, pitch = tkr_hip.build_rated_mask(rptr, rcols, len(tests), len(teids))
+    user_idx = torch.from_numpy(sc.users.astype(np.int32)).to(device)
+    rptr, rcols = torch.from_numpy(sc.rated_ptr).to(device), torch.from_numpy(sc.rated_cols).to(device)
+    mask, pitch = tkr_hip.build_rated_mask(rptr, rcols, len(sc.users), len(sc.teids))
     return tkr_hip.score_topk(umat_dev, Vt, total, bias=bias, user_idx=user_idx, mask=mask, mask_pitch=pitch,
                               want_scores=want_scores)
 
 
-def evaluate_scenario(umat_dev, vmat, bmat, uids, vids, rated, data_dir, fold, scenario, step, total, device):
-    idl = os.path.join(data_dir, 'f%dte.%s.idl' % (fold, scenario))
-    teids = read_ids(idl)
-    tests = read_test_lines(os.path.join(data_dir, 'f%dte.%s.txt' % (fold, scenario)), teids)
+def evaluate_scenario(umat_dev, vmat, bmat, uids, vids, data_dir, fold, scenario, step, total, device, umap=None):
+    sc = load_scenario(data_dir, fold, scenario, uids, umap)
     interval = total // step
-    tcount = sum(len(l) for _, l in tests)
     hits = np.zeros(interval, dtype=np.int64)
-    if tests:
-        ids = rank_scenario(umat_dev, vmat, bmat, uids, vids, rated, teids, tests, total, device)
-        lptr, lcols = _csr([l for _, l in tests], device)
+    if len(sc.users):
+        ids = rank_scenario(umat_dev, vmat, bmat, vids, sc, total, device)
+        lptr, lcols = torch.from_numpy(sc.like_ptr).to(device), torch.from_numpy(sc.like_cols).to(device)
         hits = tkr_hip.count_hits(ids, lptr, lcols, step, interval).cpu().numpy()
-    return [float(h) / tcount for h in hits]                          # ZeroDivisionError like evaluate.py:112
+    return [float(h) / sc.tcount for h in hits]                       # ZeroDivisionError like evaluate.py:112
 
 
 def main(argv=None):
@@ -133,17 +153,17 @@ def main(argv=None):
     device = torch.device('cuda', torch.cuda.current_device())
     uids = read_ids(os.path.join(args.data, 'uid'))
     vids = read_ids(os.path.join(args.data, 'vid'))
-    rated = read_history(os.path.join(args.data, 'f%dtr.txt' % args.fold))
     umat = read_matrix(os.path.join(args.model, 'final-U.dat'), uids)
     vmat = read_matrix(os.path.join(args.model, 'final-V.dat'), vids)
     bmat = None
     if os.path.exists(os.path.join(args.model, 'final-B.dat')):
         bmat = read_matrix(os.path.join(args.model, 'final-B.dat'), vids)
     umat_dev = torch.from_numpy(umat).to(device)
+    umap = textio.IdMap(uids)
     results = {}
     for scenario in args.scenarios:
-        results[scenario] = evaluate_scenario(umat_dev, vmat, bmat, uids, vids, rated, args.data, args.fold,
-                                              scenario, args.step, args.total, device)
+        results[scenario] = evaluate_scenario(umat_dev, vmat, bmat, uids, vids, args.data, args.fold,
+                                              scenario, args.step, args.total, device, umap)
     lines = []
     for scenario in args.scenarios:
         lines.append(scenario + ''.join(',%.6f' % v for v in results[scenario]))

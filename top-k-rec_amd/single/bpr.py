@@ -28,6 +28,7 @@ from collections import defaultdict
 import numpy as np
 import torch
 
+import textio
 from utils import get_data_from_file, get_id_dict_from_file, tprint
 from .rec import REC
 from . import _engine
@@ -55,21 +56,48 @@ class BPR(REC):
         tprint('Load training data from %s' % (tr_file))
         self.uids = get_id_dict_from_file(uid_file)
         self.iids = get_id_dict_from_file(iid_file)
-        self.data = get_data_from_file(tr_file, self.uids, self.iids)
-        self.epoch_sample_limit = len(self.data)
         assert isinstance(self.uids, dict)
         assert isinstance(self.iids, dict)
         self.n_users = len(self.uids)
         assert self.n_users > 0
         self.n_items = len(self.iids)
         assert self.n_items > 0
-        self.tr_data = self._data_to_training_dict(self.data, self.uids, self.iids)
-        assert isinstance(self.tr_data, dict)
+        # One native pass over the ratings file (textio.parse_ratings) instead of the per-field Python loops of
+        # utils.py:58-70 and bpr.py:167-171; the rules are theirs: known user, known item, like == 1, file order.
+        if os.path.isfile(tr_file):
+            R = textio.parse_ratings(tr_file, self.uids, self.iids)
+            eu = R.entry_user
+            keep = (eu >= 0) & (R.item >= 0) & (R.like == 1)
+            u, it = eu[keep].astype(np.int64), R.item[keep]
+        else:
+            u, it = np.zeros(0, np.int64), np.zeros(0, np.int32)
+        self.epoch_sample_limit = len(u)
+        order = np.argsort(u, kind='stable')                       # grouped by user, file order inside a user
+        us, its = u[order], it[order]
+        uniq, start, counts = np.unique(us, return_index=True, return_counts=True)
+        self.tr_data = defaultdict(list)
+        for q in np.argsort(order[start], kind='stable'):          # dict key order = first appearance in the file
+            self.tr_data[int(uniq[q])] = its[start[q]:start[q] + counts[q]].tolist()
         self.tr_users = list(self.tr_data.keys())
+        row_ptr = np.zeros(self.n_users + 1, dtype=np.int64)
+        if len(uniq):
+            row_ptr[uniq + 1] = counts
+        np.cumsum(row_ptr, out=row_ptr)
+        self._csr_arrays = (row_ptr, its.astype(np.int32), np.asarray(self.tr_users, dtype=np.int32))
         self._csr = None
-        if not data_copy:
-            del self.data
+        if data_copy:                                              # the (uid, iid) token pairs themselves: utils.py:58-70
+            self.data = get_data_from_file(tr_file, self.uids, self.iids)
+            assert len(self.data) == self.epoch_sample_limit
+        elif hasattr(self, 'data'):
+            del self.data                                          # bpr.py:67-68
         tprint('Loading finished!')
+
+    def _make_csr(self, tr_users, device):
+        """device CSR of the training positives for the listed users (all of them, or one shard)"""
+        arrays = getattr(self, '_csr_arrays', None)
+        if arrays is not None and arrays[0][-1] == sum(len(v) for v in self.tr_data.values()):
+            return _engine.TrainingCSR.from_arrays(arrays[0], arrays[1], np.asarray(list(tr_users), dtype=np.int32), device)
+        return _engine.TrainingCSR(self.tr_data, tr_users, self.n_users, device)     # tr_data assigned by hand
 
     def _data_to_training_dict(self, data: list, users: dict, items: dict):
         """user index -> item indices in file order, duplicates preserved (bpr.py:167-171)."""
@@ -91,7 +119,7 @@ class BPR(REC):
         feed placeholders; there is nothing to feed here, so the engine is returned instead."""
         self._eng = self._make_engine(device, seed)
         if self._csr is None or self._csr.row_ptr.device != self._eng.device:
-            self._csr = _engine.TrainingCSR(self.tr_data, self.tr_users, self.n_users, self._eng.device)
+            self._csr = self._make_csr(self.tr_users, self._eng.device)
         return self._eng
 
     # ------------------------------------------------------------------ train (bpr.py:103-153)
@@ -153,7 +181,7 @@ class BPR(REC):
             return
         if world > 1:
             shard = tdist.shard_users(self.tr_users, rank, world)
-            self._csr = _engine.TrainingCSR(self.tr_data, shard, self.n_users, self._eng.device)
+            self._csr = self._make_csr(shard, self._eng.device)
             n_batches = tdist.batches_per_rank(n_batches, world)
             self._eng.triplets_drawn = rank * epochs * n_batches * batch_size      # disjoint stream positions
             sync = tdist.ItemSync(self._eng)
@@ -190,7 +218,7 @@ class BPR(REC):
         nb = tdist.batches_per_rank(n_batches, S)
         csrs, hip_streams = [], []
         for i, e in enumerate(engines):
-            csrs.append(_engine.TrainingCSR(self.tr_data, tdist.shard_users(self.tr_users, i, S), self.n_users, dev))
+            csrs.append(self._make_csr(tdist.shard_users(self.tr_users, i, S), dev))
             e.triplets_drawn = i * epochs * nb * batch_size                      # disjoint stream positions, one key
             hip_streams.append(torch.cuda.Stream(device=dev))
         users_start = lead.get('U')[0].clone()
@@ -233,7 +261,7 @@ class BPR(REC):
         tr_users, i uniform over tr_data[u], j uniform over items not in tr_data[u]."""
         device = self._eng.device if self._eng is not None else _engine.default_device()
         if self._csr is None:
-            self._csr = _engine.TrainingCSR(self.tr_data, self.tr_users, self.n_users, device)
+            self._csr = self._make_csr(self.tr_users, device)
         import tkr_hip
         plan = _engine.PlanBuffers(1, batch_size, device)
         cnt = _engine.UpdateCounters(self.n_users, self.n_items, device)     # throw-away parities

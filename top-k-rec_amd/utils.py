@@ -7,8 +7,8 @@ reference's ``utils.py`` so callers switch over unchanged:
     get_embed_from_file     utils.py:28-44   '%f ' text matrix -> fp32 array
     export_embed_to_file    utils.py:47-55   fp32 array -> '%f ' text matrix
 
-The text formats stay authoritative; parsing and formatting are done in bulk (one split /
-one join per line) instead of per element.  The reference's unused helpers (``get_score``,
+The text formats stay authoritative; matrices are parsed and written by the native host code of
+libtkr_hip.so (textio.py) with a binary ``.npy`` copy beside the text.  The reference's unused helpers (``get_score``,
 ``evaluate``, ``get_history_from_file``, ``get_iv_dict_from_file``) have no callers on this
 path and are not provided.
 """
@@ -18,6 +18,8 @@ import os
 from datetime import datetime
 
 import numpy as np
+
+import textio
 
 
 def tprint(msg: str) -> None:
@@ -52,31 +54,27 @@ def get_data_from_file(file_path: str, uids: dict, iids: dict) -> list:
 
 
 def get_embed_from_file(file_path: str, ids: dict = None):
-    """Rows of a '%f ' text matrix, addressed by ``ids`` values (or every line) -> fp32."""
+    """Rows of a '%f ' text matrix, addressed by ``ids`` values (or every line) -> fp32.  Parsed by the native
+    reader (textio.read_matrix), which keeps a binary copy ``<file>.npy`` beside the authoritative text."""
     if not os.path.isfile(file_path):
         return None
-    with open(file_path) as fh:
-        rows = fh.readlines()
-    wanted = sorted(set(ids.values())) if ids is not None else range(len(rows))
-    height = len(ids) if ids is not None else len(rows)
-    out = None
-    for r in wanted:
-        vals = np.array(rows[r].split(), dtype=np.float32)
-        if out is None:
-            out = np.zeros((height, vals.shape[0]), dtype=np.float32)
-        out[r, :] = vals
+    every = textio.read_matrix(file_path)
+    if ids is None:
+        return every if len(every) else None
+    if not ids:
+        return None
+    rows = np.unique(np.fromiter(ids.values(), dtype=np.int64, count=len(ids)))
+    out = np.zeros((len(ids), every.shape[1]), dtype=np.float32)
+    out[rows, :] = every[rows]
     return out
 
 
 def export_embed_to_file(file_path: str, embed) -> None:
-    """One line per row, every element '%f' followed by a space (trailing space kept)."""
+    """One line per row, every element '%f' followed by a space (trailing space kept) -- byte-identical to
+    utils.py:47-55, written by the native writer."""
     folder = os.path.dirname(file_path)
     if not os.path.isdir(folder):
         os.mkdir(folder)
     embed = np.asarray(embed)
     n_rows, n_cols = embed.shape
-    fmt = '%f ' * n_cols + '\n'
-    with open(file_path, 'w') as fh:
-        for start in range(0, n_rows, 4096):
-            block = embed[start:start + 4096]
-            fh.write(''.join(fmt % tuple(row) for row in block.tolist()))
+    textio.write_matrix(file_path, embed)
