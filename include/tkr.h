@@ -151,6 +151,22 @@ int tkr_score_topk(const float* U, const int32_t* user_idx, int32_t n_rows, cons
 int tkr_count_hits(const int32_t* ids, int32_t n_rows, int32_t K, const int64_t* like_ptr, const int32_t* like_cols,
                    int32_t step, int32_t interval, uint64_t* first_bucket, void* stream);
 
+/* ---- K6 / K7: the rank walk of utils.evaluate (utils.py:101-127) -----------------
+ * utils.evaluate buckets a hit by the item's RAW rank t -- train-rated columns included (utils.py:113-117:
+ * j = t // step) -- and sums reciprocal ranks 1/(t+1).  With ids = K4's first K unrated columns of each row,
+ *   raw_rank[r][p] = p + #{rated columns of row r ranked before ids[r][p]}   (-1 where ids is -1)
+ * under the canonical order (descending score, ties -> higher column first); kept and rated columns are scored
+ * by the same fp32 dot routine inside the kernel.  rated_ptr/rated_cols: the CSR given to tkr_build_rated_mask.
+ * tkr_count_hits_rr: hit_first[r][j] += 1 and rr_first[r][j] += 1/(t+1) (fp64) for every kept liked column with
+ * j = t / step < interval, sequentially per row (reproducible); the caller zeroes both arrays, sums over rows and
+ * accumulates buckets <= k (utils.py:115-117).  K <= 256, k <= 256. */
+int tkr_raw_ranks(const float* U, const int32_t* user_idx, int32_t n_rows, const float* Vt, const float* bias, int32_t k,
+                  const int64_t* rated_ptr, const int32_t* rated_cols, const int32_t* ids, int32_t K, int32_t* raw_rank,
+                  void* stream);
+int tkr_count_hits_rr(const int32_t* ids, const int32_t* raw_rank, int32_t n_rows, int32_t K, const int64_t* like_ptr,
+                      const int32_t* like_cols, int32_t step, int32_t interval, int32_t* hit_first, double* rr_first,
+                      void* stream);
+
 /* ---- profiling aid: dst[r] = src[r] + 1 for the n listed rows of a [*, k] table, with the step
  * kernels' access pattern; used by scripts/pmc_calibrate.py to calibrate rocprofv3 byte counters */
 int tkr_calib_rowcopy(const float* src, float* dst, const int32_t* rows, int32_t n, int32_t k, void* stream);

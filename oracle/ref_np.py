@@ -465,6 +465,77 @@ def evaluate_scenario(umat, vmat, bmat, uids, vids, rated, teids, teivt, test_li
     return (acc, lists) if return_lists else acc
 
 
+# --------------------------------------------------------------------------------------
+# n3  utils.py:18-24, 73-127: get_iv_dict / get_history_from_file / get_score / evaluate  (pinned by golden G9)
+# --------------------------------------------------------------------------------------
+def read_iv_list(path):
+    """utils.py:18-24 get_iv_dict_from_file: line number -> stripped token ({} when the file is missing)."""
+    ivt = {}
+    if os.path.isfile(path):
+        with open(path) as fh:
+            for line in fh:
+                ivt[len(ivt)] = line.strip()
+    return ivt
+
+
+def read_history_counts(path):
+    """utils.py:73-89 get_history_from_file: (uid -> set of every iid on its LAST line, iid -> number of
+    lines liking it with the literal string '1').  Missing file -> two empty dicts."""
+    browsed, counter = {}, {}
+    if os.path.isfile(path):
+        with open(path) as fh:
+            for line in fh:
+                fields = line.strip().split(',')
+                browsed[fields[0]] = set()
+                for tok in fields[1:]:
+                    iid, like = tok.split(':')[0], tok.split(':')[1]
+                    browsed[fields[0]].add(iid)
+                    if like == '1':
+                        counter[iid] = counter.get(iid, 0) + 1
+    return browsed, counter
+
+
+def utils_get_score(U, V, iids, sub_iids):
+    """utils.py:92-98: rows of V re-ordered to the sub id list (ids missing from iids stay zero), then np.dot."""
+    subV = np.zeros((len(sub_iids), V.shape[1]), dtype=F32)
+    for iid in iids:
+        if iid in sub_iids:
+            subV[sub_iids[iid], :] = V[iids[iid], :]
+    return np.dot(U, subV.T)
+
+
+def utils_evaluate(score, rated, likes, uids, te_iids, te_ivt, step, total, interval, canonical=True):
+    """utils.py:101-127: walk every user's ranking from the top; an unrated liked item at RAW rank t (rated items
+    counted) adds 1 and 1/(t+1) to buckets t//step .. interval-1; stop after ``total`` unrated items.
+    -> (hits, trrs, count).  ``canonical``: stable argsort (ties -> higher column first) instead of numpy's
+    unspecified default kind."""
+    count = 0
+    hits, trrs = [0.0] * interval, [0.0] * interval
+    ranks = np.argsort(score, axis=1, kind='stable') if canonical else np.argsort(score, axis=1)
+    n = len(te_iids)
+    for uid in likes:
+        like = likes[uid]
+        if len(like) == 0:
+            continue
+        idx = 0
+        hit, rrs = [0.0] * interval, [0.0] * interval            # per user first, then into the totals (:110-124)
+        for t in range(n):
+            riid = te_ivt[ranks[uids[uid], n - 1 - t]]
+            if riid not in rated[uid]:
+                if riid in like:
+                    for q in range(t // step, interval):
+                        hit[q] += 1
+                        rrs[q] += 1.0 / (t + 1)
+                idx += 1
+            if idx == total:
+                break
+        for q in range(interval):
+            hits[q] += hit[q]
+            trrs[q] += rrs[q]
+        count += len(like)
+    return hits, trrs, count
+
+
 def evaluate_cli(data_dir, model_dir, fold=0, step=5, total=30, scenarios=('im', 'om'),
                  canonical=True):
     """The whole evaluate.py CLI as a function -> list of stdout lines 'S,%.6f,...'."""

@@ -293,3 +293,19 @@ def test_native_matrix_io_matches_reference_bytes(golden_dir, tmp_path, monkeypa
     os.utime(str(path), (os.path.getmtime(str(path) + '.npy') + 5,) * 2)
     np.testing.assert_array_equal(textio.read_matrix(str(path)), np.array([[1.5, 2.5]], np.float32))
     np.testing.assert_array_equal(np.load(str(path) + '.npy'), np.array([[1.5, 2.5]], np.float32))
+
+
+def test_utils_history_and_ivt_match_reference(golden_dir):
+    """utils.py:18-24, 73-89 mirrors against golden G9's counter and the oracle"""
+    import utils
+    from oracle import ref_np as R
+    exp = json.load(open(os.path.join(golden_dir, 'g9', 'expected.json')))
+    path = os.path.join(golden_dir, 'g4', 'data', 'f0tr.txt')
+    browsed, counter = utils.get_history_from_file(path)
+    assert counter == exp['counter'] and (browsed, counter) == R.read_history_counts(path)
+    assert utils.get_history_from_file(path + '.missing') == ({}, {})
+    idl = os.path.join(golden_dir, 'g4', 'data', 'f0te.om.idl')
+    assert utils.get_iv_dict_from_file(idl) == R.read_iv_list(idl) and utils.get_iv_dict_from_file(idl + '.missing') == {}
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception, match='MI355X'):
+            utils.get_score(np.zeros((2, 2), np.float32), np.zeros((2, 2), np.float32), {'a': 0}, {'a': 0})

@@ -115,3 +115,32 @@ def test_g8_legacy_pregenerated_sampler(golden_dir):
         assert i in train_dict[u] and j not in train_dict[u]
     # old/methods/bpr.py:72: while (z+1)*B < n  -- the batch that would end exactly at n is dropped too
     assert [R.legacy_batches(n, 4) for n in (0, 1, 4, 5, 8, 9)] == [0, 0, 0, 1, 1, 2]
+
+
+def test_g9_utils_evaluate(golden_dir):
+    """utils.py get_history_from_file / get_score / evaluate restated, pinned on the G4 data"""
+    exp = json.load(open(os.path.join(golden_dir, 'g9', 'expected.json')))
+    data, model = os.path.join(golden_dir, 'g4', 'data'), os.path.join(golden_dir, 'g4', 'model')
+    uids, vids = R.read_id_list(os.path.join(data, 'uid')), R.read_id_list(os.path.join(data, 'vid'))
+    U = R.read_embed_text(os.path.join(model, 'final-U.dat'), uids)
+    V = R.read_embed_text(os.path.join(model, 'final-V.dat'), vids)
+    rated, counter = R.read_history_counts(os.path.join(data, 'f0tr.txt'))
+    assert counter == exp['counter']
+    assert R.read_history_counts(os.path.join(data, 'nope.txt')) == ({}, {})
+    for run in exp['runs']:
+        sc = run['scenario']
+        te_iids = R.read_id_list(os.path.join(data, 'f0te.%s.idl' % sc))
+        te_ivt = R.read_iv_list(os.path.join(data, 'f0te.%s.idl' % sc))
+        assert {v: k for k, v in te_iids.items()} == te_ivt
+        likes = {}
+        for line in open(os.path.join(data, 'f0te.%s.txt' % sc)):
+            terms = line.strip().split(',')
+            likes[terms[0]] = set(t.split(':')[0] for t in terms[1:] if t.split(':')[1] == '1')
+        score = R.utils_get_score(U, V, vids, te_iids)
+        if sc == 'im':
+            np.testing.assert_array_equal(score, np.load(os.path.join(golden_dir, 'g9', 'score_im.npy')))
+        for canonical in (False, True):                              # G4 is tie-free: both orders agree with the reference
+            hits, trrs, count = R.utils_evaluate(score, rated, likes, uids, te_iids, te_ivt, run['step'], run['total'],
+                                                 run['total'] // run['step'], canonical=canonical)
+            assert hits == run['hits'] and count == run['count']
+            assert trrs == run['trrs']                               # same additions in the same order

@@ -41,7 +41,7 @@ EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_pl
            'tkr_vbpr_run', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy',
            'tkr_idmap_create', 'tkr_idmap_destroy', 'tkr_ratings_parse', 'tkr_ratings_sizes', 'tkr_ratings_copy',
            'tkr_ratings_destroy', 'tkr_matrix_read', 'tkr_matrix_sizes', 'tkr_matrix_copy', 'tkr_matrix_destroy',
-           'tkr_matrix_write')
+           'tkr_matrix_write', 'tkr_raw_ranks', 'tkr_count_hits_rr')
 EXPORTS_I64 = ('tkr_vbpr_workspace_floats', 'tkr_topk_workspace_bytes')
 
 
@@ -201,3 +201,29 @@ def count_hits(ids, like_ptr, like_cols, step, interval):
     _check(lib().tkr_count_hits(_p(ids), C.c_int32(ids.shape[0]), C.c_int32(ids.shape[1]), _p(like_ptr), _p(like_cols),
                                 C.c_int32(step), C.c_int32(interval), _p(first), _stream()), 'tkr_count_hits')
     return torch.cumsum(first[:interval], 0)
+
+
+def raw_ranks(U, Vt, ids, rated_ptr, rated_cols, bias=None, user_idx=None):
+    """K6 -> int32 [n_rows, K]: rank of every kept column among ALL columns of its row (utils.py:113)"""
+    assert ids.dtype == torch.int32 and rated_ptr.dtype == torch.int64 and rated_cols.dtype == torch.int32
+    n_rows, K = int(ids.shape[0]), int(ids.shape[1])
+    out = torch.empty((n_rows, K), dtype=torch.int32, device=ids.device)
+    if rated_cols.numel() == 0:
+        rated_cols = torch.zeros(1, dtype=torch.int32, device=ids.device)
+    _check(lib().tkr_raw_ranks(_p(U), _p(user_idx), C.c_int32(n_rows), _p(Vt), _p(bias), C.c_int32(U.shape[1]), _p(rated_ptr),
+                               _p(rated_cols), _p(ids), C.c_int32(K), _p(out), _stream()), 'tkr_raw_ranks')
+    return out
+
+
+def count_hits_rr(ids, raw_rank, like_ptr, like_cols, step, interval):
+    """K7 -> (hits int64[interval], trrs float64[interval]) accumulated over buckets like utils.py:115-117"""
+    n_rows = int(ids.shape[0])
+    hit = torch.zeros((n_rows, max(interval, 1)), dtype=torch.int32, device=ids.device)
+    rr = torch.zeros((n_rows, max(interval, 1)), dtype=torch.float64, device=ids.device)
+    if like_cols.numel() == 0:
+        like_cols = torch.zeros(1, dtype=torch.int32, device=ids.device)
+    if interval > 0:
+        _check(lib().tkr_count_hits_rr(_p(ids), _p(raw_rank), C.c_int32(n_rows), C.c_int32(ids.shape[1]), _p(like_ptr),
+                                       _p(like_cols), C.c_int32(step), C.c_int32(interval), _p(hit), _p(rr), _stream()),
+               'tkr_count_hits_rr')
+    return torch.cumsum(hit.sum(0, dtype=torch.int64)[:interval], 0), torch.cumsum(rr.sum(0)[:interval], 0)
