@@ -135,9 +135,17 @@ int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* 
  *   workspace (nullable, device, workspace_bytes): scratch for per-item-range partial lists; with
  *     tkr_topk_workspace_bytes(n_rows, K) bytes the launch splits the catalogue so that the grid fills
  *     the 256 CUs in whole rounds (results are identical with or without it)
+ * Arithmetic of the scores (tkr_topk_set_math, initial value from TKR_TOPK_MATH=bf16x3|fp32):
+ *   0 "bf16x3" (default, k <= 128): each fp32 factor is split exactly into three bf16 parts and a product is the six
+ *     leading partial products (each exact in fp32, the dropped ones < 2^-23 |ab|) accumulated in fp32 by
+ *     v_mfma_f32_32x32x16_bf16 -- an fp32 dot product with yet another summation order: same error against fp64 as
+ *     np.dot / the fp32 kernel, identical results whenever the partial sums are representable; finite inputs only;
+ *   1 "fp32": v_mfma_f32_32x32x2_f32 (a bitwise fmaf chain), used for every k and always for k > 128.
+ *   On gfx950 the fp32 MFMA runs at the vector-ALU rate and overlaps nothing; mode 0 is 1.4-1.6x faster.
  * K <= 32 per launch (larger K: rank 32, add the found columns to the mask with tkr_build_rated_mask, rank
  * again -- top-k-rec_amd/tkr_hip.py score_topk does this), k <= 256. */
 int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K);
+int tkr_topk_set_math(int32_t mode);
 int tkr_build_rated_mask(const int64_t* rated_ptr, const int32_t* rated_cols, int32_t n_rows, int32_t n_cols,
                          uint32_t* mask, int32_t mask_pitch, void* stream);
 int tkr_score_topk(const float* U, const int32_t* user_idx, int32_t n_rows, const float* Vt, const float* bias,

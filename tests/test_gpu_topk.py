@@ -4,7 +4,9 @@ Index work: bit-exact.  Ranked id lists are compared
   * exactly against the golden lists captured from the reference (G4-G7, tie-free by construction),
   * exactly against the oracle on exact-arithmetic inputs (every partial sum representable ->
     summation order cannot matter) including deliberate score ties (canonical tie rule),
-  * on generic fp32 inputs wherever the oracle's adjacent score gap exceeds 1e-6 relative."""
+  * on generic fp32 inputs wherever the oracle's adjacent score gap exceeds 1e-6 relative.
+Every test runs under both score arithmetics (bf16-split products on the dense matrix pipe = default, and fp32 MFMA);
+test_score_error_against_fp64 states the floating-point tolerance of each."""
 import json
 import os
 
@@ -17,12 +19,15 @@ pytestmark = pytest.mark.gpu
 from oracle import ref_np as R
 
 
-@pytest.fixture(scope='module')
-def hip():
+@pytest.fixture(scope='module', params=['bf16x3', 'fp32'])
+def hip(request):
+    """every test runs under both score arithmetics of K4 (include/tkr.h, tkr_topk_set_math)"""
     import tkr_hip
     assert torch.cuda.is_available()
     tkr_hip.lib()
-    return tkr_hip
+    tkr_hip.set_topk_math(request.param)
+    yield tkr_hip
+    tkr_hip.set_topk_math('bf16x3')
 
 
 def _dev(a):
@@ -246,3 +251,33 @@ def test_large_shape_properties(hip):
         top = np.argsort(-s, kind='stable')[:K]
         np.testing.assert_allclose(scores[r], s[ids[r]], rtol=2e-5, atol=1e-9)
         assert len(set(top.tolist()) & set(ids[r].tolist())) >= K - 1       # at most one near-tie swap at the cut
+
+
+@pytest.mark.parametrize('k,scale', [(128, 'unit'), (64, 'wide'), (100, 'unit'), (16, 'wide')])
+def test_score_error_against_fp64(hip, k, scale):
+    """Tolerance of the scores themselves, both arithmetics: |s - s64| <= 1.2e-6 * sum_k |u_k v_k| (k <= 128).
+    fp32 has eps = 1.19e-7; a sequential fp32 dot of length k may be off by k*eps/2 (7.6e-6 at k = 128) and typically
+    is by ~sqrt(k)*eps; the split kernel drops < 2^-23 |u_k v_k| per product and rounds 6 accumulations per 16 k.
+    Its MEAN error must stay within 4x of np.dot(fp32)'s.  'wide': factors spanning nine decades."""
+    rng = np.random.Generator(np.random.PCG64(k))
+    n_rows, n_cols, K = 256, 2048, 32
+    U = rng.standard_normal((n_rows, k)).astype(np.float32)
+    V = rng.standard_normal((n_cols, k)).astype(np.float32)
+    if scale == 'wide':
+        U *= (10.0 ** rng.uniform(-6, 3, (n_rows, k))).astype(np.float32)
+        V *= (10.0 ** rng.uniform(-6, 3, (n_cols, k))).astype(np.float32)
+    ids, scores = _gpu_lists(hip, U, V, None, [[] for _ in range(n_rows)], K, want_scores=True)
+    ids, scores = ids.cpu().numpy(), scores.cpu().numpy()
+    s64 = U.astype(np.float64) @ V.astype(np.float64).T
+    mag = np.abs(U).astype(np.float64) @ np.abs(V).astype(np.float64).T
+    rows = np.arange(n_rows)[:, None]
+    err = np.abs(scores.astype(np.float64) - s64[rows, ids]) / mag[rows, ids]
+    np_err = np.abs(np.dot(U, V.T).astype(np.float64) - s64)[rows, ids] / mag[rows, ids]
+    assert err.max() <= 1.2e-6, err.max()
+    assert err.mean() <= 4 * np_err.mean() + 1e-9, (err.mean(), np_err.mean())
+    # and the selection itself: the kept set is the true top-K up to scores closer than the tolerance
+    for r in range(0, n_rows, 17):
+        order = np.argsort(-s64[r], kind='stable')[:K]
+        cut = s64[r][order[-1]]
+        missing = set(order.tolist()) - set(ids[r].tolist())
+        assert all(abs(s64[r][c] - cut) <= 2.4e-6 * mag[r][c] for c in missing), (r, missing)

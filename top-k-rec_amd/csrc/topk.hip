@@ -21,6 +21,9 @@
 //
 // Roofline: fp32 MFMA, 2*k*n_items flop per user; HBM traffic per user ~ 4k B factors + 8K B
 // out + 4*n_items/32 B mask words -- three orders of magnitude below the flop ratio.
+#include <stdlib.h>
+#include <string.h>
+
 #include <algorithm>
 
 #include "tkr_common.h"
@@ -168,6 +171,101 @@ __device__ __forceinline__ float trim_all_users(const TopkSmem<IdT>& sm, int uw,
     return active ? fmaxf(thr, __uint_as_float(f)) : thr;
 }
 
+// Filter of one 32x32 score block (accumulator layout of the 32x32 MFMAs: register r of lane (ul, h) = item
+// (r&3) + 8*(r>>2) + 4h of the tile, user ul of the wave) into the candidate lists.
+// fp32 MFMA and VALU time add up on a SIMD (measured: nothing hides in the MFMA shadow, from the same wave or the
+// other one), so the common path is kept to one compare per score: hr[r] is the wave's lane mask of "score r
+// reaches my user's threshold" and lives in SGPRs; registers without a single candidate are skipped by a scalar
+// branch, the rated/tail/no-user bits (maskw) are consulted only when a lane has one.
+template <typename IdT>
+__device__ __forceinline__ void filter_tile(const TopkSmem<IdT>& sm, const f32x16& acc, const float* tbias, uint32_t maskw,
+                                            int t, int K, float& thr) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ul = lane & 31, h = lane >> 5, users = sm.users;
+    const int uw = wave * 32 + ul;
+    const uint32_t mh = maskw >> (4 * h);                        // bit (r&3)+8*(r>>2) <-> accumulator register r
+    float sc[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                                // rows 8g+4h .. 8g+4h+3 are registers 4g..4g+3
+        const float4 bq = *reinterpret_cast<const float4*>(tbias + 8 * g + 4 * h);
+        sc[4 * g + 0] = acc[4 * g + 0] + bq.x;                   // fl(fl(dot)+b)
+        sc[4 * g + 1] = acc[4 * g + 1] + bq.y;
+        sc[4 * g + 2] = acc[4 * g + 2] + bq.z;
+        sc[4 * g + 3] = acc[4 * g + 3] + bq.w;
+    }
+    uint64_t hr[16], any = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hr[r] = __ballot(sc[r] >= thr); any |= hr[r]; }
+    if (!any) return;
+    uint32_t hits = 0;                                           // bit r: register r of this lane is a candidate
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hits |= (sc[r] >= thr) ? (1u << r) : 0u;
+    // register r <-> mask bit (r&3) + 8*(r>>2): gather the four nibbles at bits 0, 8, 16, 24 of ~mh
+    const uint32_t nm = ~mh;
+    hits &= (nm & 0xfu) | ((nm >> 4) & 0xf0u) | ((nm >> 8) & 0xf00u) | ((nm >> 12) & 0xf000u);
+    uint32_t unplaced = 0;
+    int pos = 0;
+    if (hits) pos = atomicAdd(&sm.cnt[uw], __popc(hits));        // one LDS atomic per lane reserves all its slots
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (hr[r]) {                                             // scalar branch: most registers hold no candidate
+            asm volatile("" ::: "memory");                       // (keeps the branch: the body must not be if-converted)
+            if (hits & (1u << r)) {
+                if (pos < kCap) {
+                    sm.cs[pos * users + uw] = sc[r] + 0.0f;      // -0.0 -> +0.0: ties with 0.0 like numpy
+                    sm.ci[pos * users + uw] = (IdT)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                } else {
+                    unplaced |= 1u << r;                         // list full: trimmed below, then appended
+                }
+                ++pos;
+            }
+        }
+    // rare: some user's list overflowed.  Exact trim of that user (keeps K, raises the threshold), then its
+    // lanes append what still qualifies: at most 32 per user and tile, K + 32 <= kCap.
+    uint64_t ov = __ballot(unplaced != 0);
+    while (ov) {
+        const int u = (__ffsll((long long)ov) - 1) & 31;
+        const float nt = trim_user<IdT>(sm, wave * 32 + u, K, lane, nullptr);
+        if (ul == u) {
+            thr = nt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if ((unplaced & (1u << r)) && sc[r] >= thr) {
+                    const int p2 = atomicAdd(&sm.cnt[uw], 1);
+                    sm.cs[p2 * users + uw] = sc[r] + 0.0f;
+                    sm.ci[p2 * users + uw] = (IdT)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                }
+            unplaced = 0;
+        }
+        ov = __ballot(unplaced != 0);
+    }
+}
+
+// final exact sort of every user's list and output (or the partial list of this item range, merged later)
+template <typename IdT>
+__device__ __forceinline__ void write_rows(const TopkSmem<IdT>& sm, int n_rows, int K, int32_t* __restrict__ out_ids,
+                                           float* __restrict__ out_scores, uint64_t* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int u = 0; u < 32; ++u) {
+        const int r = blockIdx.x * sm.users + wave * 32 + u;
+        if (r >= n_rows) break;                                  // wave-uniform
+        uint64_t key;
+        const int n = min(sm.cnt[wave * 32 + u], kCap);
+        trim_user<IdT>(sm, wave * 32 + u, K, lane, &key);
+        if (gridDim.y > 1) {
+            if (lane < K) part[((size_t)r * gridDim.y + blockIdx.y) * K + lane] = (lane < n) ? key : 0ull;
+            continue;
+        }
+        if (lane < K) {
+            const bool have = lane < n;
+            const uint32_t ob = (uint32_t)(key >> 32);
+            const uint32_t f = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+            out_ids[(size_t)r * K + lane] = have ? (int32_t)((uint32_t)key - 1u) : -1;
+            if (out_scores) out_scores[(size_t)r * K + lane] = have ? __uint_as_float(f) : -INFINITY;
+        }
+    }
+}
+
 // waves per workgroup of an instantiation: 8 (two per SIMD: one wave's filter overlaps the other's MFMA
 // chain); 6 when candidate ids need 32 bits (LDS); 4 for wide factor rows (100+ operand registers)
 template <int KHP, typename IdT>
@@ -298,94 +396,193 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
         // ---- epilogue: bias, mask, threshold filter ----------------------------------------------
         if (!user_ok) maskw = 0xffffffffu;
         if (t == n_tiles_all - 1) maskw |= tail_mask;
-        const uint32_t mh = maskw >> (4 * h);                    // bit (r&3)+8*(r>>2) <-> accumulator register r
-        float sc[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {                            // rows 8g+4h .. 8g+4h+3 are registers 4g..4g+3
-            const float4 bq = *reinterpret_cast<const float4*>(sm.tbias + buf * 32 + 8 * g + 4 * h);
-            sc[4 * g + 0] = acc[4 * g + 0] + bq.x;               // fl(fl(dot)+b)
-            sc[4 * g + 1] = acc[4 * g + 1] + bq.y;
-            sc[4 * g + 2] = acc[4 * g + 2] + bq.z;
-            sc[4 * g + 3] = acc[4 * g + 3] + bq.w;
-        }
         if (t == next_sched) {                                   // workgroup-uniform: every wave trims all its users now
             thr = trim_all_users<IdT>(sm, uw, h, K, thr);
             next_sched = t + ((t - t_begin + 1) >> 1);
         }
-        // ---- filter.  fp32 MFMA and VALU time add up on a SIMD (measured: nothing hides in the MFMA shadow, from
-        // the same wave or the other one), so the common path is kept to one compare per score: hr[r] is the
-        // wave's lane mask of "score r reaches my user's threshold" and lives in SGPRs; registers without a
-        // single candidate are skipped by a scalar branch, the rated/tail/no-user bits are consulted only for
-        // lanes that have one.
-        uint64_t hr[16], any = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { hr[r] = __ballot(sc[r] >= thr); any |= hr[r]; }
-        if (any) {
-            uint32_t hits = 0;                                   // bit r: register r of this lane is a candidate
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hits |= (sc[r] >= thr) ? (1u << r) : 0u;
-            // register r <-> mask bit (r&3) + 8*(r>>2): gather the four nibbles at bits 0, 8, 16, 24 of ~mh
-            const uint32_t nm = ~mh;
-            hits &= (nm & 0xfu) | ((nm >> 4) & 0xf0u) | ((nm >> 8) & 0xf00u) | ((nm >> 12) & 0xf000u);
-            uint32_t unplaced = 0;
-            int pos = 0;
-            if (hits) pos = atomicAdd(&sm.cnt[uw], __popc(hits));   // one LDS atomic per lane reserves all its slots
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (hr[r]) {                                     // scalar branch: most registers hold no candidate
-                    asm volatile("" ::: "memory");               // (keeps the branch: the body must not be if-converted)
-                    if (hits & (1u << r)) {
-                        if (pos < kCap) {
-                            sm.cs[pos * users + uw] = sc[r] + 0.0f;          // -0.0 -> +0.0: ties with 0.0 like numpy
-                            sm.ci[pos * users + uw] = (IdT)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                        } else {
-                            unplaced |= 1u << r;                 // list full: trimmed below, then appended
-                        }
-                        ++pos;
-                    }
-                }
-            // rare: some user's list overflowed.  Exact trim of that user (keeps K, raises the threshold), then
-            // its lanes append what still qualifies: at most 32 per user and tile, K + 32 <= kCap.
-            uint64_t ov = __ballot(unplaced != 0);
-            while (ov) {
-                const int u = (__ffsll((long long)ov) - 1) & 31;
-                const float nt = trim_user<IdT>(sm, wave * 32 + u, K, lane, nullptr);
-                if (ul == u) {
-                    thr = nt;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if ((unplaced & (1u << r)) && sc[r] >= thr) {
-                            const int pos = atomicAdd(&sm.cnt[uw], 1);
-                            sm.cs[pos * users + uw] = sc[r] + 0.0f;
-                            sm.ci[pos * users + uw] = (IdT)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                        }
-                    unplaced = 0;
-                }
-                ov = __ballot(unplaced != 0);
-            }
-        }
+        filter_tile<IdT>(sm, acc, sm.tbias + buf * 32, maskw, t, K, thr);
         __syncthreads();                                         // tile t+1 staged; buffer `buf` may be overwritten next
     }
 
-    // ---- final sort and output --------------------------------------------------------------------
-    for (int u = 0; u < 32; ++u) {
-        const int r = blockIdx.x * users + wave * 32 + u;
-        if (r >= n_rows) break;                                  // wave-uniform
-        uint64_t key;
-        const int n = sm.cnt[wave * 32 + u];
-        trim_user<IdT>(sm, wave * 32 + u, K, lane, &key);
-        if (gridDim.y > 1) {                                     // partial list of this item range; merged later
-            if (lane < K) part[((size_t)r * gridDim.y + blockIdx.y) * K + lane] = (lane < n) ? key : 0ull;
-            continue;
-        }
-        if (lane < K) {
-            const bool have = lane < n;
-            const uint32_t ob = (uint32_t)(key >> 32);
-            const uint32_t f = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
-            out_ids[(size_t)r * K + lane] = have ? (int32_t)((uint32_t)key - 1u) : -1;
-            if (out_scores) out_scores[(size_t)r * K + lane] = have ? __uint_as_float(f) : -INFINITY;
-        }
+    write_rows<IdT>(sm, n_rows, K, out_ids, out_scores, part);
+}
+
+// ---- K4 on the dense matrix pipe: 6-product bf16 split of the fp32 factors ------------------------------------
+// Every fp32 factor is split EXACTLY into three bf16 parts a = a1 + a2 + a3 (8 significant bits each, round to
+// nearest at each step; bf16 has fp32's exponent range).  The product a*b is taken as the six partial products
+// a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1 (the dropped a2b3, a3b2, a3b3 are below 2^-23 |ab|), each EXACT in fp32
+// (8 x 8 significant bits), accumulated in fp32 by v_mfma_f32_32x32x16_bf16 -- the rounding behaviour of an fp32
+// dot product with a different summation order (measured error against fp64: same order as the fp32-MFMA path and as
+// numpy's sgemm, tests/test_gpu_topk.py).  Inputs whose products and partial sums are representable (the golden
+// fixtures) give exactly the same scores as the fp32 path.  Why: 48 bf16 MFMAs of 8 passes replace 64 fp32 MFMAs of
+// 16 passes per 32x32xk=128 block (1.8 us against 3.4 us per 256-user tile, scratch/bf16x3_ubench.hip), and on
+// gfx950 the fp32 MFMA does not overlap other work of the SIMD at all.  Finite inputs only (inf - inf in the split).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(float a, __bf16& p1, __bf16& p2, __bf16& p3) {
+    p1 = (__bf16)a;
+    const float r1 = a - (float)p1;
+    p2 = (__bf16)r1;
+    p3 = (__bf16)(r1 - (float)p2);
+}
+
+template <int KS, typename IdT>
+constexpr int topk_waves_bf16() { return sizeof(IdT) == 2 ? kTopkMaxWaves : 6; }
+
+template <int KS, typename IdT>
+__global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score_topk_bf16_kernel(
+    const float* __restrict__ U, const int32_t* __restrict__ uidx, int n_rows, const float* __restrict__ Vt,
+    const float* __restrict__ bias, int n_cols, int k, const uint32_t* __restrict__ mask, int mask_pitch, int K,
+    int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int tiles_per_split, uint64_t* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int PARTB = KS * 32;                               // bytes of one bf16 part of an item row (KS*16 elements)
+    constexpr int ROWB = 3 * PARTB + 16;                         // padded row: conflict-free ds_read_b128 (ROWB/4 = 4 mod 8)
+    constexpr int KPAD = KS * 16;
+    const int W = blockDim.x >> 6;
+    const int users = W * 32;
+    TopkSmem<IdT> sm;
+    unsigned char* tile = smem_raw;                              // [2][32][ROWB]
+    sm.tile = nullptr;
+    sm.tbias = reinterpret_cast<float*>(smem_raw + 2 * 32 * ROWB);
+    sm.cnt = reinterpret_cast<int*>(sm.tbias + 64);
+    sm.cs = reinterpret_cast<float*>(sm.cnt + users);
+    sm.ci = reinterpret_cast<IdT*>(sm.cs + (size_t)users * kCap);
+    sm.users = users;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ul = lane & 31, h = lane >> 5;                     // h = k-group of the operands AND row group of the result
+    const int uw = wave * 32 + ul;
+    const int row = blockIdx.x * users + uw;
+    const bool user_ok = row < n_rows;
+
+    // ---- B operand: lane (user ul, k-group h) holds elements 16s + 8h .. +7 of its user's row, three parts each
+    bf16x8 breg[KS][3];
+    {
+        const int urow = user_ok ? (uidx ? uidx[row] : row) : 0;
+        const float* up = U + (size_t)urow * k;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = 16 * s + 8 * h + i;
+                const float v = (user_ok && e < k) ? up[min(e, k - 1)] : 0.f;
+                __bf16 p1, p2, p3;
+                split3(v, p1, p2, p3);
+                breg[s][0][i] = p1; breg[s][1][i] = p2; breg[s][2][i] = p3;
+            }
     }
+    for (int s = tid; s < users; s += blockDim.x) sm.cnt[s] = 0;
+    float thr = -INFINITY;
+    const int n_tiles_all = (n_cols + 31) >> 5;
+    const int t_begin = blockIdx.y * tiles_per_split;
+    const int n_tiles = min(n_tiles_all, t_begin + tiles_per_split);
+
+    // ---- tile staging: float4 of Vt -> registers (early) -> three 4 x bf16 parts -> LDS (after the MFMA chain)
+    constexpr int NT_ = topk_waves_bf16<KS, IdT>() * 64;
+    constexpr int NC = (32 * KPAD / 4 + NT_ - 1) / NT_;          // float4 chunks per thread
+    const bool vec = (k & 3) == 0;
+    const int nthreads = blockDim.x;
+    const int k4 = k >> 2;
+    int src_off[NC], dst_off[NC], item_of[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const int c = tid + q * nthreads;
+        const int item = vec ? c / k4 : 0, e = vec ? (c % k4) * 4 : 0;
+        const bool live = vec && c < 32 * k4;
+        src_off[q] = live ? item * k + e : -1;
+        dst_off[q] = item * ROWB + e * 2;
+        item_of[q] = item;
+    }
+    float4 stg[NC];
+    float stg_bias = 0.f;
+    auto stage_load = [&](int t) {
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                stg[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (src_off[q] >= 0 && t * 32 + item_of[q] < n_cols)
+                    stg[q] = *reinterpret_cast<const float4*>(Vt + (size_t)t * 32 * k + src_off[q]);
+            }
+        }
+        if (tid < 32) {
+            const int col = t * 32 + tid;
+            stg_bias = (bias && col < n_cols) ? bias[col] : 0.f;
+        }
+    };
+    auto stage_store = [&](int t, int buf) {
+        unsigned char* dst = tile + buf * 32 * ROWB;
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q)
+                if (src_off[q] >= 0) {
+                    const float a[4] = {stg[q].x, stg[q].y, stg[q].z, stg[q].w};
+                    bf16x4 p1, p2, p3;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __bf16 x1, x2, x3;
+                        split3(a[i], x1, x2, x3);
+                        p1[i] = x1; p2[i] = x2; p3[i] = x3;
+                    }
+                    *reinterpret_cast<bf16x4*>(dst + dst_off[q]) = p1;
+                    *reinterpret_cast<bf16x4*>(dst + dst_off[q] + PARTB) = p2;
+                    *reinterpret_cast<bf16x4*>(dst + dst_off[q] + 2 * PARTB) = p3;
+                }
+        } else {
+            for (int c = tid; c < 32 * KPAD; c += nthreads) {
+                const int item = c / KPAD, e = c % KPAD, col = t * 32 + item;
+                float v = 0.f;
+                if (e < k && col < n_cols) v = Vt[(size_t)col * k + e];
+                __bf16 x1, x2, x3;
+                split3(v, x1, x2, x3);
+                __bf16* rowp = reinterpret_cast<__bf16*>(dst + item * ROWB);
+                rowp[e] = x1; rowp[KPAD + e] = x2; rowp[2 * KPAD + e] = x3;
+            }
+        }
+        if (tid < 32) sm.tbias[buf * 32 + tid] = stg_bias;
+    };
+    if (vec) {                                                    // zero what the vector path never writes (k..KPAD, padding)
+        for (int c = tid; c < 2 * 32 * ROWB / 4; c += nthreads) reinterpret_cast<uint32_t*>(tile)[c] = 0u;
+        __syncthreads();
+    }
+    stage_load(t_begin);
+    stage_store(t_begin, t_begin & 1);
+    __syncthreads();
+    if (t_begin + 1 < n_tiles) stage_load(t_begin + 1);
+
+    const uint32_t tail_mask = (n_cols & 31) ? (0xffffffffu << (n_cols & 31)) : 0u;
+    int next_sched = t_begin + 2;
+    for (int t = t_begin; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        uint32_t maskw = (mask && user_ok) ? mask[(size_t)t * mask_pitch + row] : 0u;
+        // ---- 32 items x 32 users x k: six bf16 partial products per 16-wide k step, fp32 accumulation.
+        // A operand: lane (item ul, k-group h) reads elements 16s + 8h .. +7 of each part; small terms first.
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned char* arow = tile + buf * 32 * ROWB + ul * ROWB + h * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(arow + s * 32);
+            const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(arow + PARTB + s * 32);
+            const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(arow + 2 * PARTB + s * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, breg[s][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, breg[s][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[s][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, breg[s][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[s][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[s][0], acc, 0, 0, 0);
+        }
+        if (t + 1 < n_tiles) stage_store(t + 1, buf ^ 1);
+        if (t + 2 < n_tiles) stage_load(t + 2);
+        if (!user_ok) maskw = 0xffffffffu;
+        if (t == n_tiles_all - 1) maskw |= tail_mask;
+        if (t == next_sched) {
+            thr = trim_all_users<IdT>(sm, uw, h, K, thr);
+            next_sched = t + ((t - t_begin + 1) >> 1);
+        }
+        filter_tile<IdT>(sm, acc, sm.tbias + buf * 32, maskw, t, K, thr);
+        __syncthreads();
+    }
+    write_rows<IdT>(sm, n_rows, K, out_ids, out_scores, part);
 }
 
 // ---- merge of the per-item-range partial lists: one wave per row ----------------------------------
@@ -485,10 +682,60 @@ static int launch_topk(int W, const float* U, const int32_t* uidx, int n_rows, c
     return (int)hipGetLastError();
 }
 
+template <int KS, typename IdT>
+static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias, int n_cols,
+                            int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
+                            void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    constexpr int ROWB = 3 * KS * 32 + 16;
+    const int W = topk_waves_bf16<KS, IdT>();
+    const int users = W * 32;
+    const size_t lds = (size_t)2 * 32 * ROWB + 64 * 4 + (size_t)users * 4 + (size_t)users * kCap * (4 + sizeof(IdT));
+    if (lds > 160 * 1024) return TKR_EUNSUPPORTED;
+    auto kern = score_topk_bf16_kernel<KS, IdT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    const int grid = (n_rows + users - 1) / users;
+    const int n_tiles = (n_cols + 31) / 32;
+    const size_t per_split = (size_t)n_rows * K * sizeof(uint64_t);
+    const int max_splits = workspace ? (int)std::min<size_t>(16, workspace_bytes / (per_split ? per_split : 1)) : 1;
+    int S = pick_splits(n_rows, users, n_tiles, max_splits < 1 ? 1 : max_splits);
+    const int tps = (n_tiles + S - 1) / S;
+    S = (n_tiles + tps - 1) / tps;
+    hipLaunchKernelGGL(kern, dim3(grid, S), dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,
+                       out_ids, out_scores, tps, reinterpret_cast<uint64_t*>(workspace));
+    if (S > 1)
+        hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream,
+                           reinterpret_cast<const uint64_t*>(workspace), n_rows, S, K, out_ids, out_scores);
+    return (int)hipGetLastError();
+}
+
+// arithmetic of the score block: 0 = bf16-split products on the dense matrix pipe (k <= 128), 1 = fp32 MFMA for every k.
+// Initial value from TKR_TOPK_MATH=fp32|bf16x3; tkr_topk_set_math changes it for the process.
+static int g_topk_math = -1;
+static bool topk_bf16_enabled() {
+    if (g_topk_math < 0) {
+        const char* e = getenv("TKR_TOPK_MATH");
+        g_topk_math = (e && strcmp(e, "fp32") == 0) ? 1 : 0;
+    }
+    return g_topk_math == 0;
+}
+
 template <typename IdT>
 static int dispatch_topk(const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias, int n_cols,
                          int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
                          void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (k <= 128 && topk_bf16_enabled()) {
+#define TKR_TOPK_BF16_CASE(KS)                                                                                          \
+    if (k <= 16 * KS)                                                                                                   \
+        return launch_topk_bf16<KS, IdT>(U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores, workspace, \
+                                         workspace_bytes, stream);
+        TKR_TOPK_BF16_CASE(1)
+        TKR_TOPK_BF16_CASE(2)
+        TKR_TOPK_BF16_CASE(4)
+        TKR_TOPK_BF16_CASE(8)
+#undef TKR_TOPK_BF16_CASE
+    }
     const int kh = (k + 1) / 2;
 #define TKR_TOPK_CASE(KHP)                                                                                   \
     if (kh <= KHP)                                                                                           \
@@ -513,6 +760,12 @@ extern "C" int tkr_build_rated_mask(const int64_t* rated_ptr, const int32_t* rat
     hipLaunchKernelGGL(tkr::build_mask_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, rated_ptr,
                        rated_cols, n_rows, n_cols, mask, pitch);
     TKR_LAUNCH_CHECK();
+    return TKR_OK;
+}
+
+extern "C" int tkr_topk_set_math(int32_t mode) {
+    if (mode != 0 && mode != 1) return TKR_EINVAL;
+    tkr::g_topk_math = mode;
     return TKR_OK;
 }
 

@@ -41,7 +41,7 @@ EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_pl
            'tkr_vbpr_run', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy',
            'tkr_idmap_create', 'tkr_idmap_destroy', 'tkr_ratings_parse', 'tkr_ratings_sizes', 'tkr_ratings_copy',
            'tkr_ratings_destroy', 'tkr_matrix_read', 'tkr_matrix_sizes', 'tkr_matrix_copy', 'tkr_matrix_destroy',
-           'tkr_matrix_write', 'tkr_raw_ranks', 'tkr_count_hits_rr')
+           'tkr_matrix_write', 'tkr_raw_ranks', 'tkr_count_hits_rr', 'tkr_topk_set_math')
 EXPORTS_I64 = ('tkr_vbpr_workspace_floats', 'tkr_topk_workspace_bytes')
 
 
@@ -161,6 +161,11 @@ def _score_topk_once(U, Vt, K, bias, user_idx, mask, mask_pitch, want_scores, sp
                                 _p(scores), _p(ws), C.c_int64(ws.numel() if ws is not None else 0), _stream()),
            'tkr_score_topk')
     return ids, scores
+
+
+def set_topk_math(mode):
+    """'bf16x3' (default: split products on the dense matrix pipe, k <= 128) or 'fp32' (fp32 MFMA) -- see include/tkr.h"""
+    _check(lib().tkr_topk_set_math(C.c_int32({'bf16x3': 0, 'fp32': 1}[mode])), 'tkr_topk_set_math')
 
 
 def score_topk(U, Vt, K, bias=None, user_idx=None, mask=None, mask_pitch=0, want_scores=False, split=True):
