@@ -20,7 +20,7 @@ Prints ONE JSON line (rank 0).  Extra objects beside the contract fields:
   sgd_mode / sgd_throughput_mode  the legacy plain-SGD optimiser (old/methods/bpr.py:57-61) at batch 256 / 8192
   streams_mode    opt-in train(streams=4): four user shards on four HIP streams of the one GPU (extra, not headline)
   topk            the other half of BASELINE.json's metric: full-catalogue top-30 scored users/s (K4)
-                  with its own fp32-MFMA roofline and cpu_baseline
+                  with its own MFMA roofline (bf16 dense peak / 6 split products; fp32 MFMA peak under TKR_TOPK_MATH=fp32) and cpu_baseline
 """
 import argparse
 import json
@@ -37,6 +37,20 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA, dense
+MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense (no sparsity)
+
+
+def topk_roofline(tf, k):
+    """K4 against the pipe it runs on.  `achieved` is always ALGORITHMIC fp32 flops (2*k*n_items per user) per
+    second.  Default arithmetic (k <= 128): every fp32 product is six bf16 partial products on the dense matrix pipe, so
+    the ceiling for algorithmic flops is the bf16 dense peak / 6; TKR_TOPK_MATH=fp32 (and k > 128): the fp32 MFMA peak."""
+    split = k <= 128 and os.environ.get('TKR_TOPK_MATH', 'bf16x3') != 'fp32'
+    peak = MFMA_BF16_PEAK_TF / 6.0 if split else MFMA_F32_PEAK_TF
+    return {'kernel': 'tkr::score_topk_bf16_kernel' if split else 'tkr::score_topk_kernel', 'bound': 'mfma', 'achieved': tf,
+            'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
+            'arithmetic': ('bf16x3 split, 6 x v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulate: executed bf16 rate %.0f TFLOP/s '
+                           'of %.0f dense' % (6 * tf, MFMA_BF16_PEAK_TF)) if split else 'v_mfma_f32_32x32x2_f32',
+            'vs_fp32_mfma_peak': tf / MFMA_F32_PEAK_TF}
 
 
 def pmc_traffic(key):
@@ -178,11 +192,9 @@ def topk_bench(r, k, device, rank, world, K=30, reps=5):
     return {'metric': 'full-catalogue top-%d scored users/sec' % K, 'value': r['n_users'] * reps / wall, 'unit': 'users/s',
             'config': {'workload': '%d users x %d items, k=%d, top-%d, train history masked' % (r['n_users'], n_items, k, K)},
             'ms_per_pass': wall * 1e3 / reps,
-            'roofline': {'kernel': 'tkr::score_topk_kernel', 'bound': 'mfma', 'achieved': tf, 'peak': MFMA_F32_PEAK_TF,
-                         'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TF,
-                         'traffic': pmc_traffic('score_topk_ml10m_k128') if (k == 128 and n_items == 10380 and world == 1) else None,
-                         'launch_ms': launch_ms,
-                         'algorithmic_flops_per_launch': flops}}
+            'roofline': dict(topk_roofline(tf, k),
+                             traffic=pmc_traffic('score_topk_ml10m_k128') if (k == 128 and n_items == 10380 and world == 1) else None,
+                             launch_ms=launch_ms, algorithmic_flops_per_launch=flops)}
 
 
 def topk_bench_netflix(k, device, K=30, reps=3):
@@ -212,8 +224,7 @@ def topk_bench_netflix(k, device, K=30, reps=3):
     tf = flops / (ms * 1e-3) / 1e12
     return {'value': n_users * reps / wall, 'unit': 'users/s', 'ms_per_pass': wall * 1e3 / reps,
             'config': {'workload': '%d users x %d items, k=%d, top-%d, %d rated items per user masked' % (n_users, n_items, k, K, deg)},
-            'roofline': {'kernel': 'tkr::score_topk_kernel', 'bound': 'mfma', 'achieved': tf, 'peak': MFMA_F32_PEAK_TF,
-                         'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TF, 'launch_ms': ms}}
+            'roofline': dict(topk_roofline(tf, k), launch_ms=ms)}
 
 
 def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):

@@ -44,6 +44,24 @@ __device__ __forceinline__ uint32_t ordered_bits(float s) {      // monotone flo
 
 // value of lane (lane ^ STRIDE).  Strides 1..8 stay in the VALU (DPP), 16 uses the LDS crossbar without
 // an address (ds_swizzle), only 32 needs a bpermute.
+__device__ __forceinline__ float unordered_bits(uint32_t ob) {    // inverse of ordered_bits; 0 -> below every float
+    if (ob == 0u) return -INFINITY;
+    return __uint_as_float((ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob);
+}
+
+// Item-range splits of one user block cooperate through thr_shared[row]: the K-th best score inside ANY subset of
+// the catalogue is a lower bound of the K-th best overall, so every range may filter with the largest bound any
+// range has published.  Ranges are dispatched range-major (blockIdx.x fastest), so later ranges start with the
+// thresholds of earlier ones instead of -inf and skip the expensive low-threshold phase.  Results do not depend on
+// the timing: a column of the global top K passes every such bound, and the final order comes from the exact sorts.
+__device__ __forceinline__ float share_threshold(uint32_t* thr_shared, int row, bool publish, float thr) {
+    if (!thr_shared) return thr;
+    uint32_t seen = 0u;
+    if (publish && thr > -INFINITY) seen = atomicMax(&thr_shared[row], ordered_bits(thr));
+    seen = max(seen, (uint32_t)__shfl_xor((int)seen, 32, 64));  // the h = 1 lane of the user gets it too
+    return fmaxf(thr, unordered_bits(seen));
+}
+
 template <int STRIDE>
 __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
     if constexpr (STRIDE == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
@@ -79,6 +97,19 @@ __device__ __forceinline__ uint64_t wave_sort_desc(uint64_t key, int lane) {
     cmpx<32, 1>(hi, lo, lane);
     cmpx<64, 32>(hi, lo, lane); cmpx<64, 16>(hi, lo, lane); cmpx<64, 8>(hi, lo, lane); cmpx<64, 4>(hi, lo, lane);
     cmpx<64, 2>(hi, lo, lane); cmpx<64, 1>(hi, lo, lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// the first 15 stages of the network: lanes 0-31 end up sorted descending, lanes 32-63 ASCENDING (two independent
+// 32-key sorts, no exchange across the halves)
+__device__ __forceinline__ uint64_t wave_sort_halves(uint64_t key, int lane) {
+    uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+    cmpx<2, 1>(hi, lo, lane);
+    cmpx<4, 2>(hi, lo, lane); cmpx<4, 1>(hi, lo, lane);
+    cmpx<8, 4>(hi, lo, lane); cmpx<8, 2>(hi, lo, lane); cmpx<8, 1>(hi, lo, lane);
+    cmpx<16, 8>(hi, lo, lane); cmpx<16, 4>(hi, lo, lane); cmpx<16, 2>(hi, lo, lane); cmpx<16, 1>(hi, lo, lane);
+    cmpx<32, 16>(hi, lo, lane); cmpx<32, 8>(hi, lo, lane); cmpx<32, 4>(hi, lo, lane); cmpx<32, 2>(hi, lo, lane);
+    cmpx<32, 1>(hi, lo, lane);
     return ((uint64_t)hi << 32) | lo;
 }
 
@@ -227,7 +258,7 @@ __device__ __forceinline__ void filter_tile(const TopkSmem<IdT>& sm, const f32x1
         const int u = (__ffsll((long long)ov) - 1) & 31;
         const float nt = trim_user<IdT>(sm, wave * 32 + u, K, lane, nullptr);
         if (ul == u) {
-            thr = nt;
+            thr = fmaxf(thr, nt);                                // never below what another item range published
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if ((unplaced & (1u << r)) && sc[r] >= thr) {
@@ -241,27 +272,52 @@ __device__ __forceinline__ void filter_tile(const TopkSmem<IdT>& sm, const f32x1
     }
 }
 
-// final exact sort of every user's list and output (or the partial list of this item range, merged later)
+// Final exact sort of every user's list and output (or the partial list of this item range, merged later).
+// One more lower-bound trim leaves most lists with K..32 entries; those are sorted two users at a time in the two
+// 32-lane halves of the wave (15 compare-exchange stages, none across the halves) instead of one 21-stage sort each.
 template <typename IdT>
-__device__ __forceinline__ void write_rows(const TopkSmem<IdT>& sm, int n_rows, int K, int32_t* __restrict__ out_ids,
+__device__ __forceinline__ void emit_row(int r, int p, bool have, uint64_t key, int K, int32_t* __restrict__ out_ids,
+                                         float* __restrict__ out_scores, uint64_t* __restrict__ part) {
+    if (gridDim.y > 1) {
+        part[((size_t)r * gridDim.y + blockIdx.y) * K + p] = have ? key : 0ull;
+        return;
+    }
+    const uint32_t ob = (uint32_t)(key >> 32);
+    const uint32_t f = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+    out_ids[(size_t)r * K + p] = have ? (int32_t)((uint32_t)key - 1u) : -1;
+    if (out_scores) out_scores[(size_t)r * K + p] = have ? __uint_as_float(f) : -INFINITY;
+}
+
+template <typename IdT>
+__device__ __forceinline__ void write_rows(const TopkSmem<IdT>& sm, int n_rows, int K, float thr, int32_t* __restrict__ out_ids,
                                            float* __restrict__ out_scores, uint64_t* __restrict__ part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int u = 0; u < 32; ++u) {
-        const int r = blockIdx.x * sm.users + wave * 32 + u;
-        if (r >= n_rows) break;                                  // wave-uniform
-        uint64_t key;
-        const int n = min(sm.cnt[wave * 32 + u], kCap);
-        trim_user<IdT>(sm, wave * 32 + u, K, lane, &key);
-        if (gridDim.y > 1) {
-            if (lane < K) part[((size_t)r * gridDim.y + blockIdx.y) * K + lane] = (lane < n) ? key : 0ull;
+    const int me = lane & 31, half = lane >> 5;
+    if (__ballot(sm.cnt[wave * 32 + me] > 32) != 0) {
+        (void)trim_all_users<IdT>(sm, wave * 32 + me, half, K, thr);
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int j = 0; j < 16; ++j) {
+        const int u0 = wave * 32 + 2 * j, r0 = blockIdx.x * sm.users + u0;
+        if (r0 >= n_rows) break;                                 // wave-uniform
+        const int n0 = min(sm.cnt[u0], kCap);
+        const int n1 = (r0 + 1 < n_rows) ? min(sm.cnt[u0 + 1], kCap) : 0;
+        if (n0 <= 32 && n1 <= 32) {
+            const int uu = u0 + half, nn = half ? n1 : n0;
+            uint64_t key = 0;                                    // below every real key (real keys have idx+1 > 0)
+            if (me < nn) key = ((uint64_t)ordered_bits(sm.cs[me * sm.users + uu]) << 32) | ((uint32_t)sm.ci[me * sm.users + uu] + 1u);
+            key = wave_sort_halves(key, lane);
+            const int p = half ? 31 - me : me;                   // the upper half comes out ascending
+            if (r0 + half < n_rows && p < K) emit_row<IdT>(r0 + half, p, p < nn, key, K, out_ids, out_scores, part);
             continue;
         }
-        if (lane < K) {
-            const bool have = lane < n;
-            const uint32_t ob = (uint32_t)(key >> 32);
-            const uint32_t f = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
-            out_ids[(size_t)r * K + lane] = have ? (int32_t)((uint32_t)key - 1u) : -1;
-            if (out_scores) out_scores[(size_t)r * K + lane] = have ? __uint_as_float(f) : -INFINITY;
+        for (int q = 0; q < 2; ++q) {
+            const int r = r0 + q;
+            if (r >= n_rows) break;
+            uint64_t key;
+            const int n = q ? n1 : n0;
+            trim_user<IdT>(sm, u0 + q, K, lane, &key);
+            if (lane < K) emit_row<IdT>(r, lane, lane < n, key, K, out_ids, out_scores, part);
         }
     }
 }
@@ -276,7 +332,8 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
     const float* __restrict__ U, const int32_t* __restrict__ uidx, int n_rows, const float* __restrict__ Vt,
     const float* __restrict__ bias, int n_cols, int k, const uint32_t* __restrict__ mask, int mask_pitch, int K,
     int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int tiles_per_split,
-    uint64_t* __restrict__ part /*[n_rows][gridDim.y][K] sorted keys, when gridDim.y > 1*/) {
+    uint64_t* __restrict__ part /*[n_rows][gridDim.y][K] sorted keys, when gridDim.y > 1*/,
+    uint32_t* __restrict__ thr_shared /*[n_rows] ordered bits of a lower bound of the row's K-th best score, or null*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int KP = 2 * KHP + 4;                              // padded LDS row (floats): conflict-free b128 reads
     const int W = blockDim.x >> 6;
@@ -308,7 +365,7 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
         }
     }
     for (int s = tid; s < users; s += blockDim.x) sm.cnt[s] = 0;
-    float thr = -INFINITY;
+    float thr = (thr_shared && user_ok) ? unordered_bits(thr_shared[row]) : -INFINITY;   // what other item ranges found so far
     const int n_tiles_all = (n_cols + 31) >> 5;
     const int t_begin = blockIdx.y * tiles_per_split;           // this workgroup ranks items of tiles [t_begin, n_tiles)
     const int n_tiles = min(n_tiles_all, t_begin + tiles_per_split);
@@ -397,14 +454,17 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
         if (!user_ok) maskw = 0xffffffffu;
         if (t == n_tiles_all - 1) maskw |= tail_mask;
         if (t == next_sched) {                                   // workgroup-uniform: every wave trims all its users now
-            thr = trim_all_users<IdT>(sm, uw, h, K, thr);
+            if (__ballot(sm.cnt[uw] > kCap / 2) != 0) {            // lists still short (thresholds shared by earlier ranges): nothing to gain
+                thr = trim_all_users<IdT>(sm, uw, h, K, thr);
+                thr = share_threshold(thr_shared, row, user_ok && h == 0, thr);
+            }
             next_sched = t + ((t - t_begin + 1) >> 1);
         }
         filter_tile<IdT>(sm, acc, sm.tbias + buf * 32, maskw, t, K, thr);
         __syncthreads();                                         // tile t+1 staged; buffer `buf` may be overwritten next
     }
 
-    write_rows<IdT>(sm, n_rows, K, out_ids, out_scores, part);
+    write_rows<IdT>(sm, n_rows, K, thr, out_ids, out_scores, part);
 }
 
 // ---- K4 on the dense matrix pipe: 6-product bf16 split of the fp32 factors ------------------------------------
@@ -434,7 +494,8 @@ template <int KS, typename IdT>
 __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score_topk_bf16_kernel(
     const float* __restrict__ U, const int32_t* __restrict__ uidx, int n_rows, const float* __restrict__ Vt,
     const float* __restrict__ bias, int n_cols, int k, const uint32_t* __restrict__ mask, int mask_pitch, int K,
-    int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int tiles_per_split, uint64_t* __restrict__ part) {
+    int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int tiles_per_split, uint64_t* __restrict__ part,
+    uint32_t* __restrict__ thr_shared) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int PARTB = KS * 32;                               // bytes of one bf16 part of an item row (KS*16 elements)
     constexpr int ROWB = 3 * PARTB + 16;                         // padded row: conflict-free ds_read_b128 (ROWB/4 = 4 mod 8)
@@ -461,19 +522,38 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
     {
         const int urow = user_ok ? (uidx ? uidx[row] : row) : 0;
         const float* up = U + (size_t)urow * k;
+        float uv[KS][8];
+        if ((k & 3) == 0) {                                      // two 16-byte loads per 16-wide k step, all issued before use
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = 16 * s + 8 * h + 4 * q;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (user_ok && e < k) v = *reinterpret_cast<const float4*>(up + e);
+                    uv[s][4 * q + 0] = v.x; uv[s][4 * q + 1] = v.y; uv[s][4 * q + 2] = v.z; uv[s][4 * q + 3] = v.w;
+                }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = 16 * s + 8 * h + i;
+                    const float v = up[min(e, k - 1)];
+                    uv[s][i] = (user_ok && e < k) ? v : 0.f;
+                }
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int e = 16 * s + 8 * h + i;
-                const float v = (user_ok && e < k) ? up[min(e, k - 1)] : 0.f;
                 __bf16 p1, p2, p3;
-                split3(v, p1, p2, p3);
+                split3(uv[s][i], p1, p2, p3);
                 breg[s][0][i] = p1; breg[s][1][i] = p2; breg[s][2][i] = p3;
             }
     }
     for (int s = tid; s < users; s += blockDim.x) sm.cnt[s] = 0;
-    float thr = -INFINITY;
+    float thr = (thr_shared && user_ok) ? unordered_bits(thr_shared[row]) : -INFINITY;   // what other item ranges found so far
     const int n_tiles_all = (n_cols + 31) >> 5;
     const int t_begin = blockIdx.y * tiles_per_split;
     const int n_tiles = min(n_tiles_all, t_begin + tiles_per_split);
@@ -576,13 +656,16 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
         if (!user_ok) maskw = 0xffffffffu;
         if (t == n_tiles_all - 1) maskw |= tail_mask;
         if (t == next_sched) {
-            thr = trim_all_users<IdT>(sm, uw, h, K, thr);
+            if (__ballot(sm.cnt[uw] > kCap / 2) != 0) {            // lists still short (thresholds shared by earlier ranges): nothing to gain
+                thr = trim_all_users<IdT>(sm, uw, h, K, thr);
+                thr = share_threshold(thr_shared, row, user_ok && h == 0, thr);
+            }
             next_sched = t + ((t - t_begin + 1) >> 1);
         }
         filter_tile<IdT>(sm, acc, sm.tbias + buf * 32, maskw, t, K, thr);
         __syncthreads();
     }
-    write_rows<IdT>(sm, n_rows, K, out_ids, out_scores, part);
+    write_rows<IdT>(sm, n_rows, K, thr, out_ids, out_scores, part);
 }
 
 // ---- merge of the per-item-range partial lists: one wave per row ----------------------------------
@@ -594,8 +677,14 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t* __restr
     const uint64_t* p = part + (size_t)r * S * K;
     uint64_t key = (lane < K) ? p[lane] : 0ull;                  // best K so far in lanes 0..K-1 (K <= 32)
     for (int s = 1; s < S; ++s) {
-        const uint64_t in = (lane >= 32 && lane - 32 < K) ? p[(size_t)s * K + lane - 32] : 0ull;
-        key = wave_sort_desc(lane < 32 ? (lane < K ? key : 0ull) : in, lane);
+        // best-so-far descending in lanes 0-31, the next (descending) list REVERSED in lanes 32-63: a bitonic sequence,
+        // which the last six stages of the network sort
+        const uint64_t in = (lane >= 32 && 63 - lane < K) ? p[(size_t)s * K + 63 - lane] : 0ull;
+        uint64_t v = lane < 32 ? (lane < K ? key : 0ull) : in;
+        uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+        cmpx<64, 32>(hi, lo, lane); cmpx<64, 16>(hi, lo, lane); cmpx<64, 8>(hi, lo, lane); cmpx<64, 4>(hi, lo, lane);
+        cmpx<64, 2>(hi, lo, lane); cmpx<64, 1>(hi, lo, lane);
+        key = ((uint64_t)hi << 32) | lo;
     }
     if (lane < K) {
         const bool have = key != 0ull;
@@ -606,10 +695,16 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t* __restr
     }
 }
 
-// item-range splits: fill the CUs in whole rounds.  cost ~ rounds x (tiles per split + fixed per-workgroup work);
-// the fixed part is large (measured ~40 tile-times: every split re-pays the low-threshold early phase), so a
-// split only pays when it removes a mostly-empty last round
+// Item-range splits: the hardware hands out the (user block, item range) workgroups in order as CUs free up, so
+// many small ranges balance the load; ranges of a block share their thresholds (share_threshold), which leaves a
+// fixed cost per range of a few tile-times (operand load, first tiles at a loose threshold, final sorts, merge).
+constexpr int kMaxSplits = 32;
+constexpr double kSplitFixedTiles = 16.0;    // measured: ~37 us final sorts + start-up, plus the looser thresholds of a short range
 static int pick_splits(int n_rows, int users_per_wg, int n_tiles, int max_splits) {
+    if (const char* e = getenv("TKR_TOPK_SPLITS")) {          // tuning aid: force the number of item ranges
+        const int f = atoi(e);
+        if (f >= 1) return std::min(std::min(f, max_splits), n_tiles);
+    }
     const int wgs = (n_rows + users_per_wg - 1) / users_per_wg;
     int best = 1;
     double best_cost = 1e30;
@@ -617,7 +712,7 @@ static int pick_splits(int n_rows, int users_per_wg, int n_tiles, int max_splits
         const int tps = (n_tiles + s - 1) / s;
         const int used = (n_tiles + tps - 1) / tps;              // splits that actually get tiles
         const double rounds = (double)(((size_t)wgs * used + 255) / 256);
-        const double cost = rounds * (tps + 40.0) * (used > 1 ? 1.03 : 1.0);
+        const double cost = rounds * (tps + kSplitFixedTiles) + (used > 1 ? 0.02 * used * kSplitFixedTiles : 0.0);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = used; }
     }
     return best;
@@ -670,12 +765,19 @@ static int launch_topk(int W, const float* U, const int32_t* uidx, int n_rows, c
     const int grid = (n_rows + users - 1) / users;
     const int n_tiles = (n_cols + 31) / 32;
     const size_t per_split = (size_t)n_rows * K * sizeof(uint64_t);
-    const int max_splits = workspace ? (int)std::min<size_t>(16, workspace_bytes / (per_split ? per_split : 1)) : 1;
+    const size_t thr_bytes = (size_t)n_rows * sizeof(uint32_t);
+    const int max_splits = (workspace && workspace_bytes > thr_bytes)
+                               ? (int)std::min<size_t>(kMaxSplits, (workspace_bytes - thr_bytes) / (per_split ? per_split : 1)) : 1;
     int S = pick_splits(n_rows, users, n_tiles, max_splits < 1 ? 1 : max_splits);
     const int tps = (n_tiles + S - 1) / S;
     S = (n_tiles + tps - 1) / tps;
+    uint32_t* thr_shared = nullptr;
+    if (S > 1) {                                                 // thresholds live behind the S partial lists
+        thr_shared = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(workspace) + (size_t)S * per_split);
+        TKR_CHECK(hipMemsetAsync(thr_shared, 0, thr_bytes, stream));
+    }
     hipLaunchKernelGGL(kern, dim3(grid, S), dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,
-                       out_ids, out_scores, tps, reinterpret_cast<uint64_t*>(workspace));
+                       out_ids, out_scores, tps, reinterpret_cast<uint64_t*>(workspace), thr_shared);
     if (S > 1)
         hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream,
                            reinterpret_cast<const uint64_t*>(workspace), n_rows, S, K, out_ids, out_scores);
@@ -698,12 +800,19 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
     const int grid = (n_rows + users - 1) / users;
     const int n_tiles = (n_cols + 31) / 32;
     const size_t per_split = (size_t)n_rows * K * sizeof(uint64_t);
-    const int max_splits = workspace ? (int)std::min<size_t>(16, workspace_bytes / (per_split ? per_split : 1)) : 1;
+    const size_t thr_bytes = (size_t)n_rows * sizeof(uint32_t);
+    const int max_splits = (workspace && workspace_bytes > thr_bytes)
+                               ? (int)std::min<size_t>(kMaxSplits, (workspace_bytes - thr_bytes) / (per_split ? per_split : 1)) : 1;
     int S = pick_splits(n_rows, users, n_tiles, max_splits < 1 ? 1 : max_splits);
     const int tps = (n_tiles + S - 1) / S;
     S = (n_tiles + tps - 1) / tps;
+    uint32_t* thr_shared = nullptr;
+    if (S > 1) {                                                 // thresholds live behind the S partial lists
+        thr_shared = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(workspace) + (size_t)S * per_split);
+        TKR_CHECK(hipMemsetAsync(thr_shared, 0, thr_bytes, stream));
+    }
     hipLaunchKernelGGL(kern, dim3(grid, S), dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,
-                       out_ids, out_scores, tps, reinterpret_cast<uint64_t*>(workspace));
+                       out_ids, out_scores, tps, reinterpret_cast<uint64_t*>(workspace), thr_shared);
     if (S > 1)
         hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream,
                            reinterpret_cast<const uint64_t*>(workspace), n_rows, S, K, out_ids, out_scores);
@@ -770,7 +879,13 @@ extern "C" int tkr_topk_set_math(int32_t mode) {
 }
 
 extern "C" int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K) {
-    return (int64_t)16 * n_rows * K * (int64_t)sizeof(uint64_t);      // up to 16 item-range splits
+    // room for the item-range partial lists a launch can use (enough (block, range) workgroups to balance 256 CUs,
+    // at most kMaxSplits ranges) + one shared threshold word per row
+    const int64_t blocks = ((int64_t)n_rows + 255) / 256;
+    int64_t splits = (16 * 256 + blocks - 1) / blocks;
+    if (splits > tkr::kMaxSplits) splits = tkr::kMaxSplits;
+    if (splits < 2) splits = 2;
+    return splits * n_rows * K * (int64_t)sizeof(uint64_t) + (int64_t)n_rows * (int64_t)sizeof(uint32_t);
 }
 
 extern "C" int tkr_score_topk(const float* U, const int32_t* user_idx, int32_t n_rows, const float* Vt,
