@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class tkr_bpr_state(C.Structure):                # include/tkr.h
     _fields_ = [(n, C.c_void_p) for n in ('U', 'msU', 'V', 'msV', 'b', 'msb')] + \
                [(n, C.c_int32) for n in ('n_users', 'n_items', 'k', 'mode')] + \
-               [(n, C.c_float) for n in ('lu', 'li', 'lj', 'lb', 'lr', 'rho', 'eps')]
+               [(n, C.c_float) for n in ('lu', 'li', 'lj', 'lb', 'lr', 'rho', 'eps')] + [('opt', C.c_int32)]
 
 
 def test_integration_md_sequence():
