@@ -228,7 +228,9 @@ def topk_bench_netflix(k, device, K=30, reps=3):
 
 
 def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
-    """BASELINE.json configs[2]: VBPR, ML-10M shape, dense content features d=20,000 (train.py:11), ~100 nnz/row"""
+    """BASELINE.json configs[2]: VBPR, ML-10M shape, content features d=20,000 (train.py:11), ~100 nnz/row, resident as a
+    dense fp32 matrix like the reference's.  Default: the engine takes the CSR/CSC view of such features (S1/S3 kernels,
+    HBM-bound); `dense_view` times the dense fp32-MFMA kernels (V1/V3) on the same data."""
     import synth
     from single import _engine
     n_users, n_items = r['n_users'], r['n_in'] + r['n_out']
@@ -239,18 +241,34 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
     feat.scatter_(1, cols, torch.rand((n_items, 100), device=device, generator=g) + 0.1)
     feat /= feat.norm(dim=1, keepdim=True)
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, le=0.0, lr=1e-4, mode='l2')
-    eng = _engine.VbprEngine(n_users, n_items, k, d, feat, hp, device, seed=3)
-    wall, step_ms = timed_run(eng, csr, B, steps, warmup, 10 ** 9, 1, names=eng.replicated_names)
     kh = k // 2
-    flops = 4.0 * d * kh * B                                               # project the difference once, fwd + dense gradient
-    tf = flops / (step_ms * 1e-3 / steps) / 1e12
-    bytes_ = B * 2 * 4 * d * 2 + 16.0 * d * kh                             # feature rows (V1 + V3) + dense optimizer traffic
-    gbs = bytes_ / (step_ms * 1e-3 / steps) / 1e9
-    return {'value': steps * B / wall, 'unit': 'triplets/s', 'steps': steps, 'ms_per_step': wall * 1e3 / steps,
-            'config': {'workload': 'VBPR ML-10M shape, k=%d (kh=%d), dense features d=%d, batch_size=%d' % (k, kh, d, B)},
-            'roofline': {'kernels': 'tkr::vbpr_project/occur/rows/dense (4 launches per batch)', 'bound': 'mfma', 'achieved': tf,
-                         'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TF,
-                         'hbm_GBps_algorithmic': gbs, 'hbm_frac': gbs / HBM_PEAK_GBS, 'step_us': step_ms * 1e3 / steps}}
+    nnz = int(torch.count_nonzero(feat))
+    out = {}
+    for key, sparse in (('sparse_view', None), ('dense_view', False)):
+        eng = _engine.VbprEngine(n_users, n_items, k, d, feat, hp, device, seed=3, sparse=sparse)
+        wall, step_ms = timed_run(eng, csr, B, steps, warmup, 10 ** 9, 1, names=eng.replicated_names)
+        step_s = step_ms * 1e-3 / steps
+        if eng.sparse is not None:
+            # dense optimizer traffic + the CSC walk + one cem row and one icb value per nonzero of the 2B gathered items
+            bytes_ = 16.0 * d * kh + 8.0 * nnz + 2.0 * B * (nnz / n_items) * (4.0 * kh + 12.0)
+            gbs = bytes_ / step_s / 1e9
+            roof = {'kernels': 'tkr::vbpr_sproject/occur/rows/sdense (4 launches per batch)', 'bound': 'hbm', 'achieved': gbs,
+                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch_chain': bytes_,
+                    'step_us': step_s * 1e6, 'traffic': None}
+        else:
+            flops = 4.0 * d * kh * B                                     # project the difference once, fwd + dense gradient
+            tf = flops / step_s / 1e12
+            bytes_ = B * 2 * 4 * d * 2 + 16.0 * d * kh                   # feature rows (V1 + V3) + dense optimizer traffic
+            roof = {'kernels': 'tkr::vbpr_project/reduce/occur/rows/dense (5 launches per batch)', 'bound': 'mfma', 'achieved': tf,
+                    'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TF,
+                    'hbm_GBps_algorithmic': bytes_ / step_s / 1e9, 'hbm_frac': bytes_ / step_s / 1e9 / HBM_PEAK_GBS, 'step_us': step_s * 1e6}
+        out[key] = {'value': steps * B / wall, 'unit': 'triplets/s', 'steps': steps, 'ms_per_step': wall * 1e3 / steps, 'roofline': roof}
+        del eng
+    res = dict(out['sparse_view'])
+    res['config'] = {'workload': 'VBPR ML-10M shape, k=%d (kh=%d), content features d=%d with %d nonzeros (%.2f %% dense), batch_size=%d'
+                                 % (k, kh, d, nnz, 100.0 * nnz / (n_items * d), B)}
+    res['dense_view'] = out['dense_view']
+    return res
 
 
 def streams_bench(r, k, device, B=256, S=4, steps=2048, warmup=2048):   # warm-up = run: plan buffers and graphs cached

@@ -22,7 +22,9 @@ def _toy(n_users, n_items, seed):
 @pytest.mark.parametrize('k,d,B,nb,mode,dense', [(16, 40, 64, 6, 'l2', True), (128, 700, 256, 4, 'l2', False),
                                                  (50, 333, 128, 3, 'l1', False), (128, 1030, 1024, 2, 'l2', False),
                                                  (200, 130, 96, 3, 'l2', True)])
-def test_vbpr_step_parity(k, d, B, nb, mode, dense):
+@pytest.mark.parametrize('view', ['dense', 'sparse'])
+def test_vbpr_step_parity(k, d, B, nb, mode, dense, view):
+    """both implementations of the feature contraction: the dense MFMA kernels (V1/V3) and the CSR/CSC view (S1/S3)"""
     import tkr_hip
     from single import _engine
     n_users, n_items = 300, 90
@@ -36,7 +38,8 @@ def test_vbpr_step_parity(k, d, B, nb, mode, dense):
     feat = feat.astype(np.float32)
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, le=1e-3, lr=0.02, mode=mode)
     dev = torch.device('cuda')
-    eng = _engine.VbprEngine(n_users, n_items, k, d, feat, hp, dev, seed=5)
+    eng = _engine.VbprEngine(n_users, n_items, k, d, feat, hp, dev, seed=5, sparse=(view == 'sparse'))
+    assert (eng.sparse is not None) == (view == 'sparse')
     # start from a non-degenerate cem / icb so every term of x is exercised
     eng.set_dense(cem=(rng.standard_normal((d, kh)) * 0.05).astype(np.float32), icb=(rng.standard_normal(d) * 0.05).astype(np.float32))
     eng.set_items(irb=(rng.standard_normal(n_items) * 0.01).astype(np.float32))
@@ -101,3 +104,28 @@ def test_vbpr_class_end_to_end(tmp_path):
     m.export_embeddings(str(tmp_path / 'vb'))
     m.train(epochs=1, batch_size=64, epoch_sample_limit=64 * 5, model_path=str(tmp_path / 'vb'), seed=4, verbose=False)
     assert np.isfinite(m.fie).all()
+
+
+def test_vbpr_sparse_view_is_deterministic_and_auto_selected():
+    """tf-idf-like features pick the sparse view on their own; two runs from the same state are bitwise identical
+    (the column walk adds the batch's items in ascending item order, no float atomics on parameters)"""
+    from single import _engine
+    n_users, n_items, k, d, B, nb = 200, 150, 64, 2000, 256, 5
+    tr, tr_users = _toy(n_users, n_items, seed=1)
+    rng = np.random.Generator(np.random.PCG64(2))
+    feat = (np.abs(rng.standard_normal((n_items, d))) * (rng.random((n_items, d)) < 0.01)).astype(np.float32)
+    feat[7] = 0.0                                                    # an item without any feature
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, le=1e-3, lr=0.02, mode='l2')
+    dev = torch.device('cuda')
+    row_ptr, pos, srt = P.build_csr(tr, n_users)
+    outs = []
+    for _ in range(2):
+        eng = _engine.VbprEngine(n_users, n_items, k, d, feat, hp, dev, seed=9)
+        assert eng.sparse is not None and int(eng.sparse['f_ptr'][-1]) == int(np.count_nonzero(feat))
+        csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
+        eng.run_batches(csr, nb, B, want_loss=False)
+        torch.cuda.synchronize()
+        outs.append([eng.cem.cpu().numpy(), eng.icb.cpu().numpy(), eng.get('U')[0].cpu().numpy(), eng.get('I')[0].cpu().numpy()])
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    assert np.abs(outs[0][0] - 2.0 / (d * k)).max() > 0            # cem moved

@@ -20,6 +20,14 @@
 //                 with TF's DENSE ApplyRMSProp fused into the epilogue (every element of cem/icb is
 //                 updated every batch; vbpr.py:65,67,73)
 //
+// Sparse view (st.f_ptr != NULL; tf-idf-like content features are ~0.5 % dense): V1/V1r are replaced by S1, one wave
+// per triplet gathering one cem row per nonzero of f_i and f_j; V2's item tasks additionally store, per unique item
+// of the batch, A = sum over its occurrences of (+/-)W_t and a = sum of (-/+)s_t and tag the item with
+// (batch serial, slot); V3 is replaced by S3, one wave per feature column walking the column's (item, value) list
+// (CSC), adding value * A[slot] for the tagged items in ascending item order (deterministic) and applying the same
+// dense RMSProp.  Work drops from 4*d*kh flop per triplet to ~2*nnz_row*kh; what remains is the 16*d*kh B of
+// dense optimizer traffic per batch plus the 8 B per nonzero of the CSC walk.
+//
 // Roofline (dense features, d = 20,000, kh = 64, B = 256): 4*d*kh = 5.12 MFLOP per triplet on the
 // fp32 MFMA (V1 + V3) against 2*4d B = 160 KB of feature rows per triplet read twice from HBM/MALL
 // and 16*d*kh B = 20 MB of dense optimizer traffic per batch: MFMA and HBM ceilings are within 10 %
@@ -28,6 +36,7 @@
 #include "../../include/tkr.h"
 
 extern "C" int tkr_plan_team(int32_t batch_size);
+extern "C" int tkr_plan_max_blocks(int32_t batch_size);
 
 namespace tkr {
 
@@ -259,8 +268,10 @@ template <int NE, int kVTeam>
 __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_rows_kernel(
     tkr_vbpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
     const int32_t* __restrict__ occt, const int4* __restrict__ hdr, const float* __restrict__ s_in,
-    const float* __restrict__ P) {
+    const float* __restrict__ P, const float* __restrict__ Wm, float* __restrict__ Aw /*[slots][kh] or null*/,
+    float* __restrict__ ab /*[slots]*/, uint32_t serial) {
     __shared__ float red[kVTeam][NE * TKR_WAVE + 1];
+    __shared__ float red2[kVTeam][NE * TKR_WAVE + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int4 h4 = *hdr;
     const int n_blocks = __builtin_amdgcn_readfirstlane(h4.x);
@@ -285,6 +296,10 @@ __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_rows_kernel(
         }
         const float br = is_item ? st.irb[(size_t)par * st.n_items + row] : 0.f;
         float gb = 0.f;
+        float aw[NE], asum = 0.f;                       // sparse view: per-item sums for the column walk of S3
+#pragma unroll
+        for (int e = 0; e < NE; ++e) aw[e] = 0.f;
+        const bool want_a = is_item && Aw != nullptr;
         for (int done = 0; done < r.n_occ; done += 4) {
             const int n = min(4, r.n_occ - done);
             int oa[4], ob[4], ot[4];
@@ -303,6 +318,15 @@ __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_rows_kernel(
                         if (c < kh) g[e] += sgn_s * ur[c] + lam * (l2 ? own[e] : sgn(own[e]));
                     }
                     gb += sgn_s + st.lb * (l2 ? br : sgn(br));
+                    if (want_a) {
+                        const float* wt = Wm + (size_t)ot[q] * kh;
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) {
+                            const int c = lane + e * 64;
+                            if (c < kh) aw[e] += role_j ? -wt[c] : wt[c];
+                        }
+                        asum += sgn_s;
+                    }
                 } else {
                     const int i = oa[q] & kIdMaskV, pi = (oa[q] >> 30) & 1;
                     const int j = ob[q] & kIdMaskV, pj = (ob[q] >> 30) & 1;
@@ -322,22 +346,36 @@ __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_rows_kernel(
         }
         if (heavy) {
 #pragma unroll
-            for (int e = 0; e < NE; ++e) red[wave][lane + e * 64] = g[e];
-            if (lane == 0) red[wave][NE * 64] = gb;
+            for (int e = 0; e < NE; ++e) { red[wave][lane + e * 64] = g[e]; red2[wave][lane + e * 64] = aw[e]; }
+            if (lane == 0) { red[wave][NE * 64] = gb; red2[wave][NE * 64] = asum; }
             __syncthreads();
             if (wave == 0) {
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {
-                    float a = 0.f;
-                    for (int w = 0; w < kVTeam; ++w) a += red[w][lane + e * 64];
+                    float a = 0.f, a2 = 0.f;
+                    for (int w = 0; w < kVTeam; ++w) { a += red[w][lane + e * 64]; a2 += red2[w][lane + e * 64]; }
                     g[e] = a;
+                    aw[e] = a2;
                 }
-                float a = 0.f;
-                for (int w = 0; w < kVTeam; ++w) a += red[w][NE * 64];
+                float a = 0.f, a2 = 0.f;
+                for (int w = 0; w < kVTeam; ++w) { a += red[w][NE * 64]; a2 += red2[w][NE * 64]; }
                 gb = a;
+                asum = a2;
             }
             __syncthreads();
             if (wave != 0) continue;
+        }
+        if (want_a) {                                   // slot = this wave's record index; tag = (serial, slot)
+            const int slot = blk * kVTeam + wave;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int c = lane + e * 64;
+                if (c < kh) Aw[(size_t)slot * kh + c] = aw[e];
+            }
+            if (lane == 0) {
+                ab[slot] = asum;
+                st.item_tag[row] = ((int64_t)serial << 32) | (uint32_t)slot;
+            }
         }
         const float* msrc = is_item ? st.msI + par * istride + (size_t)row * kh : st.msU + par * ustride + (size_t)row * k2;
         float* po = is_item ? st.I + (par ^ 1) * istride + (size_t)row * kh : st.U + (par ^ 1) * ustride + (size_t)row * k2;
@@ -481,6 +519,144 @@ __global__ __launch_bounds__(256) void vbpr_dense_kernel(tkr_vbpr_state st, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// S1 (sparse view): P_t = sum_nz(f_i) v * cem[c] - sum_nz(f_j) v * cem[c], q_t likewise with icb.  One workgroup of
+// four waves per triplet: every wave takes a contiguous quarter of each item's nonzeros, reads 64 (column, value)
+// pairs at a time and gathers one kh-wide cem row per nonzero, 16 gathers in flight; the four partial sums are added
+// in wave order (fixed summation order).  The kernel is a chain of dependent gathers, so it wants many short waves.
+template <int NH>
+__global__ __launch_bounds__(256) void vbpr_sproject_kernel(tkr_vbpr_state st, const int32_t* __restrict__ ti,
+                                                           const int32_t* __restrict__ tj, int B, float* __restrict__ P,
+                                                           float* __restrict__ Q) {
+    __shared__ float red[4][NH * 64 + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = blockIdx.x;
+    const int kh = st.kh;
+    float acc[NH], q = 0.f;
+#pragma unroll
+    for (int e = 0; e < NH; ++e) acc[e] = 0.f;
+    for (int side = 0; side < 2; ++side) {
+        const int item = side ? tj[t] : ti[t];
+        const float sign = side ? -1.f : 1.f;
+        const int b0 = st.f_ptr[item], e0i = st.f_ptr[item + 1];
+        const int chunk = (e0i - b0 + 3) >> 2;
+        const int beg = b0 + wave * chunk, end = min(e0i, beg + chunk);
+        for (int p0 = beg; p0 < end; p0 += 64) {
+            const int p = p0 + lane;
+            const int col = p < end ? st.f_col[p] : 0;
+            const float val = p < end ? sign * st.f_val[p] : 0.f;
+            const int n = min(64, end - p0);
+            // groups of 16 nonzeros: the row gathers are issued together; lanes past the end hold (column 0, value 0)
+            for (int e0 = 0; e0 < n; e0 += 16) {
+                float rowv[16][NH], bv[16], vv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int c = __builtin_amdgcn_readlane(col, (e0 + u) & 63);
+                    vv[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val), (e0 + u) & 63));
+                    const float* crow = st.cem + (size_t)c * kh;
+#pragma unroll
+                    for (int hh = 0; hh < NH; ++hh) rowv[u][hh] = crow[min(lane + hh * 64, kh - 1)];
+                    bv[u] = st.icb[c];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+#pragma unroll
+                    for (int hh = 0; hh < NH; ++hh) acc[hh] = fmaf(vv[u], rowv[u][hh], acc[hh]);
+                    q = fmaf(vv[u], bv[u], q);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) red[wave][lane + hh * 64] = acc[hh];
+    if (lane == 0) red[wave][NH * 64] = q;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            const int n2 = lane + hh * 64;
+            if (n2 < kh) P[(size_t)t * kh + n2] = ((red[0][n2] + red[1][n2]) + red[2][n2]) + red[3][n2];
+        }
+        if (lane == 0) Q[t] = ((red[0][NH * 64] + red[1][NH * 64]) + red[2][NH * 64]) + red[3][NH * 64];
+    }
+}
+
+// S3 (sparse view): one wave per feature column c.  G_cem[c] = sum over the column's items that are in the batch
+// (tag == serial) of value * A[slot], G_icb[c] likewise with a[slot], + regulariser, then TF's dense ApplyRMSProp on
+// cem[c][.] and icb[c] exactly as V3 does.
+template <int NH>
+__global__ __launch_bounds__(256) void vbpr_sdense_kernel(tkr_vbpr_state st, const float* __restrict__ Aw,
+                                                         const float* __restrict__ ab, uint32_t serial,
+                                                         float* __restrict__ loss_out) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= st.d) return;
+    const int kh = st.kh;
+    float g[NH], gi = 0.f;
+#pragma unroll
+    for (int e = 0; e < NH; ++e) g[e] = 0.f;
+    const int beg = st.c_ptr[c], end = st.c_ptr[c + 1];
+    // the row of cem / its slot do not depend on the walk: issue their loads first
+    float pv[NH], pms[NH];
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+        const size_t o = (size_t)c * kh + min(lane + hh * 64, kh - 1);
+        pv[hh] = st.cem[o];
+        pms[hh] = st.mscem[o];
+    }
+    const float bv0 = st.icb[c], bms0 = st.msicb[c];
+    for (int p0 = beg; p0 < end; p0 += 64) {
+        const int p = p0 + lane;
+        const bool valid = p < end;
+        const int item = valid ? st.c_item[p] : 0;
+        const float val = valid ? st.c_val[p] : 0.f;
+        const int64_t tag = valid ? st.item_tag[item] : 0;
+        const bool hit = valid && (uint32_t)(tag >> 32) == serial;
+        const int slot_l = (int)(uint32_t)tag;
+        uint64_t m = __ballot(hit);
+        while (m) {                                     // ascending lane = ascending item: a fixed summation order
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int slot = __builtin_amdgcn_readlane(slot_l, l);
+            const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val), l));
+            const float* arow = Aw + (size_t)slot * kh;
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) {
+                const int n2 = lane + hh * 64;
+                if (n2 < kh) g[hh] = fmaf(v, arow[n2], g[hh]);
+            }
+            gi = fmaf(v, ab[slot], gi);
+        }
+    }
+    const bool l2 = st.mode == 0;
+    float lpart = 0.f;
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+        const int n2 = lane + hh * 64;
+        if (n2 < kh) {
+            const size_t o = (size_t)c * kh + n2;
+            const float v = pv[hh];
+            const float gg = g[hh] + st.le * (l2 ? v : sgn(v));
+            lpart += l2 ? 0.5f * st.le * v * v : st.le * fabsf(v);
+            float ms = pms[hh];
+            ms += (gg * gg - ms) * (1.f - st.rho);               // TF dense ApplyRMSProp
+            st.mscem[o] = ms;
+            st.cem[o] = v - st.lr * gg / sqrtf(ms + st.eps);
+        }
+    }
+    if (lane == 0) {
+        const float v = bv0;
+        const float gg = gi + st.lb * (l2 ? v : sgn(v));
+        lpart += l2 ? 0.5f * st.lb * v * v : st.lb * fabsf(v);
+        float ms = bms0;
+        ms += (gg * gg - ms) * (1.f - st.rho);
+        st.msicb[c] = ms;
+        st.icb[c] = v - st.lr * gg / sqrtf(ms + st.eps);
+    }
+    if (loss_out) {
+        lpart = wave_sum(lpart);
+        if (lane == 0 && lpart != 0.f) atomicAdd(loss_out, lpart);
+    }
+}
+
 static int vbpr_grid(int B, int team) {
     const int lpb = team;                                // oracle/plan_np.py light_per_block
     int grid = (3 * B + lpb - 1) / lpb + 16;
@@ -500,16 +676,35 @@ static int launch_vbpr_t(const tkr_vbpr_state& st, const int32_t* ti, const int3
     const int2* occ2 = reinterpret_cast<const int2*>(occ);
     const int4* hdr4 = reinterpret_cast<const int4*>(hdr);
     const dim3 rgrid(vbpr_grid(B, TEAM)), rblock(TEAM * 64);
-    hipLaunchKernelGGL(vbpr_project_kernel<NT>, dim3(S, (B + 31) / 32), dim3(64), 0, stream, st, ti, tj, B, ppart);
-    hipLaunchKernelGGL(vbpr_reduce_kernel, dim3(B), dim3(1024), 0, stream, ppart, S, B, kh, P, Q);
     const int NH = (kh + 63) / 64, NE = (2 * kh + 63) / 64;
+    const bool sparse = st.f_ptr != nullptr;
+    float* Aw = nullptr;
+    float* ab = nullptr;
+    static uint32_t g_serial = 0;                       // batch serial for the item tags; 0 never matches
+    uint32_t serial = 0;
+    if (sparse) {
+        Aw = Q + B;
+        ab = Aw + (size_t)tkr_plan_max_blocks(B) * TEAM * kh;
+        serial = ++g_serial;
+        if (serial == 0) serial = ++g_serial;
+        if (NH == 1) hipLaunchKernelGGL(vbpr_sproject_kernel<1>, dim3(B), dim3(256), 0, stream, st, ti, tj, B, P, Q);
+        else hipLaunchKernelGGL(vbpr_sproject_kernel<2>, dim3(B), dim3(256), 0, stream, st, ti, tj, B, P, Q);
+    } else {
+        hipLaunchKernelGGL(vbpr_project_kernel<NT>, dim3(S, (B + 31) / 32), dim3(64), 0, stream, st, ti, tj, B, ppart);
+        hipLaunchKernelGGL(vbpr_reduce_kernel, dim3(B), dim3(1024), 0, stream, ppart, S, B, kh, P, Q);
+    }
     if (NH == 1) hipLaunchKernelGGL((vbpr_occur_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
     else hipLaunchKernelGGL((vbpr_occur_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
     switch (NE) {
-        case 1: hipLaunchKernelGGL((vbpr_rows_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
-        case 2: hipLaunchKernelGGL((vbpr_rows_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
-        case 3: hipLaunchKernelGGL((vbpr_rows_kernel<3, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
-        default: hipLaunchKernelGGL((vbpr_rows_kernel<4, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P); break;
+        case 1: hipLaunchKernelGGL((vbpr_rows_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab, serial); break;
+        case 2: hipLaunchKernelGGL((vbpr_rows_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab, serial); break;
+        case 3: hipLaunchKernelGGL((vbpr_rows_kernel<3, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab, serial); break;
+        default: hipLaunchKernelGGL((vbpr_rows_kernel<4, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab, serial); break;
+    }
+    if (sparse) {
+        if (NH == 1) hipLaunchKernelGGL(vbpr_sdense_kernel<1>, dim3((st.d + 3) / 4), dim3(256), 0, stream, st, Aw, ab, serial, loss);
+        else hipLaunchKernelGGL(vbpr_sdense_kernel<2>, dim3((st.d + 3) / 4), dim3(256), 0, stream, st, Aw, ab, serial, loss);
+        return (int)hipGetLastError();
     }
     const size_t lds = (size_t)(4 * 64 * (NT * 32 + 1) + 4 * 2 * 64) * sizeof(float);
     auto dense = vbpr_dense_kernel<NT>;
@@ -535,7 +730,8 @@ extern "C" int tkr_plan_max_blocks(int32_t batch_size);
 
 extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d) {
     const int64_t S = tkr::vbpr_slices(d);
-    return S * batch_size * (kh + 1) + 2ll * batch_size + 2ll * batch_size * kh;
+    const int64_t slots = (int64_t)tkr_plan_max_blocks(batch_size) * tkr_plan_team(batch_size);     // sparse view: A, a per item task
+    return S * batch_size * (kh + 1) + 2ll * batch_size + 2ll * batch_size * kh + slots * (kh + 1);
 }
 
 extern "C" int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* tri_j, const int32_t* rec,
@@ -547,6 +743,7 @@ extern "C" int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, cons
     if (st->n_users <= 0 || st->n_items <= 0 || st->kh <= 0 || st->d <= 0) return TKR_EINVAL;
     if (!tri_i || !tri_j || !rec || !occ || !hdr || !occt || !workspace || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
     if (st->kh > 128 || batch_size > 8192) return TKR_EUNSUPPORTED;
+    if (st->f_ptr && (!st->f_col || !st->f_val || !st->c_ptr || !st->c_item || !st->c_val || !st->item_tag)) return TKR_EINVAL;
     const size_t stride_r = (size_t)tkr_plan_max_blocks(batch_size) * tkr_plan_team(batch_size) * 16;
     const size_t stride_o = (size_t)3 * batch_size;
     const int NT = (st->kh + 31) / 32;

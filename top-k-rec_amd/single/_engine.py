@@ -345,7 +345,9 @@ class VbprEngine:
     User rows hold [ure | uce] (width 2*kh, the layout of the exported ``fue``); item rows hold ire;
     cem / icb are dense and single-buffered (their update is its own launch, after every read)."""
 
-    def __init__(self, n_users, n_items, k, d, feat, hp, device=None, seed=None):
+    SPARSE_DENSITY = 0.25      # below this fraction of nonzeros the step uses the CSR/CSC view of feat (csrc/vbpr_step.hip S1/S3)
+
+    def __init__(self, n_users, n_items, k, d, feat, hp, device=None, seed=None, sparse=None):
         self.device = device or default_device()
         self.n_users, self.n_items, self.k, self.kh, self.d = n_users, n_items, k, k // 2, d
         self.hp = hp
@@ -370,6 +372,27 @@ class VbprEngine:
         self.pipe = None
         self.ws = None
         self.step_events = None
+        self.sparse = None
+        nnz = int(torch.count_nonzero(self.feat))
+        if sparse or (sparse is None and nnz <= self.SPARSE_DENSITY * n_items * d):
+            self.sparse = self._sparse_view(self.feat)
+
+    @staticmethod
+    def _sparse_view(feat):
+        """CSR over items (ascending columns) and CSC over feature columns (ascending items) of the nonzeros of feat,
+        plus the zeroed per-item tag scratch the kernels own (include/tkr.h tkr_vbpr_state)"""
+        n_items, d = feat.shape
+        i32 = torch.int32
+        rc = (feat != 0).nonzero()                                   # row-major: rows ascending, columns ascending inside
+        f_ptr = torch.zeros(n_items + 1, dtype=torch.int64, device=feat.device)
+        f_ptr[1:] = torch.cumsum(torch.bincount(rc[:, 0], minlength=n_items), 0)
+        cr = (feat.t() != 0).nonzero()                               # column-major
+        c_ptr = torch.zeros(d + 1, dtype=torch.int64, device=feat.device)
+        c_ptr[1:] = torch.cumsum(torch.bincount(cr[:, 0], minlength=d), 0)
+        assert int(f_ptr[-1]) < 2 ** 31
+        return dict(f_ptr=f_ptr.to(i32), f_col=rc[:, 1].to(i32).contiguous(), f_val=feat[rc[:, 0], rc[:, 1]].contiguous(),
+                    c_ptr=c_ptr.to(i32), c_item=cr[:, 1].to(i32).contiguous(), c_val=feat[cr[:, 1], cr[:, 0]].contiguous(),
+                    item_tag=torch.zeros(n_items, dtype=torch.int64, device=feat.device))
 
     def state(self):
         hp = self.hp
@@ -382,6 +405,9 @@ class VbprEngine:
         st.mode = 0 if hp['mode'] == 'l2' else 1
         st.lu, st.li, st.lj, st.lb, st.le, st.lr = hp['lu'], hp['li'], hp['lj'], hp['lb'], hp['le'], hp['lr']
         st.rho, st.eps = RHO, EPS
+        if self.sparse is not None:
+            for name, t in self.sparse.items():
+                setattr(st, name, t.data_ptr())
         return st
 
     def get(self, name):

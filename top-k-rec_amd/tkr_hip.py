@@ -34,7 +34,8 @@ class VbprState(C.Structure):
     """mirror of tkr_vbpr_state (include/tkr.h)"""
     _fields_ = [(n, C.c_void_p) for n in ('U', 'msU', 'I', 'msI', 'irb', 'msirb', 'cem', 'mscem', 'icb', 'msicb', 'feat')] + \
                [(n, C.c_int32) for n in ('n_users', 'n_items', 'kh', 'd', 'mode')] + \
-               [(n, C.c_float) for n in ('lu', 'li', 'lj', 'lb', 'le', 'lr', 'rho', 'eps')]
+               [(n, C.c_float) for n in ('lu', 'li', 'lj', 'lb', 'le', 'lr', 'rho', 'eps')] + \
+               [(n, C.c_void_p) for n in ('f_ptr', 'f_col', 'f_val', 'c_ptr', 'c_item', 'c_val', 'item_tag')]
 
 
 EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_bpr_run',
