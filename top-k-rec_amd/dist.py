@@ -58,13 +58,26 @@ class ItemSync:
         self.start = {n: self.eng.get(n)[0].clone() for n in self.names}
 
     def end(self):
+        """ONE collective per exchange: the parameter deltas and the slots (pre-divided by the world size) of every
+        replicated table travel in one flat buffer -- xGMI all-reduces of a few MB are latency-bound, so four
+        separate calls would cost four ring set-ups per epoch."""
         _, w = world()
         if w == 1:
             return
-        new = {}
+        cur = {n: self.eng.get(n) for n in self.names}
+        parts = []
         for n in self.names:
-            p, ms = self.eng.get(n)
-            new[n] = (reduce_deltas(p, self.start[n]), reduce_mean(ms))
+            p, ms = cur[n]
+            parts.append((p - self.start[n]).reshape(-1))
+            parts.append((ms / w).reshape(-1))
+        flat = torch.cat(parts)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        new, off = {}, 0
+        for n in self.names:
+            p, ms = cur[n]
+            m = p.numel()
+            new[n] = (self.start[n] + flat[off:off + m].view_as(p), flat[off + m:off + 2 * m].view_as(ms))
+            off += 2 * m
         self.eng.set_replicated(new)
 
 
