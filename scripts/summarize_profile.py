@@ -5,7 +5,7 @@ import pandas as pd
 src, tag = sys.argv[1], sys.argv[2]
 KERN = ('bpr_step_kernel', 'sample_plan_kernel', 'resolve_kernel', 'commit_kernel', 'score_topk_bf16_kernel', 'score_topk_kernel', 'merge_topk_kernel',
         'raw_rank_kernel', 'count_hits_rr_kernel',
-        'build_mask_kernel', 'vbpr_project_kernel', 'vbpr_reduce_kernel', 'vbpr_occur_kernel', 'vbpr_rows_kernel', 'vbpr_dense_kernel',
+        'build_mask_kernel', 'vbpr_sproject_kernel', 'vbpr_sdense_kernel', 'vbpr_project_kernel', 'vbpr_reduce_kernel', 'vbpr_occur_kernel', 'vbpr_rows_kernel', 'vbpr_dense_kernel',
         'calib_rowcopy_kernel')
 def short(n):
     for k in KERN:
