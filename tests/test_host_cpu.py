@@ -309,3 +309,32 @@ def test_utils_history_and_ivt_match_reference(golden_dir):
     if not torch.cuda.is_available():
         with pytest.raises(Exception, match='MI355X'):
             utils.get_score(np.zeros((2, 2), np.float32), np.zeros((2, 2), np.float32), {'a': 0}, {'a': 0})
+
+
+def test_native_ratings_parser_fuzz(tmp_path):
+    """random well-formed files with hostile spacing / line endings / signs: the native parser and the per-field Python
+    restatement of the reference's loops agree entry for entry"""
+    import textio
+    rng = np.random.Generator(np.random.PCG64(77))
+    users = {'u%d' % x: x for x in range(40)}
+    items = {'i%d' % x: x for x in range(60)}
+    items['odd id'] = 60                                            # ids are arbitrary tokens: inner spaces survive
+    for trial in range(25):
+        lines = []
+        for _ in range(int(rng.integers(0, 30))):
+            uid = rng.choice(['u%d' % rng.integers(0, 50), ' u%d' % rng.integers(0, 40), ''])
+            fields = []
+            for _ in range(int(rng.integers(0, 12))):
+                iid = rng.choice(['i%d' % rng.integers(0, 70), 'odd id', 'i%d ' % rng.integers(0, 60)])
+                like = rng.choice(['0', '1', '+1', '-1', ' 1', '1 ', '01', '5', '1:extra', '0:1'])
+                fields.append('%s:%s' % (iid, like))
+            lines.append(','.join([uid] + fields) + rng.choice(['\n', '\r\n', ' \n', '\t\n']))
+        text = ''.join(lines)
+        if trial % 3 == 0:
+            text = text.rstrip('\r\n\t ')                         # no trailing newline
+        path = tmp_path / ('f%d.txt' % trial)
+        path.write_bytes(text.encode())
+        got = textio.parse_ratings(str(path), users, items)
+        lu, lp, it, lk = _py_ratings(str(path), users, items)
+        assert got.line_user.tolist() == lu and got.line_ptr.tolist() == lp, trial
+        assert got.item.tolist() == it and got.like.tolist() == lk, trial
