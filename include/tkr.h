@@ -189,6 +189,20 @@ int tkr_count_hits_rr(const int32_t* ids, const int32_t* raw_rank, int32_t n_row
                       const int32_t* like_cols, int32_t step, int32_t interval, int32_t* hit_first, double* rr_first,
                       void* stream);
 
+/* ---- multi-GPU: pack / unpack of the replicated item-side tables around the per-epoch all-reduce ---------
+ * (new design, the reference is single-process: SURVEY.md §8e).  Users are sharded over the GPUs, every rank updates its
+ * own copy of the item tables and once per epoch  P <- P0 + sum_g (P_g - P0),  ms <- mean_g ms_g.  For a table
+ * P, ms [2][n][w] whose current row r lives in buffer (cnt[r] & 1) (cnt NULL: a single-buffered [n][w] table):
+ *   tkr_sync_snapshot  start[r] = current P[r]                                   (at the start of the epoch)
+ *   tkr_sync_pack      flat_delta[r] = current P[r] - start[r];  flat_ms[r] = current ms[r] * inv_world
+ *   (the caller all-reduces flat_delta | flat_ms with SUM: RCCL over xGMI through torch.distributed)
+ *   tkr_sync_unpack    P[0][r] = start[r] + flat_delta[r];  ms[0][r] = flat_ms[r];  the caller then zeroes cnt */
+int tkr_sync_snapshot(const float* P, const int32_t* cnt, float* start, int64_t n, int32_t w, void* stream);
+int tkr_sync_pack(const float* P, const float* ms, const int32_t* cnt, const float* start, float* flat_delta, float* flat_ms,
+                  int64_t n, int32_t w, float inv_world, void* stream);
+int tkr_sync_unpack(float* P, float* ms, const float* start, const float* flat_delta, const float* flat_ms, int64_t n, int32_t w,
+                    void* stream);
+
 /* ---- profiling aid: dst[r] = src[r] + 1 for the n listed rows of a [*, k] table, with the step
  * kernels' access pattern; used by scripts/pmc_calibrate.py to calibrate rocprofv3 byte counters */
 int tkr_calib_rowcopy(const float* src, float* dst, const int32_t* rows, int32_t n, int32_t k, void* stream);

@@ -311,6 +311,10 @@ class BprEngine:
 
     replicated_names = ('V', 'b')
 
+    def replicated_tables(self):
+        """(name, P, ms, update counter or None) of every table all ranks update: dist.ItemSync packs them with csrc/sync.hip"""
+        return [('V', self.V.p, self.V.ms, self.cnt.icnt), ('b', self.b.p, self.b.ms, self.cnt.icnt)]
+
     def copy_model_from(self, other):
         """start from another engine's current parameters and slots (shards of one model)"""
         p, ms = other.get('U')
@@ -443,6 +447,10 @@ class VbprEngine:
         self.set_dense(cem=new['cem'][0], icb=new['icb'][0], mscem=new['cem'][1], msicb=new['icb'][1])
 
     replicated_names = ('I', 'irb', 'cem', 'icb')
+
+    def replicated_tables(self):
+        return [('I', self.I.p, self.I.ms, self.cnt.icnt), ('irb', self.irb.p, self.irb.ms, self.cnt.icnt),
+                ('cem', self.cem, self.mscem, None), ('icb', self.icb, self.msicb, None)]
     copy_model_from = BprEngine.copy_model_from
 
     def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True):

@@ -42,7 +42,8 @@ EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_pl
            'tkr_vbpr_run', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy',
            'tkr_idmap_create', 'tkr_idmap_destroy', 'tkr_ratings_parse', 'tkr_ratings_sizes', 'tkr_ratings_copy',
            'tkr_ratings_destroy', 'tkr_matrix_read', 'tkr_matrix_sizes', 'tkr_matrix_copy', 'tkr_matrix_destroy',
-           'tkr_matrix_write', 'tkr_raw_ranks', 'tkr_count_hits_rr', 'tkr_topk_set_math')
+           'tkr_matrix_write', 'tkr_raw_ranks', 'tkr_count_hits_rr', 'tkr_topk_set_math',
+           'tkr_sync_snapshot', 'tkr_sync_pack', 'tkr_sync_unpack')
 EXPORTS_I64 = ('tkr_vbpr_workspace_floats', 'tkr_topk_workspace_bytes')
 
 
@@ -233,3 +234,18 @@ def count_hits_rr(ids, raw_rank, like_ptr, like_cols, step, interval):
                                        _p(like_cols), C.c_int32(step), C.c_int32(interval), _p(hit), _p(rr), _stream()),
                'tkr_count_hits_rr')
     return torch.cumsum(hit.sum(0, dtype=torch.int64)[:interval], 0), torch.cumsum(rr.sum(0)[:interval], 0)
+
+
+# ---- per-epoch exchange of replicated tables (csrc/sync.hip) ----------------------------------------
+def sync_snapshot(P, cnt, start, n, w):
+    _check(lib().tkr_sync_snapshot(_p(P), _p(cnt), _p(start), C.c_int64(n), C.c_int32(w), _stream()), 'tkr_sync_snapshot')
+
+
+def sync_pack(P, ms, cnt, start, flat_delta, flat_ms, n, w, inv_world):
+    _check(lib().tkr_sync_pack(_p(P), _p(ms), _p(cnt), _p(start), _p(flat_delta), _p(flat_ms), C.c_int64(n), C.c_int32(w),
+                               C.c_float(inv_world), _stream()), 'tkr_sync_pack')
+
+
+def sync_unpack(P, ms, start, flat_delta, flat_ms, n, w):
+    _check(lib().tkr_sync_unpack(_p(P), _p(ms), _p(start), _p(flat_delta), _p(flat_ms), C.c_int64(n), C.c_int32(w), _stream()),
+           'tkr_sync_unpack')
