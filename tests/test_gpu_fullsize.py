@@ -1,0 +1,126 @@
+"""-m gpu: the BPR hot path at BASELINE.json's full MovieLens-10M shape (69,878 users x 10,380 items, k = 128, batch 256,
+one reference epoch = 10^6 // 256 = 3,906 batches): the whole epoch against the oracle replaying the same 999,936
+triplets, plus the size-independent properties of the path (sampler invariants on every triplet, untouched rows
+bit-identical, update counters = number of batches touching a row, run-to-run determinism, lr = 0 leaves parameters
+bit-identical while the slots move)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import plan_np as P
+from oracle import ref_np as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ml10m():
+    import synth
+    r = synth.make_ratings(seed=42, **synth.ML10M)
+    row_ptr, pos, srt, tr_users = synth.positives_csr(r)
+    return dict(n_users=r['n_users'], n_items=r['n_in'] + r['n_out'], row_ptr=row_ptr, pos=pos, srt=srt, tr_users=tr_users)
+
+
+def _run(d, hp, nb, B, k, seed):
+    from single import _engine
+    dev = torch.device('cuda')
+    eng = _engine.BprEngine(d['n_users'], d['n_items'], k, hp, dev, seed=seed)
+    init = {n: eng.get(n)[0].cpu().numpy() for n in ('U', 'V', 'b')}
+    csr = _engine.TrainingCSR.from_arrays(d['row_ptr'], d['pos'], d['tr_users'], dev)
+    eng.run_batches(csr, nb, B, want_loss=False)
+    torch.cuda.synchronize()
+    return eng, init
+
+
+def test_full_epoch_matches_oracle_and_invariants(ml10m):
+    d, k, B = ml10m, 128, 256
+    nb = 10 ** 6 // B                                                 # single/bpr.py:139: limit // batch_size
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=1.0e-4, mode='l2')       # the reference's defaults
+    eng, init = _run(d, hp, nb, B, k, seed=2024)
+    u, i, j = P.sample_triplets(d['tr_users'], d['row_ptr'], d['pos'], d['srt'], d['n_items'], 2024, 0, nb * B)
+    # the last chunk of the device stream is what the oracle sampler says (K1 is bit-exact at full size too)
+    tail = eng.plan.u.cpu().numpy()
+    last = nb % 512 or 512
+    np.testing.assert_array_equal(tail[: last * B], u[(nb - last) * B:])
+    # sampler invariants on all 999,936 triplets: i is a train positive of u, j is not
+    n_items = d['n_items']
+    key_pos = np.sort(np.repeat(np.arange(d['n_users'], dtype=np.int64), np.diff(d['row_ptr'])) * n_items + d['pos'])
+    def member(uu, cc):
+        q = uu.astype(np.int64) * n_items + cc
+        at = np.searchsorted(key_pos, q)
+        return (at < len(key_pos)) & (key_pos[np.minimum(at, len(key_pos) - 1)] == q)
+    assert member(u, i).all() and not member(u, j).any()
+    assert np.isin(u, d['tr_users']).all()
+    # update counters = number of batches that touch the row
+    ub = np.unique(np.stack([np.repeat(np.arange(nb), B), u], 1), axis=0)
+    ib = np.unique(np.stack([np.repeat(np.arange(nb), 2 * B), np.concatenate([i.reshape(nb, B), j.reshape(nb, B)], 1).ravel()], 1), axis=0)
+    np.testing.assert_array_equal(eng.cnt.ucnt.cpu().numpy(), np.bincount(ub[:, 1], minlength=d['n_users']))
+    np.testing.assert_array_equal(eng.cnt.icnt.cpu().numpy(), np.bincount(ib[:, 1], minlength=n_items))
+    # rows never drawn are bit-identical to their initial values
+    got = {n: eng.get(n)[0].cpu().numpy() for n in ('U', 'V', 'b')}
+    never = eng.cnt.ucnt.cpu().numpy() == 0
+    assert never.sum() > 0                                            # ~e^-14 of the users after 10^6 uniform draws
+    np.testing.assert_array_equal(got['U'][never], init['U'][never])
+    # the oracle replays the epoch on the same triplets
+    ref = dict(U=init['U'].copy(), V=init['V'].copy(), b=init['b'].copy(), msU=np.ones_like(init['U']), msV=np.ones_like(init['V']),
+               msb=np.ones_like(init['b']))
+    for bb in range(nb):
+        sl = slice(bb * B, (bb + 1) * B)
+        R.bpr_step(ref, u[sl], i[sl], j[sl], hp)
+    for n in ('U', 'V', 'b'):
+        np.testing.assert_allclose(got[n], ref[n], rtol=2e-4, atol=1e-6, err_msg=n)
+        np.testing.assert_allclose(eng.get(n)[1].cpu().numpy(), ref['ms' + n], rtol=2e-4, atol=1e-7, err_msg='ms' + n)
+    assert np.abs(got['V'] - init['V']).max() > 1e-4                  # and it did train
+
+
+def test_full_size_determinism_and_zero_learning_rate(ml10m):
+    d, k, B, nb = ml10m, 128, 256, 1024
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=1.0e-2, mode='l2')
+    a, _ = _run(d, hp, nb, B, k, seed=5)
+    b, _ = _run(d, hp, nb, B, k, seed=5)
+    for n in ('U', 'V', 'b'):
+        for x, y in zip(a.get(n), b.get(n)):
+            assert torch.equal(x, y), n                               # bitwise, parameters and slots
+    c, init = _run(d, dict(hp, lr=0.0), nb, B, k, seed=5)
+    for n in ('U', 'V', 'b'):
+        p, ms = c.get(n)
+        np.testing.assert_array_equal(p.cpu().numpy(), init[n])       # lr = 0: no parameter moves ...
+    assert float((c.get('V')[1] != 1).float().mean()) > 0.5           # ... but the RMSProp slots of touched rows do
+
+
+def test_vbpr_full_size_sparse_view(ml10m):
+    """BASELINE.json configs[2] shape: d = 20,000 content features (~100 nonzeros per item), k = 128, batch 256 --
+    eight batches of the CSR/CSC path against the oracle's dense arithmetic"""
+    from single import _engine
+    d_, k, B, nb, dfeat = ml10m, 128, 256, 8, 20000
+    kh = k // 2
+    rng = np.random.Generator(np.random.PCG64(3))
+    n_items = d_['n_items']
+    feat = np.zeros((n_items, dfeat), dtype=np.float32)
+    cols = rng.integers(0, dfeat, (n_items, 100))
+    np.put_along_axis(feat, cols, (rng.random((n_items, 100)) + 0.1).astype(np.float32), axis=1)
+    feat /= np.linalg.norm(feat, axis=1, keepdims=True)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, le=1e-3, lr=0.01, mode='l2')
+    dev = torch.device('cuda')
+    eng = _engine.VbprEngine(d_['n_users'], n_items, k, dfeat, feat, hp, dev, seed=11)
+    assert eng.sparse is not None                                    # 0.5 % dense: the sparse view selects itself
+    eng.set_dense(cem=(rng.standard_normal((dfeat, kh)) * 0.05).astype(np.float32), icb=(rng.standard_normal(dfeat) * 0.05).astype(np.float32))
+    U0 = eng.get('U')[0].cpu().numpy()
+    ref = dict(ure=U0[:, :kh].copy(), uce=U0[:, kh:].copy(), ire=eng.get('I')[0].cpu().numpy(), irb=eng.get('irb')[0].cpu().numpy(),
+               cem=eng.cem.cpu().numpy(), icb=eng.icb.cpu().numpy())
+    for n in list(ref):
+        ref['ms_' + n] = np.ones_like(ref[n])
+    csr = _engine.TrainingCSR.from_arrays(d_['row_ptr'], d_['pos'], d_['tr_users'], dev)
+    loss = eng.run_batches(csr, nb, B).cpu().numpy()
+    torch.cuda.synchronize()
+    u, i, j = P.sample_triplets(d_['tr_users'], d_['row_ptr'], d_['pos'], d_['srt'], n_items, 11, 0, nb * B)
+    ref_loss = [R.vbpr_step(ref, feat, u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], j[b * B:(b + 1) * B], hp) for b in range(nb)]
+    tol = dict(rtol=3e-4, atol=2e-5)
+    Uc = eng.get('U')[0].cpu().numpy()
+    np.testing.assert_allclose(Uc[:, :kh], ref['ure'], err_msg='ure', **tol)
+    np.testing.assert_allclose(Uc[:, kh:], ref['uce'], err_msg='uce', **tol)
+    np.testing.assert_allclose(eng.get('I')[0].cpu().numpy(), ref['ire'], err_msg='ire', **tol)
+    np.testing.assert_allclose(eng.cem.cpu().numpy(), ref['cem'], err_msg='cem', **tol)
+    np.testing.assert_allclose(eng.icb.cpu().numpy(), ref['icb'], err_msg='icb', **tol)
+    np.testing.assert_allclose(eng.mscem.cpu().numpy(), ref['ms_cem'], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(loss, np.array(ref_loss), rtol=2e-4)
