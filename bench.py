@@ -382,7 +382,7 @@ def main():
     launch_us = step_ms * 1e3 / args.steps
     achieved = B * algorithmic_bytes_per_triplet(k) / (launch_us * 1e-6) / 1e9
     out = {
-        'metric': 'BPR training triplets/sec (sampler + plan + step), MovieLens-10M shape',
+        'metric': 'BPR training triplets/sec (sampler + plan + step), %s shape' % ('MovieLens-10M' if args.shape == 'ml10m' else 'Netflix'),
         'value': value, 'unit': 'triplets/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': wall * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
