@@ -124,7 +124,7 @@ def _current(T, name, cnt):
 
 @pytest.mark.parametrize('k,B,nb,mode,lr', [(16, 64, 12, 'l2', 0.05), (128, 256, 10, 'l2', 0.05),
                                            (50, 256, 6, 'l1', 0.05), (200, 128, 4, 'l2', 1e-4),
-                                           (128, 2048, 3, 'l2', 0.05)])
+                                           (128, 2048, 3, 'l2', 0.05), (64, 4096, 9, 'l2', 0.05), (128, 8192, 8, 'l1', 0.05)])
 def test_bpr_step_parity(hip, k, B, nb, mode, lr):
     n_users, n_items = 400, 120               # small tables: many in-batch duplicate rows
     tr, tr_users = _toy(n_users, n_items, seed=k + B, all_but_one=False)
@@ -180,7 +180,7 @@ def test_abi_rejects_bad_arguments(hip):
     assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 513, 256, *([None] * 12), None) == -2
 
 
-@pytest.mark.parametrize('k,B,nb', [(16, 64, 12), (128, 256, 10), (50, 512, 5), (128, 2048, 3)])
+@pytest.mark.parametrize('k,B,nb', [(16, 64, 12), (128, 256, 10), (50, 512, 5), (128, 2048, 3), (64, 2048, 9)])
 def test_sgd_step_parity(hip, k, B, nb):
     """tkr_bpr_state.opt = 1: the legacy update P -= lr*g (old/methods/bpr.py:57-61), no slot traffic at all --
     the ms pointers are NULL"""
