@@ -28,6 +28,7 @@ extern "C" {
 #define TKR_E_UNSUPPORTED (-2)
 #define TKR_E_IO (-3)          /* host text I/O: file cannot be opened / written */
 #define TKR_E_PARSE (-4)       /* host text I/O: malformed line (where the reference raises) */
+#define TKR_E_NOMEM (-5)       /* host text I/O: allocation failed */
 
 int tkr_version(void);
 

@@ -24,6 +24,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <memory>
 #include <string>
 #include <string_view>
 #include <unordered_map>
@@ -100,23 +101,27 @@ inline bool parse_int(const char* b, const char* e, int32_t& out) {
 }  // namespace
 
 extern "C" int tkr_idmap_create(const char* blob, int64_t blob_len, const int32_t* index, int64_t n, void** out) {
-    if (!out || n < 0 || blob_len < 0 || (n > 0 && (!blob || !index))) return TKR_E_INVAL;
-    IdMap* m = new IdMap();
-    m->blob.assign(blob ? blob : "", (size_t)blob_len);
-    m->table.reserve((size_t)n * 2);
-    const char* p = m->blob.data();
-    const char* end = p + m->blob.size();
-    int64_t k = 0;
-    while (k < n) {                                             // n tokens separated by '\n' (the last one unterminated)
-        const char* q = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
-        if (!q) q = end;
-        m->table[std::string_view(p, (size_t)(q - p))] = index[k++];
-        if (q == end) break;
-        p = q + 1;
+    try {
+        if (!out || n < 0 || blob_len < 0 || (n > 0 && (!blob || !index))) return TKR_E_INVAL;
+        std::unique_ptr<IdMap> m(new IdMap());
+        m->blob.assign(blob ? blob : "", (size_t)blob_len);
+        m->table.reserve((size_t)n * 2);
+        const char* p = m->blob.data();
+        const char* end = p + m->blob.size();
+        int64_t k = 0;
+        while (k < n) {                                             // n tokens separated by '\n' (the last one unterminated)
+            const char* q = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+            if (!q) q = end;
+            m->table[std::string_view(p, (size_t)(q - p))] = index[k++];
+            if (q == end) break;
+            p = q + 1;
+        }
+        if (k != n) return TKR_E_INVAL;
+        *out = m.release();
+        return TKR_OK;
+    } catch (...) {
+        return TKR_E_NOMEM;                                       // nothing throws across the C ABI
     }
-    if (k != n) { delete m; return TKR_E_INVAL; }
-    *out = m;
-    return TKR_OK;
 }
 
 extern "C" int tkr_idmap_destroy(void* map) {
@@ -125,48 +130,52 @@ extern "C" int tkr_idmap_destroy(void* map) {
 }
 
 extern "C" int tkr_ratings_parse(const char* path, const void* users, const void* items, void** out) {
-    if (!path || !users || !items || !out) return TKR_E_INVAL;
-    const IdMap* um = static_cast<const IdMap*>(users);
-    const IdMap* im = static_cast<const IdMap*>(items);
-    Mapped f;
-    if (!f.open(path)) return TKR_E_IO;
-    Ratings* r = new Ratings();
-    r->line_ptr.push_back(0);
-    const char* p = f.p;
-    const char* end = f.p + f.n;
-    while (p < end) {
-        const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
-        const char* le = nl ? nl : end;
-        const char* b = p;
-        const char* e = le;
-        strip(b, e);
-        // uid = up to the first ','
-        const char* c = static_cast<const char*>(memchr(b, ',', (size_t)(e - b)));
-        const char* ue = c ? c : e;
-        auto it = um->table.find(std::string_view(b, (size_t)(ue - b)));
-        r->line_user.push_back(it == um->table.end() ? -1 : it->second);
-        const char* q = c ? c + 1 : e;
-        while (c) {                                             // one field per ','
-            const char* nc = static_cast<const char*>(memchr(q, ',', (size_t)(e - q)));
-            const char* fe = nc ? nc : e;
-            const char* colon = static_cast<const char*>(memchr(q, ':', (size_t)(fe - q)));
-            if (!colon) { delete r; return TKR_E_PARSE; }      // terms[k].split(':')[1] -> IndexError in the reference
-            const char* l0 = colon + 1;
-            const char* colon2 = static_cast<const char*>(memchr(l0, ':', (size_t)(fe - l0)));
-            const char* l1 = colon2 ? colon2 : fe;
-            int32_t like = 0;
-            if (!parse_int(l0, l1, like)) { delete r; return TKR_E_PARSE; }
-            auto jt = im->table.find(std::string_view(q, (size_t)(colon - q)));
-            r->item.push_back(jt == im->table.end() ? -1 : jt->second);
-            r->like.push_back(like);
-            c = nc;
-            q = nc ? nc + 1 : e;
+    try {
+        if (!path || !users || !items || !out) return TKR_E_INVAL;
+        const IdMap* um = static_cast<const IdMap*>(users);
+        const IdMap* im = static_cast<const IdMap*>(items);
+        Mapped f;
+        if (!f.open(path)) return TKR_E_IO;
+        std::unique_ptr<Ratings> r(new Ratings());
+        r->line_ptr.push_back(0);
+        const char* p = f.p;
+        const char* end = f.p + f.n;
+        while (p < end) {
+            const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+            const char* le = nl ? nl : end;
+            const char* b = p;
+            const char* e = le;
+            strip(b, e);
+            // uid = up to the first ','
+            const char* c = static_cast<const char*>(memchr(b, ',', (size_t)(e - b)));
+            const char* ue = c ? c : e;
+            auto it = um->table.find(std::string_view(b, (size_t)(ue - b)));
+            r->line_user.push_back(it == um->table.end() ? -1 : it->second);
+            const char* q = c ? c + 1 : e;
+            while (c) {                                             // one field per ','
+                const char* nc = static_cast<const char*>(memchr(q, ',', (size_t)(e - q)));
+                const char* fe = nc ? nc : e;
+                const char* colon = static_cast<const char*>(memchr(q, ':', (size_t)(fe - q)));
+                if (!colon) return TKR_E_PARSE;                     // terms[k].split(':')[1] -> IndexError in the reference
+                const char* l0 = colon + 1;
+                const char* colon2 = static_cast<const char*>(memchr(l0, ':', (size_t)(fe - l0)));
+                const char* l1 = colon2 ? colon2 : fe;
+                int32_t like = 0;
+                if (!parse_int(l0, l1, like)) return TKR_E_PARSE;
+                auto jt = im->table.find(std::string_view(q, (size_t)(colon - q)));
+                r->item.push_back(jt == im->table.end() ? -1 : jt->second);
+                r->like.push_back(like);
+                c = nc;
+                q = nc ? nc + 1 : e;
+            }
+            r->line_ptr.push_back((int64_t)r->item.size());
+            p = nl ? nl + 1 : end;
         }
-        r->line_ptr.push_back((int64_t)r->item.size());
-        p = nl ? nl + 1 : end;
+        *out = r.release();
+        return TKR_OK;
+    } catch (...) {
+        return TKR_E_NOMEM;                                       // nothing throws across the C ABI
     }
-    *out = r;
-    return TKR_OK;
 }
 
 extern "C" int tkr_ratings_sizes(const void* ratings, int64_t* n_lines, int64_t* n_entries) {
@@ -193,38 +202,42 @@ extern "C" int tkr_ratings_destroy(void* ratings) {
 }
 
 extern "C" int tkr_matrix_read(const char* path, void** out) {
-    if (!path || !out) return TKR_E_INVAL;
-    Mapped f;
-    if (!f.open(path)) return TKR_E_IO;
-    Matrix* m = new Matrix();
-    const char* p = f.p;
-    const char* end = f.p + f.n;
-    std::string tok;
-    while (p < end) {
-        const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
-        const char* b = p;
-        const char* e = nl ? nl : end;
-        strip(b, e);
-        int64_t cols = 0;
-        while (b < e) {                                         // terms = line.strip().split(' ')
-            const char* sp = static_cast<const char*>(memchr(b, ' ', (size_t)(e - b)));
-            const char* te = sp ? sp : e;
-            tok.assign(b, (size_t)(te - b));
-            char* stop = nullptr;
-            errno = 0;
-            const double v = strtod(tok.c_str(), &stop);        // float(str) then narrowing, like np.float32(str)
-            if (tok.empty() || stop != tok.c_str() + tok.size()) { delete m; return TKR_E_PARSE; }
-            m->data.push_back((float)v);
-            ++cols;
-            b = sp ? sp + 1 : e;
+    try {
+        if (!path || !out) return TKR_E_INVAL;
+        Mapped f;
+        if (!f.open(path)) return TKR_E_IO;
+        std::unique_ptr<Matrix> m(new Matrix());
+        const char* p = f.p;
+        const char* end = f.p + f.n;
+        std::string tok;
+        while (p < end) {
+            const char* nl = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+            const char* b = p;
+            const char* e = nl ? nl : end;
+            strip(b, e);
+            int64_t cols = 0;
+            while (b < e) {                                         // terms = line.strip().split(' ')
+                const char* sp = static_cast<const char*>(memchr(b, ' ', (size_t)(e - b)));
+                const char* te = sp ? sp : e;
+                tok.assign(b, (size_t)(te - b));
+                char* stop = nullptr;
+                errno = 0;
+                const double v = strtod(tok.c_str(), &stop);        // float(str) then narrowing, like np.float32(str)
+                if (tok.empty() || stop != tok.c_str() + tok.size()) return TKR_E_PARSE;
+                m->data.push_back((float)v);
+                ++cols;
+                b = sp ? sp + 1 : e;
+            }
+            if (m->rows == 0) m->cols = cols;
+            if (cols != m->cols) return TKR_E_PARSE; // ragged rows: numpy raises on the assignment
+            ++m->rows;
+            p = nl ? nl + 1 : end;
         }
-        if (m->rows == 0) m->cols = cols;
-        if (cols != m->cols) { delete m; return TKR_E_PARSE; } // ragged rows: numpy raises on the assignment
-        ++m->rows;
-        p = nl ? nl + 1 : end;
+        *out = m.release();
+        return TKR_OK;
+    } catch (...) {
+        return TKR_E_NOMEM;                                       // nothing throws across the C ABI
     }
-    *out = m;
-    return TKR_OK;
 }
 
 extern "C" int tkr_matrix_sizes(const void* matrix, int64_t* rows, int64_t* cols) {
@@ -248,19 +261,23 @@ extern "C" int tkr_matrix_destroy(void* matrix) {
 }
 
 extern "C" int tkr_matrix_write(const char* path, const float* data, int64_t rows, int64_t cols) {
-    if (!path || rows < 0 || cols < 0 || (rows * cols > 0 && !data)) return TKR_E_INVAL;
-    FILE* fh = fopen(path, "w");
-    if (!fh) return TKR_E_IO;
-    std::vector<char> buf((size_t)cols * 52 + 2);               // "%f" of a float: at most 1 + 39 + 1 + 6 characters
-    for (int64_t r = 0; r < rows; ++r) {
-        char* w = buf.data();
-        for (int64_t c = 0; c < cols; ++c) {
-            const double v = (double)data[r * cols + c];
-            if (isnan(v)) { memcpy(w, "nan ", 4); w += 4; }    // Python prints 'nan' for either sign
-            else w += sprintf(w, "%f ", v);
+    try {
+        if (!path || rows < 0 || cols < 0 || (rows * cols > 0 && !data)) return TKR_E_INVAL;
+        FILE* fh = fopen(path, "w");
+        if (!fh) return TKR_E_IO;
+        std::vector<char> buf((size_t)cols * 52 + 2);               // "%f" of a float: at most 1 + 39 + 1 + 6 characters
+        for (int64_t r = 0; r < rows; ++r) {
+            char* w = buf.data();
+            for (int64_t c = 0; c < cols; ++c) {
+                const double v = (double)data[r * cols + c];
+                if (isnan(v)) { memcpy(w, "nan ", 4); w += 4; }    // Python prints 'nan' for either sign
+                else w += sprintf(w, "%f ", v);
+            }
+            *w++ = '\n';
+            if (fwrite(buf.data(), 1, (size_t)(w - buf.data()), fh) != (size_t)(w - buf.data())) { fclose(fh); return TKR_E_IO; }
         }
-        *w++ = '\n';
-        if (fwrite(buf.data(), 1, (size_t)(w - buf.data()), fh) != (size_t)(w - buf.data())) { fclose(fh); return TKR_E_IO; }
+        return fclose(fh) == 0 ? TKR_OK : TKR_E_IO;
+    } catch (...) {
+        return TKR_E_NOMEM;                                       // nothing throws across the C ABI
     }
-    return fclose(fh) == 0 ? TKR_OK : TKR_E_IO;
 }
