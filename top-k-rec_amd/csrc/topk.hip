@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "tkr_common.h"
 #include "../../include/tkr.h"
@@ -275,11 +276,18 @@ __device__ __forceinline__ void filter_tile(const TopkSmem<IdT>& sm, const f32x1
 // Final exact sort of every user's list and output (or the partial list of this item range, merged later).
 // One more lower-bound trim leaves most lists with K..32 entries; those are sorted two users at a time in the two
 // 32-lane halves of the wave (15 compare-exchange stages, none across the halves) instead of one 21-stage sort each.
+// where a workgroup's result goes: straight to the output, or as one of the sorted partial lists of its rows
+struct TopkSlot {
+    int block;        // user block (rows block*users .. +users-1)
+    int slot;         // index of this partial list among the row's `stride` slots
+    int stride;       // slots per row in the partial-list buffer; 1: final output, no merge
+};
+
 template <typename IdT>
-__device__ __forceinline__ void emit_row(int r, int p, bool have, uint64_t key, int K, int32_t* __restrict__ out_ids,
-                                         float* __restrict__ out_scores, uint64_t* __restrict__ part) {
-    if (gridDim.y > 1) {
-        part[((size_t)r * gridDim.y + blockIdx.y) * K + p] = have ? key : 0ull;
+__device__ __forceinline__ void emit_row(const TopkSlot& ws, int r, int p, bool have, uint64_t key, int K,
+                                         int32_t* __restrict__ out_ids, float* __restrict__ out_scores, uint64_t* __restrict__ part) {
+    if (ws.stride > 1) {
+        part[((size_t)r * ws.stride + ws.slot) * K + p] = have ? key : 0ull;
         return;
     }
     const uint32_t ob = (uint32_t)(key >> 32);
@@ -289,8 +297,9 @@ __device__ __forceinline__ void emit_row(int r, int p, bool have, uint64_t key, 
 }
 
 template <typename IdT>
-__device__ __forceinline__ void write_rows(const TopkSmem<IdT>& sm, int n_rows, int K, float thr, int32_t* __restrict__ out_ids,
-                                           float* __restrict__ out_scores, uint64_t* __restrict__ part) {
+__device__ __forceinline__ void write_rows(const TopkSmem<IdT>& sm, const TopkSlot& ws, int n_rows, int K, float thr,
+                                           int32_t* __restrict__ out_ids, float* __restrict__ out_scores,
+                                           uint64_t* __restrict__ part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int me = lane & 31, half = lane >> 5;
     if (__ballot(sm.cnt[wave * 32 + me] > 32) != 0) {
@@ -298,7 +307,7 @@ __device__ __forceinline__ void write_rows(const TopkSmem<IdT>& sm, int n_rows, 
         __builtin_amdgcn_wave_barrier();
     }
     for (int j = 0; j < 16; ++j) {
-        const int u0 = wave * 32 + 2 * j, r0 = blockIdx.x * sm.users + u0;
+        const int u0 = wave * 32 + 2 * j, r0 = ws.block * sm.users + u0;
         if (r0 >= n_rows) break;                                 // wave-uniform
         const int n0 = min(sm.cnt[u0], kCap);
         const int n1 = (r0 + 1 < n_rows) ? min(sm.cnt[u0 + 1], kCap) : 0;
@@ -308,7 +317,7 @@ __device__ __forceinline__ void write_rows(const TopkSmem<IdT>& sm, int n_rows, 
             if (me < nn) key = ((uint64_t)ordered_bits(sm.cs[me * sm.users + uu]) << 32) | ((uint32_t)sm.ci[me * sm.users + uu] + 1u);
             key = wave_sort_halves(key, lane);
             const int p = half ? 31 - me : me;                   // the upper half comes out ascending
-            if (r0 + half < n_rows && p < K) emit_row<IdT>(r0 + half, p, p < nn, key, K, out_ids, out_scores, part);
+            if (r0 + half < n_rows && p < K) emit_row<IdT>(ws, r0 + half, p, p < nn, key, K, out_ids, out_scores, part);
             continue;
         }
         for (int q = 0; q < 2; ++q) {
@@ -317,7 +326,7 @@ __device__ __forceinline__ void write_rows(const TopkSmem<IdT>& sm, int n_rows, 
             uint64_t key;
             const int n = q ? n1 : n0;
             trim_user<IdT>(sm, u0 + q, K, lane, &key);
-            if (lane < K) emit_row<IdT>(r, lane, lane < n, key, K, out_ids, out_scores, part);
+            if (lane < K) emit_row<IdT>(ws, r, lane, lane < n, key, K, out_ids, out_scores, part);
         }
     }
 }
@@ -464,7 +473,8 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
         __syncthreads();                                         // tile t+1 staged; buffer `buf` may be overwritten next
     }
 
-    write_rows<IdT>(sm, n_rows, K, thr, out_ids, out_scores, part);
+    const TopkSlot ws = {(int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y};
+    write_rows<IdT>(sm, ws, n_rows, K, thr, out_ids, out_scores, part);
 }
 
 // ---- K4 on the dense matrix pipe: 6-product bf16 split of the fp32 factors ------------------------------------
@@ -495,7 +505,7 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
     const float* __restrict__ U, const int32_t* __restrict__ uidx, int n_rows, const float* __restrict__ Vt,
     const float* __restrict__ bias, int n_cols, int k, const uint32_t* __restrict__ mask, int mask_pitch, int K,
     int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int tiles_per_split, uint64_t* __restrict__ part,
-    uint32_t* __restrict__ thr_shared) {
+    uint32_t* __restrict__ thr_shared, const int4* __restrict__ items /*(block, t_begin, t_end, slot | stride << 16) or null*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int PARTB = KS * 32;                               // bytes of one bf16 part of an item row (KS*16 elements)
     constexpr int ROWB = 3 * PARTB + 16;                         // padded row: conflict-free ds_read_b128 (ROWB/4 = 4 mod 8)
@@ -514,7 +524,11 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ul = lane & 31, h = lane >> 5;                     // h = k-group of the operands AND row group of the result
     const int uw = wave * 32 + ul;
-    const int row = blockIdx.x * users + uw;
+    // work item: a (user block, tile range) from the balanced item table, or from the grid
+    int4 it = make_int4((int)blockIdx.x, (int)blockIdx.y * tiles_per_split, 0, (int)blockIdx.y | ((int)gridDim.y << 16));
+    if (items) it = items[blockIdx.x];
+    const TopkSlot ws = {it.x, it.w & 0xffff, it.w >> 16};
+    const int row = ws.block * users + uw;
     const bool user_ok = row < n_rows;
 
     // ---- B operand: lane (user ul, k-group h) holds elements 16s + 8h .. +7 of its user's row, three parts each
@@ -555,8 +569,8 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
     for (int s = tid; s < users; s += blockDim.x) sm.cnt[s] = 0;
     float thr = (thr_shared && user_ok) ? unordered_bits(thr_shared[row]) : -INFINITY;   // what other item ranges found so far
     const int n_tiles_all = (n_cols + 31) >> 5;
-    const int t_begin = blockIdx.y * tiles_per_split;
-    const int n_tiles = min(n_tiles_all, t_begin + tiles_per_split);
+    const int t_begin = it.y;
+    const int n_tiles = items ? it.z : min(n_tiles_all, t_begin + tiles_per_split);
 
     // ---- tile staging: float4 of Vt -> registers (early) -> three 4 x bf16 parts -> LDS (after the MFMA chain)
     constexpr int NT_ = topk_waves_bf16<KS, IdT>() * 64;
@@ -665,16 +679,22 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
         filter_tile<IdT>(sm, acc, sm.tbias + buf * 32, maskw, t, K, thr);
         __syncthreads();
     }
-    write_rows<IdT>(sm, n_rows, K, thr, out_ids, out_scores, part);
+    write_rows<IdT>(sm, ws, n_rows, K, thr, out_ids, out_scores, part);
 }
 
 // ---- merge of the per-item-range partial lists: one wave per row ----------------------------------
 __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t* __restrict__ part, int n_rows, int S, int K,
-                                                        int32_t* __restrict__ out_ids, float* __restrict__ out_scores) {
+                                                        int32_t* __restrict__ out_ids, float* __restrict__ out_scores,
+                                                        const int32_t* __restrict__ nslots /*per user block, or null: S everywhere*/,
+                                                        int users_per_block) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
-    const uint64_t* p = part + (size_t)r * S * K;
+    const uint64_t* p = part + (size_t)r * S * K;                // S slots per row; the block's first nslots are used
+    if (nslots) {
+        S = nslots[r / users_per_block];
+        if (S <= 1) return;                                      // a single workgroup ranked the block: output already final
+    }
     uint64_t key = (lane < K) ? p[lane] : 0ull;                  // best K so far in lanes 0..K-1 (K <= 32)
     for (int s = 1; s < S; ++s) {
         // best-so-far descending in lanes 0-31, the next (descending) list REVERSED in lanes 32-63: a bitonic sequence,
@@ -780,8 +800,84 @@ static int launch_topk(int W, const float* U, const int32_t* uidx, int n_rows, c
                        out_ids, out_scores, tps, reinterpret_cast<uint64_t*>(workspace), thr_shared);
     if (S > 1)
         hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream,
-                           reinterpret_cast<const uint64_t*>(workspace), n_rows, S, K, out_ids, out_scores);
+                           reinterpret_cast<const uint64_t*>(workspace), n_rows, S, K, out_ids, out_scores, nullptr, users);
     return (int)hipGetLastError();
+}
+
+// ---- balanced item table ---------------------------------------------------------------------------------------------
+// A grid of (user block, item range) workgroups only fills 256 CUs evenly when blocks x ranges happens to be a multiple of
+// 256 (ML-10M: 273 blocks).  Instead the (block, tile) space is cut into G equal spans of consecutive tiles; a span is
+// the tail of one block, whole blocks and the head of another, so the pieces ("items") that make up any span add up to
+// the same number of tiles.  The items are dispatched largest first (LPT): the hardware hands workgroups to CUs in grid
+// order as they free up, which with decreasing sizes packs the CUs to within a few tiles of equal.  Pieces of one block
+// are its partial lists (slot = order inside the block); blocks that stay whole write their final output directly.
+// The table depends only on the shape, so it is built once per shape and kept on the device (8 shapes).
+struct ItemTable {
+    int n_rows, users, n_tiles, G;
+    int n_items, n_blocks, stride;
+    int4* d_items;          // [n_items] (block, t_begin, t_end, slot | stride << 16)
+    int32_t* d_nslots;      // [n_blocks]
+    uint64_t used;
+};
+static ItemTable g_tables[8];
+static int g_tables_n = 0;
+static uint64_t g_tables_tick = 0;
+
+static const ItemTable* item_table(int n_rows, int users, int n_tiles, int G) {
+    ++g_tables_tick;
+    for (int i = 0; i < g_tables_n; ++i) {
+        ItemTable& t = g_tables[i];
+        if (t.n_rows == n_rows && t.users == users && t.n_tiles == n_tiles && t.G == G) { t.used = g_tables_tick; return &t; }
+    }
+    const int n_blocks = (n_rows + users - 1) / users;
+    const long long total = (long long)n_blocks * n_tiles;
+    std::vector<int4> items;
+    std::vector<int32_t> nslots(n_blocks, 0);
+    long long pos = 0;
+    int g = 0;
+    while (pos < total) {                                        // cut at block ends and at span ends
+        while ((long long)(g + 1) * total / G <= pos) ++g;
+        const long long span_end = (long long)(g + 1) * total / G;
+        const int block = (int)(pos / n_tiles), t0 = (int)(pos % n_tiles);
+        const long long block_end = (long long)(block + 1) * n_tiles;
+        const long long end = std::min(span_end, block_end);
+        items.push_back(make_int4(block, t0, t0 + (int)(end - pos), nslots[block]++));
+        pos = end;
+    }
+    int stride = 1;
+    for (int b = 0; b < n_blocks; ++b) stride = std::max(stride, (int)nslots[b]);
+    for (auto& it : items) it.w |= (nslots[it.x] > 1 ? stride : 1) << 16;
+    std::stable_sort(items.begin(), items.end(), [](const int4& a, const int4& b) { return (a.z - a.y) > (b.z - b.y); });
+    int slot = g_tables_n;
+    if (g_tables_n < 8) {
+        ++g_tables_n;
+    } else {
+        slot = 0;
+        for (int i = 1; i < 8; ++i)
+            if (g_tables[i].used < g_tables[slot].used) slot = i;
+        (void)hipFree(g_tables[slot].d_items);
+        (void)hipFree(g_tables[slot].d_nslots);
+    }
+    ItemTable& t = g_tables[slot];
+    t = ItemTable{n_rows, users, n_tiles, G, (int)items.size(), n_blocks, stride, nullptr, nullptr, g_tables_tick};
+    if (hipMalloc(&t.d_items, items.size() * sizeof(int4)) != hipSuccess || hipMalloc(&t.d_nslots, nslots.size() * sizeof(int32_t)) != hipSuccess ||
+        hipMemcpy(t.d_items, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(t.d_nslots, nslots.data(), nslots.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        t.n_rows = -1;                                           // never matches; fall back to the plain grid
+        return nullptr;
+    }
+    return &t;
+}
+
+// spans per CU of the item table (TKR_TOPK_SPANS=0: plain grid of (block, range) workgroups)
+static int topk_spans_per_cu() {
+    static int m = -1;
+    if (m < 0) {
+        const char* e = getenv("TKR_TOPK_SPANS");
+        m = e ? atoi(e) : 2;                                     // measured: 2 spans per CU at both benchmark shapes
+        if (m < 0 || m > 8) m = 2;
+    }
+    return m;
 }
 
 template <int KS, typename IdT>
@@ -801,6 +897,21 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
     const int n_tiles = (n_cols + 31) / 32;
     const size_t per_split = (size_t)n_rows * K * sizeof(uint64_t);
     const size_t thr_bytes = (size_t)n_rows * sizeof(uint32_t);
+    const int G = 256 * topk_spans_per_cu();
+    if (workspace && G > 0 && (long long)grid * n_tiles >= 8LL * G) {
+        const ItemTable* tab = item_table(n_rows, users, n_tiles, G);
+        if (tab && workspace_bytes >= (size_t)tab->stride * per_split + thr_bytes) {
+            uint32_t* thr_shared = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(workspace) + (size_t)tab->stride * per_split);
+            TKR_CHECK(hipMemsetAsync(thr_shared, 0, thr_bytes, stream));
+            hipLaunchKernelGGL(kern, dim3(tab->n_items), dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch,
+                               K, out_ids, out_scores, 0, reinterpret_cast<uint64_t*>(workspace), thr_shared, tab->d_items);
+            if (tab->stride > 1)
+                hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream,
+                                   reinterpret_cast<const uint64_t*>(workspace), n_rows, tab->stride, K, out_ids, out_scores,
+                                   tab->d_nslots, users);
+            return (int)hipGetLastError();
+        }
+    }
     const int max_splits = (workspace && workspace_bytes > thr_bytes)
                                ? (int)std::min<size_t>(kMaxSplits, (workspace_bytes - thr_bytes) / (per_split ? per_split : 1)) : 1;
     int S = pick_splits(n_rows, users, n_tiles, max_splits < 1 ? 1 : max_splits);
@@ -812,10 +923,10 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
         TKR_CHECK(hipMemsetAsync(thr_shared, 0, thr_bytes, stream));
     }
     hipLaunchKernelGGL(kern, dim3(grid, S), dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,
-                       out_ids, out_scores, tps, reinterpret_cast<uint64_t*>(workspace), thr_shared);
+                       out_ids, out_scores, tps, reinterpret_cast<uint64_t*>(workspace), thr_shared, nullptr);
     if (S > 1)
         hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream,
-                           reinterpret_cast<const uint64_t*>(workspace), n_rows, S, K, out_ids, out_scores);
+                           reinterpret_cast<const uint64_t*>(workspace), n_rows, S, K, out_ids, out_scores, nullptr, users);
     return (int)hipGetLastError();
 }
 
@@ -879,13 +990,16 @@ extern "C" int tkr_topk_set_math(int32_t mode) {
 }
 
 extern "C" int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K) {
-    // room for the item-range partial lists a launch can use (enough (block, range) workgroups to balance 256 CUs,
-    // at most kMaxSplits ranges) + one shared threshold word per row
+    // room for the partial lists a launch can use + one shared threshold word per row.  Plain grid of (block, range)
+    // workgroups: enough ranges to balance 256 CUs, at most kMaxSplits.  Item table: the pieces one block can be cut
+    // into, at most ceil(G / blocks) + 1 with G <= 2048 spans and blocks of at least 192 rows.
     const int64_t blocks = ((int64_t)n_rows + 255) / 256;
     int64_t splits = (16 * 256 + blocks - 1) / blocks;
     if (splits > tkr::kMaxSplits) splits = tkr::kMaxSplits;
     if (splits < 2) splits = 2;
-    return splits * n_rows * K * (int64_t)sizeof(uint64_t) + (int64_t)n_rows * (int64_t)sizeof(uint32_t);
+    const int64_t pieces = (2048 + blocks - 1) / blocks + 1;
+    const int64_t lists = splits > pieces ? splits : pieces;
+    return lists * n_rows * K * (int64_t)sizeof(uint64_t) + (int64_t)n_rows * (int64_t)sizeof(uint32_t);
 }
 
 extern "C" int tkr_score_topk(const float* U, const int32_t* user_idx, int32_t n_rows, const float* Vt,
