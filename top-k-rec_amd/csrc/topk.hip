@@ -342,7 +342,8 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
     const float* __restrict__ bias, int n_cols, int k, const uint32_t* __restrict__ mask, int mask_pitch, int K,
     int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int tiles_per_split,
     uint64_t* __restrict__ part /*[n_rows][gridDim.y][K] sorted keys, when gridDim.y > 1*/,
-    uint32_t* __restrict__ thr_shared /*[n_rows] ordered bits of a lower bound of the row's K-th best score, or null*/) {
+    uint32_t* __restrict__ thr_shared /*[n_rows] ordered bits of a lower bound of the row's K-th best score, or null*/,
+    const int4* __restrict__ items /*balanced item table (block, t_begin, t_end, slot | stride << 16), or null: the grid*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int KP = 2 * KHP + 4;                              // padded LDS row (floats): conflict-free b128 reads
     const int W = blockDim.x >> 6;
@@ -358,7 +359,10 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ul = lane & 31, h = lane >> 5;
     const int uw = wave * 32 + ul;                               // user slot inside the workgroup
-    const int row = blockIdx.x * users + uw;                     // row of the output / index into uidx
+    int4 it = make_int4((int)blockIdx.x, (int)blockIdx.y * tiles_per_split, 0, (int)blockIdx.y | ((int)gridDim.y << 16));
+    if (items) it = items[blockIdx.x];
+    const TopkSlot ws = {it.x, it.w & 0xffff, it.w >> 16};
+    const int row = ws.block * users + uw;                       // row of the output / index into uidx
     const bool user_ok = row < n_rows;
     const int KH = (k + 1) >> 1;                                 // k-range of half h: [h*KH, min(k, (h+1)*KH))
 
@@ -376,8 +380,8 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
     for (int s = tid; s < users; s += blockDim.x) sm.cnt[s] = 0;
     float thr = (thr_shared && user_ok) ? unordered_bits(thr_shared[row]) : -INFINITY;   // what other item ranges found so far
     const int n_tiles_all = (n_cols + 31) >> 5;
-    const int t_begin = blockIdx.y * tiles_per_split;           // this workgroup ranks items of tiles [t_begin, n_tiles)
-    const int n_tiles = min(n_tiles_all, t_begin + tiles_per_split);
+    const int t_begin = it.y;                                    // this workgroup ranks items of tiles [t_begin, n_tiles)
+    const int n_tiles = items ? it.z : min(n_tiles_all, t_begin + tiles_per_split);
 
     // ---- tile staging: global -> registers (issued early) -> LDS (written after the MFMA chain) ------
     // float4 path when every k-half starts 16-B aligned (k % 8 == 0); scalar path otherwise.
@@ -473,7 +477,6 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
         __syncthreads();                                         // tile t+1 staged; buffer `buf` may be overwritten next
     }
 
-    const TopkSlot ws = {(int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y};
     write_rows<IdT>(sm, ws, n_rows, K, thr, out_ids, out_scores, part);
 }
 
@@ -770,40 +773,6 @@ __global__ void count_hits_kernel(const int32_t* __restrict__ ids, int n_rows, i
     if (lo < end && like_cols[lo] == c) atomicAdd(&first_bucket[p / step], 1ull);
 }
 
-template <int KHP, typename IdT>
-static int launch_topk(int W, const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias,
-                       int n_cols, int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
-                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    constexpr int KP = 2 * KHP + 4;
-    const int users = W * 32;
-    const size_t lds = (size_t)(2 * 32 * KP + 64) * 4 + (size_t)users * 4 + (size_t)users * kCap * (4 + sizeof(IdT));
-    if (lds > 160 * 1024) return TKR_EUNSUPPORTED;
-    auto kern = score_topk_kernel<KHP, IdT>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    const int grid = (n_rows + users - 1) / users;
-    const int n_tiles = (n_cols + 31) / 32;
-    const size_t per_split = (size_t)n_rows * K * sizeof(uint64_t);
-    const size_t thr_bytes = (size_t)n_rows * sizeof(uint32_t);
-    const int max_splits = (workspace && workspace_bytes > thr_bytes)
-                               ? (int)std::min<size_t>(kMaxSplits, (workspace_bytes - thr_bytes) / (per_split ? per_split : 1)) : 1;
-    int S = pick_splits(n_rows, users, n_tiles, max_splits < 1 ? 1 : max_splits);
-    const int tps = (n_tiles + S - 1) / S;
-    S = (n_tiles + tps - 1) / tps;
-    uint32_t* thr_shared = nullptr;
-    if (S > 1) {                                                 // thresholds live behind the S partial lists
-        thr_shared = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(workspace) + (size_t)S * per_split);
-        TKR_CHECK(hipMemsetAsync(thr_shared, 0, thr_bytes, stream));
-    }
-    hipLaunchKernelGGL(kern, dim3(grid, S), dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,
-                       out_ids, out_scores, tps, reinterpret_cast<uint64_t*>(workspace), thr_shared);
-    if (S > 1)
-        hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream,
-                           reinterpret_cast<const uint64_t*>(workspace), n_rows, S, K, out_ids, out_scores, nullptr, users);
-    return (int)hipGetLastError();
-}
-
 // ---- balanced item table ---------------------------------------------------------------------------------------------
 // A grid of (user block, item range) workgroups only fills 256 CUs evenly when blocks x ranges happens to be a multiple of
 // 256 (ML-10M: 273 blocks).  Instead the (block, tile) space is cut into G equal spans of consecutive tiles; a span is
@@ -878,6 +847,55 @@ static int topk_spans_per_cu() {
         if (m < 0 || m > 8) m = 2;
     }
     return m;
+}
+
+template <int KHP, typename IdT>
+static int launch_topk(int W, const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias,
+                       int n_cols, int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
+                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    constexpr int KP = 2 * KHP + 4;
+    const int users = W * 32;
+    const size_t lds = (size_t)(2 * 32 * KP + 64) * 4 + (size_t)users * 4 + (size_t)users * kCap * (4 + sizeof(IdT));
+    if (lds > 160 * 1024) return TKR_EUNSUPPORTED;
+    auto kern = score_topk_kernel<KHP, IdT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    const int grid = (n_rows + users - 1) / users;
+    const int n_tiles = (n_cols + 31) / 32;
+    const size_t per_split = (size_t)n_rows * K * sizeof(uint64_t);
+    const size_t thr_bytes = (size_t)n_rows * sizeof(uint32_t);
+    const int G = 256 * topk_spans_per_cu();
+    if (workspace && G > 0 && (long long)grid * n_tiles >= 8LL * G) {
+        const ItemTable* tab = item_table(n_rows, users, n_tiles, G);
+        if (tab && workspace_bytes >= (size_t)tab->stride * per_split + thr_bytes) {
+            uint32_t* thr_shared = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(workspace) + (size_t)tab->stride * per_split);
+            TKR_CHECK(hipMemsetAsync(thr_shared, 0, thr_bytes, stream));
+            hipLaunchKernelGGL(kern, dim3(tab->n_items), dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch,
+                               K, out_ids, out_scores, 0, reinterpret_cast<uint64_t*>(workspace), thr_shared, tab->d_items);
+            if (tab->stride > 1)
+                hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream,
+                                   reinterpret_cast<const uint64_t*>(workspace), n_rows, tab->stride, K, out_ids, out_scores,
+                                   tab->d_nslots, users);
+            return (int)hipGetLastError();
+        }
+    }
+    const int max_splits = (workspace && workspace_bytes > thr_bytes)
+                               ? (int)std::min<size_t>(kMaxSplits, (workspace_bytes - thr_bytes) / (per_split ? per_split : 1)) : 1;
+    int S = pick_splits(n_rows, users, n_tiles, max_splits < 1 ? 1 : max_splits);
+    const int tps = (n_tiles + S - 1) / S;
+    S = (n_tiles + tps - 1) / tps;
+    uint32_t* thr_shared = nullptr;
+    if (S > 1) {                                                 // thresholds live behind the S partial lists
+        thr_shared = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(workspace) + (size_t)S * per_split);
+        TKR_CHECK(hipMemsetAsync(thr_shared, 0, thr_bytes, stream));
+    }
+    hipLaunchKernelGGL(kern, dim3(grid, S), dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,
+                       out_ids, out_scores, tps, reinterpret_cast<uint64_t*>(workspace), thr_shared, nullptr);
+    if (S > 1)
+        hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream,
+                           reinterpret_cast<const uint64_t*>(workspace), n_rows, S, K, out_ids, out_scores, nullptr, users);
+    return (int)hipGetLastError();
 }
 
 template <int KS, typename IdT>
