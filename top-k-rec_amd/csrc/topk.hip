@@ -209,7 +209,8 @@ __device__ __forceinline__ float trim_all_users(const TopkSmem<IdT>& sm, int uw,
 // other one), so the common path is kept to one compare per score: hr[r] is the wave's lane mask of "score r
 // reaches my user's threshold" and lives in SGPRs; registers without a single candidate are skipped by a scalar
 // branch, the rated/tail/no-user bits (maskw) are consulted only when a lane has one.
-template <typename IdT>
+// BIASED: `acc` already holds fl(fl(dot) + bias) (add_bias_inplace), tbias is not read
+template <typename IdT, bool BIASED = false>
 __device__ __forceinline__ void filter_tile(const TopkSmem<IdT>& sm, const f32x16& acc, const float* tbias, uint32_t maskw,
                                             int t, int K, float& thr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -217,13 +218,18 @@ __device__ __forceinline__ void filter_tile(const TopkSmem<IdT>& sm, const f32x1
     const int uw = wave * 32 + ul;
     const uint32_t mh = maskw >> (4 * h);                        // bit (r&3)+8*(r>>2) <-> accumulator register r
     float sc[16];
+    if constexpr (BIASED) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {                                // rows 8g+4h .. 8g+4h+3 are registers 4g..4g+3
-        const float4 bq = *reinterpret_cast<const float4*>(tbias + 8 * g + 4 * h);
-        sc[4 * g + 0] = acc[4 * g + 0] + bq.x;                   // fl(fl(dot)+b)
-        sc[4 * g + 1] = acc[4 * g + 1] + bq.y;
-        sc[4 * g + 2] = acc[4 * g + 2] + bq.z;
-        sc[4 * g + 3] = acc[4 * g + 3] + bq.w;
+        for (int r = 0; r < 16; ++r) sc[r] = acc[r];
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                            // rows 8g+4h .. 8g+4h+3 are registers 4g..4g+3
+            const float4 bq = *reinterpret_cast<const float4*>(tbias + 8 * g + 4 * h);
+            sc[4 * g + 0] = acc[4 * g + 0] + bq.x;               // fl(fl(dot)+b)
+            sc[4 * g + 1] = acc[4 * g + 1] + bq.y;
+            sc[4 * g + 2] = acc[4 * g + 2] + bq.z;
+            sc[4 * g + 3] = acc[4 * g + 3] + bq.w;
+        }
     }
     uint64_t hr[16], any = 0;
 #pragma unroll
@@ -276,6 +282,15 @@ __device__ __forceinline__ void filter_tile(const TopkSmem<IdT>& sm, const f32x1
 // Final exact sort of every user's list and output (or the partial list of this item range, merged later).
 // One more lower-bound trim leaves most lists with K..32 entries; those are sorted two users at a time in the two
 // 32-lane halves of the wave (15 compare-exchange stages, none across the halves) instead of one 21-stage sort each.
+// acc <- fl(acc + bias) in the accumulator's own registers (no second 16-register tuple)
+__device__ __forceinline__ void add_bias_inplace(f32x16& acc, const float* tbias, int h) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 bq = *reinterpret_cast<const float4*>(tbias + 8 * g + 4 * h);
+        acc[4 * g + 0] += bq.x; acc[4 * g + 1] += bq.y; acc[4 * g + 2] += bq.z; acc[4 * g + 3] += bq.w;
+    }
+}
+
 // where a workgroup's result goes: straight to the output, or as one of the sorted partial lists of its rows
 struct TopkSlot {
     int block;        // user block (rows block*users .. +users-1)
@@ -668,8 +683,18 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[s][1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[s][0], acc, 0, 0, 0);
         }
+        // Where the one barrier of the tile sits.  k <= 64: EARLY, right after the staging -- tile t+1 is in LDS, every wave
+        // is done reading tile t, and the filter touches only the wave's own lists, so a wave whose filter is short starts
+        // the next MFMA chain while its neighbours still append or trim (Netflix shape, k = 64: 11.2 -> 10.2 ms).  The bias
+        // is folded into the accumulator first: tile t+2's bias may land in this slot before a slow wave filters.
+        // k = 128: measured slower that way (14.4 -> 17.7 ms) -- the MFMA chains dominate there and the two waves of a SIMD
+        // interleave them best when they start together (a lone dependent chain issues at ~44 instead of 32 cycles per
+        // MFMA); there the barrier stays behind the filter.
+        constexpr bool kEarlyBarrier = KS <= 4;
+        if constexpr (kEarlyBarrier) add_bias_inplace(acc, sm.tbias + buf * 32, h);
         if (t + 1 < n_tiles) stage_store(t + 1, buf ^ 1);
         if (t + 2 < n_tiles) stage_load(t + 2);
+        if constexpr (kEarlyBarrier) __syncthreads();
         if (!user_ok) maskw = 0xffffffffu;
         if (t == n_tiles_all - 1) maskw |= tail_mask;
         if (t == next_sched) {
@@ -679,8 +704,8 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
             }
             next_sched = t + ((t - t_begin + 1) >> 1);
         }
-        filter_tile<IdT>(sm, acc, sm.tbias + buf * 32, maskw, t, K, thr);
-        __syncthreads();
+        filter_tile<IdT, kEarlyBarrier>(sm, acc, sm.tbias + buf * 32, maskw, t, K, thr);
+        if constexpr (!kEarlyBarrier) __syncthreads();
     }
     write_rows<IdT>(sm, ws, n_rows, K, thr, out_ids, out_scores, part);
 }
