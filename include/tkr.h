@@ -102,7 +102,8 @@ int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ,
  * every element of cem / icb still gets TF's dense ApplyRMSProp every batch (vbpr.py:65,67,73).
  *   f_ptr [n_items+1], f_col / f_val [nnz]   CSR over items, ascending columns inside a row
  *   c_ptr [d+1], c_item / c_val [nnz]        CSC over feature columns, ascending items inside a column
- *   item_tag [n_items] int64                 scratch, zeroed ONCE by the caller and then owned by the library */
+ *   item_tag [n_items] int64                 scratch, zeroed ONCE by the caller and then owned by the library (per-batch
+ *                                            membership bitmaps, slots and a batch counter live in it) */
 typedef struct {
     float* U;
     float* msU;

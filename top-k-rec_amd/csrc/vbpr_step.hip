@@ -22,8 +22,8 @@
 //
 // Sparse view (st.f_ptr != NULL; tf-idf-like content features are ~0.5 % dense): V1/V1r are replaced by S1, one wave
 // per triplet gathering one cem row per nonzero of f_i and f_j; V2's item tasks additionally store, per unique item
-// of the batch, A = sum over its occurrences of (+/-)W_t and a = sum of (-/+)s_t and tag the item with
-// (batch serial, slot); V3 is replaced by S3, one wave per feature column walking the column's (item, value) list
+// of the batch, A = sum over its occurrences of (+/-)W_t and a = sum of (-/+)s_t and enter the item into the
+// batch's membership bitmap; V3 is replaced by S3, one wave per feature column walking the column's (item, value) list
 // (CSC), adding value * A[slot] for the tagged items in ascending item order (deterministic) and applying the same
 // dense RMSProp.  Work drops from 4*d*kh flop per triplet to ~2*nnz_row*kh; what remains is the 16*d*kh B of
 // dense optimizer traffic per batch plus the 8 B per nonzero of the CSC walk.
@@ -46,6 +46,30 @@ constexpr int kSlice = 128;                      // d-columns per split-K slice 
 constexpr int kIdMaskV = 0x3fffffff;
 
 __host__ __device__ inline int vbpr_slices(int d) { return (d + kSlice - 1) / kSlice; }
+
+// Scratch of the sparse view inside st.item_tag (n_items x 8 bytes, zeroed once by the caller):
+//   slots [n_items] int32 | member 0 [n_items rounded to 4] bytes | member 1 [...] bytes | batch counter [1] uint32
+// Membership of an item in the current batch is one BYTE written by the wave that owns the item's task (a plain store:
+// global atomicOr on a shared bitmap word cost 25 us per batch) in a 10 KB map that the CUs' L1 holds, instead of 10^6
+// random 8-byte reads of a tag table per column walk; the slot is only fetched for the ~5 % of entries that hit.  The
+// two maps alternate by batch: S1 advances the counter and clears the map of the batch before; V2 marks items and
+// stores slots; S3 reads.  All in stream order, no host state.
+struct SparseScratch {
+    int32_t* slots;
+    unsigned char* member0;     // map of parity p: member0 + p * 4 * map_words (no pointer array: a dynamically indexed
+    uint32_t* counter;          // local array would live in scratch memory)
+    int map_words;
+    __host__ __device__ unsigned char* member(uint32_t parity) const { return member0 + (size_t)(parity & 1u) * 4 * map_words; }
+};
+__host__ __device__ inline SparseScratch sparse_scratch(const tkr_vbpr_state& st) {
+    SparseScratch x;
+    x.map_words = (st.n_items + 3) / 4;
+    x.slots = reinterpret_cast<int32_t*>(st.item_tag);
+    x.member0 = reinterpret_cast<unsigned char*>(x.slots + st.n_items);
+    x.counter = reinterpret_cast<uint32_t*>(x.member0 + 8 * x.map_words);
+    return x;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // V1: Ppart[s][t][0..kh) = sum_{c in slice s} (f_i[c]-f_j[c]) * cem[c][.],  Ppart[s][t][kh] = same with icb
@@ -269,7 +293,7 @@ __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_rows_kernel(
     tkr_vbpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
     const int32_t* __restrict__ occt, const int4* __restrict__ hdr, const float* __restrict__ s_in,
     const float* __restrict__ P, const float* __restrict__ Wm, float* __restrict__ Aw /*[slots][kh] or null*/,
-    float* __restrict__ ab /*[slots]*/, uint32_t serial) {
+    float* __restrict__ ab /*[slots]*/) {
     __shared__ float red[kVTeam][NE * TKR_WAVE + 1];
     __shared__ float red2[kVTeam][NE * TKR_WAVE + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -365,7 +389,7 @@ __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_rows_kernel(
             __syncthreads();
             if (wave != 0) continue;
         }
-        if (want_a) {                                   // slot = this wave's record index; tag = (serial, slot)
+        if (want_a) {                                   // slot = this wave's record index; the item joins the batch's bitmap
             const int slot = blk * kVTeam + wave;
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
@@ -374,7 +398,9 @@ __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_rows_kernel(
             }
             if (lane == 0) {
                 ab[slot] = asum;
-                st.item_tag[row] = ((int64_t)serial << 32) | (uint32_t)slot;
+                const SparseScratch x = sparse_scratch(st);
+                x.slots[row] = slot;
+                x.member(*x.counter)[row] = 1;
             }
         }
         const float* msrc = is_item ? st.msI + par * istride + (size_t)row * kh : st.msU + par * ustride + (size_t)row * k2;
@@ -529,8 +555,16 @@ __global__ __launch_bounds__(256) void vbpr_sproject_kernel(tkr_vbpr_state st, c
                                                            const int32_t* __restrict__ tj, int B, float* __restrict__ P,
                                                            float* __restrict__ Q) {
     __shared__ float red[4][NH * 64 + 1];
+    __shared__ uint32_t s_par;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = blockIdx.x;
     const int kh = st.kh;
+    if (t == 0) {                                       // new batch: advance the counter, clear the bitmap of the batch before
+        const SparseScratch x = sparse_scratch(st);
+        if (threadIdx.x == 0) { const uint32_t c = *x.counter + 1u; *x.counter = c; s_par = c & 1u; }
+        __syncthreads();
+        uint32_t* other = reinterpret_cast<uint32_t*>(x.member(s_par ^ 1u));
+        for (int w = threadIdx.x; w < x.map_words; w += blockDim.x) other[w] = 0u;
+    }
     float acc[NH], q = 0.f;
 #pragma unroll
     for (int e = 0; e < NH; ++e) acc[e] = 0.f;
@@ -581,12 +615,11 @@ __global__ __launch_bounds__(256) void vbpr_sproject_kernel(tkr_vbpr_state st, c
 }
 
 // S3 (sparse view): one wave per feature column c.  G_cem[c] = sum over the column's items that are in the batch
-// (tag == serial) of value * A[slot], G_icb[c] likewise with a[slot], + regulariser, then TF's dense ApplyRMSProp on
+// (bit set in the batch's bitmap) of value * A[slot], G_icb[c] likewise with a[slot], + regulariser, then TF's dense ApplyRMSProp on
 // cem[c][.] and icb[c] exactly as V3 does.
 template <int NH>
 __global__ __launch_bounds__(256) void vbpr_sdense_kernel(tkr_vbpr_state st, const float* __restrict__ Aw,
-                                                         const float* __restrict__ ab, uint32_t serial,
-                                                         float* __restrict__ loss_out) {
+                                                         const float* __restrict__ ab, float* __restrict__ loss_out) {
     const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= st.d) return;
     const int kh = st.kh;
@@ -594,6 +627,8 @@ __global__ __launch_bounds__(256) void vbpr_sdense_kernel(tkr_vbpr_state st, con
 #pragma unroll
     for (int e = 0; e < NH; ++e) g[e] = 0.f;
     const int beg = st.c_ptr[c], end = st.c_ptr[c + 1];
+    const SparseScratch x = sparse_scratch(st);
+    const unsigned char* __restrict__ member = x.member(*x.counter);
     // the row of cem / its slot do not depend on the walk: issue their loads first
     float pv[NH], pms[NH];
 #pragma unroll
@@ -608,9 +643,8 @@ __global__ __launch_bounds__(256) void vbpr_sdense_kernel(tkr_vbpr_state st, con
         const bool valid = p < end;
         const int item = valid ? st.c_item[p] : 0;
         const float val = valid ? st.c_val[p] : 0.f;
-        const int64_t tag = valid ? st.item_tag[item] : 0;
-        const bool hit = valid && (uint32_t)(tag >> 32) == serial;
-        const int slot_l = (int)(uint32_t)tag;
+        const bool hit = valid && member[item] != 0;
+        const int slot_l = hit ? x.slots[item] : 0;
         uint64_t m = __ballot(hit);
         while (m) {                                     // ascending lane = ascending item: a fixed summation order
             const int l = __ffsll((long long)m) - 1;
@@ -680,13 +714,9 @@ static int launch_vbpr_t(const tkr_vbpr_state& st, const int32_t* ti, const int3
     const bool sparse = st.f_ptr != nullptr;
     float* Aw = nullptr;
     float* ab = nullptr;
-    static uint32_t g_serial = 0;                       // batch serial for the item tags; 0 never matches
-    uint32_t serial = 0;
     if (sparse) {
         Aw = Q + B;
         ab = Aw + (size_t)tkr_plan_max_blocks(B) * TEAM * kh;
-        serial = ++g_serial;
-        if (serial == 0) serial = ++g_serial;
         if (NH == 1) hipLaunchKernelGGL(vbpr_sproject_kernel<1>, dim3(B), dim3(256), 0, stream, st, ti, tj, B, P, Q);
         else hipLaunchKernelGGL(vbpr_sproject_kernel<2>, dim3(B), dim3(256), 0, stream, st, ti, tj, B, P, Q);
     } else {
@@ -696,14 +726,14 @@ static int launch_vbpr_t(const tkr_vbpr_state& st, const int32_t* ti, const int3
     if (NH == 1) hipLaunchKernelGGL((vbpr_occur_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
     else hipLaunchKernelGGL((vbpr_occur_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
     switch (NE) {
-        case 1: hipLaunchKernelGGL((vbpr_rows_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab, serial); break;
-        case 2: hipLaunchKernelGGL((vbpr_rows_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab, serial); break;
-        case 3: hipLaunchKernelGGL((vbpr_rows_kernel<3, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab, serial); break;
-        default: hipLaunchKernelGGL((vbpr_rows_kernel<4, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab, serial); break;
+        case 1: hipLaunchKernelGGL((vbpr_rows_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab); break;
+        case 2: hipLaunchKernelGGL((vbpr_rows_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab); break;
+        case 3: hipLaunchKernelGGL((vbpr_rows_kernel<3, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab); break;
+        default: hipLaunchKernelGGL((vbpr_rows_kernel<4, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab); break;
     }
     if (sparse) {
-        if (NH == 1) hipLaunchKernelGGL(vbpr_sdense_kernel<1>, dim3((st.d + 3) / 4), dim3(256), 0, stream, st, Aw, ab, serial, loss);
-        else hipLaunchKernelGGL(vbpr_sdense_kernel<2>, dim3((st.d + 3) / 4), dim3(256), 0, stream, st, Aw, ab, serial, loss);
+        if (NH == 1) hipLaunchKernelGGL(vbpr_sdense_kernel<1>, dim3((st.d + 3) / 4), dim3(256), 0, stream, st, Aw, ab, loss);
+        else hipLaunchKernelGGL(vbpr_sdense_kernel<2>, dim3((st.d + 3) / 4), dim3(256), 0, stream, st, Aw, ab, loss);
         return (int)hipGetLastError();
     }
     const size_t lds = (size_t)(4 * 64 * (NT * 32 + 1) + 4 * 2 * 64) * sizeof(float);
