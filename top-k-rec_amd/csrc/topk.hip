@@ -863,13 +863,23 @@ static const ItemTable* item_table(int n_rows, int users, int n_tiles, int G) {
     return &t;
 }
 
+// Number of spans for a problem of `total` (block, tile) cells: 256 x (spans per CU) when every span still gets a few
+// dozen tiles (an item costs ~37 us = ~10 tile-times of its own), one span per CU for smaller problems, and 0 (plain
+// grid) when even that would leave fewer than 8 tiles per span.
+static int topk_spans_per_cu();
+static int topk_span_count(long long total) {
+    const int m = topk_spans_per_cu();
+    if (m == 0 || total < 8 * 256) return 0;
+    return (total >= 64LL * 256 * m) ? 256 * m : 256;
+}
+
 // spans per CU of the item table (TKR_TOPK_SPANS=0: plain grid of (block, range) workgroups)
 static int topk_spans_per_cu() {
     static int m = -1;
     if (m < 0) {
         const char* e = getenv("TKR_TOPK_SPANS");
         m = e ? atoi(e) : 2;                                     // measured: 2 spans per CU at both benchmark shapes
-        if (m < 0 || m > 8) m = 2;
+        if (m < 0 || m > 2) m = 2;
     }
     return m;
 }
@@ -890,8 +900,8 @@ static int launch_topk(int W, const float* U, const int32_t* uidx, int n_rows, c
     const int n_tiles = (n_cols + 31) / 32;
     const size_t per_split = (size_t)n_rows * K * sizeof(uint64_t);
     const size_t thr_bytes = (size_t)n_rows * sizeof(uint32_t);
-    const int G = 256 * topk_spans_per_cu();
-    if (workspace && G > 0 && (long long)grid * n_tiles >= 8LL * G) {
+    const int G = topk_span_count((long long)grid * n_tiles);
+    if (workspace && G > 0) {
         const ItemTable* tab = item_table(n_rows, users, n_tiles, G);
         if (tab && workspace_bytes >= (size_t)tab->stride * per_split + thr_bytes) {
             uint32_t* thr_shared = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(workspace) + (size_t)tab->stride * per_split);
@@ -940,8 +950,8 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
     const int n_tiles = (n_cols + 31) / 32;
     const size_t per_split = (size_t)n_rows * K * sizeof(uint64_t);
     const size_t thr_bytes = (size_t)n_rows * sizeof(uint32_t);
-    const int G = 256 * topk_spans_per_cu();
-    if (workspace && G > 0 && (long long)grid * n_tiles >= 8LL * G) {
+    const int G = topk_span_count((long long)grid * n_tiles);
+    if (workspace && G > 0) {
         const ItemTable* tab = item_table(n_rows, users, n_tiles, G);
         if (tab && workspace_bytes >= (size_t)tab->stride * per_split + thr_bytes) {
             uint32_t* thr_shared = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(workspace) + (size_t)tab->stride * per_split);
@@ -1035,12 +1045,12 @@ extern "C" int tkr_topk_set_math(int32_t mode) {
 extern "C" int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K) {
     // room for the partial lists a launch can use + one shared threshold word per row.  Plain grid of (block, range)
     // workgroups: enough ranges to balance 256 CUs, at most kMaxSplits.  Item table: the pieces one block can be cut
-    // into, at most ceil(G / blocks) + 1 with G <= 2048 spans and blocks of at least 192 rows.
+    // into, at most ceil(G / blocks) + 1 with G <= 512 spans.
     const int64_t blocks = ((int64_t)n_rows + 255) / 256;
     int64_t splits = (16 * 256 + blocks - 1) / blocks;
     if (splits > tkr::kMaxSplits) splits = tkr::kMaxSplits;
     if (splits < 2) splits = 2;
-    const int64_t pieces = (2048 + blocks - 1) / blocks + 1;
+    const int64_t pieces = (512 + blocks - 1) / blocks + 1;      // 256 x (spans per CU <= 2)
     const int64_t lists = splits > pieces ? splits : pieces;
     return lists * n_rows * K * (int64_t)sizeof(uint64_t) + (int64_t)n_rows * (int64_t)sizeof(uint32_t);
 }
