@@ -1,0 +1,52 @@
+"""-m gpu: the bench.py contract -- one JSON line with the driver's fields plus `roofline` and `cpu_baseline`, at N = 1
+and at N = 2 (two ranks on this one GPU through the gloo test hook; the real multi-GPU run uses RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+            'dtype', 'data', 'config', 'roofline')
+
+
+def _last_json(out):
+    lines = [l for l in out.strip().split('\n') if l.startswith('{')]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '512', '--warmup', '64', '--no-extras'],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    for key in REQUIRED + ('cpu_baseline',):
+        assert key in d, key
+    assert d['n_gpus'] == 1 and d['steps'] == 512 and d['warmup'] == 64 and d['unit'] == 'triplets/s'
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['data'] == 'synthetic'
+    assert d['dtype'] == 'f32' and 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and r['peak'] == 8000.0
+    assert abs(d['value'] - 512 * 256 / (d['ms_per_step'] * 512 * 1e-3)) / d['value'] < 1e-6
+    c = d['cpu_baseline']
+    assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'triplets/s' and c['sample']
+    assert d['value'] > 10 * c['value']                                # north_star: >= 10x the reference CPU path on one GPU
+
+
+def test_two_rank_line():
+    env = dict(os.environ, TKR_BENCH_SINGLE_DEVICE='1', TKR_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', '29611', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '256', '--warmup', '32',
+                          '--no-extras', '--epoch-sample-limit', '65536'],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    for key in REQUIRED:
+        assert key in d, key
+    assert d['n_gpus'] == 2 and d['steps'] == 256 and 'cpu_baseline' not in d      # rank 0 at N = 1 only
+    assert 'all-reduce every 128 steps' in d['config']['sharding']                  # (65536 // 256) // 2: two exchanges inside the timed region
+    assert abs(d['value'] - 2 * 256 * 256 / (d['ms_per_step'] * 256 * 1e-3)) / d['value'] < 1e-6
