@@ -503,7 +503,7 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
 // dot product with a different summation order (measured error against fp64: same order as the fp32-MFMA path and as
 // numpy's sgemm, tests/test_gpu_topk.py).  Inputs whose products and partial sums are representable (the golden
 // fixtures) give exactly the same scores as the fp32 path.  Why: 48 bf16 MFMAs of 8 passes replace 64 fp32 MFMAs of
-// 16 passes per 32x32xk=128 block (1.8 us against 3.4 us per 256-user tile, scratch/bf16x3_ubench.hip), and on
+// 16 passes per 32x32xk=128 block (1.8 us against 3.4 us per 256-user tile, scripts/ubench/bf16x3_ubench.hip), and on
 // gfx950 the fp32 MFMA does not overlap other work of the SIMD at all.  Finite inputs only (inf - inf in the split).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
