@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TKR_VERSION 102 /* 0.1.2: tkr_bpr_state.opt, sparse view in tkr_vbpr_state */
+#define TKR_VERSION 103 /* 0.1.3: tkr_bpr_state.opt, sparse view in tkr_vbpr_state, per-triplet parities */
 #define TKR_OK 0
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
@@ -51,6 +51,8 @@ int tkr_version(void);
  *   rec                      [n_batches][tkr_plan_max_blocks(B)*tkr_plan_team(B)][16]  per-wave launch records
  *   hdr                      [n_batches][4]  (workgroups used, light workgroups, heavy tasks, tasks)
  *   occt                     [n_batches][3B] triplet index t of every sorted occurrence (used by K3)
+ *   tpar                     (nullable) [n_batches*B] per triplet: parity of u | parity of i << 1 | parity of j << 2 at its
+ *                            batch -- lets K3's sparse view score a triplet where it projects it (no per-occurrence launch)
  * batch_size <= 8192, n_batches <= 512, ids < 2^30.  Output is bit-exact against oracle/plan_np.py. */
 int tkr_plan_team(int32_t batch_size);        /* waves per step workgroup / heavy-row team: 4 (B <= 1024) or 16 */
 int tkr_plan_max_blocks(int32_t batch_size);  /* workgroups a batch can need */
@@ -59,7 +61,7 @@ int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_pt
                     uint64_t first_triplet, const int64_t* ctl, int32_t n_batches, int32_t batch_size,
                     int32_t* ucnt, int32_t* icnt, uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u,
                     int32_t* out_i, int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr,
-                    int32_t* occt, void* stream);
+                    int32_t* occt, int32_t* tpar, void* stream);
 
 /* ---- K2: BPR mini-batch step ---------------------------------------------------------------
  * Replaces sess.run([solver, obj]) (single/bpr.py:141) on the graph of single/bpr.py:81-100.
@@ -134,7 +136,8 @@ int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d);
 /* n_batches consecutive batches planned by tkr_sample_plan (tri_i / tri_j = its out_i / out_j);
  * kh <= 128, batch_size <= 8192; loss_out as in tkr_bpr_run */
 int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* tri_j, const int32_t* rec,
-                 const int32_t* occ, const int32_t* hdr, const int32_t* occt, int32_t batch_size,
+                 const int32_t* occ, const int32_t* hdr, const int32_t* occt, const int32_t* tri_u /*nullable*/,
+                 const int32_t* tpar /*nullable*/, int32_t batch_size,
                  int32_t n_batches, float* workspace, float* loss_out, void* stream);
 
 /* ---- K4: full-catalogue score -> rated mask -> top-K -------------------------------------------

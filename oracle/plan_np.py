@@ -235,6 +235,11 @@ def resolve_parity(task, occ, B, ucnt, icnt):
     icnt[rows[is_item]] += 1
 
 
+def triplet_parity(u, i, j, ucnt, icnt):
+    """per triplet: parity of u | parity of i << 1 | parity of j << 2 BEFORE this batch's updates (tkr_sample_plan `tpar`)"""
+    return ((ucnt[u] & 1) | ((icnt[i] & 1) << 1) | ((icnt[j] & 1) << 2)).astype(np.int32)
+
+
 def _pack_t(ts):
     ts = [int(x) for x in ts] + [0] * (4 - len(ts))
     return ts[0] | (ts[1] << 16), ts[2] | (ts[3] << 16)
@@ -289,9 +294,12 @@ def sample_and_plan(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed, fir
     recs = np.zeros((n_batches, max_blocks(B) * team_for(B), 16), dtype=np.int32)
     hdrs = np.zeros((n_batches, 4), dtype=np.int32)
     occts = np.zeros((n_batches, 3 * B), dtype=np.int32)
+    tpars = np.zeros((n_batches, B), dtype=np.int32)
     for b in range(n_batches):
         sl = slice(b * B, (b + 1) * B)
         tasks[b], occs[b], occts[b] = plan_batch(u[sl], i[sl], j[sl], return_t=True)
+        tpars[b] = triplet_parity(u[sl], i[sl], j[sl], ucnt, icnt)
         resolve_parity(tasks[b], occs[b], B, ucnt, icnt)
         recs[b], hdrs[b] = launch_plan(tasks[b], occs[b], B, occts[b])
+    sample_and_plan.last_tpars = tpars            # per-triplet parities of the last call (kept off the return tuple)
     return u, i, j, tasks, occs, recs, hdrs, occts

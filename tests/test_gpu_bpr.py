@@ -56,6 +56,7 @@ def _run_plan(hip, tr, tr_users, n_users, n_items, seed, first, nb, B, chunks=1)
            plan.task.cpu().numpy().reshape(nb, 3 * B, 4), plan.occ.cpu().numpy().reshape(nb, 3 * B, 2),
            plan.rec.cpu().numpy().reshape(nb, -1, 16), plan.hdr.cpu().numpy().reshape(nb, 4),
            plan.occt.cpu().numpy().reshape(nb, 3 * B)]
+    np.testing.assert_array_equal(plan.tpar.cpu().numpy()[: nb * B].reshape(nb, B), P.sample_and_plan.last_tpars, err_msg='tpar')
     np.testing.assert_array_equal(cnt.ucnt.cpu().numpy(), ucnt)
     np.testing.assert_array_equal(cnt.icnt.cpu().numpy(), icnt)
     assert int(cnt.touch_u.abs().sum()) == 0 and int(cnt.touch_i.abs().sum()) == 0

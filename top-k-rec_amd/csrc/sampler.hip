@@ -223,7 +223,8 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
     int B, int rec_stride /*records per batch*/, int4* __restrict__ task_all, int2* __restrict__ occ_all,
     const int32_t* __restrict__ occt_all,
     const int32_t* __restrict__ ucnt, const int32_t* __restrict__ icnt, const uint32_t* __restrict__ touch_u,
-    const uint32_t* __restrict__ touch_i, int32_t* __restrict__ rec_all, int4* __restrict__ hdr_all) {
+    const uint32_t* __restrict__ touch_i, int32_t* __restrict__ rec_all, int4* __restrict__ hdr_all,
+    const int32_t* __restrict__ out_u_all, int32_t* __restrict__ tpar_all /*nullable: per-triplet parities*/) {
     __shared__ int scan[2 * (kPlanThreads + 1)];
     const int kTeam = team_for(B);
     const int lmax = light_max(B);
@@ -243,9 +244,15 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
     }
     for (int p = threadIdx.x; p < B; p += kPlanThreads) {           // user occurrences: (i, j)
         int2 o = occ[p];
-        o.x |= parity_of(icnt, touch_i, o.x, b) << 30;
-        o.y |= parity_of(icnt, touch_i, o.y, b) << 30;
+        const int pi = parity_of(icnt, touch_i, o.x, b), pj = parity_of(icnt, touch_i, o.y, b);
+        o.x |= pi << 30;
+        o.y |= pj << 30;
         occ[p] = o;
+        if (tpar_all) {                                             // every triplet is exactly one user occurrence
+            const int t = occt[p];
+            const int u = out_u_all[(size_t)b * B + t];
+            tpar_all[(size_t)b * B + t] = parity_of(ucnt, touch_u, u, b) | (pi << 1) | (pj << 2);
+        }
     }
     for (int p = threadIdx.x; p < 2 * B; p += kPlanThreads) {       // item occurrences: (u, other|role<<31)
         int2 o = occ[B + p];
@@ -345,7 +352,7 @@ extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int3
                                int32_t n_batches, int32_t batch_size, int32_t* ucnt, int32_t* icnt,
                                uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u, int32_t* out_i,
                                int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr,
-                               int32_t* occt, void* stream) {
+                               int32_t* occt, int32_t* tpar, void* stream) {
     if (n_tr <= 0 || n_items <= 0 || n_users <= 0 || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
     if (n_users >= (1 << 30) || n_items >= (1 << 30)) return TKR_EUNSUPPORTED;   // id bits 30/31 carry flags
     if (batch_size > 8192) return TKR_EUNSUPPORTED;   // 2B 64-bit keys must fit the 160 KiB LDS
@@ -378,7 +385,7 @@ extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int3
     hipLaunchKernelGGL(tkr::resolve_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), 0, s, batch_size,
                        tkr_plan_max_blocks(batch_size) * tkr::team_for(batch_size), reinterpret_cast<int4*>(task),
                        reinterpret_cast<int2*>(occ), occt, ucnt, icnt, touch_u, touch_i, rec,
-                       reinterpret_cast<int4*>(hdr));
+                       reinterpret_cast<int4*>(hdr), out_u, tpar);
     TKR_LAUNCH_CHECK();
     const int rows = n_users + n_items;
     hipLaunchKernelGGL(tkr::commit_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, n_users, n_items, ucnt, icnt,

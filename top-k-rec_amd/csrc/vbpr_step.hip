@@ -553,7 +553,9 @@ __global__ __launch_bounds__(256) void vbpr_dense_kernel(tkr_vbpr_state st, cons
 template <int NH>
 __global__ __launch_bounds__(256) void vbpr_sproject_kernel(tkr_vbpr_state st, const int32_t* __restrict__ ti,
                                                            const int32_t* __restrict__ tj, int B, float* __restrict__ P,
-                                                           float* __restrict__ Q) {
+                                                           float* __restrict__ Q, const int32_t* __restrict__ tu,
+                                                           const int32_t* __restrict__ tpar, float* __restrict__ s_out,
+                                                           float* __restrict__ Wm, float* __restrict__ loss_out) {
     __shared__ float red[4][NH * 64 + 1];
     __shared__ uint32_t s_par;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = blockIdx.x;
@@ -568,6 +570,25 @@ __global__ __launch_bounds__(256) void vbpr_sproject_kernel(tkr_vbpr_state st, c
     float acc[NH], q = 0.f;
 #pragma unroll
     for (int e = 0; e < NH; ++e) acc[e] = 0.f;
+    // Fused scoring (K1 handed over the three row parities of the triplet): wave 0 issues the loads of [ure|uce]_u, ire_i,
+    // ire_j and the two biases now, so they are in flight while the four waves gather the feature projections.
+    const bool fused = tpar != nullptr;
+    float ure[NH], uce[NH], vi[NH], vj[NH], bi = 0.f, bj = 0.f;
+    if (fused && wave == 0) {
+        const int pr = tpar[t], k2 = 2 * kh;
+        const float* urow = st.U + ((size_t)(pr & 1) * st.n_users + tu[t]) * k2;
+        const float* ri = st.I + ((size_t)((pr >> 1) & 1) * st.n_items + ti[t]) * kh;
+        const float* rj = st.I + ((size_t)((pr >> 2) & 1) * st.n_items + tj[t]) * kh;
+#pragma unroll
+        for (int e = 0; e < NH; ++e) {
+            const int c = min(lane + e * 64, kh - 1);
+            const bool ok = lane + e * 64 < kh;
+            const float a = urow[c], b = urow[kh + c], x = ri[c], y = rj[c];
+            ure[e] = ok ? a : 0.f; uce[e] = ok ? b : 0.f; vi[e] = ok ? x : 0.f; vj[e] = ok ? y : 0.f;
+        }
+        bi = st.irb[(size_t)((pr >> 1) & 1) * st.n_items + ti[t]];
+        bj = st.irb[(size_t)((pr >> 2) & 1) * st.n_items + tj[t]];
+    }
     for (int side = 0; side < 2; ++side) {
         const int item = side ? tj[t] : ti[t];
         const float sign = side ? -1.f : 1.f;
@@ -605,12 +626,49 @@ __global__ __launch_bounds__(256) void vbpr_sproject_kernel(tkr_vbpr_state st, c
     if (lane == 0) red[wave][NH * 64] = q;
     __syncthreads();
     if (wave == 0) {
+        float p[NH];
 #pragma unroll
         for (int hh = 0; hh < NH; ++hh) {
             const int n2 = lane + hh * 64;
-            if (n2 < kh) P[(size_t)t * kh + n2] = ((red[0][n2] + red[1][n2]) + red[2][n2]) + red[3][n2];
+            p[hh] = ((red[0][n2] + red[1][n2]) + red[2][n2]) + red[3][n2];
+            if (n2 < kh) P[(size_t)t * kh + n2] = p[hh];
+            else p[hh] = 0.f;
         }
-        if (lane == 0) Q[t] = ((red[0][NH * 64] + red[1][NH * 64]) + red[2][NH * 64]) + red[3][NH * 64];
+        const float qsum = ((red[0][NH * 64] + red[1][NH * 64]) + red[2][NH * 64]) + red[3][NH * 64];
+        if (lane == 0) Q[t] = qsum;
+        if (fused) {                                     // what V1b does per user occurrence, here per triplet
+            float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < NH; ++e) {
+                d1 = fmaf(ure[e], vi[e] - vj[e], d1);
+                d2 = fmaf(uce[e], p[e], d2);
+            }
+            const float x = bi - bj + wave_sum(d1) + wave_sum(d2) + qsum;
+            const float sg = sigmoid_neg(x);
+#pragma unroll
+            for (int e = 0; e < NH; ++e) {
+                const int c = lane + e * 64;
+                if (c < kh) Wm[(size_t)t * kh + c] = -sg * uce[e];
+            }
+            if (lane == 0) s_out[t] = sg;
+            if (loss_out) {
+                const bool l2 = st.mode == 0;
+                float loss = softplus_neg(x), loss_lane = 0.f;
+                if (l2) {
+                    loss += 0.5f * (bi * bi + bj * bj) * st.lb;
+#pragma unroll
+                    for (int e = 0; e < NH; ++e)
+                        loss_lane += 0.5f * ((ure[e] * ure[e] + uce[e] * uce[e]) * st.lu + vi[e] * vi[e] * st.li + vj[e] * vj[e] * st.lj);
+                } else {
+                    loss += (fabsf(bi) + fabsf(bj)) * st.lb;
+#pragma unroll
+                    for (int e = 0; e < NH; ++e)
+                        loss_lane += (fabsf(ure[e]) + fabsf(uce[e])) * st.lu + fabsf(vi[e]) * st.li + fabsf(vj[e]) * st.lj;
+                }
+                const float tot = wave_sum(loss_lane) + loss;
+                if (lane == 0) atomicAdd(loss_out, tot);
+            }
+        }
     }
 }
 
@@ -700,7 +758,7 @@ static int vbpr_grid(int B, int team) {
 template <int NT, int TEAM>
 static int launch_vbpr_t(const tkr_vbpr_state& st, const int32_t* ti, const int32_t* tj, const int32_t* rec,
                          const int32_t* occ, const int32_t* hdr, const int32_t* occt, int B, float* ws, float* loss,
-                         hipStream_t stream) {
+                         hipStream_t stream, const int32_t* tu, const int32_t* tpar) {
     const int kh = st.kh, S = vbpr_slices(st.d);
     float* ppart = ws;
     float* s_buf = ppart + (size_t)S * B * (kh + 1);
@@ -717,14 +775,17 @@ static int launch_vbpr_t(const tkr_vbpr_state& st, const int32_t* ti, const int3
     if (sparse) {
         Aw = Q + B;
         ab = Aw + (size_t)tkr_plan_max_blocks(B) * TEAM * kh;
-        if (NH == 1) hipLaunchKernelGGL(vbpr_sproject_kernel<1>, dim3(B), dim3(256), 0, stream, st, ti, tj, B, P, Q);
-        else hipLaunchKernelGGL(vbpr_sproject_kernel<2>, dim3(B), dim3(256), 0, stream, st, ti, tj, B, P, Q);
+        // with the per-triplet parities of K1 the projection also scores the triplet: no per-occurrence launch
+        if (NH == 1) hipLaunchKernelGGL(vbpr_sproject_kernel<1>, dim3(B), dim3(256), 0, stream, st, ti, tj, B, P, Q, tu, tpar, s_buf, Wm, loss);
+        else hipLaunchKernelGGL(vbpr_sproject_kernel<2>, dim3(B), dim3(256), 0, stream, st, ti, tj, B, P, Q, tu, tpar, s_buf, Wm, loss);
     } else {
         hipLaunchKernelGGL(vbpr_project_kernel<NT>, dim3(S, (B + 31) / 32), dim3(64), 0, stream, st, ti, tj, B, ppart);
         hipLaunchKernelGGL(vbpr_reduce_kernel, dim3(B), dim3(1024), 0, stream, ppart, S, B, kh, P, Q);
     }
-    if (NH == 1) hipLaunchKernelGGL((vbpr_occur_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
-    else hipLaunchKernelGGL((vbpr_occur_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
+    if (!(sparse && tpar)) {
+        if (NH == 1) hipLaunchKernelGGL((vbpr_occur_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
+        else hipLaunchKernelGGL((vbpr_occur_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
+    }
     switch (NE) {
         case 1: hipLaunchKernelGGL((vbpr_rows_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab); break;
         case 2: hipLaunchKernelGGL((vbpr_rows_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab); break;
@@ -749,9 +810,9 @@ static int launch_vbpr_t(const tkr_vbpr_state& st, const int32_t* ti, const int3
 template <int NT>
 static int launch_vbpr(const tkr_vbpr_state& st, const int32_t* ti, const int32_t* tj, const int32_t* rec,
                        const int32_t* occ, const int32_t* hdr, const int32_t* occt, int B, float* ws, float* loss,
-                       hipStream_t stream) {
-    return tkr_plan_team(B) == 4 ? launch_vbpr_t<NT, 4>(st, ti, tj, rec, occ, hdr, occt, B, ws, loss, stream)
-                                 : launch_vbpr_t<NT, 16>(st, ti, tj, rec, occ, hdr, occt, B, ws, loss, stream);
+                       hipStream_t stream, const int32_t* tu, const int32_t* tpar) {
+    return tkr_plan_team(B) == 4 ? launch_vbpr_t<NT, 4>(st, ti, tj, rec, occ, hdr, occt, B, ws, loss, stream, tu, tpar)
+                                 : launch_vbpr_t<NT, 16>(st, ti, tj, rec, occ, hdr, occt, B, ws, loss, stream, tu, tpar);
 }
 
 }  // namespace tkr
@@ -765,8 +826,9 @@ extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int
 }
 
 extern "C" int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* tri_j, const int32_t* rec,
-                            const int32_t* occ, const int32_t* hdr, const int32_t* occt, int32_t batch_size,
-                            int32_t n_batches, float* workspace, float* loss_out, void* stream) {
+                            const int32_t* occ, const int32_t* hdr, const int32_t* occt, const int32_t* tri_u,
+                            const int32_t* tpar, int32_t batch_size, int32_t n_batches, float* workspace, float* loss_out,
+                            void* stream) {
     if (!st || !st->U || !st->msU || !st->I || !st->msI || !st->irb || !st->msirb || !st->cem || !st->mscem ||
         !st->icb || !st->msicb || !st->feat)
         return TKR_EINVAL;
@@ -784,13 +846,15 @@ extern "C" int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, cons
         const int32_t* o = occ + b * stride_o * 2;
         const int32_t* h = hdr + (size_t)b * 4;
         const int32_t* ot = occt + b * stride_o;
+        const int32_t* tu = (tri_u && tpar) ? tri_u + (size_t)b * batch_size : nullptr;
+        const int32_t* tp = (tri_u && tpar) ? tpar + (size_t)b * batch_size : nullptr;
         float* l = loss_out ? loss_out + b : nullptr;
         int rc;
         switch (NT) {
-            case 1: rc = tkr::launch_vbpr<1>(*st, ti, tj, r, o, h, ot, batch_size, workspace, l, (hipStream_t)stream); break;
-            case 2: rc = tkr::launch_vbpr<2>(*st, ti, tj, r, o, h, ot, batch_size, workspace, l, (hipStream_t)stream); break;
-            case 3: rc = tkr::launch_vbpr<3>(*st, ti, tj, r, o, h, ot, batch_size, workspace, l, (hipStream_t)stream); break;
-            default: rc = tkr::launch_vbpr<4>(*st, ti, tj, r, o, h, ot, batch_size, workspace, l, (hipStream_t)stream); break;
+            case 1: rc = tkr::launch_vbpr<1>(*st, ti, tj, r, o, h, ot, batch_size, workspace, l, (hipStream_t)stream, tu, tp); break;
+            case 2: rc = tkr::launch_vbpr<2>(*st, ti, tj, r, o, h, ot, batch_size, workspace, l, (hipStream_t)stream, tu, tp); break;
+            case 3: rc = tkr::launch_vbpr<3>(*st, ti, tj, r, o, h, ot, batch_size, workspace, l, (hipStream_t)stream, tu, tp); break;
+            default: rc = tkr::launch_vbpr<4>(*st, ti, tj, r, o, h, ot, batch_size, workspace, l, (hipStream_t)stream, tu, tp); break;
         }
         if (rc != 0) return rc;
     }

@@ -68,6 +68,7 @@ class PlanBuffers:
         self.rec = torch.empty(cap * self.rec_stride, **i32)
         self.hdr = torch.empty(cap * 4, **i32)
         self.occt = torch.empty(cap * 3 * B, **i32)
+        self.tpar = torch.empty(cap * B, **i32)              # per-triplet row parities (K3 sparse view)
         self.loss = torch.zeros(cap, dtype=torch.float32, device=device)
 
 

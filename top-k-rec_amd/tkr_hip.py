@@ -107,7 +107,7 @@ def sample_plan(csr, n_users, n_items, seed, first_triplet, n_batches, B, cnt, p
                                  C.c_uint64(first_triplet), _p(ctl), C.c_int32(n_batches), C.c_int32(B),
                                  _p(cnt.ucnt), _p(cnt.icnt), _p(cnt.touch_u), _p(cnt.touch_i),
                                  _p(plan.u), _p(plan.i), _p(plan.j), _p(plan.task), _p(plan.occ), _p(plan.rec),
-                                 _p(plan.hdr), _p(plan.occt), _stream()), 'tkr_sample_plan')
+                                 _p(plan.hdr), _p(plan.occt), _p(getattr(plan, 'tpar', None)), _stream()), 'tkr_sample_plan')
 
 
 def bpr_run(state, plan, B, n_batches, loss_out=None):
@@ -121,8 +121,8 @@ def vbpr_workspace_floats(B, kh, d):
 
 def vbpr_run(state, plan, B, n_batches, workspace, loss_out=None):
     _check(lib().tkr_vbpr_run(C.byref(state), _p(plan.i), _p(plan.j), _p(plan.rec), _p(plan.occ), _p(plan.hdr),
-                              _p(plan.occt), C.c_int32(B), C.c_int32(n_batches), _p(workspace), _p(loss_out),
-                              _stream()), 'tkr_vbpr_run')
+                              _p(plan.occt), _p(plan.u), _p(getattr(plan, 'tpar', None)), C.c_int32(B), C.c_int32(n_batches),
+                              _p(workspace), _p(loss_out), _stream()), 'tkr_vbpr_run')
 
 
 # ---- K4 / K5 -------------------------------------------------------------------------------------
