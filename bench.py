@@ -252,7 +252,7 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
             # dense optimizer traffic + the CSC walk + one cem row and one icb value per nonzero of the 2B gathered items
             bytes_ = 16.0 * d * kh + 8.0 * nnz + 2.0 * B * (nnz / n_items) * (4.0 * kh + 12.0)
             gbs = bytes_ / step_s / 1e9
-            roof = {'kernels': 'tkr::vbpr_sproject/occur/rows/sdense (4 launches per batch)', 'bound': 'hbm', 'achieved': gbs,
+            roof = {'kernels': 'tkr::vbpr_sproject (project + score) / rows / sdense (3 launches per batch)', 'bound': 'hbm', 'achieved': gbs,
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch_chain': bytes_,
                     'step_us': step_s * 1e6, 'traffic': None}
         else:
