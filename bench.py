@@ -13,7 +13,9 @@ of the item-side state per epoch (every (limit//B)//N steps); weak scaling (K st
 
 Prints ONE JSON line (rank 0).  Extra objects beside the contract fields:
   roofline        dominant kernel (K2) against the HBM roofline: algorithmic bytes per launch
-                  (B x (48k+56) B) / average launch duration from HIP events
+                  (B x (48k+56) B, SURVEY.md §8d) / average launch duration from HIP events;
+                  `traffic` (PMC bytes measured in THIS run) is null -- counters need rocprofv3 --
+                  `traffic_from_profile` replays the figure of the committed profiles/rNN_pmc_traffic.json
   cpu_baseline    the numpy oracle with the reference's cost structure (per-element legacy
                   np.random sampler + numpy step), bounded sample, rank 0, N = 1 only
   throughput_mode the same path at batch_size 8192 (a legal train() argument; NOT the headline)
@@ -141,7 +143,7 @@ def cpu_baseline(r, k, B, budget_s=12.0):
         R.bpr_step(st, ub, ib, jb, hp)
         nb += 1
     dt = time.perf_counter() - t0
-    return dict(value=nb * B / dt, unit='triplets/s', cores=1, kind='port',
+    return dict(value=nb * B / dt, unit='triplets/s', cores=1, host_cores=os.cpu_count(), kind='port',
                 sample='%d batches of %d triplets (%.1f s): oracle/ref_np legacy np.random sampler + numpy step, '
                        'ML-10M shape k=%d' % (nb, B, dt, k))
 
@@ -193,7 +195,8 @@ def topk_bench(r, k, device, rank, world, K=30, reps=5):
             'config': {'workload': '%d users x %d items, k=%d, top-%d, train history masked' % (r['n_users'], n_items, k, K)},
             'ms_per_pass': wall * 1e3 / reps,
             'roofline': dict(topk_roofline(tf, k),
-                             traffic=pmc_traffic('score_topk_ml10m_k128') if (k == 128 and n_items == 10380 and world == 1) else None,
+                             traffic=None,
+                             traffic_from_profile=pmc_traffic('score_topk_ml10m_k128') if (k == 128 and n_items == 10380 and world == 1) else None,
                              launch_ms=launch_ms, algorithmic_flops_per_launch=flops)}
 
 
@@ -392,7 +395,8 @@ def main():
                    'batch_size': B, 'k': k, 'sharding': 'users sharded over %d GPU(s), item tables replicated, '
                                                         'all-reduce every %d steps' % (world, sync_every) if world > 1 else 'single GPU'},
         'roofline': {'kernel': 'tkr::bpr_step_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic('bpr_step_B%d' % B) if (k == 128 and args.shape == 'ml10m') else None,
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'traffic_from_profile': pmc_traffic('bpr_step_B%d' % B) if (k == 128 and args.shape == 'ml10m') else None,
                      'launch_us': launch_us,
                      'algorithmic_bytes_per_launch': B * algorithmic_bytes_per_triplet(k)},
     }
@@ -408,7 +412,8 @@ def main():
                                   'ms_per_step': w2 * 1e3 / T2,
                                   'roofline': {'bound': 'hbm', 'achieved': a2, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                                'frac': a2 / HBM_PEAK_GBS, 'launch_us': s2 * 1e3 / T2,
-                                               'traffic': pmc_traffic('bpr_step_B8192') if (k == 128 and args.shape == 'ml10m') else None}}
+                                               'traffic': None,
+                                               'traffic_from_profile': pmc_traffic('bpr_step_B8192') if (k == 128 and args.shape == 'ml10m') else None}}
         # legacy plain-SGD optimiser (old/methods/bpr.py:57-61): same path, no RMSProp slot traffic
         for Bs, key, steps_s in ((B, 'sgd_mode', 2048), (B2, 'sgd_throughput_mode', T2)):
             eng3 = _engine.BprEngine(eng.n_users, eng.n_items, k, dict(eng.hp, opt='sgd'), device, seed=77)

@@ -9,7 +9,8 @@
  * Conventions
  *   - every function returns int: 0 = ok, > 0 = hipError_t, < 0 = TKR_E* below; nothing throws
  *   - all buffers are caller-owned DEVICE pointers (e.g. torch tensor.data_ptr()) with explicit
- *     sizes; the library allocates no persistent memory
+ *     sizes; the library keeps no device memory of its own, with one stated exception: K4's per-shape
+ *     work-item table (a few KB, cached per device for the 8 most recent shapes)
  *   - `stream` is a hipStream_t passed as void*; all calls are asynchronous and stream-ordered;
  *     scalar results are written to device memory
  *   - ids are int32, parameters fp32
@@ -22,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TKR_VERSION 103 /* 0.1.3: tkr_bpr_state.opt, sparse view in tkr_vbpr_state, per-triplet parities */
+#define TKR_VERSION 104 /* 0.1.4: tkr_plan_rollback; tkr_bpr_run launches directly (no graph cache) */
 #define TKR_OK 0
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
@@ -62,6 +63,13 @@ int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_pt
                     int32_t* ucnt, int32_t* icnt, uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u,
                     int32_t* out_i, int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr,
                     int32_t* occt, int32_t* tpar, void* stream);
+
+/* Take batches [first_batch, first_batch + n_batches) of a plan out of the update counters again.  tkr_sample_plan
+ * advances ucnt / icnt for every batch it PLANS; a caller that drops the rest of a plan (BPR.train stopping inside a
+ * chunk, a parameter read-back between chunks) calls this so that the counters equal the updates that really RAN.
+ * `task` is the array tkr_sample_plan wrote. */
+int tkr_plan_rollback(const int32_t* task, int32_t batch_size, int32_t first_batch, int32_t n_batches, int32_t* ucnt,
+                      int32_t* icnt, void* stream);
 
 /* ---- K2: BPR mini-batch step ---------------------------------------------------------------
  * Replaces sess.run([solver, obj]) (single/bpr.py:141) on the graph of single/bpr.py:81-100.

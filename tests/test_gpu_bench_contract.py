@@ -37,6 +37,20 @@ def test_single_gpu_line():
     assert d['value'] > 10 * c['value']                                # north_star: >= 10x the reference CPU path on one GPU
 
 
+def test_driver_command_measures_the_steady_state():
+    """the round-end driver runs exactly `--gpus 1 --steps 20 --warmup 5`: the 20 timed steps must be the steady state of
+    the loop of single/bpr.py:136-147 (plan, buffers and everything else one-off sit outside the timed region), not set-up"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '5', '--no-extras',
+                          '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d['steps'] == 20 and d['warmup'] == 5
+    assert d['value'] > 40e6, d['value']                                # round 1 printed 0.88 M here (one-off costs inside the timed region)
+    r = d['roofline']
+    wall_us = d['ms_per_step'] * 1e3
+    assert r['launch_us'] <= wall_us * 1.05 and wall_us < 2.0 * r['launch_us'] + 2.0, (r['launch_us'], wall_us)
+
+
 def test_two_rank_line():
     env = dict(os.environ, TKR_BENCH_SINGLE_DEVICE='1', TKR_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',

@@ -134,7 +134,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(tkr_hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.tkr_version() == 103
+    assert lib.tkr_version() == tkr_hip.VERSION
     assert lib.tkr_plan_team(256) == 4 and lib.tkr_plan_team(8192) == 16
     assert lib.tkr_plan_max_blocks(256) == 192 + 153 and lib.tkr_plan_max_blocks(2048) == 384 + 1228 and lib.tkr_plan_max_blocks(8192) == 1536 + 1445
     # argument validation happens before any device access

@@ -23,9 +23,6 @@
 // Roofline: HBM / cache-bandwidth bound gather-scatter.  Algorithmic bytes per triplet
 // (no credit for in-batch duplicates): 3 rows x (param+ms) x (read+write)
 // = 48k B + 32 B biases + 24 B ids  ->  6,200 B at k = 128.
-#include <stdlib.h>
-#include <string.h>
-
 #include "tkr_common.h"
 #include "../../include/tkr.h"
 
@@ -378,89 +375,20 @@ static int check_state(const tkr_bpr_state* st) {
 }
 
 // ---- launch path -------------------------------------------------------------------------------------
-// The n_batches launches of a chunk have the same arguments every time a plan buffer is reused (K1 only
-// rewrites the buffer contents), so the chain is captured once into a hipGraph and replayed: one host call
-// per chunk instead of one per batch.  TKR_GRAPH=0 disables it.
-namespace {
-struct GraphKey {
-    tkr_bpr_state st;
-    const int32_t *rec, *occ, *hdr;
-    float* loss;
-    int B, nb;
-    hipStream_t stream;
-};
-struct GraphEntry {
-    GraphKey key;
-    hipGraphExec_t exec;
-    hipGraph_t graph;
-    uint64_t used;
-};
-constexpr int kGraphCache = 64;      // (state, plan buffer, n_batches) combinations kept instantiated
-GraphEntry g_cache[kGraphCache];
-int g_cache_n = 0;
-uint64_t g_tick = 0;
-
-bool graphs_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("TKR_GRAPH");
-        on = (e && e[0] == '0') ? 0 : 1;
-    }
-    return on == 1;
-}
-
-int launch_chain(const tkr_bpr_state& st, const int32_t* rec, const int32_t* occ, const int32_t* hdr, int B, int nb,
-                 float* loss_out, hipStream_t stream) {
-    const size_t stride_r = (size_t)tkr_plan_max_blocks(B) * tkr_plan_team(B) * 16;
-    const size_t stride_o = (size_t)3 * B * 2;
-    for (int b = 0; b < nb; ++b) {
-        const int r = tkr::dispatch_step(st, rec + b * stride_r, occ + b * stride_o, hdr + (size_t)b * 4, B,
-                                         loss_out ? loss_out + b : nullptr, stream);
-        if (r != 0) return r;
-    }
-    return TKR_OK;
-}
-}  // namespace
-
+// One direct launch per batch, in plan order on the caller's stream (the kernel boundary is what makes batch
+// t+1 see batch t, single/bpr.py:141).  No hidden state: nothing is captured, cached or allocated here.
 extern "C" int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ, const int32_t* hdr,
                            int32_t batch_size, int32_t n_batches, float* loss_out, void* stream) {
     const int rc = check_state(st);
     if (rc != TKR_OK) return rc;
     if (!rec || !occ || !hdr || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (!graphs_enabled() || n_batches < 8) return launch_chain(*st, rec, occ, hdr, batch_size, n_batches, loss_out, s);
-
-    GraphKey key;
-    memset(&key, 0, sizeof(key));
-    key.st = *st; key.rec = rec; key.occ = occ; key.hdr = hdr; key.loss = loss_out;
-    key.B = batch_size; key.nb = n_batches; key.stream = nullptr;
-    ++g_tick;
-    for (int i = 0; i < g_cache_n; ++i)
-        if (memcmp(&g_cache[i].key, &key, sizeof(key)) == 0) {
-            g_cache[i].used = g_tick;
-            return (int)hipGraphLaunch(g_cache[i].exec, s);
-        }
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    static hipStream_t cap = nullptr;               // the caller's stream may be the (uncapturable) default stream
-    if (!cap) TKR_CHECK(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
-    TKR_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed));
-    const int lr = launch_chain(*st, rec, occ, hdr, batch_size, n_batches, loss_out, cap);
-    const hipError_t ee = hipStreamEndCapture(cap, &graph);
-    if (lr != 0) { if (graph) (void)hipGraphDestroy(graph); return lr; }
-    if (ee != hipSuccess) return (int)ee;
-    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (ie != hipSuccess) { (void)hipGraphDestroy(graph); return (int)ie; }
-    int slot = g_cache_n;
-    if (g_cache_n < kGraphCache) {
-        ++g_cache_n;
-    } else {
-        slot = 0;
-        for (int i = 1; i < kGraphCache; ++i)
-            if (g_cache[i].used < g_cache[slot].used) slot = i;
-        (void)hipGraphExecDestroy(g_cache[slot].exec);
-        (void)hipGraphDestroy(g_cache[slot].graph);
+    const size_t stride_r = (size_t)tkr_plan_max_blocks(batch_size) * tkr_plan_team(batch_size) * 16;
+    const size_t stride_o = (size_t)3 * batch_size * 2;
+    for (int b = 0; b < n_batches; ++b) {
+        const int r = tkr::dispatch_step(*st, rec + b * stride_r, occ + b * stride_o, hdr + (size_t)b * 4, batch_size,
+                                         loss_out ? loss_out + b : nullptr, s);
+        if (r != 0) return r;
     }
-    g_cache[slot].key = key; g_cache[slot].exec = exec; g_cache[slot].graph = graph; g_cache[slot].used = g_tick;
-    return (int)hipGraphLaunch(exec, s);
+    return TKR_OK;
 }

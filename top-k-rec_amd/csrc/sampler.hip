@@ -337,6 +337,19 @@ __global__ void commit_kernel(int n_users, int n_items, int32_t* __restrict__ uc
     }
 }
 
+// ---- K1d: take planned-but-never-run batches out of the update counters ----------------------------
+// A plan is consumed incrementally (BPR.train may stop inside a chunk; bench warm-up and run share one chunk).
+// When the rest of a plan is dropped, the counters -- already advanced by commit_kernel for every planned
+// batch -- must again equal the number of updates that really ran: one decrement per task of a dropped batch.
+__global__ void rollback_kernel(const int4* __restrict__ task, size_t n_slots, int32_t* __restrict__ ucnt,
+                                int32_t* __restrict__ icnt) {
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots) return;
+    const int rowk = task[s].x;
+    if (rowk == -1) return;
+    atomicSub((rowk < 0) ? icnt + (rowk & 0x7fffffff) : ucnt + rowk, 1);
+}
+
 }  // namespace tkr
 
 extern "C" int tkr_plan_team(int32_t batch_size) { return tkr::team_for(batch_size); }
@@ -370,11 +383,13 @@ extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int3
                            reinterpret_cast<int2*>(occ), occt, touch_u, touch_i);
     } else {
         const size_t lds = (size_t)npad * 8 + (tkr::kPlanThreadsBig + 1) * sizeof(int);
-        static bool attr_set = false;
-        if (lds > 64 * 1024 && !attr_set) {
+        static bool attr_set[64] = {};                 // per device: the attribute belongs to the device's code object
+        int dev = 0;
+        TKR_CHECK(hipGetDevice(&dev));
+        if (lds > 64 * 1024 && !(dev >= 0 && dev < 64 && attr_set[dev])) {
             TKR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tkr::sample_plan_kernel<tkr::kPlanThreadsBig>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
         hipLaunchKernelGGL(tkr::sample_plan_kernel<tkr::kPlanThreadsBig>, dim3(n_batches), dim3(tkr::kPlanThreadsBig), lds,
                            s, tr_users, (uint32_t)n_tr, row_ptr, pos_cols, cols_sorted, (uint32_t)n_items, seed,
@@ -390,6 +405,17 @@ extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int3
     const int rows = n_users + n_items;
     hipLaunchKernelGGL(tkr::commit_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, n_users, n_items, ucnt, icnt,
                        touch_u, touch_i);
+    TKR_LAUNCH_CHECK();
+    return TKR_OK;
+}
+
+extern "C" int tkr_plan_rollback(const int32_t* task, int32_t batch_size, int32_t first_batch, int32_t n_batches,
+                                 int32_t* ucnt, int32_t* icnt, void* stream) {
+    if (!task || !ucnt || !icnt || batch_size <= 0 || first_batch < 0 || n_batches < 0) return TKR_EINVAL;
+    if (n_batches == 0) return TKR_OK;
+    const size_t per = (size_t)3 * batch_size, n_slots = per * n_batches;
+    hipLaunchKernelGGL(tkr::rollback_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const int4*>(task) + per * first_batch, n_slots, ucnt, icnt);
     TKR_LAUNCH_CHECK();
     return TKR_OK;
 }

@@ -807,6 +807,7 @@ __global__ void count_hits_kernel(const int32_t* __restrict__ ids, int n_rows, i
 // are its partial lists (slot = order inside the block); blocks that stay whole write their final output directly.
 // The table depends only on the shape, so it is built once per shape and kept on the device (8 shapes).
 struct ItemTable {
+    int dev;                // device that owns d_items / d_nslots
     int n_rows, users, n_tiles, G;
     int n_items, n_blocks, stride;
     int4* d_items;          // [n_items] (block, t_begin, t_end, slot | stride << 16)
@@ -819,9 +820,11 @@ static uint64_t g_tables_tick = 0;
 
 static const ItemTable* item_table(int n_rows, int users, int n_tiles, int G) {
     ++g_tables_tick;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     for (int i = 0; i < g_tables_n; ++i) {
         ItemTable& t = g_tables[i];
-        if (t.n_rows == n_rows && t.users == users && t.n_tiles == n_tiles && t.G == G) { t.used = g_tables_tick; return &t; }
+        if (t.dev == dev && t.n_rows == n_rows && t.users == users && t.n_tiles == n_tiles && t.G == G) { t.used = g_tables_tick; return &t; }
     }
     const int n_blocks = (n_rows + users - 1) / users;
     const long long total = (long long)n_blocks * n_tiles;
@@ -853,7 +856,7 @@ static const ItemTable* item_table(int n_rows, int users, int n_tiles, int G) {
         (void)hipFree(g_tables[slot].d_nslots);
     }
     ItemTable& t = g_tables[slot];
-    t = ItemTable{n_rows, users, n_tiles, G, (int)items.size(), n_blocks, stride, nullptr, nullptr, g_tables_tick};
+    t = ItemTable{dev, n_rows, users, n_tiles, G, (int)items.size(), n_blocks, stride, nullptr, nullptr, g_tables_tick};
     if (hipMalloc(&t.d_items, items.size() * sizeof(int4)) != hipSuccess || hipMalloc(&t.d_nslots, nslots.size() * sizeof(int32_t)) != hipSuccess ||
         hipMemcpy(t.d_items, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(t.d_nslots, nslots.data(), nslots.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {

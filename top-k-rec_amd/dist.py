@@ -20,6 +20,35 @@ def world():
     return 0, 1
 
 
+def shared_seed(seed):
+    """the seed every rank uses for the model init and as the key of the sample stream: rank 0's (drawn there when the
+    caller gave none, like the single-process default) broadcast to all.  Ranks that initialised differently would
+    never agree again: the per-epoch exchange moves deltas, not values."""
+    rank, w = world()
+    if w == 1:
+        return seed
+    box = [int(seed) if seed is not None else int(np.random.SeedSequence().entropy % (2 ** 63))]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def assert_replicated(engine, names=None):
+    """every rank holds bit-identical replicated tables (checked through a min/max all-reduce of two checksums each)"""
+    _, w = world()
+    if w == 1:
+        return
+    sums = []
+    for n in (names or engine.replicated_names):
+        p = engine.get(n)[0].double()
+        sums += [p.sum(), (p * p).sum()]
+    lo = torch.stack(sums)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if not torch.equal(lo, hi):
+        raise RuntimeError('replicated model tables differ between ranks before training (different seed or warm start)')
+
+
 def shard_users(tr_users, rank: int, world_size: int):
     """deal tr_users round-robin: every shard keeps the uniform-over-users marginal"""
     return list(tr_users)[rank::world_size]

@@ -84,17 +84,17 @@ class UpdateCounters:
 
 
 class PlanPipeline:
-    """Double-buffered plans: K1 for chunk c+1 runs on a side stream while the main stream runs the step
-    kernels of chunk c (the planner only needs the sample stream position and the update counters, never
-    the model tables).  Events order (a) steps after their plan, (b) re-planning of a buffer after the
-    steps that read it."""
+    """Two plan buffers and the stream discipline around them.  K1 for the chunk after the current one may run on
+    a side stream while the main stream runs the step kernels of the current chunk (the planner only needs the
+    sample stream position and the update counters, never the model tables).  A side-stream plan starts after
+    everything the main stream holds at that moment (the steps that last read the buffer, an in-order K1 that owns
+    the counters); the steps of a chunk wait for the event of its plan."""
 
     def __init__(self, device):
         self.device = device
         self._side = None                # created on first overlapped use: an idle second queue is not free
         self.bufs = [None, None]
         self.planned = [None, None]      # event: plan in bufs[i] complete (side stream)
-        self.consumed = [None, None]     # event: steps that read bufs[i] complete (main stream)
 
     @property
     def side(self):
@@ -106,21 +106,18 @@ class PlanPipeline:
         for i in range(2):
             if self.bufs[i] is None or self.bufs[i].B != B or self.bufs[i].cap < cap:
                 self.bufs[i] = PlanBuffers(cap, B, self.device)
-                self.planned[i] = self.consumed[i] = None
+                self.planned[i] = None
 
     def plan(self, i, fn, overlap=True):
-        """run fn(plan_buffer) on the side stream once the previous consumer of buffer i is done
-        (or simply in order on the current stream when overlap is off)"""
+        """run fn(plan_buffer) on the side stream (or simply in order on the current stream when overlap is off)"""
         main = torch.cuda.current_stream(self.device)
         if not overlap:
+            self.drain()                              # an earlier side-stream K1 owns the counters until it is done
             fn(self.bufs[i])
             self.planned[i] = None
             return
         with torch.cuda.stream(self.side):
-            if self.consumed[i] is not None:
-                self.side.wait_event(self.consumed[i])
-            else:
-                self.side.wait_stream(main)           # first use: buffers were just allocated on the main stream
+            self.side.wait_stream(main)
             fn(self.bufs[i])
             ev = torch.cuda.Event()
             ev.record(self.side)
@@ -129,79 +126,133 @@ class PlanPipeline:
     def acquire(self, i):
         if self.planned[i] is not None:
             torch.cuda.current_stream(self.device).wait_event(self.planned[i])
+            self.planned[i] = None
         return self.bufs[i]
 
-    def release(self, i, overlap=True):
-        if not overlap:
-            self.consumed[i] = None
-            return
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        self.consumed[i] = ev
-
     def drain(self):
-        torch.cuda.current_stream(self.device).wait_stream(self.side)
+        if self._side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
 
 
 OVERLAP_MIN_BATCH = int(__import__('os').environ.get('TKR_OVERLAP_MIN_BATCH', 2048))     # below this the planner is < 5 % of the time and a second active queue slows
                              # the dependent launch cadence of the step kernels (measured: 5.8 -> 6.8 us at B=256)
 
 
-def _chunk_cap(n_batches, B):
+def _chunk_cap(B):
     """batches planned per K1 call: <= 512 (bitmap words), <= 1M triplets of plan resident per buffer"""
-    cap = min(MAX_PLAN_BATCHES, max(8, (1 << 20) // B))
-    return max(1, min(cap, n_batches))
+    return min(MAX_PLAN_BATCHES, max(8, (1 << 20) // B))
 
 
-def _run_pipelined(eng, csr, n_batches, B, want_loss, step_fn):
-    """sample + plan (side stream) and step (main stream) for n_batches consecutive batches"""
-    if eng.pipe is None:
-        eng.pipe = PlanPipeline(eng.device)
-    pipe = eng.pipe
-    cap = _chunk_cap(n_batches, B)
-    pipe.ensure(_chunk_cap(MAX_PLAN_BATCHES, B) if n_batches > 16 else cap, B)   # sized by B: no re-allocation later
-    chunks, left = [], n_batches
-    while left:
-        chunks.append(min(cap, left))
-        left -= chunks[-1]
+class _Chunk:
+    """a planned chunk: batches [used, nb) of plan buffer `idx` have not run yet; batch 0 starts at triplet `first`"""
+    __slots__ = ('idx', 'nb', 'used', 'B', 'first', 'csr')
 
-    def make_plan(nb, first):
-        return lambda buf: tkr_hip.sample_plan(csr, eng.n_users, eng.n_items, eng.seed, first, nb, B, eng.cnt, buf)
+    def __init__(self, idx, nb, B, first, csr):
+        self.idx, self.nb, self.used, self.B, self.first, self.csr = idx, nb, 0, B, first, csr
 
-    overlap = B >= OVERLAP_MIN_BATCH and len(chunks) > 1
-    first = eng.triplets_drawn
-    pipe.plan(0, make_plan(chunks[0], first), overlap)
-    loss = None
-    for c, nb in enumerate(chunks):
-        first += nb * B
-        if c + 1 < len(chunks):
-            if overlap:
-                pipe.plan((c + 1) & 1, make_plan(chunks[c + 1], first), True)
-        if not overlap and c > 0:
-            pipe.plan(c & 1, make_plan(nb, first - nb * B), False)
-        plan = pipe.acquire(c & 1)
-        if want_loss:
-            plan.loss[:nb].zero_()
-        if eng.step_events is not None:          # bench: HIP events around the step launches
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        step_fn(plan, nb, plan.loss if want_loss else None)
-        if eng.step_events is not None:
-            e1.record()
-            eng.step_events.append((e0, e1, nb))
-        pipe.release(c & 1, overlap)
-        loss = plan.loss[:nb] if want_loss else None
-        eng.plan = plan
-    eng.triplets_drawn = first
-    if overlap:
-        pipe.drain()
-    return loss
+
+class PlanMixin:
+    """Sample stream position + plans of an engine.
+
+    K1 always plans a FULL chunk (512 batches at B = 256) from the current stream position; run_batches consumes it
+    piecewise, across calls: a second call continues in the chunk the first one left (BPR.train's epochs, the
+    warm-up and the timed steps of bench.py), so no call pays for a plan, a buffer or anything else it does not use up.
+    K1 advances the update counters for every PLANNED batch; whenever something needs the counters of the batches that
+    really RAN (get / set of parameters, the per-epoch exchange, a different batch size or sample position) settle()
+    takes the rest of the plan out again (tkr_plan_rollback).  The stream is counter-based, so re-planning from the
+    same position reproduces the same triplets."""
+
+    def _init_plans(self):
+        self._cnt = UpdateCounters(self.n_users, self.n_items, self.device)
+        self._drawn = 0                 # position in the counter-based sample stream = triplets that RAN
+        self._cur = None                # chunk being consumed
+        self._ahead = None              # chunk planned on the side stream while _cur runs (large batches only)
+        self.plan = None                # the plan buffer of the last chunk that ran
+        self.pipe = None
+        self.step_events = None         # list of (start, end, n_launches) when a bench wants kernel time
+
+    @property
+    def cnt(self):
+        self.settle()
+        return self._cnt
+
+    @property
+    def triplets_drawn(self):
+        return self._drawn
+
+    @triplets_drawn.setter
+    def triplets_drawn(self, value):
+        self.settle()
+        self._drawn = int(value)
+
+    def settle(self):
+        """drop what is planned but has not run; afterwards the counters describe the tables"""
+        if self._cur is None and self._ahead is None:
+            return
+        self.pipe.drain()
+        for ch in (self._ahead, self._cur):          # newest first, like unwinding
+            if ch is not None and ch.used < ch.nb:
+                buf = self.pipe.bufs[ch.idx]
+                tkr_hip.plan_rollback(buf, ch.B, ch.used, ch.nb - ch.used, self._cnt)
+        self._cur = self._ahead = None
+
+    def _plan_chunk(self, idx, csr, B, first, overlap):
+        nb = _chunk_cap(B)
+        self.pipe.plan(idx, lambda buf: tkr_hip.sample_plan(csr, self.n_users, self.n_items, self.seed, first, nb, B,
+                                                            self._cnt, buf), overlap)
+        return _Chunk(idx, nb, B, first, csr)
+
+    def _next_chunk(self, csr, B):
+        """the chunk that holds the batch at the current stream position"""
+        cur = self._cur
+        if cur is not None and (cur.B != B or cur.csr is not csr):
+            self.settle()
+            cur = None
+        if cur is not None and cur.used < cur.nb:
+            return cur
+        if self.pipe is None:
+            self.pipe = PlanPipeline(self.device)
+        self.pipe.ensure(_chunk_cap(B), B)
+        overlap = B >= OVERLAP_MIN_BATCH
+        if cur is not None and self._ahead is not None:
+            nxt, self._ahead = self._ahead, None
+        else:
+            nxt = self._plan_chunk(0 if cur is None else cur.idx ^ 1, csr, B, self._drawn, False)
+        if overlap:                                   # the chunk after it, behind the steps of this one
+            self._ahead = self._plan_chunk(nxt.idx ^ 1, csr, B, nxt.first + nxt.nb * B, True)
+        self._cur = nxt
+        return nxt
+
+    def _run(self, csr, n_batches, B, want_loss, step_fn):
+        """n_batches consecutive batches from the current stream position; step_fn(plan, first_batch, nb, loss)"""
+        loss, left = None, n_batches
+        while left > 0:
+            ch = self._next_chunk(csr, B)
+            plan = self.pipe.acquire(ch.idx)
+            m = min(left, ch.nb - ch.used)
+            lo = ch.used
+            if want_loss:
+                plan.loss[lo:lo + m].zero_()
+            if self.step_events is not None:          # bench: HIP events around the step launches
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            step_fn(plan, lo, m, plan.loss if want_loss else None)
+            if self.step_events is not None:
+                e1.record()
+                self.step_events.append((e0, e1, m))
+            ch.used += m
+            left -= m
+            self._drawn += m * B
+            loss = plan.loss[lo:lo + m] if want_loss else None
+            self.plan = plan
+        return loss
 
 
 def plan_ahead(eng, csr, n_batches, B):
     """K1 for n_batches batches into freshly held buffers (no stepping): -> [(PlanBuffers, nb), ...].
     Used by the multi-stream mode, where planner launches would disturb the other streams' step chains."""
-    cap = _chunk_cap(n_batches, B)
+    eng.settle()
+    cap = _chunk_cap(B)
     planned, left = [], n_batches
     pool = getattr(eng, '_plan_pool', [])
     idx = 0
@@ -214,8 +265,8 @@ def plan_ahead(eng, csr, n_batches, B):
             else:
                 pool.append(buf)
         buf = pool[idx]
-        tkr_hip.sample_plan(csr, eng.n_users, eng.n_items, eng.seed, eng.triplets_drawn, nb, B, eng.cnt, buf)
-        eng.triplets_drawn += nb * B
+        tkr_hip.sample_plan(csr, eng.n_users, eng.n_items, eng.seed, eng._drawn, nb, B, eng._cnt, buf)
+        eng._drawn += nb * B
         planned.append((buf, nb))
         left -= nb
         idx += 1
@@ -229,7 +280,7 @@ def run_planned(eng, planned, B, want_loss, step_fn):
     for plan, nb in planned:
         if want_loss:
             plan.loss[:nb].zero_()
-        step_fn(plan, nb, plan.loss if want_loss else None)
+        step_fn(plan, 0, nb, plan.loss if want_loss else None)
         loss = plan.loss[:nb] if want_loss else None
         eng.plan = plan
     return loss
@@ -259,7 +310,7 @@ class DoubleTable:
             self.ms[0].copy_(ms)
 
 
-class BprEngine:
+class BprEngine(PlanMixin):
     """Tables + sampler + step loop of one BPR model on one GPU."""
 
     def __init__(self, n_users, n_items, k, hp, device=None, seed=None):
@@ -273,11 +324,7 @@ class BprEngine:
         self.U = DoubleTable(n_users, k, self.device, 0.01, gen)
         self.V = DoubleTable(n_items, k, self.device, 0.01, gen)
         self.b = DoubleTable(n_items, 0, self.device)
-        self.cnt = UpdateCounters(n_users, n_items, self.device)
-        self.triplets_drawn = 0         # position in the counter-based sample stream
-        self.plan = None                # the plan buffer of the last chunk that ran
-        self.pipe = None
-        self.step_events = None         # list of (start, end, n_launches) when a bench wants kernel time
+        self._init_plans()
 
     # ---- C-ABI state struct ------------------------------------------------------------
     def state(self):
@@ -335,16 +382,14 @@ class BprEngine:
     def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True):
         """sample + plan + step for n_batches consecutive batches; returns the per-batch
         losses of the LAST chunk as a device tensor (or None)."""
-        state = self.state()
-        return _run_pipelined(self, csr, n_batches, B, want_loss,
-                              lambda plan, nb, loss: tkr_hip.bpr_run(state, plan, B, nb, loss))
+        return self._run(csr, n_batches, B, want_loss, self.step_fn(B))
 
     def step_fn(self, B):
         state = self.state()
-        return lambda plan, nb, loss: tkr_hip.bpr_run(state, plan, B, nb, loss)
+        return lambda plan, lo, nb, loss: tkr_hip.bpr_run(state, plan, B, nb, loss, first=lo)
 
 
-class VbprEngine:
+class VbprEngine(PlanMixin):
     """Tables + sampler + step loop of one VBPR model on one GPU (single/vbpr.py:29-74).
 
     User rows hold [ure | uce] (width 2*kh, the layout of the exported ``fue``); item rows hold ire;
@@ -371,12 +416,8 @@ class VbprEngine:
         self.feat = feat if isinstance(feat, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(feat, dtype=np.float32))
         self.feat = self.feat.to(self.device).contiguous()
         assert self.feat.shape == (n_items, d)
-        self.cnt = UpdateCounters(n_users, n_items, self.device)
-        self.triplets_drawn = 0
-        self.plan = None
-        self.pipe = None
+        self._init_plans()
         self.ws = None
-        self.step_events = None
         self.sparse = None
         nnz = int(torch.count_nonzero(self.feat))
         if sparse or (sparse is None and nnz <= self.SPARSE_DENSITY * n_items * d):
@@ -455,16 +496,11 @@ class VbprEngine:
     copy_model_from = BprEngine.copy_model_from
 
     def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True):
-        need = tkr_hip.vbpr_workspace_floats(B, self.kh, self.d)
-        if self.ws is None or self.ws.numel() < need:
-            self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
-        state = self.state()
-        return _run_pipelined(self, csr, n_batches, B, want_loss,
-                              lambda plan, nb, loss: tkr_hip.vbpr_run(state, plan, B, nb, self.ws, loss))
+        return self._run(csr, n_batches, B, want_loss, self.step_fn(B))
 
     def step_fn(self, B):
         need = tkr_hip.vbpr_workspace_floats(B, self.kh, self.d)
         if self.ws is None or self.ws.numel() < need:
             self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
         state = self.state()
-        return lambda plan, nb, loss: tkr_hip.vbpr_run(state, plan, B, nb, self.ws, loss)
+        return lambda plan, lo, nb, loss: tkr_hip.vbpr_run(state, plan, B, nb, self.ws, loss, first=lo)

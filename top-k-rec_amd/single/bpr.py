@@ -156,6 +156,9 @@ class BPR(REC):
         n_batches = batch_limit - 1                      # bno runs 1 .. batch_limit-1 (bpr.py:138-147)
         if n_batches < 1:
             raise ValueError('epoch_sample_limit < batch_size: the reference loop would never terminate')
+        import dist as tdist
+        rank, world = tdist.world()
+        seed = tdist.shared_seed(seed)                   # one init and one sample-stream key for every rank
         self.build_graph(device=device, seed=seed)
         if model_path is not None:
             assert isinstance(model_path, str)
@@ -167,8 +170,6 @@ class BPR(REC):
         self._warm_start()
         # one process per GPU (torch.distributed initialised by the launcher): users sharded, item-side
         # tables replicated and reconciled once per epoch (dist.py; the reference is single-process)
-        import dist as tdist
-        rank, world = tdist.world()
         if streams > 1:
             # opt-in: the multi-GPU layout inside ONE GPU -- `streams` user shards with replicated item tables run
             # concurrently on separate HIP streams and are reconciled once per epoch by the same rule (dist.py).
@@ -184,6 +185,7 @@ class BPR(REC):
             self._csr = self._make_csr(shard, self._eng.device)
             n_batches = tdist.batches_per_rank(n_batches, world)
             self._eng.triplets_drawn = rank * epochs * n_batches * batch_size      # disjoint stream positions
+            tdist.assert_replicated(self._eng)             # same seed, same warm start: the replicas must start equal
             sync = tdist.ItemSync(self._eng)
             users_start = self._eng.get('U')[0].clone()
         for eid in range(epochs):
@@ -221,7 +223,7 @@ class BPR(REC):
             csrs.append(self._make_csr(tdist.shard_users(self.tr_users, i, S), dev))
             e.triplets_drawn = i * epochs * nb * batch_size                      # disjoint stream positions, one key
             hip_streams.append(torch.cuda.Stream(device=dev))
-        users_start = lead.get('U')[0].clone()
+        users_start, users_ms_start = (t.clone() for t in lead.get('U'))
         for eid in range(epochs):
             t0 = time.time()
             start = {n: lead.get(n)[0].clone() for n in names}
@@ -249,7 +251,8 @@ class BPR(REC):
                 sys.stderr.flush()
                 print()
         parts = [e.get('U') for e in engines]               # every user row was changed by at most one shard
-        lead.set_users(U=users_start + sum(p - users_start for p, _ in parts), msU=sum(ms - 1.0 for _, ms in parts) + 1.0)
+        lead.set_users(U=users_start + sum(p - users_start for p, _ in parts),
+                       msU=users_ms_start + sum(ms - users_ms_start for _, ms in parts))     # slots may come from a checkpoint, not 1
 
     def _run_epoch(self, n_batches, batch_size):
         losses = self._eng.run_batches(self._csr, n_batches, batch_size, want_loss=True)

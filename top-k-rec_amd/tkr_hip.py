@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtkr_hip.so')
 
 _lib = None
+VERSION = 104          # TKR_VERSION of include/tkr.h this binding was written against
 
 
 class TkrError(RuntimeError):
@@ -38,7 +39,7 @@ class VbprState(C.Structure):
                [(n, C.c_void_p) for n in ('f_ptr', 'f_col', 'f_val', 'c_ptr', 'c_item', 'c_val', 'item_tag')]
 
 
-EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_bpr_run',
+EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_plan_rollback', 'tkr_bpr_run',
            'tkr_vbpr_run', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy',
            'tkr_idmap_create', 'tkr_idmap_destroy', 'tkr_ratings_parse', 'tkr_ratings_sizes', 'tkr_ratings_copy',
            'tkr_ratings_destroy', 'tkr_matrix_read', 'tkr_matrix_sizes', 'tkr_matrix_copy', 'tkr_matrix_destroy',
@@ -59,6 +60,9 @@ def lib():
             getattr(_lib, name).restype = C.c_int
         for name in EXPORTS_I64:
             getattr(_lib, name).restype = C.c_int64
+        if _lib.tkr_version() != VERSION:
+            raise TkrError('%s is version %d, this binding expects %d: rebuild it (make -C top-k-rec_amd/csrc)'
+                           % (LIB_PATH, _lib.tkr_version(), VERSION))
     return _lib
 
 
@@ -75,8 +79,18 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _call(name, anchor, *args):
+    """lib().<name>(*args, stream) on the device that owns tensor `anchor` and on torch's current stream OF THAT
+    DEVICE: a kernel launched while another device is current would run there against this device's pointers"""
+    dev = anchor.device.index
+    prev = torch.cuda.current_device()
+    if prev != dev:
+        torch.cuda.set_device(dev)
+    try:
+        _check(getattr(lib(), name)(*args, C.c_void_p(torch.cuda.current_stream(anchor.device).cuda_stream)), name)
+    finally:
+        if prev != dev:
+            torch.cuda.set_device(prev)
 
 
 def version():
@@ -102,27 +116,45 @@ def sample_plan(csr, n_users, n_items, seed, first_triplet, n_batches, B, cnt, p
     assert plan.rec.numel() >= n_batches * plan_max_blocks(B) * plan_team(B) * 16 and plan.hdr.numel() >= n_batches * 4
     assert cnt.ucnt.numel() == n_users and cnt.touch_u.numel() == n_users * 16
     assert cnt.icnt.numel() == n_items and cnt.touch_i.numel() == n_items * 16
-    _check(lib().tkr_sample_plan(_p(csr.tr_users), C.c_int32(csr.tr_users.numel()), _p(csr.row_ptr), _p(csr.pos_cols),
+    _call('tkr_sample_plan', plan.u, _p(csr.tr_users), C.c_int32(csr.tr_users.numel()), _p(csr.row_ptr), _p(csr.pos_cols),
                                  _p(csr.cols_sorted), C.c_int32(n_users), C.c_int32(n_items), C.c_uint64(seed),
                                  C.c_uint64(first_triplet), _p(ctl), C.c_int32(n_batches), C.c_int32(B),
                                  _p(cnt.ucnt), _p(cnt.icnt), _p(cnt.touch_u), _p(cnt.touch_i),
                                  _p(plan.u), _p(plan.i), _p(plan.j), _p(plan.task), _p(plan.occ), _p(plan.rec),
-                                 _p(plan.hdr), _p(plan.occt), _p(getattr(plan, 'tpar', None)), _stream()), 'tkr_sample_plan')
+                                 _p(plan.hdr), _p(plan.occt), _p(getattr(plan, 'tpar', None)))
 
 
-def bpr_run(state, plan, B, n_batches, loss_out=None):
-    _check(lib().tkr_bpr_run(C.byref(state), _p(plan.rec), _p(plan.occ), _p(plan.hdr), C.c_int32(B),
-                             C.c_int32(n_batches), _p(loss_out), _stream()), 'tkr_bpr_run')
+def plan_rollback(plan, B, first_batch, n_batches, cnt):
+    """take batches [first_batch, first_batch + n_batches) of a plan out of the update counters again"""
+    _call('tkr_plan_rollback', plan.task, _p(plan.task), C.c_int32(B), C.c_int32(first_batch), C.c_int32(n_batches),
+                                   _p(cnt.ucnt), _p(cnt.icnt))
+
+
+def _at(t, offset):
+    """device pointer `offset` elements into tensor t (None -> NULL)"""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous() and 0 <= offset <= t.numel()
+    return C.c_void_p(t.data_ptr() + offset * t.element_size())
+
+
+def bpr_run(state, plan, B, n_batches, loss_out=None, first=0):
+    """batches [first, first + n_batches) of a plan"""
+    rs = plan_max_blocks(B) * plan_team(B) * 16
+    _call('tkr_bpr_run', plan.rec, C.byref(state), _at(plan.rec, first * rs), _at(plan.occ, first * 6 * B), _at(plan.hdr, first * 4),
+                             C.c_int32(B), C.c_int32(n_batches), _at(loss_out, first))
 
 
 def vbpr_workspace_floats(B, kh, d):
     return int(lib().tkr_vbpr_workspace_floats(C.c_int32(B), C.c_int32(kh), C.c_int32(d)))
 
 
-def vbpr_run(state, plan, B, n_batches, workspace, loss_out=None):
-    _check(lib().tkr_vbpr_run(C.byref(state), _p(plan.i), _p(plan.j), _p(plan.rec), _p(plan.occ), _p(plan.hdr),
-                              _p(plan.occt), _p(plan.u), _p(getattr(plan, 'tpar', None)), C.c_int32(B), C.c_int32(n_batches),
-                              _p(workspace), _p(loss_out), _stream()), 'tkr_vbpr_run')
+def vbpr_run(state, plan, B, n_batches, workspace, loss_out=None, first=0):
+    rs = plan_max_blocks(B) * plan_team(B) * 16
+    _call('tkr_vbpr_run', plan.rec, C.byref(state), _at(plan.i, first * B), _at(plan.j, first * B), _at(plan.rec, first * rs),
+                              _at(plan.occ, first * 6 * B), _at(plan.hdr, first * 4), _at(plan.occt, first * 3 * B),
+                              _at(plan.u, first * B), _at(getattr(plan, 'tpar', None), first * B), C.c_int32(B),
+                              C.c_int32(n_batches), _p(workspace), _at(loss_out, first))
 
 
 # ---- K4 / K5 -------------------------------------------------------------------------------------
@@ -133,8 +165,7 @@ def build_rated_mask(rated_ptr, rated_cols, n_rows, n_cols):
     mask = torch.zeros(((n_cols + 31) // 32) * pitch, dtype=torch.int32, device=rated_ptr.device)
     if rated_cols.numel() == 0:
         rated_cols = torch.zeros(1, dtype=torch.int32, device=rated_ptr.device)
-    _check(lib().tkr_build_rated_mask(_p(rated_ptr), _p(rated_cols), C.c_int32(n_rows), C.c_int32(n_cols), _p(mask),
-                                      C.c_int32(pitch), _stream()), 'tkr_build_rated_mask')
+    _call('tkr_build_rated_mask', mask, _p(rated_ptr), _p(rated_cols), C.c_int32(n_rows), C.c_int32(n_cols), _p(mask), C.c_int32(pitch))
     return mask, pitch
 
 
@@ -158,10 +189,9 @@ def _score_topk_once(U, Vt, K, bias, user_idx, mask, mask_pitch, want_scores, sp
     ids = torch.empty((n_rows, K), dtype=torch.int32, device=U.device)
     scores = torch.empty((n_rows, K), dtype=torch.float32, device=U.device) if want_scores else None
     ws = _topk_workspace(n_rows, K, U.device) if split else None
-    _check(lib().tkr_score_topk(_p(U), _p(user_idx), C.c_int32(n_rows), _p(Vt), _p(bias), C.c_int32(Vt.shape[0]),
+    _call('tkr_score_topk', U, _p(U), _p(user_idx), C.c_int32(n_rows), _p(Vt), _p(bias), C.c_int32(Vt.shape[0]),
                                 C.c_int32(U.shape[1]), _p(mask), C.c_int32(mask_pitch), C.c_int32(K), _p(ids),
-                                _p(scores), _p(ws), C.c_int64(ws.numel() if ws is not None else 0), _stream()),
-           'tkr_score_topk')
+                                _p(scores), _p(ws), C.c_int64(ws.numel() if ws is not None else 0))
     return ids, scores
 
 
@@ -193,8 +223,7 @@ def score_topk(U, Vt, K, bias=None, user_idx=None, mask=None, mask_pitch=0, want
             parts_s.append(scores[:, :take])
         left -= take
         if left > 0:      # found columns join the mask (negative ids = padding are skipped by the kernel)
-            _check(lib().tkr_build_rated_mask(_p(ptr), _p(ids.reshape(-1)), C.c_int32(n_rows), C.c_int32(n_cols), _p(work),
-                                              C.c_int32(pitch), _stream()), 'tkr_build_rated_mask')
+            _call('tkr_build_rated_mask', work, _p(ptr), _p(ids.reshape(-1)), C.c_int32(n_rows), C.c_int32(n_cols), _p(work), C.c_int32(pitch))
     ids = torch.cat(parts_i, dim=1).contiguous()
     return (ids, torch.cat(parts_s, dim=1).contiguous()) if want_scores else ids
 
@@ -205,8 +234,8 @@ def count_hits(ids, like_ptr, like_cols, step, interval):
     first = torch.zeros(max(interval, 1), dtype=torch.int64, device=ids.device)
     if like_cols.numel() == 0:
         like_cols = torch.zeros(1, dtype=torch.int32, device=ids.device)
-    _check(lib().tkr_count_hits(_p(ids), C.c_int32(ids.shape[0]), C.c_int32(ids.shape[1]), _p(like_ptr), _p(like_cols),
-                                C.c_int32(step), C.c_int32(interval), _p(first), _stream()), 'tkr_count_hits')
+    _call('tkr_count_hits', ids, _p(ids), C.c_int32(ids.shape[0]), C.c_int32(ids.shape[1]), _p(like_ptr), _p(like_cols),
+                                C.c_int32(step), C.c_int32(interval), _p(first))
     return torch.cumsum(first[:interval], 0)
 
 
@@ -217,8 +246,8 @@ def raw_ranks(U, Vt, ids, rated_ptr, rated_cols, bias=None, user_idx=None):
     out = torch.empty((n_rows, K), dtype=torch.int32, device=ids.device)
     if rated_cols.numel() == 0:
         rated_cols = torch.zeros(1, dtype=torch.int32, device=ids.device)
-    _check(lib().tkr_raw_ranks(_p(U), _p(user_idx), C.c_int32(n_rows), _p(Vt), _p(bias), C.c_int32(U.shape[1]), _p(rated_ptr),
-                               _p(rated_cols), _p(ids), C.c_int32(K), _p(out), _stream()), 'tkr_raw_ranks')
+    _call('tkr_raw_ranks', ids, _p(U), _p(user_idx), C.c_int32(n_rows), _p(Vt), _p(bias), C.c_int32(U.shape[1]), _p(rated_ptr),
+                               _p(rated_cols), _p(ids), C.c_int32(K), _p(out))
     return out
 
 
@@ -230,22 +259,20 @@ def count_hits_rr(ids, raw_rank, like_ptr, like_cols, step, interval):
     if like_cols.numel() == 0:
         like_cols = torch.zeros(1, dtype=torch.int32, device=ids.device)
     if interval > 0:
-        _check(lib().tkr_count_hits_rr(_p(ids), _p(raw_rank), C.c_int32(n_rows), C.c_int32(ids.shape[1]), _p(like_ptr),
-                                       _p(like_cols), C.c_int32(step), C.c_int32(interval), _p(hit), _p(rr), _stream()),
-               'tkr_count_hits_rr')
+        _call('tkr_count_hits_rr', ids, _p(ids), _p(raw_rank), C.c_int32(n_rows), C.c_int32(ids.shape[1]), _p(like_ptr),
+                                       _p(like_cols), C.c_int32(step), C.c_int32(interval), _p(hit), _p(rr))
     return torch.cumsum(hit.sum(0, dtype=torch.int64)[:interval], 0), torch.cumsum(rr.sum(0)[:interval], 0)
 
 
 # ---- per-epoch exchange of replicated tables (csrc/sync.hip) ----------------------------------------
 def sync_snapshot(P, cnt, start, n, w):
-    _check(lib().tkr_sync_snapshot(_p(P), _p(cnt), _p(start), C.c_int64(n), C.c_int32(w), _stream()), 'tkr_sync_snapshot')
+    _call('tkr_sync_snapshot', P, _p(P), _p(cnt), _p(start), C.c_int64(n), C.c_int32(w))
 
 
 def sync_pack(P, ms, cnt, start, flat_delta, flat_ms, n, w, inv_world):
-    _check(lib().tkr_sync_pack(_p(P), _p(ms), _p(cnt), _p(start), _p(flat_delta), _p(flat_ms), C.c_int64(n), C.c_int32(w),
-                               C.c_float(inv_world), _stream()), 'tkr_sync_pack')
+    _call('tkr_sync_pack', P, _p(P), _p(ms), _p(cnt), _p(start), _p(flat_delta), _p(flat_ms), C.c_int64(n), C.c_int32(w),
+                               C.c_float(inv_world))
 
 
 def sync_unpack(P, ms, start, flat_delta, flat_ms, n, w):
-    _check(lib().tkr_sync_unpack(_p(P), _p(ms), _p(start), _p(flat_delta), _p(flat_ms), C.c_int64(n), C.c_int32(w), _stream()),
-           'tkr_sync_unpack')
+    _call('tkr_sync_unpack', P, _p(P), _p(ms), _p(start), _p(flat_delta), _p(flat_ms), C.c_int64(n), C.c_int32(w))
