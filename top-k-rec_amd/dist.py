@@ -104,7 +104,14 @@ class ItemSync:
         n = P.shape[1] if cnt is not None else P.shape[0]
         return int(n), int(P.numel() // (2 if cnt is not None else 1) // n)
 
+    def _settle(self):
+        """the counters this object holds must describe the tables: drop planned-but-not-run batches (PlanMixin.settle)"""
+        settle = getattr(self.eng, 'settle', None)
+        if settle is not None:
+            settle()
+
     def begin(self):
+        self._settle()
         if self.tabs is None:
             self.start = {n: self.eng.get(n)[0].clone() for n in self.names}
             return
@@ -120,6 +127,7 @@ class ItemSync:
         _, w = world()
         if w == 1:
             return
+        self._settle()
         if self.tabs is None:
             cur = {n: self.eng.get(n) for n in self.names}
             parts = []
