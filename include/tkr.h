@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TKR_VERSION 104 /* 0.1.4: tkr_plan_rollback; tkr_bpr_run launches directly (no graph cache) */
+#define TKR_VERSION 105 /* 0.1.5: K2f persistent dataflow step (tkr_bpr_flow_run), tkr_plan_rollback, no graph cache */
 #define TKR_OK 0
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
@@ -54,6 +54,11 @@ int tkr_version(void);
  *   occt                     [n_batches][3B] triplet index t of every sorted occurrence (used by K3)
  *   tpar                     (nullable) [n_batches*B] per triplet: parity of u | parity of i << 1 | parity of j << 2 at its
  *                            batch -- lets K3's sparse view score a triplet where it projects it (no per-occurrence launch)
+ *   prec, pocc               (both NULL, or both set = DATAFLOW form for K2f; rec / hdr / tpar are then not written and may
+ *                            be NULL)  pocc [n_batches][3B][4]: per sorted occurrence (a, version of a, b | role<<31,
+ *                            version of b); prec [n_batches][3B][32]: one 128-byte record per task slot:
+ *                            [0] row | kind<<31 (-1 = unused slot) [1] version of the row [2] occurrences [3] index of its
+ *                            first occurrence in pocc counted from batch 0 [4] batch [8+4q..] pocc of occurrence q < 4
  * batch_size <= 8192, n_batches <= 512, ids < 2^30.  Output is bit-exact against oracle/plan_np.py. */
 int tkr_plan_team(int32_t batch_size);        /* waves per step workgroup / heavy-row team: 4 (B <= 1024) or 16 */
 int tkr_plan_max_blocks(int32_t batch_size);  /* workgroups a batch can need */
@@ -62,7 +67,7 @@ int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_pt
                     uint64_t first_triplet, const int64_t* ctl, int32_t n_batches, int32_t batch_size,
                     int32_t* ucnt, int32_t* icnt, uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u,
                     int32_t* out_i, int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr,
-                    int32_t* occt, int32_t* tpar, void* stream);
+                    int32_t* occt, int32_t* tpar, int32_t* prec, int32_t* pocc, void* stream);
 
 /* Take batches [first_batch, first_batch + n_batches) of a plan out of the update counters again.  tkr_sample_plan
  * advances ucnt / icnt for every batch it PLANS; a caller that drops the rest of a plan (BPR.train stopping inside a
@@ -98,6 +103,43 @@ typedef struct {
  * batch objective (single/bpr.py:93-99) is added to loss_out[b] */
 int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ, const int32_t* hdr,
                 int32_t batch_size, int32_t n_batches, float* loss_out, void* stream);
+
+/* ---- K2f: the same step as ONE persistent launch per chunk (dataflow form; csrc/bpr_flow.hip) ------------------
+ * Replaces the same call site as K2 (single/bpr.py:139-147, the loop around sess.run) for small batches, where one launch
+ * per batch is 96 % idle.  Batches are ordered by the data instead of by kernel boundaries: every table element is an
+ * 8-byte granule {fp32 value, uint32 version tag}, double-buffered (version v of a row lives in buffer v & 1):
+ *   U, msU   [2][n_users][kp] granules, kp = tkr_flow_row_granules(k) (k rounded up to 64; padding: value 0 / slot 1)
+ *   V, msV   [2][n_items][kp]
+ *   tailU/V  [2][n][4] granules per row: {item bias, its RMSProp slot, expect[0], expect[1] (uint32 bits)}; users carry
+ *            zeros for the first two
+ *   rdU/V    [n][2] uint32: acknowledged partner reads of the row, by parity of the version read
+ * A freshly assigned table holds version 0 in buffer 0 (all tags 0, expects 0, rd 0) and tags 0xffffffff in buffer 1.
+ * The plan is tkr_sample_plan's dataflow form (prec / pocc non-NULL there): `prec` points at the record of the first
+ * task of the first batch to run, `pocc` and `loss_out` (nullable, pre-zeroed) at batch 0 of that plan call.
+ * ctl: tkr_flow_ctl_words() uint32 of caller-owned device memory, zeroed once; the kernel leaves the ticket counters
+ * zeroed for the next launch; ctl[status word] != 0 after a launch means a bounded spin ran out (results invalid).
+ * waves_per_cu: 0 = default.  k <= 256, 3 * batch_size * n_batches < 2^29. */
+typedef struct {
+    void* U;
+    void* msU;
+    void* tailU;
+    uint32_t* rdU;
+    void* V;
+    void* msV;
+    void* tailV;
+    uint32_t* rdV;
+    int32_t n_users, n_items, k;
+    int32_t mode;            /* as tkr_bpr_state */
+    float lu, li, lj, lb;
+    float lr, rho, eps;
+    int32_t opt;             /* 0 = sparse RMSProp, 1 = plain SGD (ms tables unused, may be NULL) */
+} tkr_flow_state;
+int32_t tkr_flow_row_granules(int32_t k);
+int32_t tkr_flow_ctl_words(void);
+#define TKR_FLOW_CTL_STATUS 258 /* index of the status word inside ctl */
+#define TKR_FLOW_CTL_SPINS 259  /* diagnostics: spin passes taken since the caller last zeroed it */
+int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, int32_t batch_size,
+                     int32_t n_batches, uint32_t* ctl, float* loss_out, int32_t waves_per_cu, void* stream);
 
 /* ---- K3: VBPR mini-batch step -------------------------------------------------------------
  * Replaces sess.run([solver, obj]) of single/vbpr.py:114 on the graph of single/vbpr.py:50-73 and the

@@ -235,6 +235,37 @@ def resolve_parity(task, occ, B, ucnt, icnt):
     icnt[rows[is_item]] += 1
 
 
+def flow_records(task, occ, B, ucnt, icnt, batch):
+    """Dataflow form of one batch's plan (tkr_sample_plan with prec / pocc; consumed by the persistent step kernel,
+    csrc/bpr_flow.hip).  `task`, `occ` are plan_batch's output BEFORE resolve_parity; ucnt / icnt the update counters
+    before this batch = the VERSION of every row this batch reads.
+      pocc[3B,4]   per sorted occurrence (a, version of a, b | role<<31, version of b)
+      prec[3B,32]  per task slot: [0] row|kind<<31 (-1 unused) [1] version [2] occurrences [3] batch*3B + first occurrence
+                   [4] batch [8+4q..11+4q] pocc of occurrence q < min(4, occurrences); everything else 0"""
+    pocc = np.zeros((3 * B, 4), dtype=np.int32)
+    pocc[:B, 0] = occ[:B, 0]
+    pocc[:B, 1] = icnt[occ[:B, 0]]
+    pocc[:B, 2] = occ[:B, 1]
+    pocc[:B, 3] = icnt[occ[:B, 1]]
+    pocc[B:, 0] = occ[B:, 0]
+    pocc[B:, 1] = ucnt[occ[B:, 0]]
+    pocc[B:, 2] = occ[B:, 1]
+    pocc[B:, 3] = icnt[occ[B:, 1] & 0x3FFFFFFF]
+    prec = np.zeros((3 * B, 32), dtype=np.int32)
+    prec[:, 0] = -1
+    for s in np.flatnonzero(task[:, 0] != -1):
+        rowk, start, cnt, _ = task[s]
+        row = int(rowk) & 0x7FFFFFFF
+        prec[s, 0] = rowk
+        prec[s, 1] = icnt[row] if rowk < 0 else ucnt[row]
+        prec[s, 2] = cnt
+        prec[s, 3] = batch * 3 * B + start
+        prec[s, 4] = batch
+        inl = min(int(cnt), 4)
+        prec[s, 8:8 + 4 * inl] = pocc[start:start + inl].reshape(-1)
+    return pocc, prec
+
+
 def triplet_parity(u, i, j, ucnt, icnt):
     """per triplet: parity of u | parity of i << 1 | parity of j << 2 BEFORE this batch's updates (tkr_sample_plan `tpar`)"""
     return ((ucnt[u] & 1) | ((icnt[i] & 1) << 1) | ((icnt[j] & 1) << 2)).astype(np.int32)
@@ -295,11 +326,18 @@ def sample_and_plan(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed, fir
     hdrs = np.zeros((n_batches, 4), dtype=np.int32)
     occts = np.zeros((n_batches, 3 * B), dtype=np.int32)
     tpars = np.zeros((n_batches, B), dtype=np.int32)
+    poccs = np.zeros((n_batches, 3 * B, 4), dtype=np.int32)
+    precs = np.zeros((n_batches, 3 * B, 32), dtype=np.int32)
+    raw_tasks = np.zeros((n_batches, 3 * B, 4), dtype=np.int32)
+    raw_occs = np.zeros((n_batches, 3 * B, 2), dtype=np.int32)
     for b in range(n_batches):
         sl = slice(b * B, (b + 1) * B)
         tasks[b], occs[b], occts[b] = plan_batch(u[sl], i[sl], j[sl], return_t=True)
         tpars[b] = triplet_parity(u[sl], i[sl], j[sl], ucnt, icnt)
+        raw_tasks[b], raw_occs[b] = tasks[b], occs[b]
+        poccs[b], precs[b] = flow_records(tasks[b], occs[b], B, ucnt, icnt, b)
         resolve_parity(tasks[b], occs[b], B, ucnt, icnt)
         recs[b], hdrs[b] = launch_plan(tasks[b], occs[b], B, occts[b])
     sample_and_plan.last_tpars = tpars            # per-triplet parities of the last call (kept off the return tuple)
+    sample_and_plan.last_flow = dict(pocc=poccs, prec=precs, task=raw_tasks, occ=raw_occs)      # dataflow form of the same plan
     return u, i, j, tasks, occs, recs, hdrs, occts

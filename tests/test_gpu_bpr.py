@@ -176,9 +176,9 @@ def test_abi_rejects_bad_arguments(hip):
     st = hip.BprState()
     assert hip.lib().tkr_bpr_run(C.byref(st), None, None, None, 256, 1, None, None) == -1
     args = [None] * 24
-    assert hip.lib().tkr_sample_plan(None, 0, None, None, None, 5, 10, 0, 0, None, 1, 256, *([None] * 12), None) == -1
-    assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 1, 16384, *([None] * 12), None) == -2
-    assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 513, 256, *([None] * 12), None) == -2
+    assert hip.lib().tkr_sample_plan(None, 0, None, None, None, 5, 10, 0, 0, None, 1, 256, *([None] * 14), None) == -1
+    assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 1, 16384, *([None] * 14), None) == -2
+    assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 513, 256, *([None] * 14), None) == -2
 
 
 @pytest.mark.parametrize('k,B,nb', [(16, 64, 12), (128, 256, 10), (50, 512, 5), (128, 2048, 3), (64, 2048, 9)])

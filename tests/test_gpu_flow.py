@@ -1,0 +1,279 @@
+"""-m gpu: the persistent dataflow form of the BPR step (K2f, csrc/bpr_flow.hip) and the dataflow form of K1's plan.
+
+K1's extra outputs are integer work: bit-exact against oracle/plan_np.flow_records.  K2f is held to the SAME bars as K2
+(tests/test_gpu_bpr.py): tables after N sequential mini-batches within 1e-5 + 2e-4*|x| of oracle/ref_np.bpr_step on the
+same init and (u,i,j) stream, bitwise run-to-run determinism, plus what only a persistent kernel can get wrong: a chunk
+cut into several launches equals one launch, rows that are hammered in every batch (long hand-off chains), rows with many
+occurrences per batch (one wave walks them), and the version / acknowledge bookkeeping left in the tables."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import plan_np as P
+from oracle import ref_np as R
+
+
+@pytest.fixture(scope='module')
+def hip():
+    import tkr_hip
+    assert torch.cuda.is_available(), 'GPU tests need a MI355X'
+    tkr_hip.lib()
+    return tkr_hip
+
+
+def _toy(n_users, n_items, seed, max_deg=12):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tr = {}
+    for u in rng.permutation(n_users)[: max(1, n_users - n_users // 8)]:
+        tr[int(u)] = [int(x) for x in rng.integers(0, n_items, int(rng.integers(1, max_deg)))]
+    return tr, list(tr.keys())
+
+
+def _plan(hip, tr, tr_users, n_users, n_items, seed, first, nb, B, chunks=1):
+    from single import _engine
+    dev = torch.device('cuda')
+    row_ptr, pos, srt = P.build_csr(tr, n_users)
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
+    cnt = _engine.UpdateCounters(n_users, n_items, dev)
+    plan = _engine.PlanBuffers(nb, B, dev, flow=True)
+    ucnt, icnt = np.zeros(n_users, np.int32), np.zeros(n_items, np.int32)
+    for c in range(chunks):
+        hip.sample_plan(csr, n_users, n_items, seed, first + c * nb * B, nb, B, cnt, plan)
+        exp = P.sample_and_plan(tr_users, row_ptr, pos, srt, n_items, seed, first + c * nb * B, nb, B, ucnt, icnt)
+    torch.cuda.synchronize()
+    return plan, exp, cnt, (ucnt, icnt)
+
+
+@pytest.mark.parametrize('n_users,n_items,B,nb,chunks', [(60, 40, 32, 5, 1), (300, 150, 256, 7, 3), (300, 150, 100, 3, 2),
+                                                         (5000, 900, 1024, 3, 1), (40, 30, 1, 4, 1), (300, 150, 64, 512, 2)])
+def test_flow_plan_bit_exact(hip, n_users, n_items, B, nb, chunks):
+    tr, tr_users = _toy(n_users, n_items, seed=n_users + B)
+    plan, exp, cnt, (ucnt, icnt) = _plan(hip, tr, tr_users, n_users, n_items, 0x1234567890ABCDEF, (1 << 33) + 17, nb, B, chunks)
+    flow = P.sample_and_plan.last_flow
+    np.testing.assert_array_equal(plan.u.cpu().numpy(), exp[0])
+    np.testing.assert_array_equal(plan.j.cpu().numpy(), exp[2])
+    np.testing.assert_array_equal(plan.pocc.cpu().numpy().reshape(nb, 3 * B, 4), flow['pocc'], err_msg='pocc')
+    np.testing.assert_array_equal(plan.prec.cpu().numpy().reshape(nb, 3 * B, 32), flow['prec'], err_msg='prec')
+    np.testing.assert_array_equal(plan.task.cpu().numpy().reshape(nb, 3 * B, 4)[:, :, :3], flow['task'][:, :, :3], err_msg='task')
+    np.testing.assert_array_equal(cnt.ucnt.cpu().numpy(), ucnt)
+    np.testing.assert_array_equal(cnt.icnt.cpu().numpy(), icnt)
+    assert int(cnt.touch_u.abs().sum()) == 0 and int(cnt.touch_i.abs().sum()) == 0
+
+
+class _Flow:
+    """granule tables of one model, initialised from an oracle state dict"""
+
+    def __init__(self, hip, ref, n_users, n_items, k, hp):
+        from single import _engine
+        dev = torch.device('cuda')
+        self.hip, self.n_users, self.n_items, self.k = hip, n_users, n_items, k
+        self.U, self.V = _engine.FlowTable(n_users, k, dev), _engine.FlowTable(n_items, k, dev)
+        self.tU, self.tV = _engine.FlowTail(n_users, dev), _engine.FlowTail(n_items, dev)
+        self.U.assign(torch.from_numpy(ref['U']).cuda(), torch.from_numpy(ref['msU']).cuda())
+        self.V.assign(torch.from_numpy(ref['V']).cuda(), torch.from_numpy(ref['msV']).cuda())
+        self.tU.assign()
+        self.tV.assign(torch.from_numpy(ref['b']).cuda(), torch.from_numpy(ref['msb']).cuda())
+        self.ctl = torch.zeros(hip.flow_ctl_words(), dtype=torch.int32, device=dev)
+        st = hip.FlowState()
+        st.U, st.msU, st.tailU, st.rdU = self.U.p.data_ptr(), self.U.ms.data_ptr(), self.tU.t.data_ptr(), self.tU.rd.data_ptr()
+        st.V, st.msV, st.tailV, st.rdV = self.V.p.data_ptr(), self.V.ms.data_ptr(), self.tV.t.data_ptr(), self.tV.rd.data_ptr()
+        st.n_users, st.n_items, st.k = n_users, n_items, k
+        st.mode = 0 if hp['mode'] == 'l2' else 1
+        st.lu, st.li, st.lj, st.lb, st.lr = hp['lu'], hp['li'], hp['lj'], hp['lb'], hp['lr']
+        st.rho, st.eps = 0.9, 1e-10
+        st.opt = 1 if hp.get('opt') == 'sgd' else 0
+        self.st = st
+
+    def run(self, plan, B, nb, loss=None, first=0, waves_per_cu=0):
+        self.hip.bpr_flow_run(self.st, plan, B, nb, self.ctl, loss, first=first, waves_per_cu=waves_per_cu)
+
+    def status(self):
+        torch.cuda.synchronize()
+        c = self.ctl.cpu().numpy()
+        return int(c[self.hip.FLOW_CTL_STATUS]), c
+
+    def current(self, ucnt, icnt):
+        cu, ci = torch.from_numpy(ucnt).cuda(), torch.from_numpy(icnt).cuda()
+        out = {}
+        out['U'], out['msU'] = (t.cpu().numpy() for t in self.U.current(cu))
+        out['V'], out['msV'] = (t.cpu().numpy() for t in self.V.current(ci))
+        out['b'], out['msb'] = (t.cpu().numpy() for t in self.tV.current(ci))
+        return out
+
+    def raw(self):
+        return [t.view(torch.int32).clone()           # bits: a tag of 0xffffffff is a NaN as fp32
+                for t in (self.U.p, self.U.ms, self.V.p, self.V.ms, self.tU.t, self.tV.t, self.tU.rd, self.tV.rd)]
+
+
+def _oracle(ref, exp, n_users, n_items, nb, B, hp):
+    u, i, j = exp[0], exp[1], exp[2]
+    ucnt, icnt = np.zeros(n_users, np.int32), np.zeros(n_items, np.int32)
+    uocc, iocc = np.zeros(n_users, np.int64), np.zeros(n_items, np.int64)
+    losses = []
+    for b in range(nb):
+        sl = slice(b * B, (b + 1) * B)
+        losses.append(R.bpr_step(ref, u[sl], i[sl], j[sl], hp))
+        ucnt[np.unique(u[sl])] += 1
+        icnt[np.unique(np.concatenate([i[sl], j[sl]]))] += 1
+        np.add.at(uocc, u[sl], 1)
+        np.add.at(iocc, np.concatenate([i[sl], j[sl]]), 1)
+    return ucnt, icnt, uocc, iocc, np.array(losses)
+
+
+def _check(F, ref, ucnt, icnt, uocc, iocc, tol=dict(rtol=2e-4, atol=1e-5), slots=True):
+    status, ctl = F.status()
+    assert status == 0, 'a bounded spin ran out'
+    assert not ctl[: 8 * 32].any() and ctl[256] == 0 and ctl[257] == 0         # ticket counters left ready for the next launch
+    got = F.current(ucnt, icnt)
+    for name in ('U', 'V', 'b'):
+        np.testing.assert_allclose(got[name], ref[name], err_msg=name, **tol)
+        if slots:
+            np.testing.assert_allclose(got['ms' + name], ref['ms' + name], rtol=2e-4, atol=1e-7, err_msg='ms' + name)
+    # bookkeeping the kernel leaves behind: every partner read acknowledged (2 per occurrence), current tags = update counts
+    np.testing.assert_array_equal(F.tU.rd.cpu().numpy().reshape(-1, 2).sum(1), 2 * uocc)
+    np.testing.assert_array_equal(F.tV.rd.cpu().numpy().reshape(-1, 2).sum(1), 2 * iocc)
+    from single._engine import _tags
+    for tab, cnt in ((F.U.p, ucnt), (F.V.p, icnt), (F.tV.t, icnt), (F.tU.t, ucnt)):
+        sel = torch.from_numpy(cnt & 1).cuda().long()
+        idx = torch.arange(len(cnt), device='cuda')
+        tags = _tags(tab)[sel, idx].cpu().numpy()
+        assert (tags == cnt.reshape(-1, 1)).all()
+    for tail, rd, cnt in ((F.tU, F.tU.rd, ucnt), (F.tV, F.tV.rd, icnt)):              # expect[parity] of the current version = rd[parity]
+        cur = tail.t.view(torch.int32)[torch.from_numpy(cnt & 1).cuda().long(), torch.arange(len(cnt), device='cuda')]
+        np.testing.assert_array_equal(cur[:, 2:4, 0].cpu().numpy(), rd.cpu().numpy().reshape(-1, 2))
+
+
+@pytest.mark.parametrize('k,B,nb,mode,lr', [(16, 64, 12, 'l2', 0.05), (128, 256, 10, 'l2', 0.05), (50, 256, 6, 'l1', 0.05),
+                                           (200, 128, 4, 'l2', 1e-4), (64, 1024, 5, 'l2', 0.05), (128, 256, 40, 'l1', 0.02),
+                                           (256, 64, 6, 'l2', 0.05)])
+def test_bpr_flow_parity(hip, k, B, nb, mode, lr):
+    n_users, n_items = 400, 120               # small tables: every item is updated in (almost) every batch, many rows have > 4 occurrences
+    tr, tr_users = _toy(n_users, n_items, seed=k + B)
+    rng = np.random.Generator(np.random.PCG64(k))
+    ref = R.init_bpr_state(n_users, n_items, k, rng)
+    ref['b'][:] = (rng.standard_normal(n_items) * 0.01).astype(np.float32)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=lr, mode=mode)
+    F = _Flow(hip, ref, n_users, n_items, k, hp)
+    plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 42, 0, nb, B)
+    loss = torch.zeros(nb, device='cuda')
+    F.run(plan, B, nb, loss)
+    ucnt, icnt, uocc, iocc, ref_loss = _oracle(ref, exp, n_users, n_items, nb, B, hp)
+    _check(F, ref, ucnt, icnt, uocc, iocc)
+    np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, rtol=1e-4)
+    heavy = (P.sample_and_plan.last_flow['prec'][:, :, 2] > 4).sum()
+    assert B < 256 or heavy > 0               # the walk over more than 4 occurrences is exercised
+
+
+def test_flow_is_deterministic_and_launch_split_invariant(hip):
+    """bitwise: two runs of one launch, and the same chunk cut into launches of 1 + 3 + the rest"""
+    n_users, n_items, k, B, nb = 300, 80, 128, 256, 12
+    tr, tr_users = _toy(n_users, n_items, seed=9)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=0.01, mode='l2')
+    plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 3, 0, nb, B)
+    outs = []
+    for cuts in ((nb,), (nb,), (1, 3, nb - 4)):
+        ref = R.init_bpr_state(n_users, n_items, k, np.random.Generator(np.random.PCG64(0)))
+        F = _Flow(hip, ref, n_users, n_items, k, hp)
+        at = 0
+        for m in cuts:
+            F.run(plan, B, m, None, first=at)
+            at += m
+        assert F.status()[0] == 0
+        outs.append(F.raw())
+    for a, b, c in zip(*outs):
+        assert torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize('waves_per_cu', [4, 8, 12])
+def test_flow_few_waves_and_hot_rows(hip, waves_per_cu):
+    """12 items: every item row is rewritten in every batch (a hand-off chain through all 64 batches), all of them with dozens of
+    occurrences; and the result must not depend on how many waves run"""
+    n_users, n_items, k, B, nb = 500, 12, 64, 128, 64
+    rng = np.random.Generator(np.random.PCG64(1))
+    tr = {u: [int(x) for x in rng.choice(n_items, 3, replace=False)] for u in range(n_users)}
+    tr_users = list(tr.keys())
+    ref = R.init_bpr_state(n_users, n_items, k, rng)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.02, mode='l2')
+    F = _Flow(hip, ref, n_users, n_items, k, hp)
+    plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 77, 0, nb, B)
+    F.run(plan, B, nb, None, waves_per_cu=waves_per_cu)
+    ucnt, icnt, uocc, iocc, _ = _oracle(ref, exp, n_users, n_items, nb, B, hp)
+    assert icnt.min() >= nb - 2
+    _check(F, ref, ucnt, icnt, uocc, iocc, tol=dict(rtol=5e-4, atol=2e-5))
+
+
+def test_flow_sgd(hip):
+    n_users, n_items, k, B, nb = 400, 120, 128, 256, 8
+    tr, tr_users = _toy(n_users, n_items, seed=5)
+    rng = np.random.Generator(np.random.PCG64(2))
+    ref = R.init_bpr_state(n_users, n_items, k, rng)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.05, mode='l2', opt='sgd')
+    F = _Flow(hip, ref, n_users, n_items, k, hp)
+    F.st.msU = F.st.msV = None                # the slots are neither read nor written
+    plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 43, 0, nb, B)
+    loss = torch.zeros(nb, device='cuda')
+    F.run(plan, B, nb, loss)
+    ucnt, icnt, uocc, iocc, ref_loss = _oracle(ref, exp, n_users, n_items, nb, B, hp)
+    _check(F, ref, ucnt, icnt, uocc, iocc, slots=False)
+    np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, rtol=1e-4)
+    st = hip.FlowState()
+    assert hip.lib().tkr_bpr_flow_run(C.byref(st), None, None, 256, 1, None, None, 0, None) == -1
+
+
+def test_engine_layouts_and_piecewise_plans():
+    """BprEngine: batch 256 runs on the granule layout, batch 4096 on the plain one, the model survives the conversions; a plan
+    consumed in pieces equals one consumed at once; the counters seen from outside are those of the batches that RAN"""
+    from single import _engine
+    n_users, n_items, k = 900, 200, 64
+    tr, tr_users = _toy(n_users, n_items, seed=3)
+    row_ptr, pos, srt = P.build_csr(tr, n_users)
+    dev = torch.device('cuda')
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.02, mode='l2')
+
+    def fresh():
+        return _engine.BprEngine(n_users, n_items, k, hp, dev, seed=21)
+
+    a = fresh()
+    init = {n: a.get(n)[0].cpu().numpy() for n in ('U', 'V', 'b')}
+    a.run_batches(csr, 30, 256, want_loss=False)
+    assert a.layout == 'flow'
+    b = fresh()
+    for m in (1, 4, 25):
+        b.run_batches(csr, m, 256, want_loss=False)
+        b.check()
+    for n in ('U', 'V', 'b'):
+        for x, y in zip(a.get(n), b.get(n)):
+            assert torch.equal(x, y), n
+    u, i, j = P.sample_triplets(tr_users, row_ptr, pos, srt, n_items, 21, 0, 30 * 256)
+    ub = np.unique(np.stack([np.repeat(np.arange(30), 256), u], 1), axis=0)
+    np.testing.assert_array_equal(a.cnt.ucnt.cpu().numpy(), np.bincount(ub[:, 1], minlength=n_users))     # 30 batches, not the 512 planned
+    assert a.triplets_drawn == 30 * 256
+    # the oracle on the same stream
+    ref = dict(U=init['U'].copy(), V=init['V'].copy(), b=init['b'].copy(), msU=np.ones_like(init['U']), msV=np.ones_like(init['V']),
+               msb=np.ones_like(init['b']))
+    for bb in range(30):
+        sl = slice(bb * 256, (bb + 1) * 256)
+        R.bpr_step(ref, u[sl], i[sl], j[sl], hp)
+    for n in ('U', 'V', 'b'):
+        np.testing.assert_allclose(a.get(n)[0].cpu().numpy(), ref[n], rtol=2e-4, atol=1e-5, err_msg=n)
+    # on to a large batch: tables convert to the plain layout, values and slots carried over, and back again
+    before = {n: [t.clone() for t in a.get(n)] for n in ('U', 'V', 'b')}
+    a.prepare(4096)
+    assert a.layout == 'bulk'
+    for n in ('U', 'V', 'b'):
+        for x, y in zip(before[n], a.get(n)):
+            assert torch.equal(x, y), n
+    a.run_batches(csr, 3, 4096, want_loss=False)
+    a.run_batches(csr, 5, 256, want_loss=False)
+    a.check()
+    assert a.layout == 'flow' and a.triplets_drawn == 30 * 256 + 3 * 4096 + 5 * 256
+    u2, i2, j2 = P.sample_triplets(tr_users, row_ptr, pos, srt, n_items, 21, 30 * 256, 3 * 4096 + 5 * 256)
+    for lo, B_ in [(q * 4096, 4096) for q in range(3)] + [(3 * 4096 + q * 256, 256) for q in range(5)]:
+        R.bpr_step(ref, u2[lo:lo + B_], i2[lo:lo + B_], j2[lo:lo + B_], hp)
+    for n in ('U', 'V', 'b'):
+        np.testing.assert_allclose(a.get(n)[0].cpu().numpy(), ref[n], rtol=3e-4, atol=2e-5, err_msg=n)

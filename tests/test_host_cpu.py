@@ -128,7 +128,7 @@ def test_load_content_data(tmp_path, golden_dir):
 def test_library_exports_every_declared_symbol():
     import tkr_hip
     header = open(os.path.join(ROOT, 'include', 'tkr.h')).read()
-    declared = set(re.findall(r'^int(?:64_t)? (tkr_\w+)\(', header, flags=re.M))
+    declared = set(re.findall(r'^int(?:32_t|64_t)? (tkr_\w+)\(', header, flags=re.M))
     exported = set(tkr_hip.EXPORTS) | set(tkr_hip.EXPORTS_I64)
     assert declared == exported, declared ^ exported
     lib = ctypes.CDLL(tkr_hip.LIB_PATH)

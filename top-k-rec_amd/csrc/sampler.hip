@@ -192,14 +192,19 @@ __global__ __launch_bounds__(T) void sample_plan_kernel(
 }
 
 // ---- K1b: parities + per-wave launch records ------------------------------------------------
-__device__ __forceinline__ int parity_of(const int32_t* __restrict__ cnt, const uint32_t* __restrict__ touch,
-                                         int row, int batch) {
+// number of updates of `row` before batch `batch` of this call = the VERSION of the row that batch reads
+__device__ __forceinline__ int version_of(const int32_t* __restrict__ cnt, const uint32_t* __restrict__ touch,
+                                          int row, int batch) {
     const uint32_t* w = touch + (size_t)row * kTouchWords;
     int c = cnt[row];
     const int full = batch >> 5;
     for (int q = 0; q < full; ++q) c += __popc(w[q]);
     c += __popc(w[full] & ((1u << (batch & 31)) - 1u));
-    return c & 1;
+    return c;
+}
+__device__ __forceinline__ int parity_of(const int32_t* __restrict__ cnt, const uint32_t* __restrict__ touch,
+                                         int row, int batch) {
+    return version_of(cnt, touch, row, batch) & 1;
 }
 
 __device__ __forceinline__ int block_exclusive_scan2(int a, int b, int* scan /*LDS [2*(T+1)]*/, int& tot_a,
@@ -316,6 +321,56 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
     if (threadIdx.x == 0) hdr_all[b] = make_int4(nlb + tot_h, nlb, tot_h, tot_l + tot_h);
 }
 
+// ---- K1b', dataflow form: full versions + one 128-byte record per task -----------------------------------
+// The persistent step kernel (csrc/bpr_flow.hip) runs the batches of a chunk inside ONE launch; what orders them is
+// data: every row carries the number of updates it has seen (its version) in-band, and a task names the exact version
+// of its own row and of every partner row.  Output per batch (oracle/plan_np.py flow_plan):
+//   pocc[3B] int4   per sorted occurrence: (a, version of a, b | role<<31, version of b); user occurrence: a = i, b = j;
+//                   item occurrence: a = u, b = the other item
+//   prec[3B][32]    per task slot: [0] row | kind<<31 (-1 = unused slot)  [1] version of the row  [2] occurrences
+//                   [3] index of its first occurrence in pocc, counted from batch 0 of this call  [4] batch  [5..7] 0
+//                   [8+4q .. 11+4q] = pocc of occurrence q < min(4, occurrences)  [24..31] 0
+__global__ __launch_bounds__(kPlanThreads) void resolve_flow_kernel(
+    int B, const int4* __restrict__ task_all, const int2* __restrict__ occ_all, const int32_t* __restrict__ ucnt,
+    const int32_t* __restrict__ icnt, const uint32_t* __restrict__ touch_u, const uint32_t* __restrict__ touch_i,
+    int4* __restrict__ pocc_all, int4* __restrict__ prec_all) {
+    const int b = blockIdx.x;
+    const int4* task = task_all + (size_t)b * 3 * B;
+    const int2* occ = occ_all + (size_t)b * 3 * B;
+    int4* pocc = pocc_all + (size_t)b * 3 * B;
+    int4* prec = prec_all + (size_t)b * 3 * B * 8;
+
+    for (int p = threadIdx.x; p < B; p += kPlanThreads) {           // user occurrences: (i, j)
+        const int2 o = occ[p];
+        pocc[p] = make_int4(o.x, version_of(icnt, touch_i, o.x, b), o.y, version_of(icnt, touch_i, o.y, b));
+    }
+    for (int p = threadIdx.x; p < 2 * B; p += kPlanThreads) {       // item occurrences: (u, other|role<<31)
+        const int2 o = occ[B + p];
+        pocc[B + p] = make_int4(o.x, version_of(ucnt, touch_u, o.x, b), o.y,
+                                version_of(icnt, touch_i, o.y & 0x3fffffff, b));
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int s = threadIdx.x; s < 3 * B; s += kPlanThreads) {
+        const int4 t = task[s];
+        int4* r = prec + (size_t)s * 8;
+        if (t.x == -1) {
+            r[0] = make_int4(-1, 0, 0, 0);
+#pragma unroll
+            for (int q = 1; q < 8; ++q) r[q] = make_int4(0, 0, 0, 0);
+            continue;
+        }
+        const int row = t.x & 0x7fffffff;
+        const int ver = (t.x < 0) ? version_of(icnt, touch_i, row, b) : version_of(ucnt, touch_u, row, b);
+        r[0] = make_int4(t.x, ver, t.z, b * 3 * B + t.y);
+        r[1] = make_int4(b, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[2 + q] = (q < t.z) ? pocc[t.y + q] : make_int4(0, 0, 0, 0);
+        r[6] = make_int4(0, 0, 0, 0);
+        r[7] = make_int4(0, 0, 0, 0);
+    }
+}
+
 // ---- K1c: fold the chunk's touch bitmap into the update counters and clear it --------------
 __global__ void commit_kernel(int n_users, int n_items, int32_t* __restrict__ ucnt, int32_t* __restrict__ icnt,
                               uint32_t* __restrict__ touch_u, uint32_t* __restrict__ touch_i) {
@@ -365,13 +420,15 @@ extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int3
                                int32_t n_batches, int32_t batch_size, int32_t* ucnt, int32_t* icnt,
                                uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u, int32_t* out_i,
                                int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr,
-                               int32_t* occt, int32_t* tpar, void* stream) {
+                               int32_t* occt, int32_t* tpar, int32_t* prec, int32_t* pocc, void* stream) {
     if (n_tr <= 0 || n_items <= 0 || n_users <= 0 || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
     if (n_users >= (1 << 30) || n_items >= (1 << 30)) return TKR_EUNSUPPORTED;   // id bits 30/31 carry flags
     if (batch_size > 8192) return TKR_EUNSUPPORTED;   // 2B 64-bit keys must fit the 160 KiB LDS
     if (n_batches > 32 * tkr::kTouchWords) return TKR_EUNSUPPORTED;
     if (n_batches == 0) return TKR_OK;
-    if (!ucnt || !icnt || !touch_u || !touch_i || !rec || !hdr || !occt) return TKR_EINVAL;
+    if (!ucnt || !icnt || !touch_u || !touch_i || !occt) return TKR_EINVAL;
+    const bool flow = prec != nullptr;                      // dataflow form of the plan (csrc/bpr_flow.hip)
+    if (flow ? !pocc : (!rec || !hdr)) return TKR_EINVAL;
     int npad = 1;
     while (npad < 2 * batch_size) npad <<= 1;
     hipStream_t s = (hipStream_t)stream;
@@ -397,10 +454,15 @@ extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int3
                            reinterpret_cast<int2*>(occ), occt, touch_u, touch_i);
     }
     TKR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(tkr::resolve_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), 0, s, batch_size,
-                       tkr_plan_max_blocks(batch_size) * tkr::team_for(batch_size), reinterpret_cast<int4*>(task),
-                       reinterpret_cast<int2*>(occ), occt, ucnt, icnt, touch_u, touch_i, rec,
-                       reinterpret_cast<int4*>(hdr), out_u, tpar);
+    if (flow)
+        hipLaunchKernelGGL(tkr::resolve_flow_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), 0, s, batch_size,
+                           reinterpret_cast<const int4*>(task), reinterpret_cast<const int2*>(occ), ucnt, icnt, touch_u,
+                           touch_i, reinterpret_cast<int4*>(pocc), reinterpret_cast<int4*>(prec));
+    else
+        hipLaunchKernelGGL(tkr::resolve_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), 0, s, batch_size,
+                           tkr_plan_max_blocks(batch_size) * tkr::team_for(batch_size), reinterpret_cast<int4*>(task),
+                           reinterpret_cast<int2*>(occ), occt, ucnt, icnt, touch_u, touch_i, rec,
+                           reinterpret_cast<int4*>(hdr), out_u, tpar);
     TKR_LAUNCH_CHECK();
     const int rows = n_users + n_items;
     hipLaunchKernelGGL(tkr::commit_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, n_users, n_items, ucnt, icnt,

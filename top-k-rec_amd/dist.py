@@ -88,7 +88,17 @@ class ItemSync:
         self.names = tuple(names or getattr(engine, 'replicated_names', ('V', 'b')))
         self.start = None
         self.tabs = None
-        tables = getattr(engine, 'replicated_tables', None)
+        self._bound = None
+        self._bind()
+
+    def _bind(self):
+        """(re-)attach to the engine's tables: an engine re-allocates them when it changes layout (layout_epoch)"""
+        epoch = getattr(self.eng, 'layout_epoch', 0)
+        if self._bound == epoch:
+            return
+        self._bound = epoch
+        self.tabs = None
+        tables = getattr(self.eng, 'replicated_tables', None)
         if tables is not None:
             tabs = [t for t in tables() if t[0] in self.names]
             if tabs and all(t[1].is_cuda for t in tabs):
@@ -112,6 +122,7 @@ class ItemSync:
 
     def begin(self):
         self._settle()
+        self._bind()
         if self.tabs is None:
             self.start = {n: self.eng.get(n)[0].clone() for n in self.names}
             return

@@ -54,21 +54,26 @@ class TrainingCSR:
 
 
 class PlanBuffers:
-    """Output of K1 for up to ``cap`` batches of ``B`` triplets."""
+    """Output of K1 for up to ``cap`` batches of ``B`` triplets.  ``flow``: the dataflow form for the persistent step
+    kernel K2f (128-byte task records + versioned occurrences) instead of per-launch wave records."""
 
-    def __init__(self, cap: int, B: int, device):
-        self.cap, self.B = cap, B
+    def __init__(self, cap: int, B: int, device, flow: bool = False):
+        self.cap, self.B, self.flow = cap, B, flow
         i32 = dict(dtype=torch.int32, device=device)
         self.u = torch.empty(cap * B, **i32)
         self.i = torch.empty(cap * B, **i32)
         self.j = torch.empty(cap * B, **i32)
         self.task = torch.empty(cap * 3 * B * 4, **i32)
         self.occ = torch.empty(cap * 3 * B * 2, **i32)
-        self.rec_stride = tkr_hip.plan_max_blocks(B) * tkr_hip.plan_team(B) * 16
-        self.rec = torch.empty(cap * self.rec_stride, **i32)
-        self.hdr = torch.empty(cap * 4, **i32)
         self.occt = torch.empty(cap * 3 * B, **i32)
-        self.tpar = torch.empty(cap * B, **i32)              # per-triplet row parities (K3 sparse view)
+        if flow:
+            self.prec = torch.empty(cap * 3 * B * 32, **i32)
+            self.pocc = torch.empty(cap * 3 * B * 4, **i32)
+        else:
+            self.rec_stride = tkr_hip.plan_max_blocks(B) * tkr_hip.plan_team(B) * 16
+            self.rec = torch.empty(cap * self.rec_stride, **i32)
+            self.hdr = torch.empty(cap * 4, **i32)
+            self.tpar = torch.empty(cap * B, **i32)          # per-triplet row parities (K3 sparse view)
         self.loss = torch.zeros(cap, dtype=torch.float32, device=device)
 
 
@@ -102,10 +107,11 @@ class PlanPipeline:
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
-    def ensure(self, cap, B):
+    def ensure(self, cap, B, flow=False):
         for i in range(2):
-            if self.bufs[i] is None or self.bufs[i].B != B or self.bufs[i].cap < cap:
-                self.bufs[i] = PlanBuffers(cap, B, self.device)
+            if self.bufs[i] is None or self.bufs[i].B != B or self.bufs[i].cap < cap or self.bufs[i].flow != flow:
+                self.bufs[i] = None                   # release before allocating the replacement
+                self.bufs[i] = PlanBuffers(cap, B, self.device, flow)
                 self.planned[i] = None
 
     def plan(self, i, fn, overlap=True):
@@ -162,6 +168,16 @@ class PlanMixin:
     takes the rest of the plan out again (tkr_plan_rollback).  The stream is counter-based, so re-planning from the
     same position reproduces the same triplets."""
 
+    def _plan_flow(self):
+        """does the step of this engine read the dataflow form of the plan?"""
+        return False
+
+    def prepare(self, B, layout=None):
+        """engines with more than one table layout pick the one batch size B runs on"""
+
+    def check(self):
+        """raise if the device reported a failed step (engines with a persistent kernel)"""
+
     def _init_plans(self):
         self._cnt = UpdateCounters(self.n_users, self.n_items, self.device)
         self._drawn = 0                 # position in the counter-based sample stream = triplets that RAN
@@ -212,7 +228,7 @@ class PlanMixin:
             return cur
         if self.pipe is None:
             self.pipe = PlanPipeline(self.device)
-        self.pipe.ensure(_chunk_cap(B), B)
+        self.pipe.ensure(_chunk_cap(B), B, self._plan_flow())
         overlap = B >= OVERLAP_MIN_BATCH
         if cur is not None and self._ahead is not None:
             nxt, self._ahead = self._ahead, None
@@ -310,8 +326,69 @@ class DoubleTable:
             self.ms[0].copy_(ms)
 
 
+FLOW_MAX_BATCH = int(__import__('os').environ.get('TKR_FLOW_MAX_BATCH', 1024))    # batch sizes up to this take the persistent dataflow step (K2f)
+FLOW_WAVES_PER_CU = int(__import__('os').environ.get('TKR_FLOW_WAVES_PER_CU', 0))    # 0 = the library default
+
+
+def _tags(t):
+    """the version tags of a granule tensor [..., 2] (float32 storage; [..., 0] value bits, [..., 1] tag bits)"""
+    return t.view(torch.int32)[..., 1]
+
+
+class FlowTable:
+    """A parameter table + its RMSProp slot in the layout of the dataflow step (csrc/bpr_flow.hip): [2][n][kp] granules
+    {fp32 value, uint32 version tag}, kp = k rounded up to 64; version v of a row lives in buffer v & 1.  Same
+    interface as DoubleTable."""
+
+    def __init__(self, n, k, device):
+        self.n, self.k, self.kp = n, k, tkr_hip.flow_row_granules(k)
+        self.p = torch.zeros((2, n, self.kp, 2), dtype=torch.float32, device=device)
+        self.ms = torch.zeros((2, n, self.kp, 2), dtype=torch.float32, device=device)
+
+    def current(self, cnt):
+        sel = (cnt & 1).long()
+        idx = torch.arange(self.n, device=self.p.device)
+        return self.p[sel, idx, :self.k, 0], self.ms[sel, idx, :self.k, 0]
+
+    def assign(self, values, ms):
+        """version 0 of every row in buffer 0 (the caller zeroes the update counters); buffer 1 holds no version"""
+        for t, v, pad in ((self.p, values, 0.0), (self.ms, ms, 1.0)):
+            t.zero_()
+            t[0, :, :, 0] = pad
+            t[0, :, :self.k, 0] = v
+            _tags(t)[1] = -1
+
+
+class FlowTail:
+    """[2][n][4] granules per row: {item bias, its RMSProp slot, expect[0], expect[1]} + the two rd words of every row"""
+
+    def __init__(self, n, device):
+        self.n = n
+        self.t = torch.zeros((2, n, 4, 2), dtype=torch.float32, device=device)
+        self.rd = torch.zeros(2 * n, dtype=torch.int32, device=device)
+        _tags(self.t)[1] = -1
+
+    def current(self, cnt):
+        sel = (cnt & 1).long()
+        idx = torch.arange(self.n, device=self.t.device)
+        return self.t[sel, idx, 0, 0], self.t[sel, idx, 1, 0]
+
+    def assign(self, b=None, msb=None):
+        self.t.zero_()
+        if b is not None:
+            self.t[0, :, 0, 0] = b
+            self.t[0, :, 1, 0] = msb
+        _tags(self.t)[1] = -1
+        self.rd.zero_()
+
+
 class BprEngine(PlanMixin):
-    """Tables + sampler + step loop of one BPR model on one GPU."""
+    """Tables + sampler + step loop of one BPR model on one GPU.
+
+    Two layouts of the same model.  ``bulk``: plain double-buffered tables, one launch of K2 per batch (large batches:
+    bandwidth-bound).  ``flow``: granule tables with in-band versions, ONE persistent launch of K2f per chunk (batch sizes
+    up to FLOW_MAX_BATCH, where a launch per batch is latency-bound).  run_batches picks by batch size and converts the
+    tables when it changes; get / set work on either."""
 
     def __init__(self, n_users, n_items, k, hp, device=None, seed=None):
         self.device = device or default_device()
@@ -321,18 +398,59 @@ class BprEngine(PlanMixin):
         gen = torch.Generator(device=self.device)
         gen.manual_seed(self.seed & 0x7FFFFFFFFFFFFFFF)
         # single/bpr.py:77-79: U, V ~ N(0, 0.01); b = 0.  RMSProp `rms` slots start at one.
+        self.layout = 'bulk'
+        self.layout_epoch = 0           # bumped whenever the tables are re-allocated (dist.ItemSync re-binds)
         self.U = DoubleTable(n_users, k, self.device, 0.01, gen)
         self.V = DoubleTable(n_items, k, self.device, 0.01, gen)
         self.b = DoubleTable(n_items, 0, self.device)
+        self.tailU = self.tailV = self.ctl = None
         self._init_plans()
 
-    # ---- C-ABI state struct ------------------------------------------------------------
-    def state(self):
+    # ---- layout ----------------------------------------------------------------------------------
+    def _plan_flow(self):
+        return self.layout == 'flow'
+
+    def wants_flow(self, B):
+        return B <= FLOW_MAX_BATCH and __import__('os').environ.get('TKR_FLOW', '1') != '0'
+
+    def prepare(self, B, layout=None):
+        """put the tables into the layout that batch size B runs on (or the one named)"""
+        layout = layout or ('flow' if self.wants_flow(B) else 'bulk')
+        if layout == self.layout:
+            return
+        self.settle()
+        (pu, mu), (pv, mv), (pb, mb) = (tuple(t.clone() for t in self.get(n)) for n in ('U', 'V', 'b'))
+        self.U = self.V = self.b = self.tailU = self.tailV = None
+        if layout == 'flow':
+            self.U, self.V = FlowTable(self.n_users, self.k, self.device), FlowTable(self.n_items, self.k, self.device)
+            self.tailU, self.tailV = FlowTail(self.n_users, self.device), FlowTail(self.n_items, self.device)
+            if self.ctl is None:
+                self.ctl = torch.zeros(tkr_hip.flow_ctl_words(), dtype=torch.int32, device=self.device)
+        else:
+            self.U, self.V = DoubleTable(self.n_users, self.k, self.device), DoubleTable(self.n_items, self.k, self.device)
+            self.b = DoubleTable(self.n_items, 0, self.device)
+        self.layout = layout
+        self.layout_epoch += 1
+        self.U.assign(pu, mu)
+        self.V.assign(pv, mv)
+        if layout == 'flow':
+            self.tailU.assign()
+            self.tailV.assign(pb, mb)
+        else:
+            self.b.assign(pb, mb)
+        self._cnt.ucnt.zero_()
+        self._cnt.icnt.zero_()
+
+    def check(self):
+        """raise if a bounded spin of the persistent kernel ran out (synchronises)"""
+        if self.ctl is not None and int(self.ctl[tkr_hip.FLOW_CTL_STATUS]) != 0:
+            code = int(self.ctl[tkr_hip.FLOW_CTL_STATUS])
+            self.ctl.zero_()
+            raise tkr_hip.TkrError('persistent BPR step gave up waiting for a row version (status %d): tables are invalid' % code)
+
+    # ---- C-ABI state structs ------------------------------------------------------------
+    def _hyper_into(self, st):
         hp = self.hp
-        st = tkr_hip.BprState()
-        st.U, st.msU = self.U.p.data_ptr(), self.U.ms.data_ptr()
-        st.V, st.msV = self.V.p.data_ptr(), self.V.ms.data_ptr()
-        st.b, st.msb = self.b.p.data_ptr(), self.b.ms.data_ptr()
         st.n_users, st.n_items, st.k = self.n_users, self.n_items, self.k
         st.mode = 0 if hp['mode'] == 'l2' else 1
         st.lu, st.li, st.lj, st.lb, st.lr = hp['lu'], hp['li'], hp['lj'], hp['lb'], hp['lr']
@@ -340,27 +458,52 @@ class BprEngine(PlanMixin):
         st.opt = 1 if hp.get('opt', 'rmsprop') == 'sgd' else 0       # 'sgd': old/methods/bpr.py:57-61
         return st
 
+    def state(self):
+        if self.layout == 'flow':
+            st = tkr_hip.FlowState()
+            st.U, st.msU, st.tailU, st.rdU = self.U.p.data_ptr(), self.U.ms.data_ptr(), self.tailU.t.data_ptr(), self.tailU.rd.data_ptr()
+            st.V, st.msV, st.tailV, st.rdV = self.V.p.data_ptr(), self.V.ms.data_ptr(), self.tailV.t.data_ptr(), self.tailV.rd.data_ptr()
+            return self._hyper_into(st)
+        st = tkr_hip.BprState()
+        st.U, st.msU = self.U.p.data_ptr(), self.U.ms.data_ptr()
+        st.V, st.msV = self.V.p.data_ptr(), self.V.ms.data_ptr()
+        st.b, st.msb = self.b.p.data_ptr(), self.b.ms.data_ptr()
+        return self._hyper_into(st)
+
     # ---- parameter access (host <-> current buffers) -----------------------------------------
     def get(self, name):
-        table, cnt = {'U': (self.U, self.cnt.ucnt), 'V': (self.V, self.cnt.icnt), 'b': (self.b, self.cnt.icnt)}[name]
-        return table.current(cnt)
+        if name == 'U':
+            return self.U.current(self.cnt.ucnt)
+        if name == 'V':
+            return self.V.current(self.cnt.icnt)
+        return (self.tailV if self.layout == 'flow' else self.b).current(self.cnt.icnt)
 
     def set_users(self, U=None, msU=None):
         cur, ms = self.U.current(self.cnt.ucnt)
-        self.U.assign(cur if U is None else self._dev(U), ms if msU is None else self._dev(msU))
-        self.cnt.ucnt.zero_()
+        self.U.assign(cur.clone() if U is None else self._dev(U), ms.clone() if msU is None else self._dev(msU))
+        if self.layout == 'flow':
+            self.tailU.assign()
+        self._cnt.ucnt.zero_()
 
     def set_items(self, V=None, b=None, msV=None, msb=None):
         cv, mv = self.V.current(self.cnt.icnt)
-        cb, mb = self.b.current(self.cnt.icnt)
-        self.V.assign(cv if V is None else self._dev(V), mv if msV is None else self._dev(msV))
-        self.b.assign(cb if b is None else self._dev(b).reshape(-1), mb if msb is None else self._dev(msb).reshape(-1))
-        self.cnt.icnt.zero_()
+        cb, mb = self.get('b')
+        nb = cb.clone() if b is None else self._dev(b).reshape(-1)
+        nmb = mb.clone() if msb is None else self._dev(msb).reshape(-1)
+        self.V.assign(cv.clone() if V is None else self._dev(V), mv.clone() if msV is None else self._dev(msV))
+        if self.layout == 'flow':
+            self.tailV.assign(nb, nmb)
+        else:
+            self.b.assign(nb, nmb)
+        self._cnt.icnt.zero_()
 
     replicated_names = ('V', 'b')
 
     def replicated_tables(self):
-        """(name, P, ms, update counter or None) of every table all ranks update: dist.ItemSync packs them with csrc/sync.hip"""
+        """(name, P, ms, update counter or None) of every table all ranks update: dist.ItemSync packs them with
+        csrc/sync.hip.  The granule layout is exchanged through get / set_replicated instead (empty list)."""
+        if self.layout == 'flow':
+            return []
         return [('V', self.V.p, self.V.ms, self.cnt.icnt), ('b', self.b.p, self.b.ms, self.cnt.icnt)]
 
     def copy_model_from(self, other):
@@ -382,10 +525,14 @@ class BprEngine(PlanMixin):
     def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True):
         """sample + plan + step for n_batches consecutive batches; returns the per-batch
         losses of the LAST chunk as a device tensor (or None)."""
+        self.prepare(B)
         return self._run(csr, n_batches, B, want_loss, self.step_fn(B))
 
     def step_fn(self, B):
         state = self.state()
+        if self.layout == 'flow':
+            return lambda plan, lo, nb, loss: tkr_hip.bpr_flow_run(state, plan, B, nb, self.ctl, loss, first=lo,
+                                                                   waves_per_cu=FLOW_WAVES_PER_CU)
         return lambda plan, lo, nb, loss: tkr_hip.bpr_run(state, plan, B, nb, loss, first=lo)
 
 

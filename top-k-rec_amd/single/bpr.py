@@ -168,6 +168,7 @@ class BPR(REC):
         tprint('Learning rate is %.6f, regularization mode is %s' % (self.lr, self.mode))
         tprint('Training for %d epochs of %d batches using %s sampler' % (epochs, batch_limit, sampling))
         self._warm_start()
+        self._eng.prepare(batch_size, 'bulk' if streams > 1 else None)     # table layout of this batch size (see _engine.BprEngine)
         # one process per GPU (torch.distributed initialised by the launcher): users sharded, item-side
         # tables replicated and reconciled once per epoch (dist.py; the reference is single-process)
         if streams > 1:
@@ -216,6 +217,7 @@ class BPR(REC):
         engines = [self._eng] + [self._make_engine(dev, self._eng.seed) for _ in range(S - 1)]
         lead = engines[0]
         for e in engines[1:]:                              # every shard starts from the same (possibly warm-started) model
+            e.prepare(batch_size, 'bulk')
             e.copy_model_from(lead)
         nb = tdist.batches_per_rank(n_batches, S)
         csrs, hip_streams = [], []
@@ -256,7 +258,9 @@ class BPR(REC):
 
     def _run_epoch(self, n_batches, batch_size):
         losses = self._eng.run_batches(self._csr, n_batches, batch_size, want_loss=True)
-        return float(losses[-1])
+        last = float(losses[-1])
+        self._eng.check()
+        return last
 
     # ------------------------------------------------------------------ sampler (bpr.py:155-165)
     def _uniform_user_sampling(self, batch_size: int):

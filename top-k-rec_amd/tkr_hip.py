@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtkr_hip.so')
 
 _lib = None
-VERSION = 104          # TKR_VERSION of include/tkr.h this binding was written against
+VERSION = 105          # TKR_VERSION of include/tkr.h this binding was written against
 
 
 class TkrError(RuntimeError):
@@ -31,6 +31,13 @@ class BprState(C.Structure):
                 ('lr', C.c_float), ('rho', C.c_float), ('eps', C.c_float), ('opt', C.c_int32)]
 
 
+class FlowState(C.Structure):
+    """mirror of tkr_flow_state (include/tkr.h): granule tables of the persistent dataflow step"""
+    _fields_ = [(n, C.c_void_p) for n in ('U', 'msU', 'tailU', 'rdU', 'V', 'msV', 'tailV', 'rdV')] + \
+               [(n, C.c_int32) for n in ('n_users', 'n_items', 'k', 'mode')] + \
+               [(n, C.c_float) for n in ('lu', 'li', 'lj', 'lb', 'lr', 'rho', 'eps')] + [('opt', C.c_int32)]
+
+
 class VbprState(C.Structure):
     """mirror of tkr_vbpr_state (include/tkr.h)"""
     _fields_ = [(n, C.c_void_p) for n in ('U', 'msU', 'I', 'msI', 'irb', 'msirb', 'cem', 'mscem', 'icb', 'msicb', 'feat')] + \
@@ -39,7 +46,7 @@ class VbprState(C.Structure):
                [(n, C.c_void_p) for n in ('f_ptr', 'f_col', 'f_val', 'c_ptr', 'c_item', 'c_val', 'item_tag')]
 
 
-EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_plan_rollback', 'tkr_bpr_run',
+EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_plan_rollback', 'tkr_bpr_run', 'tkr_bpr_flow_run', 'tkr_flow_row_granules', 'tkr_flow_ctl_words',
            'tkr_vbpr_run', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy',
            'tkr_idmap_create', 'tkr_idmap_destroy', 'tkr_ratings_parse', 'tkr_ratings_sizes', 'tkr_ratings_copy',
            'tkr_ratings_destroy', 'tkr_matrix_read', 'tkr_matrix_sizes', 'tkr_matrix_copy', 'tkr_matrix_destroy',
@@ -110,18 +117,23 @@ def plan_max_blocks(B):
 
 def sample_plan(csr, n_users, n_items, seed, first_triplet, n_batches, B, cnt, plan, ctl=None):
     """csr: tensors tr_users,row_ptr,pos_cols,cols_sorted; cnt: ucnt,icnt,touch_u,touch_i;
-    plan: u,i,j,task,occ,rec,hdr (all int32 device tensors)."""
+    plan: u,i,j,task,occ,occt + either rec,hdr,tpar (one launch per batch, K2/K3) or prec,pocc (dataflow form, K2f);
+    all int32 device tensors."""
     assert n_batches <= PLAN_MAX_BATCHES
     assert plan.u.numel() >= n_batches * B and plan.task.numel() >= n_batches * 3 * B * 4
-    assert plan.rec.numel() >= n_batches * plan_max_blocks(B) * plan_team(B) * 16 and plan.hdr.numel() >= n_batches * 4
+    prec, pocc = getattr(plan, 'prec', None), getattr(plan, 'pocc', None)
+    if prec is not None:
+        assert prec.numel() >= n_batches * 3 * B * 32 and pocc.numel() >= n_batches * 3 * B * 4
+    else:
+        assert plan.rec.numel() >= n_batches * plan_max_blocks(B) * plan_team(B) * 16 and plan.hdr.numel() >= n_batches * 4
     assert cnt.ucnt.numel() == n_users and cnt.touch_u.numel() == n_users * 16
     assert cnt.icnt.numel() == n_items and cnt.touch_i.numel() == n_items * 16
     _call('tkr_sample_plan', plan.u, _p(csr.tr_users), C.c_int32(csr.tr_users.numel()), _p(csr.row_ptr), _p(csr.pos_cols),
                                  _p(csr.cols_sorted), C.c_int32(n_users), C.c_int32(n_items), C.c_uint64(seed),
                                  C.c_uint64(first_triplet), _p(ctl), C.c_int32(n_batches), C.c_int32(B),
                                  _p(cnt.ucnt), _p(cnt.icnt), _p(cnt.touch_u), _p(cnt.touch_i),
-                                 _p(plan.u), _p(plan.i), _p(plan.j), _p(plan.task), _p(plan.occ), _p(plan.rec),
-                                 _p(plan.hdr), _p(plan.occt), _p(getattr(plan, 'tpar', None)))
+                                 _p(plan.u), _p(plan.i), _p(plan.j), _p(plan.task), _p(plan.occ), _p(getattr(plan, 'rec', None)),
+                                 _p(getattr(plan, 'hdr', None)), _p(plan.occt), _p(getattr(plan, 'tpar', None)), _p(prec), _p(pocc))
 
 
 def plan_rollback(plan, B, first_batch, n_batches, cnt):
@@ -143,6 +155,23 @@ def bpr_run(state, plan, B, n_batches, loss_out=None, first=0):
     rs = plan_max_blocks(B) * plan_team(B) * 16
     _call('tkr_bpr_run', plan.rec, C.byref(state), _at(plan.rec, first * rs), _at(plan.occ, first * 6 * B), _at(plan.hdr, first * 4),
                              C.c_int32(B), C.c_int32(n_batches), _at(loss_out, first))
+
+
+def flow_row_granules(k):
+    return int(lib().tkr_flow_row_granules(C.c_int32(k)))
+
+
+def flow_ctl_words():
+    return int(lib().tkr_flow_ctl_words())
+
+
+FLOW_CTL_STATUS, FLOW_CTL_SPINS = 258, 259      # TKR_FLOW_CTL_* of include/tkr.h
+
+
+def bpr_flow_run(state, plan, B, n_batches, ctl, loss_out=None, first=0, waves_per_cu=0):
+    """batches [first, first + n_batches) of a dataflow plan in ONE persistent launch"""
+    _call('tkr_bpr_flow_run', plan.prec, C.byref(state), _at(plan.prec, first * 3 * B * 32), _p(plan.pocc), C.c_int32(B),
+          C.c_int32(n_batches), _p(ctl), _p(loss_out), C.c_int32(waves_per_cu))
 
 
 def vbpr_workspace_floats(B, kh, d):
