@@ -108,7 +108,7 @@ int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ,
  * Replaces the same call site as K2 (single/bpr.py:139-147, the loop around sess.run) for small batches, where one launch
  * per batch is 96 % idle.  Batches are ordered by the data instead of by kernel boundaries: every table element is an
  * 8-byte granule {fp32 value, uint32 version tag}, double-buffered (version v of a row lives in buffer v & 1):
- *   U, msU   [2][n_users][kp] granules, kp = tkr_flow_row_granules(k) (k rounded up to 64; padding: value 0 / slot 1)
+ *   U, msU   [2][n_users][kp] granules, kp = tkr_flow_row_granules(k) (k rounded up to 128; padding: value 0 / slot 1)
  *   V, msV   [2][n_items][kp]
  *   tailU/V  [2][n][4] granules per row: {item bias, its RMSProp slot, expect[0], expect[1] (uint32 bits)}; users carry
  *            zeros for the first two
@@ -136,8 +136,8 @@ typedef struct {
 } tkr_flow_state;
 int32_t tkr_flow_row_granules(int32_t k);
 int32_t tkr_flow_ctl_words(void);
-#define TKR_FLOW_CTL_STATUS 258 /* index of the status word inside ctl */
-#define TKR_FLOW_CTL_SPINS 259  /* diagnostics: spin passes taken since the caller last zeroed it */
+#define TKR_FLOW_CTL_STATUS 1026 /* index of the status word inside ctl */
+#define TKR_FLOW_CTL_SPINS 1027  /* diagnostics: spin passes taken since the caller last zeroed it */
 int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, int32_t batch_size,
                      int32_t n_batches, uint32_t* ctl, float* loss_out, int32_t waves_per_cu, void* stream);
 

@@ -20,9 +20,9 @@ plan, exp, _, _ = T._plan(tkr_hip, tr, tr_users, n_users, n_items, 42, 0, nb, B)
 t0 = time.time()
 F.run(plan, B, nb, None)
 st, ctl = F.status()
-print('nb', nb, 'B', B, 'k', k, 'status', st, 'time %.3f s' % (time.time() - t0), 'spins', ctl[259])
-print('debug', ctl[264:280].tolist())
-print('heads', ctl[0:256:32].tolist(), 'arrive/exit', ctl[256:258].tolist())
+print('nb', nb, 'B', B, 'k', k, 'status', st, 'time %.3f s' % (time.time() - t0), 'spins', ctl[tkr_hip.FLOW_CTL_SPINS])
+print('debug', ctl[tkr_hip.FLOW_CTL_DEBUG:tkr_hip.FLOW_CTL_DEBUG + 16].tolist())
+print('heads', ctl[0:1024:32].tolist(), 'arrive/exit', ctl[1024:1026].tolist())
 if st == 0:
     ucnt, icnt, uocc, iocc, _ = T._oracle(ref, exp, n_users, n_items, nb, B, hp)
     T._check(F, ref, ucnt, icnt, uocc, iocc)

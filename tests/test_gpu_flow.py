@@ -127,7 +127,8 @@ def _oracle(ref, exp, n_users, n_items, nb, B, hp):
 def _check(F, ref, ucnt, icnt, uocc, iocc, tol=dict(rtol=2e-4, atol=1e-5), slots=True):
     status, ctl = F.status()
     assert status == 0, 'a bounded spin ran out'
-    assert not ctl[: 8 * 32].any() and ctl[256] == 0 and ctl[257] == 0         # ticket counters left ready for the next launch
+    A = F.hip.FLOW_CTL_ARRIVE
+    assert not ctl[:A].any() and ctl[A] == 0 and ctl[A + 1] == 0                # ticket counters left ready for the next launch
     got = F.current(ucnt, icnt)
     for name in ('U', 'V', 'b'):
         np.testing.assert_allclose(got[name], ref[name], err_msg=name, **tol)

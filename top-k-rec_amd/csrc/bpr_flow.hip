@@ -6,10 +6,11 @@
 // profiles/README.md): it is carried by the data.
 //
 //   * Every table element is an 8-byte GRANULE {fp32 value, uint32 tag}; the tag is the VERSION of its row = the number
-//     of updates the row has seen.  A granule is written by one aligned 8-byte agent-scope store and read by one 8-byte
-//     agent-scope load (global_store/load_dwordx2 sc1), so a reader that sees tag == v holds a value of version v: the
-//     data is its own flag, no fence and no separate ready word (MI355X_MICROARCH.md, R2 form of the hand-off recipe;
-//     per-XCD L2s are not coherent, L1s are never refreshed: plain loads of another workgroup's stores would be stale).
+//     of updates the row has seen.  Granules are written and read as aligned 16-byte PAIRS by write-through stores and
+//     L1-bypassing loads (buffer_store/load_dwordx4 sc1); every aligned 8-byte half arrives whole, so a reader that sees
+//     tag == v holds a value of version v: the data is its own flag, no fence and no separate ready word
+//     (MI355X_MICROARCH.md, R2 form of the hand-off recipe; per-XCD L2s are not coherent, L1s are never refreshed: plain
+//     loads of another workgroup's stores would be stale).
 //   * K1 (csrc/sampler.hip resolve_flow_kernel) names, for every task, the exact version of its own row and of every
 //     partner row.  A wave takes a task, loads own row + slot + partner rows and re-loads what does not carry the
 //     wanted tags yet; rows that the preceding batches did not touch are ready at once, so batch t+1 streams its cold
@@ -24,12 +25,12 @@
 //     stores only once rd[(v+1) & 1] >= expect[(v+1) & 1] as carried by version v -- normally long true: the readers of
 //     batch t finished while batch t+1 was still loading.  (One counter for both parities would not do: early reads of
 //     v would stand in for a straggling read of v-1.)
-//   * Tasks are handed out in plan order (batch-major) by 8 ticket counters (one word saturates at ~90 tickets/us,
-//     a 256-batch needs ~500/us): task index = 8 * ticket + queue.  A wave's home queue is its arrival number & 7; it
-//     takes from home unless home runs ahead of the slowest queue, then from that one.  Every producer of a task sits
-//     in an earlier batch, i.e. holds a lower task index: the lowest untaken task is always taken next by a wave of its
-//     home queue (or a thief), and the lowest unfinished task never waits on anything unfinished: no deadlock with
-//     >= 8 running waves, whatever the dispatch order, placement or residency.  Every spin is bounded (status word).
+//   * Tasks are handed out in plan order (batch-major) by 32 ticket counters (one word saturates at ~90 tickets/us,
+//     a 256-batch needs ~500/us): task index = 32 * ticket + queue.  A wave's queue is its ARRIVAL number & 31 (an
+//     atomic at start, not its block index), so the first 32 waves that actually run cover every queue whatever the
+//     dispatch order, placement or residency, and the queues advance at the same rate.  Every producer of a task sits in
+//     an earlier batch, i.e. holds a lower task index: the lowest untaken task is the next one its queue's waves take, and
+//     the lowest unfinished task never waits on anything unfinished -- no deadlock.  Every spin is bounded (status word).
 //
 // Run-to-run results are bitwise identical (each task reads exact versions; sums run in plan order); the only float
 // atomic is the reported loss.  Against K2 the sums differ in the last bits (lane -> element mapping, heavy rows are
@@ -38,6 +39,8 @@
 // Roofline: the same algorithmic bytes as K2 (48k + 56 per triplet); granules double the bytes that
 // really move, which is irrelevant where this kernel is used (B <= 1024: latency-bound) -- large batches keep the
 // plain tables and K2.
+#include <stdlib.h>
+
 #include "tkr_common.h"
 #include "../../include/tkr.h"
 
@@ -45,46 +48,72 @@ namespace tkr {
 
 typedef unsigned long long u64;
 
-constexpr int kQueues = 8;
+constexpr int kQueues = 32;
 constexpr int kQueueStride = 32;          // uint32 words between ticket counters (one 128-byte line each)
 constexpr int kCtlArrive = kQueues * kQueueStride;
 constexpr int kCtlExit = kCtlArrive + 1;
 constexpr int kCtlStatus = kCtlArrive + 2;
 constexpr int kCtlSpins = kCtlArrive + 3;     // diagnostics: spin passes taken
 constexpr int kCtlDebug = kCtlArrive + 8;     // 16 words: what the first wave that gave up was waiting for
+constexpr int kCtlProf = kCtlArrive + 32;     // TKR_FLOW_PROFILE=1: 8 x uint64 cycle sums (grab, record, rows, war, finish, tasks, idle slots, -)
 constexpr uint32_t kSpinLimit = 1u << 20;     // passes of ONE wait (each >= ~0.3 us) before a wave gives up
-constexpr int kStealSlack = 4;                // tickets a home queue may lead the slowest queue
 
-__device__ __forceinline__ u64 ld_gran(const u64* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));      // two granules: {value0, tag0, value1, tag1}
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));      // one granule: {value, tag}
+
+// Granules travel in PAIRS: one 16-byte access per lane (buffer_load/store_dwordx4 sc1 = past the L1, write-through past
+// the L2).  8-byte write-through stores are one fabric write EACH (a 128-wide row + slot = 256 of them; measured: 17 us per
+// 256-batch); 16-byte ones go at the plain rate, and every aligned 8-byte half still arrives whole (MI355X_MICROARCH.md).
+// aux: bit 4 = sc1 (agent scope).  Not "volatile" (bit 31): that adds sc0 = system scope; the spin loop carries a
+// compiler barrier instead so that every pass really re-loads.
+constexpr int kAuxLoad = 16;
+constexpr int kAuxStore = 16;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const void* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
-__device__ __forceinline__ void st_gran_bits(u64* p, uint32_t bits, uint32_t tag) {
-    __hip_atomic_store(p, ((u64)tag << 32) | (u64)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_gran(u64* p, float v, uint32_t tag) { st_gran_bits(p, __float_as_uint(v), tag); }
-__device__ __forceinline__ float gran_val(u64 g) { return __uint_as_float((uint32_t)g); }
-__device__ __forceinline__ uint32_t gran_tag(u64 g) { return (uint32_t)(g >> 32); }
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// lane l holds elements q*64 + l of a row (512 contiguous bytes per wave instruction)
-template <int NE>
-__device__ __forceinline__ void issue_row(const u64* __restrict__ row, int lane, u64 (&x)[NE]) {
+// lane l holds elements 128*q + 2*l + {0,1} of a row: NP 16-byte loads per lane, 1 KiB contiguous per wave instruction
+template <int NP>
+__device__ __forceinline__ void issue_row(const u64* __restrict__ row, int lane, v4u (&x)[NP]) {
+    const __amdgpu_buffer_rsrc_t r = row_rsrc(row, NP * 1024);
 #pragma unroll
-    for (int q = 0; q < NE; ++q) x[q] = ld_gran(row + q * TKR_WAVE + lane);
+    for (int q = 0; q < NP; ++q) x[q] = __builtin_amdgcn_raw_buffer_load_b128(r, q * 1024 + lane * 16, 0, kAuxLoad);
 }
-template <int NE>
-__device__ __forceinline__ bool row_tagged(const u64 (&x)[NE], uint32_t tag) {
+template <int NP>
+__device__ __forceinline__ bool row_tagged(const v4u (&x)[NP], uint32_t tag) {
     bool ok = true;
 #pragma unroll
-    for (int q = 0; q < NE; ++q) ok &= gran_tag(x[q]) == tag;
+    for (int q = 0; q < NP; ++q) ok &= (x[q].y == tag) & (x[q].w == tag);
     return ok;
 }
-template <int NE>
-__device__ __forceinline__ void row_values(const u64 (&x)[NE], float (&v)[NE]) {
+template <int NP>
+__device__ __forceinline__ void row_values(const v4u (&x)[NP], float (&v)[2 * NP]) {
 #pragma unroll
-    for (int q = 0; q < NE; ++q) v[q] = gran_val(x[q]);
+    for (int q = 0; q < NP; ++q) {
+        v[2 * q] = __uint_as_float(x[q].x);
+        v[2 * q + 1] = __uint_as_float(x[q].z);
+    }
+}
+template <int NP>
+__device__ __forceinline__ void store_row(u64* __restrict__ row, int lane, const float (&v)[2 * NP], uint32_t tag) {
+    const __amdgpu_buffer_rsrc_t r = row_rsrc(row, NP * 1024);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        v4u x;
+        x.x = __float_as_uint(v[2 * q]); x.y = tag; x.z = __float_as_uint(v[2 * q + 1]); x.w = tag;
+        __builtin_amdgcn_raw_buffer_store_b128(x, r, q * 1024 + lane * 16, 0, kAuxStore);
+    }
+}
+// granule 0 of an item's tail: {bias, tag}
+__device__ __forceinline__ v2u issue_bias(const u64* __restrict__ tail) {
+    return __builtin_amdgcn_raw_buffer_load_b64(row_rsrc(tail, 32), 0, 0, kAuxLoad);
+}
+// a row's tail (4 granules = 32 bytes): `half` 0 = {bias, its slot}, 1 = {expect[0], expect[1]}
+__device__ __forceinline__ v4u issue_tail(const u64* __restrict__ tail, int half) {
+    return __builtin_amdgcn_raw_buffer_load_b128(row_rsrc(tail, 32), half * 16, 0, kAuxLoad);
 }
 
 template <int NE>
@@ -98,6 +127,29 @@ __device__ __forceinline__ void dotf2(const float (&a)[NE], const float (&b1)[NE
     }
     d1 = wave_sum(p1);
     d2 = wave_sum(p2);
+}
+
+// Sums of M per-lane values over the wave by recursive halving: lane L ends up with the total of value L >> SH,
+// SH = 6 - log2(M) (M = 16: L >> 2).  M - 1 exchanges + SH butterflies instead of 6 M: the reductions of a popular
+// item's dozen occurrences sit on the chain that limits the batch.  Fixed pattern, so results are repeatable.
+template <int M>
+__device__ __forceinline__ float reduce_multi(float (&v)[M], int lane) {
+    int D = 32;
+#pragma unroll
+    for (int m = M; m > 1; m >>= 1, D >>= 1) {
+        const int half = m >> 1;
+        const bool upper = (lane & D) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const float send = upper ? v[i] : v[i + half];
+            const float keep = upper ? v[i + half] : v[i];
+            v[i] = keep + __shfl_xor(send, D);
+        }
+    }
+    float r = v[0];
+#pragma unroll
+    for (; D >= 1; D >>= 1) r += __shfl_xor(r, D);
+    return r;
 }
 
 struct FlowTables {                       // device view of tkr_flow_state
@@ -114,6 +166,7 @@ struct Own {                              // a task's own row while it is proces
 };
 
 __device__ __forceinline__ bool spin_fail(uint32_t& spins, uint32_t* ctl) {
+    asm volatile("" ::: "memory");                 // the next pass re-loads
     __builtin_amdgcn_s_sleep(4);
     ++spins;
     if ((spins & 255u) == 0u && ld_u32(ctl + kCtlStatus) != 0u) return true;      // somebody else gave up
@@ -124,64 +177,71 @@ __device__ __forceinline__ bool spin_fail(uint32_t& spins, uint32_t* ctl) {
     return false;
 }
 
-// One group of G <= 4 occurrences of a task.  ITEM = false: the row is a user; a = positive item, b = negative item.
-// ITEM = true: the row is an item; a = user, b = the other item (bit 31 of its id: this row is the NEGATIVE item).
+// One group of n <= G occurrences of a task; lane q < n holds occurrence q in `d` = (a, version of a, b | role<<31,
+// version of b).  ITEM = false: the row is a user; a = positive item, b = negative item.  ITEM = true: the row is an item;
+// a = user, b = the other item (bit 31: this row is the NEGATIVE item).  All 2G partner rows are in flight at once -- a
+// popular item occurs a dozen times in a 256-batch, and every extra group is a memory round trip on the chain that
+// limits the whole batch.  The loads are STRAIGHT-LINE code: slots q >= n repeat occurrence 0 (hits in L2, ignored by
+// the arithmetic) -- a branch per slot makes the compiler drain the memory pipe (s_waitcnt vmcnt(0)) at every join, one
+// round trip per occurrence instead of one per group (seen in the ISA, and as 5.3 instead of 3.9 us per batch).
 // Returns false when a spin ran out.
-template <int NE, int G, bool ITEM>
-__device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowTables& T, int lane, const int4 (&oc)[4],
+template <int NP, int G, bool ITEM>
+__device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowTables& T, int lane, int n, const int4 d,
                                            const u64* own_p, const u64* own_ms, const u64* own_tail, const uint32_t* own_rd,
-                                           uint32_t own_ver, float (&own)[NE], float (&ms)[NE], Own& o, float (&g)[NE],
-                                           float& gb, float& loss_lane, float& loss_x, bool want_loss, bool sgd,
-                                           uint32_t* ctl, uint32_t& spins) {
-    // Every pass first ISSUES all loads it still needs (own row, slot, tail, rd; both partner rows and the item tails of
-    // every occurrence) and only then looks at tags: one memory round trip per pass, not one per row.
-    u64 xo[NE], xm[NE], xt = 0;
-    u64 xa[G][NE], xb[G][NE], xta[G], xtb[G];
+                                           uint32_t own_ver, float (&own)[2 * NP], float (&ms)[2 * NP], Own& o,
+                                           float (&g)[2 * NP], float& gb, float& loss_lane, float& loss_x, bool want_loss,
+                                           bool sgd, uint32_t* ctl, uint32_t& spins) {
+    constexpr int NE = 2 * NP;
+    v4u xo[NP], xm[NP], xt = {0u, 0u, 0u, 0u};
+    v4u xa[G][NP], xb[G][NP];
+    v2u xta[G], xtb[G];
     bool part_ok = false;
     uint32_t waited = 0;
     for (;;) {
+        // a pass first ISSUES every load it still needs and only then looks at tags: one round trip per pass, not per row
         if (!o.ok) {
-            issue_row<NE>(own_p, lane, xo);
-            if (!sgd) issue_row<NE>(own_ms, lane, xm);
-            xt = ld_gran(own_tail + (lane & 3));
+            issue_row<NP>(own_p, lane, xo);
+            if (!sgd) issue_row<NP>(own_ms, lane, xm);
+            xt = issue_tail(own_tail, lane & 1);
             o.rd = ld_u32(own_rd);
         }
         if (!part_ok) {
 #pragma unroll
             for (int q = 0; q < G; ++q) {
-                const int a = oc[q].x, b = oc[q].z & 0x3fffffff;
-                const uint32_t va = (uint32_t)oc[q].y, vb = (uint32_t)oc[q].w;
+                const int src = (q < n) ? q : 0;
+                const int a = bcast_i(d.x, src), b = bcast_i(d.z, src) & 0x3fffffff;
+                const uint32_t va = (uint32_t)bcast_i(d.y, src), vb = (uint32_t)bcast_i(d.w, src);
                 if constexpr (ITEM) {
-                    issue_row<NE>(T.U + (va & 1u) * T.ustride + (size_t)a * T.kp, lane, xa[q]);
-                    xta[q] = 0;
+                    issue_row<NP>(T.U + (va & 1u) * T.ustride + (size_t)a * T.kp, lane, xa[q]);
+                    xta[q] = v2u{0u, va};
                 } else {
-                    issue_row<NE>(T.V + (va & 1u) * T.istride + (size_t)a * T.kp, lane, xa[q]);
-                    xta[q] = ld_gran(T.tailV + ((size_t)(va & 1u) * st.n_items + a) * 4);
+                    issue_row<NP>(T.V + (va & 1u) * T.istride + (size_t)a * T.kp, lane, xa[q]);
+                    xta[q] = issue_bias(T.tailV + ((size_t)(va & 1u) * st.n_items + a) * 4);
                 }
-                issue_row<NE>(T.V + (vb & 1u) * T.istride + (size_t)b * T.kp, lane, xb[q]);
-                xtb[q] = ld_gran(T.tailV + ((size_t)(vb & 1u) * st.n_items + b) * 4);
+                issue_row<NP>(T.V + (vb & 1u) * T.istride + (size_t)b * T.kp, lane, xb[q]);
+                xtb[q] = issue_bias(T.tailV + ((size_t)(vb & 1u) * st.n_items + b) * 4);
             }
         }
         if (!o.ok) {
-            bool lane_own = row_tagged<NE>(xo, own_ver) && gran_tag(xt) == own_ver;
-            if (!sgd) lane_own = lane_own && row_tagged<NE>(xm, own_ver);
+            bool lane_own = row_tagged<NP>(xo, own_ver) && xt.y == own_ver && xt.w == own_ver;
+            if (!sgd) lane_own = lane_own && row_tagged<NP>(xm, own_ver);
             if (__all(lane_own)) {
                 o.ok = true;
-                row_values<NE>(xo, own);
-                if (!sgd) row_values<NE>(xm, ms);
-                o.b = bcast_f(gran_val(xt), 0);
-                o.msb = bcast_f(gran_val(xt), 1);
-                o.exp_even = (uint32_t)bcast_i((int)(uint32_t)xt, 2);
-                o.exp_odd = (uint32_t)bcast_i((int)(uint32_t)xt, 3);
+                row_values<NP>(xo, own);
+                if (!sgd) row_values<NP>(xm, ms);
+                o.b = bcast_f(__uint_as_float(xt.x), 0);
+                o.msb = bcast_f(__uint_as_float(xt.z), 0);
+                o.exp_even = (uint32_t)bcast_i((int)xt.x, 1);
+                o.exp_odd = (uint32_t)bcast_i((int)xt.z, 1);
             }
         }
         if (!part_ok) {
             bool lane_part = true;
 #pragma unroll
             for (int q = 0; q < G; ++q) {
-                const uint32_t va = (uint32_t)oc[q].y, vb = (uint32_t)oc[q].w;
-                lane_part = lane_part && row_tagged<NE>(xa[q], va) && row_tagged<NE>(xb[q], vb) && gran_tag(xtb[q]) == vb;
-                if constexpr (!ITEM) lane_part = lane_part && gran_tag(xta[q]) == va;
+                const int src = (q < n) ? q : 0;
+                const uint32_t va = (uint32_t)bcast_i(d.y, src), vb = (uint32_t)bcast_i(d.w, src);
+                lane_part = lane_part && row_tagged<NP>(xa[q], va) && row_tagged<NP>(xb[q], vb) && xtb[q].y == vb && xta[q].y == va;
             }
             part_ok = __all(lane_part);
         }
@@ -192,137 +252,153 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
                 ctl[kCtlDebug + 1] = o.ok;
                 ctl[kCtlDebug + 2] = part_ok;
                 ctl[kCtlDebug + 3] = own_ver;
-                ctl[kCtlDebug + 4] = gran_tag(xo[0]);
-                ctl[kCtlDebug + 5] = gran_tag(xt);
-                ctl[kCtlDebug + 6] = (uint32_t)oc[0].x;
-                ctl[kCtlDebug + 7] = (uint32_t)oc[0].y;
-                ctl[kCtlDebug + 8] = gran_tag(xa[0][0]);
-                ctl[kCtlDebug + 9] = (uint32_t)oc[0].z;
-                ctl[kCtlDebug + 10] = (uint32_t)oc[0].w;
-                ctl[kCtlDebug + 11] = gran_tag(xb[0][0]);
-                ctl[kCtlDebug + 12] = gran_tag(xtb[0]);
+                ctl[kCtlDebug + 4] = xo[0].y;
+                ctl[kCtlDebug + 5] = xt.y;
+                ctl[kCtlDebug + 6] = (uint32_t)d.x;
+                ctl[kCtlDebug + 7] = (uint32_t)d.y;
+                ctl[kCtlDebug + 8] = xa[0][0].y;
+                ctl[kCtlDebug + 9] = (uint32_t)d.z;
+                ctl[kCtlDebug + 10] = (uint32_t)d.w;
+                ctl[kCtlDebug + 11] = xb[0][0].y;
+                ctl[kCtlDebug + 12] = xtb[0].y;
                 ctl[kCtlDebug + 13] = ITEM;
-                ctl[kCtlDebug + 14] = G;
-                ctl[kCtlDebug + 15] = sgd ? 0u : gran_tag(xm[0]);
+                ctl[kCtlDebug + 14] = (uint32_t)n;
+                ctl[kCtlDebug + 15] = sgd ? 0u : xm[0].y;
             }
             return false;
         }
     }
     spins += waited;
-    float pa[G][NE], pb[G][NE], ta[G], tb[G];
-#pragma unroll
-    for (int q = 0; q < G; ++q) {
-        row_values<NE>(xa[q], pa[q]);
-        row_values<NE>(xb[q], pb[q]);
-        ta[q] = gran_val(xta[q]);
-        tb[q] = gran_val(xtb[q]);
-    }
 
+    // x_t of every occurrence: one dot product each (user row: <u, v_i - v_j>; item row: <u, v_row - v_other>,
+    // single/bpr.py:87-89), all reduced together; lane L then holds occurrence L >> SH and the sigmoids run side by side
+    constexpr int SH = G <= 4 ? 4 : (G == 8 ? 3 : 2);
+    static_assert(G <= 4 || G == 8 || G == 16, "group width");
     const bool l2 = (st.mode == 0);
+    float part[G];
 #pragma unroll
     for (int q = 0; q < G; ++q) {
-        if constexpr (!ITEM) {
-            // x = b_i - b_j + <u, v_i> - <u, v_j>     (single/bpr.py:87-89)
-            float xui, xuj;
-            dotf2<NE>(own, pa[q], pb[q], xui, xuj);
-            const float x = ta[q] - tb[q] + xui - xuj;
-            const float s = sigmoid_neg(x);
-            if (want_loss) loss_x += softplus_neg(x);
-            if (l2) {
+        float acc = 0.f;
+        if (q < n) {
 #pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    g[e] += -s * (pa[q][e] - pb[q][e]) + st.lu * own[e];
-                    if (want_loss)
-                        loss_lane += 0.5f * (own[e] * own[e] * st.lu + pa[q][e] * pa[q][e] * st.li + pb[q][e] * pb[q][e] * st.lj);
+            for (int p = 0; p < NP; ++p) {
+                const float a0 = __uint_as_float(xa[q][p].x), a1 = __uint_as_float(xa[q][p].z);
+                const float b0 = __uint_as_float(xb[q][p].x), b1 = __uint_as_float(xb[q][p].z);
+                if constexpr (ITEM) {
+                    acc = fmaf(a0, own[2 * p] - b0, acc);
+                    acc = fmaf(a1, own[2 * p + 1] - b1, acc);
+                } else {
+                    acc = fmaf(own[2 * p], a0 - b0, acc);
+                    acc = fmaf(own[2 * p + 1], a1 - b1, acc);
                 }
-                if (want_loss) loss_x += 0.5f * (ta[q] * ta[q] + tb[q] * tb[q]) * st.lb;
-            } else {
-#pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    g[e] += -s * (pa[q][e] - pb[q][e]) + st.lu * sgn(own[e]);
-                    if (want_loss) loss_lane += fabsf(own[e]) * st.lu + fabsf(pa[q][e]) * st.li + fabsf(pb[q][e]) * st.lj;
-                }
-                if (want_loss) loss_x += (fabsf(ta[q]) + fabsf(tb[q])) * st.lb;
             }
-        } else {
-            const bool role_j = oc[q].z < 0;
-            float dr, dn;                                  // <u, v_row>, <u, v_other>
-            dotf2<NE>(pa[q], own, pb[q], dr, dn);
-            const float br = o.b, bo = tb[q];
-            const float x = role_j ? (bo - br + dn - dr) : (br - bo + dr - dn);
-            const float s = sigmoid_neg(x);
-            const float sg = role_j ? s : -s;
-            const float lam = role_j ? st.lj : st.li;
-            if (l2) {
+        }
+        part[q] = acc;
+    }
+    float dotv;
+    const int myq = lane >> SH;
+    if constexpr (G <= 4) {                      // few values: DPP trees (cross-lane permutes cost ~100 cycles per stage)
+        dotv = 0.f;
 #pragma unroll
-                for (int e = 0; e < NE; ++e) g[e] += sg * pa[q][e] + lam * own[e];
-                gb += sg + st.lb * br;
+        for (int q = 0; q < G; ++q) {
+            if (q < n) {
+                const float t = wave_sum(part[q]);
+                if (myq == q) dotv = t;
+            }
+        }
+    } else {
+        dotv = reduce_multi<G>(part, lane);
+    }
+    float bd = 0.f, ta_me = 0.f, tb_me = 0.f;
+    bool role_me = false;
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        if (myq == q) {
+            ta_me = __uint_as_float(xta[q].x);
+            tb_me = __uint_as_float(xtb[q].x);
+        }
+    }
+    if constexpr (ITEM) {
+        role_me = __shfl(d.z, myq) < 0;
+        bd = o.b - tb_me;
+    } else {
+        bd = ta_me - tb_me;
+    }
+    const float x_me = (ITEM && role_me) ? -(bd + dotv) : (bd + dotv);
+    const float s_me = sigmoid_neg(x_me);
+    if constexpr (!ITEM) {
+        if (want_loss && myq < n && (lane & ((1 << SH) - 1)) == 0) {
+            loss_lane += softplus_neg(x_me);
+            loss_lane += l2 ? 0.5f * (ta_me * ta_me + tb_me * tb_me) * st.lb : (fabsf(ta_me) + fabsf(tb_me)) * st.lb;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        if (q < n) {
+            float pa[NE], pb[NE];
+            row_values<NP>(xa[q], pa);
+            const float s = bcast_f(s_me, q << SH);
+            if constexpr (!ITEM) {
+                row_values<NP>(xb[q], pb);
+                if (l2) {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        g[e] += -s * (pa[e] - pb[e]) + st.lu * own[e];
+                        if (want_loss) loss_lane += 0.5f * (own[e] * own[e] * st.lu + pa[e] * pa[e] * st.li + pb[e] * pb[e] * st.lj);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        g[e] += -s * (pa[e] - pb[e]) + st.lu * sgn(own[e]);
+                        if (want_loss) loss_lane += fabsf(own[e]) * st.lu + fabsf(pa[e]) * st.li + fabsf(pb[e]) * st.lj;
+                    }
+                }
             } else {
+                const bool role_j = bcast_i(d.z, q) < 0;
+                const float sg = role_j ? s : -s;
+                const float lam = role_j ? st.lj : st.li;
+                if (l2) {
 #pragma unroll
-                for (int e = 0; e < NE; ++e) g[e] += sg * pa[q][e] + lam * sgn(own[e]);
-                gb += sg + st.lb * sgn(br);
+                    for (int e = 0; e < NE; ++e) g[e] += sg * pa[e] + lam * own[e];
+                    gb += sg + st.lb * o.b;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) g[e] += sg * pa[e] + lam * sgn(own[e]);
+                    gb += sg + st.lb * sgn(o.b);
+                }
             }
         }
     }
 
-    // acknowledge the partner reads of this group: one add per (occurrence, partner) on the partner row's rd word
-    uint32_t* ack = nullptr;
-#pragma unroll
-    for (int q = 0; q < G; ++q) {
-        uint32_t* pa_rd = (ITEM ? T.rdU : T.rdV) + 2 * (size_t)oc[q].x + (oc[q].y & 1);
-        uint32_t* pb_rd = T.rdV + 2 * (size_t)(oc[q].z & 0x3fffffff) + (oc[q].w & 1);
-        if (lane == 2 * q) ack = pa_rd;
-        if (lane == 2 * q + 1) ack = pb_rd;
+    // acknowledge the partner reads of this group: lane q adds one to rd[version & 1] of both partner rows of occurrence q
+    if (lane < n) {
+        uint32_t* pa_rd = (ITEM ? T.rdU : T.rdV) + 2 * (size_t)d.x + (d.y & 1);
+        uint32_t* pb_rd = T.rdV + 2 * (size_t)(d.z & 0x3fffffff) + (d.w & 1);
+        __hip_atomic_fetch_add(pa_rd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(pb_rd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (lane < 2 * G) __hip_atomic_fetch_add(ack, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
 
-template <int NE, bool ITEM>
-__device__ __forceinline__ bool flow_groups(const tkr_flow_state& st, const FlowTables& T, int lane, int n,
-                                            const int4 (&oc)[4], const u64* own_p, const u64* own_ms, const u64* own_tail,
-                                            const uint32_t* own_rd, uint32_t own_ver, float (&own)[NE], float (&ms)[NE],
-                                            Own& o, float (&g)[NE], float& gb, float& loss_lane, float& loss_x,
-                                            bool want_loss, bool sgd, uint32_t* ctl, uint32_t& spins) {
-    switch (n) {
-        case 1: return flow_group<NE, 1, ITEM>(st, T, lane, oc, own_p, own_ms, own_tail, own_rd, own_ver, own, ms, o, g, gb, loss_lane, loss_x, want_loss, sgd, ctl, spins);
-        case 2: return flow_group<NE, 2, ITEM>(st, T, lane, oc, own_p, own_ms, own_tail, own_rd, own_ver, own, ms, o, g, gb, loss_lane, loss_x, want_loss, sgd, ctl, spins);
-        case 3: return flow_group<NE, 3, ITEM>(st, T, lane, oc, own_p, own_ms, own_tail, own_rd, own_ver, own, ms, o, g, gb, loss_lane, loss_x, want_loss, sgd, ctl, spins);
-        default: return flow_group<NE, 4, ITEM>(st, T, lane, oc, own_p, own_ms, own_tail, own_rd, own_ver, own, ms, o, g, gb, loss_lane, loss_x, want_loss, sgd, ctl, spins);
-    }
-}
-
-// next task index of this wave, or 0xffffffff when every queue is exhausted
+// next task index of this wave, or 0xffffffff when its queue is exhausted: ONE returning atomic per task on the wave's
+// home counter.  (A first version also read all counters to steal from a lagging queue: 768 tasks x 8 loads per batch on
+// 8 lines that are being atomically updated serialise at the atomic rate -- measured 10 us per grab.)
 __device__ __forceinline__ uint32_t grab(uint32_t* ctl, int lane, int home, uint32_t total) {
-    for (;;) {
-        const uint32_t h = (lane < kQueues) ? ld_u32(ctl + lane * kQueueStride) : 0xffffffffu;
-        uint32_t best = 0xffffffffu, mine = 0xffffffffu;
-        int bq = -1;
-#pragma unroll
-        for (int q = 0; q < kQueues; ++q) {
-            const uint32_t hq = (uint32_t)bcast_i((int)h, q);
-            const bool live = (u64)hq * kQueues + q < total;
-            if (q == home && live) mine = hq;
-            if (live && hq < best) { best = hq; bq = q; }             // lowest queue index among equal heads
-        }
-        if (bq < 0) return 0xffffffffu;
-        const int q = (mine != 0xffffffffu && mine <= best + kStealSlack) ? home : bq;
-        uint32_t t = 0;
-        if (lane == 0) t = __hip_atomic_fetch_add(ctl + q * kQueueStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t = (uint32_t)bcast_i((int)t, 0);
-        const u64 idx = (u64)t * kQueues + q;
-        if (idx < total) return (uint32_t)idx;
-        // this queue ran dry between the look and the take: look again (its head now shows it)
-    }
+    uint32_t t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(ctl + home * kQueueStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = (uint32_t)bcast_i((int)t, 0);
+    const u64 idx = (u64)t * kQueues + home;
+    return idx < total ? (uint32_t)idx : 0xffffffffu;
 }
 
-template <int NE>
+template <int NP, bool PROF = false>
 __global__ __launch_bounds__(256) void bpr_flow_kernel(tkr_flow_state st, const int4* __restrict__ prec,
                                                        const int4* __restrict__ pocc, uint32_t total,
                                                        uint32_t* __restrict__ ctl, float* __restrict__ loss_out) {
+    constexpr int NE = 2 * NP;
     const int lane = threadIdx.x & (TKR_WAVE - 1);
     FlowTables T;
-    T.kp = NE * TKR_WAVE;
+    T.kp = NP * 128;
     T.ustride = (size_t)st.n_users * T.kp;
     T.istride = (size_t)st.n_items * T.kp;
     T.U = reinterpret_cast<u64*>(st.U); T.msU = reinterpret_cast<u64*>(st.msU); T.tailU = reinterpret_cast<u64*>(st.tailU);
@@ -337,13 +413,24 @@ __global__ __launch_bounds__(256) void bpr_flow_kernel(tkr_flow_state st, const 
     uint32_t spins = 0;
     bool alive = true;
 
+    u64 prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 tq = 0;
+#define TKR_PROF_MARK(slot)                                   \
+    if constexpr (PROF) {                                     \
+        const u64 now_ = __builtin_amdgcn_s_memtime();        \
+        prof[slot] += now_ - tq;                              \
+        tq = now_;                                            \
+    }
+    if constexpr (PROF) tq = __builtin_amdgcn_s_memtime();
     while (alive) {
         const uint32_t idx = grab(ctl, lane, home, total);
+        TKR_PROF_MARK(0)
         if (idx == 0xffffffffu) break;
         const int4* r = prec + (size_t)idx * 8;
         const int4 w = (lane < 8) ? r[lane] : make_int4(0, 0, 0, 0);      // 128-byte record, one int4 per lane
         const int rowk = bcast_i(w.x, 0);
-        if (rowk == -1) continue;                                          // unused slot of its batch
+        TKR_PROF_MARK(1)
+        if (rowk == -1) { if constexpr (PROF) prof[6] += 1; continue; }    // unused slot of its batch
         const uint32_t ver = (uint32_t)bcast_i(w.y, 0);
         const int n_occ = bcast_i(w.z, 0);
         const int first = bcast_i(w.w, 0);
@@ -365,27 +452,34 @@ __global__ __launch_bounds__(256) void bpr_flow_kernel(tkr_flow_state st, const 
         Own o = {0.f, 0.f, 0u, 0u, 0u, false};
         float gb = 0.f, loss_lane = 0.f, loss_x = 0.f;
 
-        for (int done = 0; done < n_occ && alive; done += 4) {
-            const int n = min(4, n_occ - done);
-            int4 oc[4];
-            if (done == 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    oc[q] = make_int4(bcast_i(w.x, 2 + q), bcast_i(w.y, 2 + q), bcast_i(w.z, 2 + q), bcast_i(w.w, 2 + q));
-            } else {                              // rows with more than 4 occurrences: the next 4 from the occurrence list
-                int4 x = make_int4(0, 0, 0, 0);
-                if (lane < n) x = pocc[first + done + lane];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) oc[q] = make_int4(bcast_i(x.x, q), bcast_i(x.y, q), bcast_i(x.z, q), bcast_i(x.w, q));
+        const u64* own_tail = tabT + ((size_t)(ver & 1u) * n_rows + row) * 4;
+#define TKR_FLOW_GROUP(GG, nn, dd)                                                                                             \
+    (is_item ? flow_group<NP, GG, true>(st, T, lane, nn, dd, tabP + roff, tabM + roff, own_tail, own_rd, ver, own, ms, o, g, gb,   \
+                                        loss_lane, loss_x, false, sgd, ctl, spins)                                              \
+             : flow_group<NP, GG, false>(st, T, lane, nn, dd, tabP + roff, tabM + roff, own_tail, own_rd, ver, own, ms, o, g, gb,  \
+                                         loss_lane, loss_x, want_loss, sgd, ctl, spins))
+        if (n_occ <= 4) {                         // the common case: its occurrences sit in the record (lanes 2..5)
+            const int src = (lane + 2) & 7;
+            const int4 d = make_int4(__shfl(w.x, src), __shfl(w.y, src), __shfl(w.z, src), __shfl(w.w, src));
+            switch (n_occ) {
+                case 1: alive = TKR_FLOW_GROUP(1, 1, d); break;
+                case 2: alive = TKR_FLOW_GROUP(2, 2, d); break;
+                case 3: alive = TKR_FLOW_GROUP(3, 3, d); break;
+                default: alive = TKR_FLOW_GROUP(4, 4, d); break;
             }
-            const bool okg = is_item
-                ? flow_groups<NE, true>(st, T, lane, n, oc, tabP + roff, tabM + roff, tabT + ((size_t)(ver & 1u) * n_rows + row) * 4,
-                                        own_rd, ver, own, ms, o, g, gb, loss_lane, loss_x, false, sgd, ctl, spins)
-                : flow_groups<NE, false>(st, T, lane, n, oc, tabP + roff, tabM + roff, tabT + ((size_t)(ver & 1u) * n_rows + row) * 4,
-                                         own_rd, ver, own, ms, o, g, gb, loss_lane, loss_x, want_loss, sgd, ctl, spins);
-            if (!okg) alive = false;
+        } else {                                  // popular rows: up to kBig occurrences per pass from the occurrence list
+            constexpr int kBig = NP == 1 ? 16 : 8;
+            for (int done = 0; done < n_occ && alive; done += kBig) {
+                const int n = min(kBig, n_occ - done);
+                int4 d = make_int4(0, 0, 0, 0);
+                if (lane < n) d = pocc[first + done + lane];
+                if (kBig == 16 && n > 8) alive = TKR_FLOW_GROUP(kBig, n, d);
+                else alive = TKR_FLOW_GROUP(8, n, d);
+            }
         }
+#undef TKR_FLOW_GROUP
         if (!alive) break;
+        TKR_PROF_MARK(2)
 
         if (!is_item && want_loss) {
             const float tot = wave_sum(loss_lane) + loss_x;
@@ -407,9 +501,12 @@ __global__ __launch_bounds__(256) void bpr_flow_kernel(tkr_flow_state st, const 
         }
         spins += waited;
         if (!alive) break;
+        TKR_PROF_MARK(3)
 
         const uint32_t nv = ver + 1u;
         float pn[NE], mn[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) mn[e] = 0.f;
         float bn, mbn = 0.f;
         if (sgd) {                                  // old/methods/bpr.py:57-61: P <- P - lr * dcost/dP
 #pragma unroll
@@ -425,20 +522,27 @@ __global__ __launch_bounds__(256) void bpr_flow_kernel(tkr_flow_state st, const 
             mbn = st.rho * o.msb + (1.f - st.rho) * gb * gb;
             bn = o.b - st.lr * gb / sqrtf(mbn + st.eps);
         }
-#pragma unroll
-        for (int e = 0; e < NE; ++e) st_gran(tabP + woff + e * TKR_WAVE + lane, pn[e], nv);
-        if (!sgd) {
-#pragma unroll
-            for (int e = 0; e < NE; ++e) st_gran(tabM + woff + e * TKR_WAVE + lane, mn[e], nv);
+        store_row<NP>(tabP + woff, lane, pn, nv);
+        if (!sgd) store_row<NP>(tabM + woff, lane, mn, nv);
+        if (lane < 2) {                             // tail = {bias, its slot | expect[0], expect[1]}
+            v4u tv;
+            tv.y = nv; tv.w = nv;
+            if (lane == 0) {
+                tv.x = is_item ? __float_as_uint(bn) : 0u;
+                tv.z = is_item ? __float_as_uint(mbn) : 0u;
+            } else {                                // this batch read version ver: its parity's total grows by 2 per occurrence
+                tv.x = o.exp_even + ((ver & 1u) ? 0u : 2u * (uint32_t)n_occ);
+                tv.z = o.exp_odd + ((ver & 1u) ? 2u * (uint32_t)n_occ : 0u);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(tv, row_rsrc(tabT + ((size_t)(nv & 1u) * n_rows + row) * 4, 32), lane * 16, 0, kAuxStore);
         }
-        if (lane < 4) {
-            uint32_t tv = 0u;                       // tail = {bias, its slot, expect[0], expect[1]}
-            if (lane == 0) tv = is_item ? __float_as_uint(bn) : 0u;
-            if (lane == 1) tv = is_item ? __float_as_uint(mbn) : 0u;
-            if (lane == 2) tv = o.exp_even + ((ver & 1u) ? 0u : 2u * (uint32_t)n_occ);      // this batch read version ver
-            if (lane == 3) tv = o.exp_odd + ((ver & 1u) ? 2u * (uint32_t)n_occ : 0u);
-            st_gran_bits(tabT + ((size_t)(nv & 1u) * n_rows + row) * 4 + lane, tv, nv);
-        }
+        if constexpr (PROF) prof[5] += 1;
+        TKR_PROF_MARK(4)
+    }
+#undef TKR_PROF_MARK
+    if constexpr (PROF) {
+        if (lane == 0)
+            for (int q = 0; q < 8; ++q) atomicAdd(reinterpret_cast<u64*>(ctl + kCtlProf) + q, prof[q]);
     }
 
     if (lane == 0) {
@@ -455,8 +559,8 @@ __global__ __launch_bounds__(256) void bpr_flow_kernel(tkr_flow_state st, const 
 
 }  // namespace tkr
 
-extern "C" int32_t tkr_flow_row_granules(int32_t k) { return (k + TKR_WAVE - 1) / TKR_WAVE * TKR_WAVE; }
-extern "C" int32_t tkr_flow_ctl_words(void) { return tkr::kCtlArrive + 32; }
+extern "C" int32_t tkr_flow_row_granules(int32_t k) { return (k + 127) / 128 * 128; }
+extern "C" int32_t tkr_flow_ctl_words(void) { return tkr::kCtlArrive + 64; }
 
 extern "C" int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, int32_t batch_size,
                                 int32_t n_batches, uint32_t* ctl, float* loss_out, int32_t waves_per_cu, void* stream) {
@@ -473,9 +577,8 @@ extern "C" int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, c
     int dev = 0, cus = 0;
     TKR_CHECK(hipGetDevice(&dev));
     TKR_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int ne = (st->k + TKR_WAVE - 1) / TKR_WAVE;
-    const void* fn = ne == 1 ? (const void*)tkr::bpr_flow_kernel<1> : ne == 2 ? (const void*)tkr::bpr_flow_kernel<2>
-                   : ne == 3 ? (const void*)tkr::bpr_flow_kernel<3> : (const void*)tkr::bpr_flow_kernel<4>;
+    const int np = (st->k + 127) / 128;
+    const void* fn = np == 1 ? (const void*)tkr::bpr_flow_kernel<1, false> : (const void*)tkr::bpr_flow_kernel<2, false>;
     int per_cu = 0;
     TKR_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0));
     if (per_cu < 1) return TKR_EUNSUPPORTED;
@@ -484,16 +587,17 @@ extern "C" int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, c
     if (want > per_cu - (per_cu > 2 ? 1 : 0)) want = per_cu - (per_cu > 2 ? 1 : 0);   // stay inside what is resident at once
     uint32_t grid = (uint32_t)(want * cus);
     const uint32_t need = (total + 3) / 4;                           // never more waves than tasks
-    if (grid > need) grid = need < 2 ? 2 : need;                     // >= 8 waves: every home queue has a wave
+    if (grid > need) grid = need;
+    if (grid < 8) grid = 8;                                          // >= 32 waves: every queue has a wave
     hipStream_t s = (hipStream_t)stream;
     const int4* r4 = reinterpret_cast<const int4*>(prec);
     const int4* o4 = reinterpret_cast<const int4*>(pocc);
-    switch (ne) {
-        case 1: hipLaunchKernelGGL(tkr::bpr_flow_kernel<1>, dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out); break;
-        case 2: hipLaunchKernelGGL(tkr::bpr_flow_kernel<2>, dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out); break;
-        case 3: hipLaunchKernelGGL(tkr::bpr_flow_kernel<3>, dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out); break;
-        default: hipLaunchKernelGGL(tkr::bpr_flow_kernel<4>, dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out); break;
-    }
+    static const bool prof = getenv("TKR_FLOW_PROFILE") && getenv("TKR_FLOW_PROFILE")[0] == '1';     // cycle sums into ctl (scripts/probe_flow_bench.py)
+    if (prof) {
+        if (np == 1) hipLaunchKernelGGL((tkr::bpr_flow_kernel<1, true>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out);
+        else hipLaunchKernelGGL((tkr::bpr_flow_kernel<2, true>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out);
+    } else if (np == 1) hipLaunchKernelGGL((tkr::bpr_flow_kernel<1, false>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out);
+    else hipLaunchKernelGGL((tkr::bpr_flow_kernel<2, false>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out);
     TKR_LAUNCH_CHECK();
     return TKR_OK;
 }

@@ -165,7 +165,8 @@ def flow_ctl_words():
     return int(lib().tkr_flow_ctl_words())
 
 
-FLOW_CTL_STATUS, FLOW_CTL_SPINS = 258, 259      # TKR_FLOW_CTL_* of include/tkr.h
+FLOW_CTL_ARRIVE, FLOW_CTL_STATUS, FLOW_CTL_SPINS = 1024, 1026, 1027      # TKR_FLOW_CTL_* of include/tkr.h (32 ticket counters, 32 words apart, come first)
+FLOW_CTL_DEBUG, FLOW_CTL_PROF = 1032, 1056       # post-mortem of a timed-out wait (16 words); TKR_FLOW_PROFILE=1 cycle sums (8 x uint64)
 
 
 def bpr_flow_run(state, plan, B, n_batches, ctl, loss_out=None, first=0, waves_per_cu=0):
