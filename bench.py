@@ -394,10 +394,11 @@ def main():
                                                                         r['n_users'], r['n_in'] + r['n_out'], nnz, k, B),
                    'batch_size': B, 'k': k, 'sharding': 'users sharded over %d GPU(s), item tables replicated, '
                                                         'all-reduce every %d steps' % (world, sync_every) if world > 1 else 'single GPU'},
-        'roofline': {'kernel': 'tkr::bpr_step_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'roofline': {'kernel': 'tkr::bpr_flow_kernel (one persistent launch per chunk of batches)' if eng.layout == 'flow' else 'tkr::bpr_step_kernel',
+                     'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                      'traffic_from_profile': pmc_traffic('bpr_step_B%d' % B) if (k == 128 and args.shape == 'ml10m') else None,
-                     'launch_us': launch_us,
+                     'launch_us': launch_us,          # per BATCH: the persistent kernel's launch covers many batches, duration / batches
                      'algorithmic_bytes_per_launch': B * algorithmic_bytes_per_triplet(k)},
     }
     if rank == 0 and world == 1 and not args.no_extras:

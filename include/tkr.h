@@ -116,8 +116,9 @@ int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ,
  * A freshly assigned table holds version 0 in buffer 0 (all tags 0, expects 0, rd 0) and tags 0xffffffff in buffer 1.
  * The plan is tkr_sample_plan's dataflow form (prec / pocc non-NULL there): `prec` points at the record of the first
  * task of the first batch to run, `pocc` and `loss_out` (nullable, pre-zeroed) at batch 0 of that plan call.
- * ctl: tkr_flow_ctl_words() uint32 of caller-owned device memory, zeroed once; the kernel leaves the ticket counters
- * zeroed for the next launch; ctl[status word] != 0 after a launch means a bounded spin ran out (results invalid).
+ * ctl: tkr_flow_ctl_words() uint32 of caller-owned device memory, zeroed once by the caller (the call itself re-zeroes
+ * the ticket counters on the stream before the launch); ctl[status word] != 0 after a launch means a bounded spin ran
+ * out (results invalid).
  * waves_per_cu: 0 = default.  k <= 256, 3 * batch_size * n_batches < 2^29. */
 typedef struct {
     void* U;

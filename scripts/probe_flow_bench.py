@@ -7,7 +7,7 @@ import bench, tkr_hip
 from single import _engine
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-waves = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [8]
+waves = [int(x, 0) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [8]     # 0xTTWW: tune bits TT, waves per CU WW
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 dev = torch.device('cuda', 0)
 r, csr, eng, nnz = bench.build_problem('ml10m', 128, 0, 1, dev)
@@ -26,7 +26,7 @@ for w in waves:
     wall = time.perf_counter() - t0
     eng.check()
     spins = int(eng.ctl[tkr_hip.FLOW_CTL_SPINS])
-    print('B %d waves/CU %2d: %.2f us/batch (events %.2f), %.1f M triplets/s, %.1f spin passes per task' %
+    print('B %d waves/CU 0x%04x: %.2f us/batch (events %.2f), %.1f M triplets/s, %.1f spin passes per task' %
           (B, w, wall / steps * 1e6, e0.elapsed_time(e1) * 1e3 / steps, steps * B / wall / 1e6, spins / (steps * 3.0 * B)), flush=True)
     if os.environ.get('TKR_FLOW_PROFILE') == '1':
         pr = eng.ctl[tkr_hip.FLOW_CTL_PROF:tkr_hip.FLOW_CTL_PROF + 16].cpu().numpy().view(np.uint64)

@@ -51,7 +51,8 @@ def test_integration_md_sequence():
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     assert lib.tkr_sample_plan(ptr(tr_users), len(tr_users_l), ptr(row_ptr), ptr(pos_cols), ptr(cols_sorted), n_users, n_items,
                                C.c_uint64(seed), C.c_uint64(0), None, nb, B, ptr(ucnt), ptr(icnt), ptr(touch_u), ptr(touch_i),
-                               ptr(out_u), ptr(out_i), ptr(out_j), ptr(task), ptr(occ), ptr(rec), ptr(hdr), ptr(occt), None, stream) == 0
+                               ptr(out_u), ptr(out_i), ptr(out_j), ptr(task), ptr(occ), ptr(rec), ptr(hdr), ptr(occt), None, None, None,
+                               stream) == 0                                # tpar, prec, pocc unused: one launch per batch (K2)
     assert lib.tkr_bpr_run(C.byref(st), ptr(rec), ptr(occ), ptr(hdr), B, nb, ptr(loss), stream) == 0
     torch.cuda.synchronize()
     u, i, j = P.sample_triplets(tr_users_l, row_ptr_n, pos_n, srt_n, n_items, seed, 0, nb * B)

@@ -51,7 +51,6 @@ typedef unsigned long long u64;
 constexpr int kQueues = 32;
 constexpr int kQueueStride = 32;          // uint32 words between ticket counters (one 128-byte line each)
 constexpr int kCtlArrive = kQueues * kQueueStride;
-constexpr int kCtlExit = kCtlArrive + 1;
 constexpr int kCtlStatus = kCtlArrive + 2;
 constexpr int kCtlSpins = kCtlArrive + 3;     // diagnostics: spin passes taken
 constexpr int kCtlDebug = kCtlArrive + 8;     // 16 words: what the first wave that gave up was waiting for
@@ -152,11 +151,19 @@ __device__ __forceinline__ float reduce_multi(float (&v)[M], int lane) {
     return r;
 }
 
+// sigma(-x) on the hardware exp / rcp (1 ulp each): this sits on the chain through the most popular rows
+__device__ __forceinline__ float fast_sigmoid_neg(float x) {
+    const float e = __expf(-fabsf(x));
+    const float r = __builtin_amdgcn_rcpf(1.f + e);
+    return x >= 0.f ? e * r : r;
+}
+
 struct FlowTables {                       // device view of tkr_flow_state
     u64 *U, *msU, *tailU, *V, *msV, *tailV;
     uint32_t *rdU, *rdV;
     size_t ustride, istride;              // granules per buffer
     int kp;
+    uint32_t tune;                        // experiment switches (scripts/probe_flow_bench.py): bit 0 late acks, bit 1 nap while only the own row is missing
 };
 
 struct Own {                              // a task's own row while it is processed
@@ -165,9 +172,9 @@ struct Own {                              // a task's own row while it is proces
     bool ok;
 };
 
-__device__ __forceinline__ bool spin_fail(uint32_t& spins, uint32_t* ctl) {
+__device__ __forceinline__ bool spin_fail(uint32_t& spins, uint32_t* ctl, int nap = 4) {
     asm volatile("" ::: "memory");                 // the next pass re-loads
-    __builtin_amdgcn_s_sleep(4);
+    if (nap) __builtin_amdgcn_s_sleep(4);
     ++spins;
     if ((spins & 255u) == 0u && ld_u32(ctl + kCtlStatus) != 0u) return true;      // somebody else gave up
     if (spins >= kSpinLimit) {
@@ -203,8 +210,8 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
             issue_row<NP>(own_p, lane, xo);
             if (!sgd) issue_row<NP>(own_ms, lane, xm);
             xt = issue_tail(own_tail, lane & 1);
-            o.rd = ld_u32(own_rd);
         }
+        o.rd = ld_u32(own_rd);                      // every pass: as fresh as the rows when the last one validates
         if (!part_ok) {
 #pragma unroll
             for (int q = 0; q < G; ++q) {
@@ -243,10 +250,21 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
                 const uint32_t va = (uint32_t)bcast_i(d.y, src), vb = (uint32_t)bcast_i(d.w, src);
                 lane_part = lane_part && row_tagged<NP>(xa[q], va) && row_tagged<NP>(xb[q], vb) && xtb[q].y == vb && xta[q].y == va;
             }
-            part_ok = __all(lane_part);
+            if (__all(lane_part)) {
+                part_ok = true;
+                // The partner rows are in registers: acknowledge the reads NOW (lane q: one add on rd[version & 1] of both
+                // partner rows of occurrence q), not after this task's own row has arrived too -- the next writers of those
+                // rows are waiting for exactly this.
+                if (!(T.tune & 1u) && lane < n) {
+                    uint32_t* pa_rd = (ITEM ? T.rdU : T.rdV) + 2 * (size_t)d.x + (d.y & 1);
+                    uint32_t* pb_rd = T.rdV + 2 * (size_t)(d.z & 0x3fffffff) + (d.w & 1);
+                    __hip_atomic_fetch_add(pa_rd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(pb_rd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
         if (o.ok && part_ok) break;
-        if (spin_fail(waited, ctl)) {
+        if (spin_fail(waited, ctl, (part_ok && !(T.tune & 2u)) ? 0 : 4)) {      // only the own row missing: three loads per pass, poll at the round-trip rate
             if (waited >= kSpinLimit && lane == 0 &&                     // post-mortem of the first wave that gave up
                 atomicCAS(ctl + kCtlDebug, 0u, 1u) == 0u) {
                 ctl[kCtlDebug + 1] = o.ok;
@@ -325,7 +343,7 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
         bd = ta_me - tb_me;
     }
     const float x_me = (ITEM && role_me) ? -(bd + dotv) : (bd + dotv);
-    const float s_me = sigmoid_neg(x_me);
+    const float s_me = fast_sigmoid_neg(x_me);
     if constexpr (!ITEM) {
         if (want_loss && myq < n && (lane & ((1 << SH) - 1)) == 0) {
             loss_lane += softplus_neg(x_me);
@@ -370,8 +388,7 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
         }
     }
 
-    // acknowledge the partner reads of this group: lane q adds one to rd[version & 1] of both partner rows of occurrence q
-    if (lane < n) {
+    if ((T.tune & 1u) && lane < n) {
         uint32_t* pa_rd = (ITEM ? T.rdU : T.rdV) + 2 * (size_t)d.x + (d.y & 1);
         uint32_t* pb_rd = T.rdV + 2 * (size_t)(d.z & 0x3fffffff) + (d.w & 1);
         __hip_atomic_fetch_add(pa_rd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -383,21 +400,24 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
 // next task index of this wave, or 0xffffffff when its queue is exhausted: ONE returning atomic per task on the wave's
 // home counter.  (A first version also read all counters to steal from a lagging queue: 768 tasks x 8 loads per batch on
 // 8 lines that are being atomically updated serialise at the atomic rate -- measured 10 us per grab.)
-__device__ __forceinline__ uint32_t grab(uint32_t* ctl, int lane, int home, uint32_t total) {
+__device__ __forceinline__ uint32_t grab_issue(uint32_t* ctl, int lane, int home) {     // lane 0 holds the ticket when it lands
     uint32_t t = 0;
     if (lane == 0) t = __hip_atomic_fetch_add(ctl + home * kQueueStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = (uint32_t)bcast_i((int)t, 0);
-    const u64 idx = (u64)t * kQueues + home;
+    return t;
+}
+__device__ __forceinline__ uint32_t grab_index(uint32_t ticket, int home, uint32_t total) {
+    const u64 idx = (u64)(uint32_t)bcast_i((int)ticket, 0) * kQueues + home;
     return idx < total ? (uint32_t)idx : 0xffffffffu;
 }
 
 template <int NP, bool PROF = false>
-__global__ __launch_bounds__(256) void bpr_flow_kernel(tkr_flow_state st, const int4* __restrict__ prec,
+__global__ __launch_bounds__(256, (NP == 1 ? 3 : 1)) void bpr_flow_kernel(tkr_flow_state st, const int4* __restrict__ prec,
                                                        const int4* __restrict__ pocc, uint32_t total,
-                                                       uint32_t* __restrict__ ctl, float* __restrict__ loss_out) {
+                                                       uint32_t* __restrict__ ctl, float* __restrict__ loss_out, uint32_t tune) {
     constexpr int NE = 2 * NP;
     const int lane = threadIdx.x & (TKR_WAVE - 1);
     FlowTables T;
+    T.tune = tune;
     T.kp = NP * 128;
     T.ustride = (size_t)st.n_users * T.kp;
     T.istride = (size_t)st.n_items * T.kp;
@@ -407,9 +427,12 @@ __global__ __launch_bounds__(256) void bpr_flow_kernel(tkr_flow_state st, const 
     const bool sgd = st.opt == 1;
     const bool want_loss = loss_out != nullptr;
 
-    uint32_t arrive = 0;
-    if (lane == 0) arrive = __hip_atomic_fetch_add(ctl + kCtlArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int home = bcast_i((int)arrive, 0) & (kQueues - 1);
+    // queue of this wave = (arrival number of its workgroup * 4 + wave) & 31: one atomic per workgroup (a word takes ~12 ns
+    // per atomic: per wave that was 12 us of start-up), and still independent of block index, placement and residency
+    __shared__ uint32_t wg_arrival;
+    if (threadIdx.x == 0) wg_arrival = __hip_atomic_fetch_add(ctl + kCtlArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int home = (int)((wg_arrival * (blockDim.x / TKR_WAVE) + (threadIdx.x / TKR_WAVE)) & (kQueues - 1));
     uint32_t spins = 0;
     bool alive = true;
 
@@ -422,12 +445,18 @@ __global__ __launch_bounds__(256) void bpr_flow_kernel(tkr_flow_state st, const 
         tq = now_;                                            \
     }
     if constexpr (PROF) tq = __builtin_amdgcn_s_memtime();
+    // The ticket of the NEXT task is taken while the current one runs (its round trip is off the wave's cycle).  Safe: a
+    // wave's next ticket is higher than its current one and a task only ever waits for lower ones.
+    uint32_t ticket = grab_issue(ctl, lane, home);
     while (alive) {
-        const uint32_t idx = grab(ctl, lane, home, total);
+        const uint32_t idx = grab_index(ticket, home, total);
         TKR_PROF_MARK(0)
         if (idx == 0xffffffffu) break;
         const int4* r = prec + (size_t)idx * 8;
-        const int4 w = (lane < 8) ? r[lane] : make_int4(0, 0, 0, 0);      // 128-byte record, one int4 per lane
+        int4 w = make_int4(0, 0, 0, 0);
+        if (lane < 8) w = r[lane];                                          // 128-byte record, one int4 per lane (an L2 hit: K1 just wrote it)
+        asm volatile("" : "+v"(w.x), "+v"(w.y), "+v"(w.z), "+v"(w.w) :: "memory");   // the record lands BEFORE the atomic is issued: memory
+        ticket = grab_issue(ctl, lane, home);                               // returns in order, and the record must not queue behind its round trip
         const int rowk = bcast_i(w.x, 0);
         TKR_PROF_MARK(1)
         if (rowk == -1) { if constexpr (PROF) prof[6] += 1; continue; }    // unused slot of its batch
@@ -468,13 +497,14 @@ __global__ __launch_bounds__(256) void bpr_flow_kernel(tkr_flow_state st, const 
                 default: alive = TKR_FLOW_GROUP(4, 4, d); break;
             }
         } else {                                  // popular rows: up to kBig occurrences per pass from the occurrence list
-            constexpr int kBig = NP == 1 ? 16 : 8;
+            // (8 per pass: at the ML-10M shape the most popular item occurs ~7 times in a 256-batch; wider groups cost
+            // registers -- 16 slots are 192 VGPRs of loads in flight -- and with them the waves that hide everything else)
+            constexpr int kBig = 8;
             for (int done = 0; done < n_occ && alive; done += kBig) {
                 const int n = min(kBig, n_occ - done);
                 int4 d = make_int4(0, 0, 0, 0);
                 if (lane < n) d = pocc[first + done + lane];
-                if (kBig == 16 && n > 8) alive = TKR_FLOW_GROUP(kBig, n, d);
-                else alive = TKR_FLOW_GROUP(8, n, d);
+                alive = TKR_FLOW_GROUP(kBig, n, d);
             }
         }
 #undef TKR_FLOW_GROUP
@@ -517,10 +547,10 @@ __global__ __launch_bounds__(256) void bpr_flow_kernel(tkr_flow_state st, const 
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 mn[e] = st.rho * ms[e] + (1.f - st.rho) * g[e] * g[e];
-                pn[e] = own[e] - st.lr * g[e] / sqrtf(mn[e] + st.eps);
+                pn[e] = own[e] - st.lr * g[e] * __builtin_amdgcn_rsqf(mn[e] + st.eps);
             }
             mbn = st.rho * o.msb + (1.f - st.rho) * gb * gb;
-            bn = o.b - st.lr * gb / sqrtf(mbn + st.eps);
+            bn = o.b - st.lr * gb * __builtin_amdgcn_rsqf(mbn + st.eps);
         }
         store_row<NP>(tabP + woff, lane, pn, nv);
         if (!sgd) store_row<NP>(tabM + woff, lane, mn, nv);
@@ -545,16 +575,7 @@ __global__ __launch_bounds__(256) void bpr_flow_kernel(tkr_flow_state st, const 
             for (int q = 0; q < 8; ++q) atomicAdd(reinterpret_cast<u64*>(ctl + kCtlProf) + q, prof[q]);
     }
 
-    if (lane == 0) {
-        if (spins) atomicAdd(ctl + kCtlSpins, spins);
-        const uint32_t waves = gridDim.x * (blockDim.x / TKR_WAVE);
-        const uint32_t e = __hip_atomic_fetch_add(ctl + kCtlExit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (e + 1u == waves) {                      // last wave out: counters ready for the next launch (status stays)
-            for (int q = 0; q < kQueues; ++q) __hip_atomic_store(ctl + q * kQueueStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ctl + kCtlArrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ctl + kCtlExit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    if (lane == 0 && spins) atomicAdd(ctl + kCtlSpins, spins);
 }
 
 }  // namespace tkr
@@ -574,15 +595,26 @@ extern "C" int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, c
     const uint64_t total64 = (uint64_t)n_batches * 3u * (uint64_t)batch_size;
     if (total64 >= 0xffffffffull / 8) return TKR_EUNSUPPORTED;
     const uint32_t total = (uint32_t)total64;
-    int dev = 0, cus = 0;
+    int dev = 0;
     TKR_CHECK(hipGetDevice(&dev));
-    TKR_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int np = (st->k + 127) / 128;
-    const void* fn = np == 1 ? (const void*)tkr::bpr_flow_kernel<1, false> : (const void*)tkr::bpr_flow_kernel<2, false>;
-    int per_cu = 0;
-    TKR_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0));
-    if (per_cu < 1) return TKR_EUNSUPPORTED;
-    int want = (waves_per_cu > 0 ? waves_per_cu : 8) / 4;            // 256-thread workgroups
+    static int cached_cus[64], cached_per_cu[64][2];              // per device and kernel variant: the queries cost more than a short launch
+    int cus, per_cu;
+    if (dev >= 0 && dev < 64 && cached_per_cu[dev][np - 1] > 0) {
+        cus = cached_cus[dev];
+        per_cu = cached_per_cu[dev][np - 1];
+    } else {
+        const void* fn = np == 1 ? (const void*)tkr::bpr_flow_kernel<1, false> : (const void*)tkr::bpr_flow_kernel<2, false>;
+        TKR_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        TKR_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0));
+        if (per_cu < 1) return TKR_EUNSUPPORTED;
+        if (dev >= 0 && dev < 64) { cached_cus[dev] = cus; cached_per_cu[dev][np - 1] = per_cu; }
+    }
+    const uint32_t tune = ((uint32_t)waves_per_cu >> 8) & 0xffu;     // experiment switches ride in bits 8..15
+    waves_per_cu &= 0xff;
+    // default: one 4-wave workgroup per CU = 1024 waves, about 1.3 batches of 256 in flight.  Measured at the ML-10M shape:
+    // 3.4-3.8 us per batch with 4 waves per CU, 4.0 with 8 (waves that wait poll, and the polls slow everybody's loads)
+    int want = (waves_per_cu > 0 ? waves_per_cu : 4) / 4;            // 256-thread workgroups
     if (want < 1) want = 1;
     if (want > per_cu - (per_cu > 2 ? 1 : 0)) want = per_cu - (per_cu > 2 ? 1 : 0);   // stay inside what is resident at once
     uint32_t grid = (uint32_t)(want * cus);
@@ -590,14 +622,15 @@ extern "C" int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, c
     if (grid > need) grid = need;
     if (grid < 8) grid = 8;                                          // >= 32 waves: every queue has a wave
     hipStream_t s = (hipStream_t)stream;
+    TKR_CHECK(hipMemsetAsync(ctl, 0, (size_t)(tkr::kCtlArrive + 1) * sizeof(uint32_t), s));      // ticket counters + arrival counter
     const int4* r4 = reinterpret_cast<const int4*>(prec);
     const int4* o4 = reinterpret_cast<const int4*>(pocc);
     static const bool prof = getenv("TKR_FLOW_PROFILE") && getenv("TKR_FLOW_PROFILE")[0] == '1';     // cycle sums into ctl (scripts/probe_flow_bench.py)
     if (prof) {
-        if (np == 1) hipLaunchKernelGGL((tkr::bpr_flow_kernel<1, true>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out);
-        else hipLaunchKernelGGL((tkr::bpr_flow_kernel<2, true>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out);
-    } else if (np == 1) hipLaunchKernelGGL((tkr::bpr_flow_kernel<1, false>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out);
-    else hipLaunchKernelGGL((tkr::bpr_flow_kernel<2, false>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out);
+        if (np == 1) hipLaunchKernelGGL((tkr::bpr_flow_kernel<1, true>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out, tune);
+        else hipLaunchKernelGGL((tkr::bpr_flow_kernel<2, true>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out, tune);
+    } else if (np == 1) hipLaunchKernelGGL((tkr::bpr_flow_kernel<1, false>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out, tune);
+    else hipLaunchKernelGGL((tkr::bpr_flow_kernel<2, false>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out, tune);
     TKR_LAUNCH_CHECK();
     return TKR_OK;
 }

@@ -526,7 +526,10 @@ class BprEngine(PlanMixin):
         """sample + plan + step for n_batches consecutive batches; returns the per-batch
         losses of the LAST chunk as a device tensor (or None)."""
         self.prepare(B)
-        return self._run(csr, n_batches, B, want_loss, self.step_fn(B))
+        key = (self.layout_epoch, B, FLOW_WAVES_PER_CU)
+        if getattr(self, '_step_key', None) != key:       # the C struct and the closure are built once per layout, not per call
+            self._step_key, self._step = key, self.step_fn(B)
+        return self._run(csr, n_batches, B, want_loss, self._step)
 
     def step_fn(self, B):
         state = self.state()
