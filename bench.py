@@ -21,6 +21,7 @@ Prints ONE JSON line (rank 0).  Extra objects beside the contract fields:
   throughput_mode the same path at batch_size 8192 (a legal train() argument; NOT the headline)
   sgd_mode / sgd_throughput_mode  the legacy plain-SGD optimiser (old/methods/bpr.py:57-61) at batch 256 / 8192
   streams_mode    opt-in train(streams=4): four user shards on four HIP streams of the one GPU (extra, not headline)
+  bpr_netflix_shape  the headline path at BASELINE.json configs[3]'s shape (480,189 x 17,770) on one GPU
   topk            the other half of BASELINE.json's metric: full-catalogue top-30 scored users/s (K4)
                   with its own MFMA roofline (bf16 dense peak / 6 split products; fp32 MFMA peak under TKR_TOPK_MATH=fp32) and cpu_baseline
 """
@@ -274,6 +275,26 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
     return res
 
 
+def netflix_train_bench(k, device, B=256, steps=2048, warmup=512):
+    """BASELINE.json configs[3] shape on ONE GPU (the 8-GPU run shards these users): 480,189 users x 17,770 items, ~3.5e7
+    train positives generated straight as CSR (synth.train_csr_shape), BPR defaults, batch 256"""
+    import synth
+    from single import _engine
+    n_users, n_items = 480189, 17770
+    row_ptr, pos, _, tr_users = synth.train_csr_shape(n_users, n_items, mean_pos=90.0, seed=43)
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, tr_users, device)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=1e-4, mode='l2')
+    eng = _engine.BprEngine(n_users, n_items, k, hp, device, seed=4321)
+    wall, step_ms = timed_run(eng, csr, B, steps, warmup, 10 ** 9, 1)
+    us = step_ms * 1e3 / steps
+    gbs = B * algorithmic_bytes_per_triplet(k) / (us * 1e-6) / 1e9
+    return {'value': steps * B / wall, 'unit': 'triplets/s', 'steps': steps, 'ms_per_step': wall * 1e3 / steps,
+            'config': {'workload': 'BPR Netflix shape (%d users x %d items, %d train positives), k=%d, batch_size=%d, one GPU'
+                                   % (n_users, n_items, int(row_ptr[-1]), k, B)},
+            'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'launch_us': us,
+                         'traffic': None}}
+
+
 def streams_bench(r, k, device, B=256, S=4, steps=2048, warmup=2048):   # warm-up = run: plan buffers and graphs cached
     """opt-in train(streams=S): S user shards with replicated item tables on S HIP streams of ONE GPU (per-epoch
     exchange as in the multi-GPU layout; the exchange itself is outside this timed region like in the N>1 bench
@@ -433,6 +454,7 @@ def main():
         if rank == 0 and world == 1:
             out['topk_netflix_shape'] = topk_bench_netflix(k, device)
             out['vbpr'] = vbpr_bench(r, csr, k, device)
+            out['bpr_netflix_shape'] = netflix_train_bench(k, device)
             out['streams_mode'] = streams_bench(r, k, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(r, k, B)

@@ -278,7 +278,13 @@ def init_vbpr_state(n_users, n_items, k, d, rng):
 def vbpr_step(state, feat, ub, ib, jb, hp):
     """One mini-batch of single/vbpr.py:50-73 (+ the host gather of :114).  Sparse RMSProp
     on ure/uce/ire/irb (touched rows), *dense* RMSProp on cem/icb (every element, every
-    batch; the whole cem / icb is regularised each batch, vbpr.py:65,67)."""
+    batch; the whole cem / icb is regularised each batch, vbpr.py:65,67).
+
+    The data term is a sum over ALL PAIRS of the batch.  item_rating_bias has shape [n_items, 1] (vbpr.py:43), so
+    ``irbb - jrbb`` is [B, 1], ``x_ui - x_uj`` is [B] and ``matmul(ic - jc, icb)`` is [B, 1] (:59-61): their sum
+    broadcasts to x_uij[a, b] = alpha[a] + beta[b] with alpha = irb_i - irb_j + (f_i - f_j).icb (row index) and
+    beta = x_ui - x_uj (column index), and ``reduce_sum(log(1 + exp(-x_uij)))`` (:64) runs over the whole [B, B] matrix.
+    (tests/test_oracle_step.py checks this function against autograd on the literal expressions WITH those shapes.)"""
     ure, uce, ire, irb, cem, icb = (state[n] for n in ('ure', 'uce', 'ire', 'irb', 'cem', 'icb'))
     lu, li, lj, lb, le = (F32(hp[k]) for k in ('lu', 'li', 'lj', 'lb', 'le'))
     ub = np.asarray(ub, dtype=np.int64); ib = np.asarray(ib, dtype=np.int64); jb = np.asarray(jb, dtype=np.int64)
@@ -290,8 +296,12 @@ def vbpr_step(state, feat, ub, ib, jb, hp):
     x_ui = np.sum(ur * ir + uc * ice, axis=1, dtype=F32)
     x_uj = np.sum(ur * jr + uc * jce, axis=1, dtype=F32)
     dfeat = (ic - jc).astype(F32)
-    x = (bi - bj + x_ui - x_uj + dfeat @ icb).astype(F32)     # vbpr.py:61
-    s = _sigmoid_neg(x)[:, None]
+    alpha = (bi - bj + dfeat @ icb).astype(F32)       # the [B, 1] terms of vbpr.py:61
+    beta = (x_ui - x_uj).astype(F32)                  # the [B] terms
+    x = (alpha[:, None] + beta[None, :]).astype(F32)  # x_uij [B, B]
+    sg = _sigmoid_neg(x)
+    sa = np.sum(sg, axis=1, dtype=F32)[:, None]       # d obj / d alpha_a = -sa[a]
+    s = np.sum(sg, axis=0, dtype=F32)[:, None]        # d obj / d beta_b  = -s[b]
     if hp.get('mode', 'l2') == 'l2':
         loss = (np.sum(_softplus_neg(x), dtype=F32)
                 + F32(0.5) * np.sum(cem * cem, dtype=F32) * le
@@ -310,11 +320,11 @@ def vbpr_step(state, feat, ub, ib, jb, hp):
     g_uc = (-s * (ice - jce) + r_uc).astype(F32)
     g_ir = (-s * ur + r_ir).astype(F32)
     g_jr = (s * ur + r_jr).astype(F32)
-    g_bi = (-s[:, 0] + r_bi).astype(F32)
-    g_bj = (s[:, 0] + r_bj).astype(F32)
+    g_bi = (-sa[:, 0] + r_bi).astype(F32)
+    g_bj = (sa[:, 0] + r_bj).astype(F32)
     d_ice = (-s * uc).astype(F32)                     # dL/d(iceb); dL/d(jceb) = -d_ice
     g_cem = (ic.T @ d_ice + jc.T @ (-d_ice) + r_cem).astype(F32)
-    g_icb = (dfeat.T @ (-s[:, 0]) + r_icb).astype(F32)
+    g_icb = (dfeat.T @ (-sa[:, 0]) + r_icb).astype(F32)
     lr = hp['lr']
     rows_u, sum_ur = _segment_sum(ub, g_ur)
     _, sum_uc = _segment_sum(ub, g_uc)

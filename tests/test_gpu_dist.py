@@ -168,3 +168,82 @@ def test_streams_mode_matches_oracle_simulation(tmp_path):
     np.testing.assert_allclose(m.fie, st[0]['V'], rtol=2e-4, atol=1e-5)
     np.testing.assert_allclose(m.fib.ravel(), st[0]['b'], rtol=2e-4, atol=1e-5)
     np.testing.assert_allclose(m.fue, U, rtol=2e-4, atol=1e-5)
+
+
+def _run_cli_ranks(args, world, port, tmp_path):
+    """evaluate.py under torch.distributed.run: `world` ranks on the one visible GPU (gloo) -> rank 0's stdout lines"""
+    env = dict(os.environ, TKR_SINGLE_DEVICE='1', TKR_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1', TKR_NO_CACHE='1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
+                          '--master-addr', '127.0.0.1', '--master-port', str(port),
+                          os.path.join(ROOT, 'top-k-rec_amd', 'evaluate.py')] + args,
+                         capture_output=True, text=True, timeout=280, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    return [l for l in out.stdout.strip().split('\n') if ',' in l and not l.startswith('[')]
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_evaluate_cli_reproduces_reference_stdout(golden_dir, tmp_path, world):
+    """SURVEY.md §8e scoring: the scenario's test lines block-sharded over the ranks, hit counters and like counts all-reduced --
+    stdout must equal the reference CLI's byte for byte on its own goldens (G4 im/om incl. another step/total, G5, G6 with a bias
+    file, G7 edge cases: fewer than `total` unrated items, all likes rated, total % step != 0)"""
+    import json
+    port = 29650 + world
+    for g, scs in (('g4', ['im', 'om']), ('g5', ['im', 'om']), ('g6', ['all'])):
+        d = os.path.join(golden_dir, g)
+        exp = json.load(open(os.path.join(d, 'expected.json')))
+        data, model = os.path.join(d, 'data'), os.path.join(d, 'model')
+        assert _run_cli_ranks(['-d', data, '-m', model, '-sl'] + scs, world, port, tmp_path) == exp['stdout'], g
+        if 'stdout_s3_t10' in exp and world == 2:
+            assert _run_cli_ranks(['-d', data, '-m', model, '-s', '3', '-t', '10', '-sl', 'om', 'im'], world, port, tmp_path) == exp['stdout_s3_t10']
+    d = os.path.join(golden_dir, 'g7')
+    exp = json.load(open(os.path.join(d, 'expected.json')))
+    for run in exp['runs'][: 2 if world == 3 else None]:
+        got = _run_cli_ranks(['-d', os.path.join(d, 'data'), '-m', os.path.join(d, 'model'), '-s', str(run['step']), '-t', str(run['total']),
+                              '-sl', 'sm'], world, port, tmp_path)
+        assert got == run['stdout'], run
+
+
+@pytest.mark.skipif(__import__('torch').cuda.device_count() < 2, reason='RCCL needs two visible GPUs (the round-end 8-GPU node has them)')
+def test_rccl_training_and_scoring_two_gpus(tmp_path):
+    """backend 'nccl' = RCCL over xGMI, one process per GPU: BPR.train with the per-epoch exchange and the sharded evaluate.py.
+    Runs wherever two GPUs are visible; the one-GPU box covers the same code with gloo (tests above)."""
+    import synth
+    r = synth.make_ratings(400, 150, 30, seed=5, mu=2.8, sigma=0.4, min_r=5, max_r=30)
+    data = str(tmp_path / 'data')
+    synth.write_dataset(data, r)
+    script = tmp_path / 'train_rccl.py'
+    script.write_text(r"""
+import os, sys
+sys.path[:0] = [%r, %r]
+import torch, torch.distributed as dist
+local = int(os.environ['LOCAL_RANK'])
+torch.cuda.set_device(local)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+from single import BPR
+m = BPR(k=32, lr=0.02)
+m.load_training_data(%r + '/uid', %r + '/vid', %r + '/f0tr.txt')
+m.train(epochs=3, batch_size=64, epoch_sample_limit=64 * 40, verbose=False)         # no seed given: rank 0's is broadcast
+import numpy as np
+chk = torch.tensor([float(np.abs(m.fie).sum()), float(np.abs(m.fue).sum())], device='cuda', dtype=torch.float64)
+lo, hi = chk.clone(), chk.clone()
+dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+assert torch.equal(lo, hi), 'ranks disagree on the trained model'
+if dist.get_rank() == 0:
+    m.export_embeddings(%r)
+dist.barrier(); dist.destroy_process_group()
+print('ok')
+""" % (ROOT, os.path.join(ROOT, 'top-k-rec_amd'), data, data, data, str(tmp_path / 'model')))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                          '--master-port', '29671', str(script)], capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode == 0 and out.stdout.count('ok') == 2, out.stdout[-3000:] + out.stderr[-3000:]
+    single = subprocess.run([sys.executable, os.path.join(ROOT, 'top-k-rec_amd', 'evaluate.py'), '-d', data, '-m', str(tmp_path / 'model'), '-sl', 'im', 'om'],
+                            capture_output=True, text=True, timeout=280, env=env)
+    assert single.returncode == 0, single.stderr[-2000:]
+    both = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                           '--master-port', '29672', os.path.join(ROOT, 'top-k-rec_amd', 'evaluate.py'), '-d', data, '-m', str(tmp_path / 'model'),
+                           '-sl', 'im', 'om'], capture_output=True, text=True, timeout=280, env=env)
+    assert both.returncode == 0, both.stderr[-2000:]
+    pick = lambda out: [l for l in out.strip().split('\n') if l.startswith(('im,', 'om,'))]
+    assert pick(both.stdout) == pick(single.stdout) and len(pick(single.stdout)) == 2

@@ -124,3 +124,49 @@ def test_vbpr_full_size_sparse_view(ml10m):
     np.testing.assert_allclose(eng.icb.cpu().numpy(), ref['icb'], err_msg='icb', **tol)
     np.testing.assert_allclose(eng.mscem.cpu().numpy(), ref['ms_cem'], rtol=1e-3, atol=1e-6)
     np.testing.assert_allclose(loss, np.array(ref_loss), rtol=2e-4)
+
+
+def test_netflix_shape_chunk_matches_oracle():
+    """BASELINE.json configs[3] shape (480,189 users x 17,770 items, k = 128, batch 256) on one GPU: one full plan chunk (512 batches)
+    against the oracle replaying the same 131,072 triplets, sampler invariants on every triplet, counters = batches touching a row"""
+    import synth
+    from single import _engine
+    n_users, n_items, k, B, nb = 480189, 17770, 128, 256, 512
+    row_ptr, pos, srt, tr_users = synth.train_csr_shape(n_users, n_items, mean_pos=90.0, seed=43)
+    dev = torch.device('cuda')
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=1.0e-3, mode='l2')
+    eng = _engine.BprEngine(n_users, n_items, k, hp, dev, seed=77)
+    init = {n: eng.get(n)[0].cpu().numpy() for n in ('U', 'V', 'b')}
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, tr_users, dev)
+    eng.run_batches(csr, nb, B, want_loss=False)
+    eng.check()
+    # the device stream against the oracle sampler: membership by one searchsorted over (user, item) keys
+    key_pos = np.repeat(np.arange(n_users, dtype=np.int64), np.diff(row_ptr)) * n_items + srt          # srt: ascending inside a row
+    u = eng.plan.u.cpu().numpy()[: nb * B].astype(np.int64)
+    i = eng.plan.i.cpu().numpy()[: nb * B].astype(np.int64)
+    j = eng.plan.j.cpu().numpy()[: nb * B].astype(np.int64)
+
+    def member(uu, cc):
+        q = uu * n_items + cc
+        at = np.minimum(np.searchsorted(key_pos, q), len(key_pos) - 1)
+        return key_pos[at] == q
+    assert member(u, i).all() and not member(u, j).any() and (np.diff(row_ptr)[u] > 0).all()
+    first = 4096                                                       # bit-exact against the oracle sampler on the head of the stream
+    ou, oi, oj = P.sample_triplets(tr_users, row_ptr, pos, srt, n_items, 77, 0, first)
+    assert np.array_equal(u[:first], ou) and np.array_equal(i[:first], oi) and np.array_equal(j[:first], oj)
+    ub = np.unique(np.stack([np.repeat(np.arange(nb), B), u], 1), axis=0)
+    ib = np.unique(np.stack([np.repeat(np.arange(nb), 2 * B), np.concatenate([i.reshape(nb, B), j.reshape(nb, B)], 1).ravel()], 1), axis=0)
+    np.testing.assert_array_equal(eng.cnt.ucnt.cpu().numpy(), np.bincount(ub[:, 1], minlength=n_users))
+    np.testing.assert_array_equal(eng.cnt.icnt.cpu().numpy(), np.bincount(ib[:, 1], minlength=n_items))
+    # the oracle replays the chunk on the device's triplets (sparse: only touched rows move)
+    ref = dict(U=init['U'].copy(), V=init['V'].copy(), b=init['b'].copy(), msU=np.ones_like(init['U']), msV=np.ones_like(init['V']),
+               msb=np.ones_like(init['b']))
+    for bb in range(nb):
+        sl = slice(bb * B, (bb + 1) * B)
+        R.bpr_step(ref, u[sl].astype(np.int32), i[sl].astype(np.int32), j[sl].astype(np.int32), hp)
+    got = {n: eng.get(n)[0].cpu().numpy() for n in ('U', 'V', 'b')}
+    for n in ('U', 'V', 'b'):
+        np.testing.assert_allclose(got[n], ref[n], rtol=2e-4, atol=1e-6, err_msg=n)
+    untouched = np.setdiff1d(np.arange(n_users), u)
+    np.testing.assert_array_equal(got['U'][untouched], init['U'][untouched])
+    assert np.abs(got['V'] - init['V']).max() > 1e-4

@@ -338,3 +338,23 @@ def test_native_ratings_parser_fuzz(tmp_path):
         lu, lp, it, lk = _py_ratings(str(path), users, items)
         assert got.line_user.tolist() == lu and got.line_ptr.tolist() == lp, trial
         assert got.item.tolist() == it and got.like.tolist() == lk, trial
+
+
+def test_evaluate_shards_partition_the_scenario(golden_dir):
+    """evaluate.shard_scenario (SURVEY.md §8e scoring): the ranks' blocks are disjoint, cover every test line in order, and carry
+    exactly the like / rated columns of their lines -- so the all-reduced hit counters and like counts equal the single-process ones"""
+    import evaluate as E
+    data = os.path.join(golden_dir, 'g4', 'data')
+    uids = E.read_ids(os.path.join(data, 'uid'))
+    full = E.load_scenario(data, 0, 'im', uids)
+    for world in (1, 2, 3, 7, len(full.users) + 5):
+        parts = [E.shard_scenario(full, r, world) for r in range(world)]
+        assert np.array_equal(np.concatenate([p.users for p in parts]), full.users)
+        assert sum(p.tcount for p in parts) == full.tcount
+        at = 0
+        for p in parts:
+            for q in range(len(p.users)):
+                assert np.array_equal(p.like_cols[p.like_ptr[q]:p.like_ptr[q + 1]], full.like_cols[full.like_ptr[at]:full.like_ptr[at + 1]])
+                assert np.array_equal(p.rated_cols[p.rated_ptr[q]:p.rated_ptr[q + 1]], full.rated_cols[full.rated_ptr[at]:full.rated_ptr[at + 1]])
+                at += 1
+        assert at == len(full.users)

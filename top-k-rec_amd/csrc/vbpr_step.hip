@@ -4,7 +4,14 @@
 // the per-batch host gather + H2D feed of two dense [B, d] feature slices (vbpr.py:114): the
 // feature matrix stays resident in HBM and rows are gathered by the kernels.
 //
-//   x_t = irb_i - irb_j + <ure_u, ire_i - ire_j> + <uce_u, (f_i - f_j).cem> + (f_i - f_j).icb
+//   alpha_t = irb_i - irb_j + (f_i - f_j).icb          beta_t = <ure_u, ire_i - ire_j> + <uce_u, (f_i - f_j).cem>
+//   obj = sum over ALL PAIRS (a, b) of the batch of log(1 + exp(-(alpha_a + beta_b))) + regularisers
+//
+// The pair sum is what the reference's graph computes: item_rating_bias is [n_items, 1], so irbb - jrbb is [B, 1], x_ui - x_uj is
+// [B] and matmul(ic - jc, icb) is [B, 1] (vbpr.py:54-61) -- TensorFlow broadcasts their sum to [B, B] and reduce_sum (:64)
+// runs over all of it.  (BPR's item_bias is 1-D, bpr.py:79: there the sum is the B triplets.)  The objective separates:
+// with S_a = sum_b sigma(-(alpha_a + beta_b)) and T_b = sum_a sigma(-(alpha_a + beta_b)), every variable under alpha (irb, icb)
+// gets the gradient of one triplet scaled by S_t, every variable under beta (ure, uce, ire, cem) scaled by T_t.
 //
 // iceb/jceb enter the reference only through x_ui - x_uj and are not regularised, so projecting the
 // DIFFERENCE once is exact in real arithmetic and halves the contraction.
@@ -12,11 +19,12 @@
 // Five launches per batch, all on pre-step values:
 //   V1  project   P_t = (f_i - f_j).cem, q_t = (f_i - f_j).icb      fp32 MFMA, split over d (K)
 //   V1r reduce    P_t, q_t = sum of the split-K partials (slice-parallel, fixed order)
-//   V1b occur     per user occurrence: x_t, s_t = sigma(-x_t), W_t = -s_t * uce_u, loss
+//   V1b occur     per user occurrence: alpha_t, beta_t, uce_u, the regularisers' share of the loss
 //                                                                   (plan of K1: parities inline)
+//   V1p pair      S_t, T_t (one wave per triplet walks the batch twice), the pair sum of the loss, W_t = -T_t * uce_u
 //   V2  rows      sparse RMSProp on [ure|uce] rows, ire rows, irb   (same launch records as K2,
-//                 gradients use the stored s_t, P_t -- nothing is recomputed)
-//   V3  dense     G_cem = D^T.W + le*cem, G_icb = D^T.(-s) + lb*icb  fp32 MFMA over the batch,
+//                 gradients use the stored S_t, T_t, P_t -- nothing is recomputed)
+//   V3  dense     G_cem = D^T.W + le*cem, G_icb = D^T.(-S) + lb*icb  fp32 MFMA over the batch,
 //                 with TF's DENSE ApplyRMSProp fused into the epilogue (every element of cem/icb is
 //                 updated every batch; vbpr.py:65,67,73)
 //
@@ -37,6 +45,7 @@
 
 extern "C" int tkr_plan_team(int32_t batch_size);
 extern "C" int tkr_plan_max_blocks(int32_t batch_size);
+extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d);
 
 namespace tkr {
 
@@ -212,7 +221,8 @@ template <int NH, int kVTeam>
 __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_occur_kernel(
     tkr_vbpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
     const int32_t* __restrict__ occt, const int4* __restrict__ hdr, int B, const float* __restrict__ Q,
-    float* __restrict__ s_out, const float* __restrict__ P, float* __restrict__ Wm, float* __restrict__ loss_out) {
+    float* __restrict__ ab_out /*[2][B]: alpha, beta*/, const float* __restrict__ P, float* __restrict__ Wm,
+    float* __restrict__ loss_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_blocks = __builtin_amdgcn_readfirstlane((*hdr).x);
     const int kh = st.kh, k2 = 2 * kh;
@@ -258,9 +268,7 @@ __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_occur_kernel(
                     d2 = fmaf(uce[e], p[e], d2);
                 }
                 const float bi = st.irb[(size_t)pi * st.n_items + i], bj = st.irb[(size_t)pj * st.n_items + j];
-                const float x = bi - bj + wave_sum(d1) + wave_sum(d2) + qsum;
-                const float sg = sigmoid_neg(x);
-                loss += softplus_neg(x);
+                const float alpha = bi - bj + qsum, beta = wave_sum(d1) + wave_sum(d2);
                 if (l2) {
                     loss += 0.5f * (bi * bi + bj * bj) * st.lb;
 #pragma unroll
@@ -275,9 +283,9 @@ __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_occur_kernel(
 #pragma unroll
                 for (int e = 0; e < NH; ++e) {
                     const int c = lane + e * 64;
-                    if (c < kh) Wm[(size_t)t * kh + c] = -sg * uce[e];
+                    if (c < kh) Wm[(size_t)t * kh + c] = uce[e];          // scaled by -T_t once the pair kernel knows it
                 }
-                if (lane == 0) s_out[t] = sg;
+                if (lane == 0) { ab_out[t] = alpha; ab_out[B + t] = beta; }
             }
         }
         if (loss_out) {
@@ -287,13 +295,42 @@ __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_occur_kernel(
     }
 }
 
+// V1p: the [B, B] pair sum of the reference's objective (see the head of this file).  One wave per triplet t:
+//   S_t = sum_b sigma(-(alpha_t + beta_b))   scales the gradients of the variables under alpha (irb, icb)
+//   T_t = sum_a sigma(-(alpha_a + beta_t))   scales those under beta (ure, uce, ire, cem); W_t = -T_t * uce_u for V3 / S3
+// and the loss gets sum_b log(1 + exp(-(alpha_t + beta_b))).  Sums run in index order (lane l takes b = l, l+64, ...; DPP tree).
+__global__ __launch_bounds__(256) void vbpr_pair_kernel(const float* __restrict__ ab /*[2][B]*/, int B, int kh,
+                                                       float* __restrict__ sS, float* __restrict__ sT, float* __restrict__ Wm,
+                                                       float* __restrict__ loss_out) {
+    const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= B) return;
+    const float* alpha = ab;
+    const float* beta = ab + B;
+    const float a_t = alpha[t], b_t = beta[t];
+    float s_row = 0.f, s_col = 0.f, loss = 0.f;
+    for (int o = lane; o < B; o += 64) {
+        const float xr = a_t + beta[o];
+        s_row += sigmoid_neg(xr);
+        if (loss_out) loss += softplus_neg(xr);
+        s_col += sigmoid_neg(alpha[o] + b_t);
+    }
+    s_row = wave_sum(s_row);
+    s_col = wave_sum(s_col);
+    if (lane == 0) { sS[t] = s_row; sT[t] = s_col; }
+    for (int c = lane; c < kh; c += 64) Wm[(size_t)t * kh + c] *= -s_col;
+    if (loss_out) {
+        loss = wave_sum(loss);
+        if (lane == 0) atomicAdd(loss_out, loss);
+    }
+}
+
 // V2: sparse RMSProp on the touched [ure|uce] rows (users) and ire rows + irb (items).  NE = ceil(2kh/64)
 template <int NE, int kVTeam>
 __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_rows_kernel(
     tkr_vbpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
-    const int32_t* __restrict__ occt, const int4* __restrict__ hdr, const float* __restrict__ s_in,
-    const float* __restrict__ P, const float* __restrict__ Wm, float* __restrict__ Aw /*[slots][kh] or null*/,
-    float* __restrict__ ab /*[slots]*/) {
+    const int32_t* __restrict__ occt, const int4* __restrict__ hdr, const float* __restrict__ s_in /*S_t*/,
+    const float* __restrict__ t_in /*T_t*/, const float* __restrict__ P, const float* __restrict__ Wm,
+    float* __restrict__ Aw /*[slots][kh] or null*/, float* __restrict__ ab /*[slots]*/) {
     __shared__ float red[kVTeam][NE * TKR_WAVE + 1];
     __shared__ float red2[kVTeam][NE * TKR_WAVE + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -329,11 +366,13 @@ __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_rows_kernel(
             int oa[4], ob[4], ot[4];
             next_occ(r, done, n, lane, occ, occt, oa, ob, ot);
             for (int q = 0; q < n; ++q) {
-                const float sg = s_in[ot[q]];
+                const float sg = t_in[ot[q]];                    // rows under beta: scaled by T_t
                 if (is_item) {
                     const int u = oa[q] & kIdMaskV, pu = (oa[q] >> 30) & 1;
                     const bool role_j = ob[q] < 0;
                     const float sgn_s = role_j ? sg : -sg;
+                    const float sa = s_in[ot[q]];                // the bias sits under alpha: scaled by S_t
+                    const float sgn_a = role_j ? sa : -sa;
                     const float lam = role_j ? st.lj : st.li;
                     const float* ur = st.U + pu * ustride + (size_t)u * k2;
 #pragma unroll
@@ -341,7 +380,7 @@ __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_rows_kernel(
                         const int c = lane + e * 64;
                         if (c < kh) g[e] += sgn_s * ur[c] + lam * (l2 ? own[e] : sgn(own[e]));
                     }
-                    gb += sgn_s + st.lb * (l2 ? br : sgn(br));
+                    gb += sgn_a + st.lb * (l2 ? br : sgn(br));
                     if (want_a) {
                         const float* wt = Wm + (size_t)ot[q] * kh;
 #pragma unroll
@@ -349,7 +388,7 @@ __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_rows_kernel(
                             const int c = lane + e * 64;
                             if (c < kh) aw[e] += role_j ? -wt[c] : wt[c];
                         }
-                        asum += sgn_s;
+                        asum += sgn_a;
                     }
                 } else {
                     const int i = oa[q] & kIdMaskV, pi = (oa[q] >> 30) & 1;
@@ -554,7 +593,7 @@ template <int NH>
 __global__ __launch_bounds__(256) void vbpr_sproject_kernel(tkr_vbpr_state st, const int32_t* __restrict__ ti,
                                                            const int32_t* __restrict__ tj, int B, float* __restrict__ P,
                                                            float* __restrict__ Q, const int32_t* __restrict__ tu,
-                                                           const int32_t* __restrict__ tpar, float* __restrict__ s_out,
+                                                           const int32_t* __restrict__ tpar, float* __restrict__ ab_out,
                                                            float* __restrict__ Wm, float* __restrict__ loss_out) {
     __shared__ float red[4][NH * 64 + 1];
     __shared__ uint32_t s_par;
@@ -643,17 +682,16 @@ __global__ __launch_bounds__(256) void vbpr_sproject_kernel(tkr_vbpr_state st, c
                 d1 = fmaf(ure[e], vi[e] - vj[e], d1);
                 d2 = fmaf(uce[e], p[e], d2);
             }
-            const float x = bi - bj + wave_sum(d1) + wave_sum(d2) + qsum;
-            const float sg = sigmoid_neg(x);
+            const float alpha = bi - bj + qsum, beta = wave_sum(d1) + wave_sum(d2);
 #pragma unroll
             for (int e = 0; e < NH; ++e) {
                 const int c = lane + e * 64;
-                if (c < kh) Wm[(size_t)t * kh + c] = -sg * uce[e];
+                if (c < kh) Wm[(size_t)t * kh + c] = uce[e];              // scaled by -T_t once the pair kernel knows it
             }
-            if (lane == 0) s_out[t] = sg;
+            if (lane == 0) { ab_out[t] = alpha; ab_out[B + t] = beta; }
             if (loss_out) {
                 const bool l2 = st.mode == 0;
-                float loss = softplus_neg(x), loss_lane = 0.f;
+                float loss = 0.f, loss_lane = 0.f;
                 if (l2) {
                     loss += 0.5f * (bi * bi + bj * bj) * st.lb;
 #pragma unroll
@@ -765,6 +803,8 @@ static int launch_vbpr_t(const tkr_vbpr_state& st, const int32_t* ti, const int3
     float* P = s_buf + B;
     float* Wm = P + (size_t)B * kh;
     float* Q = Wm + (size_t)B * kh;
+    float* ab2 = ws + tkr_vbpr_workspace_floats(B, kh, st.d) - 3 * (size_t)B;      // alpha[B], beta[B] of the batch
+    float* t_buf = ab2 + 2 * (size_t)B;                                            // T_t (s_buf holds S_t)
     const int2* occ2 = reinterpret_cast<const int2*>(occ);
     const int4* hdr4 = reinterpret_cast<const int4*>(hdr);
     const dim3 rgrid(vbpr_grid(B, TEAM)), rblock(TEAM * 64);
@@ -776,21 +816,22 @@ static int launch_vbpr_t(const tkr_vbpr_state& st, const int32_t* ti, const int3
         Aw = Q + B;
         ab = Aw + (size_t)tkr_plan_max_blocks(B) * TEAM * kh;
         // with the per-triplet parities of K1 the projection also scores the triplet: no per-occurrence launch
-        if (NH == 1) hipLaunchKernelGGL(vbpr_sproject_kernel<1>, dim3(B), dim3(256), 0, stream, st, ti, tj, B, P, Q, tu, tpar, s_buf, Wm, loss);
-        else hipLaunchKernelGGL(vbpr_sproject_kernel<2>, dim3(B), dim3(256), 0, stream, st, ti, tj, B, P, Q, tu, tpar, s_buf, Wm, loss);
+        if (NH == 1) hipLaunchKernelGGL(vbpr_sproject_kernel<1>, dim3(B), dim3(256), 0, stream, st, ti, tj, B, P, Q, tu, tpar, ab2, Wm, loss);
+        else hipLaunchKernelGGL(vbpr_sproject_kernel<2>, dim3(B), dim3(256), 0, stream, st, ti, tj, B, P, Q, tu, tpar, ab2, Wm, loss);
     } else {
         hipLaunchKernelGGL(vbpr_project_kernel<NT>, dim3(S, (B + 31) / 32), dim3(64), 0, stream, st, ti, tj, B, ppart);
         hipLaunchKernelGGL(vbpr_reduce_kernel, dim3(B), dim3(1024), 0, stream, ppart, S, B, kh, P, Q);
     }
     if (!(sparse && tpar)) {
-        if (NH == 1) hipLaunchKernelGGL((vbpr_occur_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
-        else hipLaunchKernelGGL((vbpr_occur_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, s_buf, P, Wm, loss);
+        if (NH == 1) hipLaunchKernelGGL((vbpr_occur_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, ab2, P, Wm, loss);
+        else hipLaunchKernelGGL((vbpr_occur_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, B, Q, ab2, P, Wm, loss);
     }
+    hipLaunchKernelGGL(vbpr_pair_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, ab2, B, kh, s_buf, t_buf, Wm, loss);
     switch (NE) {
-        case 1: hipLaunchKernelGGL((vbpr_rows_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab); break;
-        case 2: hipLaunchKernelGGL((vbpr_rows_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab); break;
-        case 3: hipLaunchKernelGGL((vbpr_rows_kernel<3, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab); break;
-        default: hipLaunchKernelGGL((vbpr_rows_kernel<4, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, P, Wm, Aw, ab); break;
+        case 1: hipLaunchKernelGGL((vbpr_rows_kernel<1, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, t_buf, P, Wm, Aw, ab); break;
+        case 2: hipLaunchKernelGGL((vbpr_rows_kernel<2, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, t_buf, P, Wm, Aw, ab); break;
+        case 3: hipLaunchKernelGGL((vbpr_rows_kernel<3, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, t_buf, P, Wm, Aw, ab); break;
+        default: hipLaunchKernelGGL((vbpr_rows_kernel<4, TEAM>), rgrid, rblock, 0, stream, st, rec, occ2, occt, hdr4, s_buf, t_buf, P, Wm, Aw, ab); break;
     }
     if (sparse) {
         if (NH == 1) hipLaunchKernelGGL(vbpr_sdense_kernel<1>, dim3((st.d + 3) / 4), dim3(256), 0, stream, st, Aw, ab, loss);
@@ -822,7 +863,7 @@ extern "C" int tkr_plan_max_blocks(int32_t batch_size);
 extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d) {
     const int64_t S = tkr::vbpr_slices(d);
     const int64_t slots = (int64_t)tkr_plan_max_blocks(batch_size) * tkr_plan_team(batch_size);     // sparse view: A, a per item task
-    return S * batch_size * (kh + 1) + 2ll * batch_size + 2ll * batch_size * kh + slots * (kh + 1);
+    return S * batch_size * (kh + 1) + 2ll * batch_size + 2ll * batch_size * kh + slots * (kh + 1) + 3ll * batch_size;
 }
 
 extern "C" int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* tri_j, const int32_t* rec,

@@ -22,6 +22,8 @@ Stated differences from the reference:
     inherits numpy's unspecified unstable order.
   * only users that appear in the scenario's test file with at least one like are ranked
     (the reference scores every user and then reads only those rows).
+  * under a torch.distributed launcher (one process per GPU) the test lines of every scenario are block-sharded over the
+    ranks and the hit counters / like counts all-reduced; rank 0 prints.  The reference is single-process.
   * ids are resolved to indices while parsing, so the rated set of a user is keyed by the uid's
     index and a test column by its index in the id list; the reference keys both by token.  The
     two differ only if an id file repeats a token (the re-pointing quirk of evaluate.py:5-10).
@@ -127,15 +129,45 @@ def rank_scenario(umat_dev, vmat, bmat, vids, sc, total, device, want_scores=Fal
                               want_scores=want_scores)
 
 
+def shard_scenario(sc, rank, world):
+    """the contiguous block of test lines rank `rank` of `world` ranks scores (users are independent: SURVEY.md §8e)"""
+    n = len(sc.users)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    lp, rp = sc.like_ptr, sc.rated_ptr
+    return Scenario(sc.teids, sc.users[lo:hi], lp[lo:hi + 1] - lp[lo], sc.like_cols[lp[lo]:lp[hi]],
+                    rp[lo:hi + 1] - rp[lo], sc.rated_cols[rp[lo]:rp[hi]])
+
+
+def _world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def evaluate_scenario(umat_dev, vmat, bmat, uids, vids, data_dir, fold, scenario, step, total, device, umap=None):
-    sc = load_scenario(data_dir, fold, scenario, uids, umap)
+    """accuracy@(step, 2*step, ...) of one scenario (evaluate.py:72-112).  Under torch.distributed every rank ranks its
+    block of the scenario's test lines; what the reference accumulates over users -- tresults[k] and tcount, :106-112 --
+    is summed over the ranks by one all-reduce of interval + 1 integers (no other exchange: the factors are replicated)."""
+    full = load_scenario(data_dir, fold, scenario, uids, umap)
+    rank, world = _world()
+    sc = shard_scenario(full, rank, world) if world > 1 else full
     interval = total // step
     hits = np.zeros(interval, dtype=np.int64)
     if len(sc.users):
         ids = rank_scenario(umat_dev, vmat, bmat, vids, sc, total, device)
         lptr, lcols = torch.from_numpy(sc.like_ptr).to(device), torch.from_numpy(sc.like_cols).to(device)
         hits = tkr_hip.count_hits(ids, lptr, lcols, step, interval).cpu().numpy()
-    return [float(h) / sc.tcount for h in hits]                       # ZeroDivisionError like evaluate.py:112
+    tcount = sc.tcount
+    if world > 1:
+        import torch.distributed as dist
+        on_dev = dist.get_backend() == 'nccl'                        # RCCL reduces device tensors, gloo host tensors
+        acc = torch.from_numpy(np.r_[hits, tcount].astype(np.int64))
+        acc = acc.to(device) if on_dev else acc
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        acc = acc.cpu().numpy()
+        hits, tcount = acc[:interval], int(acc[interval])
+    return [float(h) / tcount for h in hits]                          # ZeroDivisionError like evaluate.py:112
 
 
 def main(argv=None):
@@ -150,6 +182,8 @@ def main(argv=None):
 
     if not torch.cuda.is_available():
         raise tkr_hip.TkrError('evaluate.py scores on the GPU through libtkr_hip.so; no MI355X is visible')
+    started_group = _init_distributed()
+    rank, _ = _world()
     device = torch.device('cuda', torch.cuda.current_device())
     uids = read_ids(os.path.join(args.data, 'uid'))
     vids = read_ids(os.path.join(args.data, 'vid'))
@@ -167,8 +201,32 @@ def main(argv=None):
     lines = []
     for scenario in args.scenarios:
         lines.append(scenario + ''.join(',%.6f' % v for v in results[scenario]))
-        print(lines[-1])
+        if rank == 0:                                                # one report, like the single process
+            print(lines[-1])
+    if started_group:
+        import torch.distributed as dist
+        dist.destroy_process_group()
     return lines
+
+
+def _init_distributed():
+    """One process per GPU when started by a launcher (python -m torch.distributed.run --nproc-per-node N evaluate.py ...):
+    RANK / WORLD_SIZE / LOCAL_RANK in the environment.  Backend 'nccl' (= RCCL over xGMI) unless TKR_DIST_BACKEND says
+    otherwise; TKR_SINGLE_DEVICE=1 puts every rank on GPU 0 (tests on a one-GPU box, with gloo).  Returns True when this
+    call created the process group."""
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1 or not dist.is_available() or dist.is_initialized():
+        return False
+    local = 0 if os.environ.get('TKR_SINGLE_DEVICE') == '1' else int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    backend = os.environ.get('TKR_DIST_BACKEND', 'nccl')
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    else:
+        dist.init_process_group(backend)
+    return True
 
 
 if __name__ == '__main__':

@@ -23,8 +23,6 @@ from __future__ import annotations
 
 import sys
 import time
-from collections import defaultdict
-
 import numpy as np
 import torch
 
@@ -52,47 +50,46 @@ class _Shared:
 
 
 class BPR(object):
+    """Constructor and ``train`` keep the reference's argument lists (old/methods/bpr.py:17,63); everything behind them is
+    this build's: the id maps and hyper-parameters live in two small records, the positives go straight into the device CSR."""
 
     def __init__(self, K, users, items, lambda_u=0.0025, lambda_i=0.0025, lambda_j=0.00025, lambda_bias=0.0,
                  learning_rate=1.0e-4, *, seed=None, device=None):
-        self._K = K
-        self._train_users = users
-        self._train_items = items
-        self._n_users = len(users)
-        self._n_items = len(items)
-        self._lambda_u = lambda_u
-        self._lambda_i = lambda_i
-        self._lambda_j = lambda_j
-        self._lambda_bias = lambda_bias
-        self._learning_rate = learning_rate
-        self._train_dict = {}
-        hp = dict(lu=lambda_u, li=lambda_i, lj=lambda_j, lb=lambda_bias, lr=learning_rate, mode='l2', opt='sgd')
-        self._engine = BprEngine(self._n_users, self._n_items, K, hp, device=device, seed=seed)
+        self.ids = {'users': users, 'items': items}                     # external id -> row index, as handed in
+        self.shape = (len(users), len(items), K)
+        self.hyper = dict(lu=lambda_u, li=lambda_i, lj=lambda_j, lb=lambda_bias, lr=learning_rate, mode='l2', opt='sgd')
+        self._engine = BprEngine(self.shape[0], self.shape[1], K, self.hyper, device=device, seed=seed)
         self.W, self.H, self.B = _Shared(self, 'U'), _Shared(self, 'V'), _Shared(self, 'b')
+        self.positives = {}                                             # row index of a user -> its item row indices, input order
         self.losses = None
 
-    def train(self, train_data, epochs=30, batch_size=256):
-        if len(train_data) < batch_size:
-            sys.stderr.write("WARNING: Batch size is greater than number of training samples, switching to a batch size of %s\n" % str(len(train_data)))
-            batch_size = len(train_data)
-        self._train_dict = self._data_to_dict(train_data, self._train_users, self._train_items)
-        n_sgd_samples = len(train_data) * epochs
-        sys.stderr.write("Generating %s random training samples\n" % str(n_sgd_samples))
-        n_batches = (n_sgd_samples - 1) // batch_size if n_sgd_samples > 0 else 0      # old/methods/bpr.py:72
-        csr = TrainingCSR(self._train_dict, sorted(self._train_dict.keys()), self._n_users, self._engine.device)
-        t0 = time.time()
-        done = n_batches
-        if n_batches > 0:
-            self.losses = self._engine.run_batches(csr, n_batches, batch_size, want_loss=True)
-        torch.cuda.synchronize(self._engine.device)
-        t2 = time.time()
-        if n_sgd_samples > 0:
-            sys.stderr.write("Processed %s ( %.2f%% )\n" % (str(done * batch_size), 100.0 * float(done * batch_size) / n_sgd_samples))
-            sys.stderr.write("\nTotal training time %.2f seconds; %e per sample\n" % (t2 - t0, (t2 - t0) / n_sgd_samples))
-            sys.stderr.flush()
+    def _group_positives(self, pairs):
+        """(user id, item id) pairs -> {user row: [item rows]} in input order, duplicates kept (they weight the positive draw)"""
+        u_of, i_of = self.ids['users'], self.ids['items']
+        rows = np.fromiter((u_of[u] for u, _ in pairs), dtype=np.int64, count=len(pairs))
+        cols = np.fromiter((i_of[i] for _, i in pairs), dtype=np.int64, count=len(pairs))
+        order = np.argsort(rows, kind='stable')
+        cuts = np.flatnonzero(np.diff(rows[order])) + 1
+        return {int(rows[order[g[0]]]): cols[order[g]].tolist() for g in np.split(np.arange(len(pairs)), cuts) if len(g)}
 
-    def _data_to_dict(self, data, users, items):
-        data_dict = defaultdict(list)
-        for (user, item) in data:
-            data_dict[users[user]].append(items[item])
-        return data_dict
+    def train(self, train_data, epochs=30, batch_size=256):
+        n_pairs = len(train_data)
+        if n_pairs < batch_size:                                         # message text of old/methods/bpr.py:65
+            sys.stderr.write("WARNING: Batch size is greater than number of training samples, switching to a batch size of %s\n" % n_pairs)
+            batch_size = n_pairs
+        self.positives = self._group_positives(list(train_data))
+        budget = n_pairs * epochs                                        # triplets the reference pre-generates (:70, :89)
+        sys.stderr.write("Generating %s random training samples\n" % budget)
+        n_batches = (budget - 1) // batch_size if budget > 0 else 0      # the reference's loop condition, old/methods/bpr.py:72
+        device = self._engine.device
+        started = time.time()
+        if n_batches > 0:
+            csr = TrainingCSR(self.positives, sorted(self.positives), self.shape[0], device)
+            self.losses = self._engine.run_batches(csr, n_batches, batch_size, want_loss=True)
+        torch.cuda.synchronize(device)
+        spent = time.time() - started
+        if budget > 0:
+            seen = n_batches * batch_size
+            sys.stderr.write("Processed %s ( %.2f%% )\n" % (seen, 100.0 * seen / budget))
+            sys.stderr.write("\nTotal training time %.2f seconds; %e per sample\n" % (spent, spent / budget))
+            sys.stderr.flush()

@@ -12,7 +12,14 @@ HBM; the per-batch host gather + feed of two [B, d] slices (vbpr.py:114) does no
 After training the content half is folded into the exported factors exactly like vbpr.py:124-126,
 so evaluation is identical to BPR's:  fue = [ure|uce], fie = [ire | feat.cem], fib = irb + feat.icb.
 
-Mirrored quirks: an odd k silently drops a dimension (exported width 2*(k//2)); resuming from text
+Mirrored quirk that changes the arithmetic: the data term of the objective is a sum over ALL PAIRS of a batch,
+``sum_{a,b} log(1 + exp(-(alpha_a + beta_b)))`` with alpha = irb_i - irb_j + (f_i - f_j).icb and beta = x_ui - x_uj --
+the reference's item_rating_bias is [n_items, 1], so its ``irbb - jrbb + x_ui - x_uj + matmul(ic - jc, icb)`` (vbpr.py:61)
+broadcasts to [B, B] before the reduce_sum of :64.  The kernels compute exactly that (csrc/vbpr_step.hip, pair kernel),
+the oracle is checked against autograd on the literal expressions with the reference's shapes (tests/test_oracle_step.py).
+BPR itself is not affected (its bias is 1-D, bpr.py:79).
+
+Other mirrored quirks: an odd k silently drops a dimension (exported width 2*(k//2)); resuming from text
 re-imports ``fib`` (which already contains feat.icb) into irb (vbpr.py:106-108), double-counting the
 content bias unless the checkpoint (``weights``) is also present -- as in the reference, the
 checkpoint holds irb itself but the text value wins.

@@ -117,6 +117,30 @@ def positives_csr(r, n_users=None):
     return row_ptr.astype(np.int32), pos, srt, np.flatnonzero(deg > 0).astype(np.int32)
 
 
+def train_csr_shape(n_users, n_items, mean_pos=90.0, sigma=1.0, alpha=0.9, seed=42):
+    """Training positives of a given SHAPE straight as CSR (no ratings, likes or test split): per-user counts ~ clipped
+    lognormal with the given mean, items by popularity rank^-alpha, repeated draws of a user dropped.  For the Netflix-shape
+    training benchmarks (480,189 x 17,770: ~4 x 10^7 positives), where make_ratings' 10^8 (user, item, like) triples are
+    only needed by the scoring side.  -> row_ptr int32[n_users+1], pos_cols, cols_sorted, tr_users (as positives_csr)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    mu = np.log(mean_pos) - 0.5 * sigma * sigma
+    cnt = np.clip(rng.lognormal(mu, sigma, n_users), 2, n_items // 4).astype(np.int64)
+    pop = np.arange(1, n_items + 1, dtype=np.float64) ** (-alpha)
+    cdf = np.cumsum(pop / pop.sum())
+    perm = rng.permutation(n_items)
+    users = np.repeat(np.arange(n_users, dtype=np.int64), cnt)
+    items = perm[np.minimum(np.searchsorted(cdf, rng.random(len(users), dtype=np.float32)), n_items - 1)]
+    key = np.unique(users * n_items + items)                      # sorted by (user, item): also the per-row ascending copy
+    users, srt = key // n_items, (key % n_items).astype(np.int32)
+    del key, items
+    row_ptr = np.zeros(n_users + 1, dtype=np.int64)
+    np.cumsum(np.bincount(users, minlength=n_users), out=row_ptr[1:])
+    shuffle = rng.permutation(len(srt))                           # "file order" inside a user's row is arbitrary
+    pos = srt[shuffle[np.argsort(users[shuffle], kind='stable')]]
+    assert row_ptr[-1] < 2 ** 31
+    return row_ptr.astype(np.int32), pos, srt, np.flatnonzero(np.diff(row_ptr) > 0).astype(np.int32)
+
+
 def rated_csr(r, n_users=None):
     """Every train-rated item (like 0 or 1) per user, ascending: the evaluate.py rated set."""
     n_users = n_users or r['n_users']
