@@ -81,10 +81,14 @@ def build_problem(shape, k, rank, world, device, seed=42):
     row_ptr, pos, _, tr_users = synth.positives_csr(r)
     n_users, n_items = r['n_users'], r['n_in'] + r['n_out']
     import dist as tdist
-    mine = np.asarray(tdist.shard_users(tr_users, rank, world), dtype=np.int32)
-    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, mine, device)
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=1e-4, mode='l2')       # single/bpr.py:20 defaults
-    eng = _engine.BprEngine(n_users, n_items, k, hp, device, seed=1234 + rank)
+    if world == 1:
+        csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, dtype=np.int32), device)
+        eng = _engine.BprEngine(n_users, n_items, k, hp, device, seed=1234)
+    else:           # as BPR.train: the rank allocates only the rows of its users, the item tables are replicas (same seed)
+        mine = np.asarray(tdist.shard_users(tr_users, rank, world), dtype=np.int64)
+        csr = _engine.TrainingCSR.shard(row_ptr, pos, mine, device)
+        eng = _engine.BprEngine(len(mine), n_items, k, hp, device, seed=1234, user_seed=99991 * (rank + 1))
     return r, csr, eng, int(row_ptr[-1])
 
 
@@ -256,14 +260,14 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
             # dense optimizer traffic + the CSC walk + one cem row and one icb value per nonzero of the 2B gathered items
             bytes_ = 16.0 * d * kh + 8.0 * nnz + 2.0 * B * (nnz / n_items) * (4.0 * kh + 12.0)
             gbs = bytes_ / step_s / 1e9
-            roof = {'kernels': 'tkr::vbpr_sproject (project + score) / rows / sdense (3 launches per batch)', 'bound': 'hbm', 'achieved': gbs,
+            roof = {'kernels': 'tkr::vbpr_sproject (project + alpha, beta) / pair / rows / sdense (4 launches per batch)', 'bound': 'hbm', 'achieved': gbs,
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch_chain': bytes_,
                     'step_us': step_s * 1e6, 'traffic': None}
         else:
             flops = 4.0 * d * kh * B                                     # project the difference once, fwd + dense gradient
             tf = flops / step_s / 1e12
             bytes_ = B * 2 * 4 * d * 2 + 16.0 * d * kh                   # feature rows (V1 + V3) + dense optimizer traffic
-            roof = {'kernels': 'tkr::vbpr_project/reduce/occur/rows/dense (5 launches per batch)', 'bound': 'mfma', 'achieved': tf,
+            roof = {'kernels': 'tkr::vbpr_project/reduce/occur/pair/rows/dense (6 launches per batch)', 'bound': 'mfma', 'achieved': tf,
                     'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s', 'frac': tf / MFMA_F32_PEAK_TF,
                     'hbm_GBps_algorithmic': bytes_ / step_s / 1e9, 'hbm_frac': bytes_ / step_s / 1e9 / HBM_PEAK_GBS, 'step_us': step_s * 1e6}
         out[key] = {'value': steps * B / wall, 'unit': 'triplets/s', 'steps': steps, 'ms_per_step': wall * 1e3 / steps, 'roofline': roof}
@@ -272,6 +276,31 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
     res['config'] = {'workload': 'VBPR ML-10M shape, k=%d (kh=%d), content features d=%d with %d nonzeros (%.2f %% dense), batch_size=%d'
                                  % (k, kh, d, nnz, 100.0 * nnz / (n_items * d), B)}
     res['dense_view'] = out['dense_view']
+    # throughput mode of the same model: batch_size 8192 (a legal train() argument), sparse view
+    eng = _engine.VbprEngine(n_users, n_items, k, d, feat, hp, device, seed=3)
+    Bt, st_ = 8192, 48
+    wall, step_ms = timed_run(eng, csr, Bt, st_, st_, 10 ** 9, 1, names=eng.replicated_names)
+    step_s = step_ms * 1e-3 / st_
+    bytes_ = 16.0 * d * kh + 8.0 * nnz + 2.0 * Bt * (nnz / n_items) * (4.0 * kh + 12.0) + Bt * (48.0 * kh + 56)
+    res['throughput_mode'] = {'batch_size': Bt, 'steps': st_, 'value': st_ * Bt / wall, 'unit': 'triplets/s', 'ms_per_step': wall * 1e3 / st_,
+                              'roofline': {'bound': 'hbm', 'achieved': bytes_ / step_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                           'frac': bytes_ / step_s / 1e9 / HBM_PEAK_GBS, 'step_us': step_s * 1e6, 'traffic': None}}
+    del eng
+    # the literal reading of BASELINE.json configs[2] ("d=128"): DENSE content features of width d_c = 128
+    dc = 128
+    featd = torch.rand((n_items, dc), device=device, generator=g) + 0.1
+    featd /= featd.norm(dim=1, keepdim=True)
+    eng = _engine.VbprEngine(n_users, n_items, k, dc, featd, hp, device, seed=3)
+    assert eng.sparse is None                                            # fully dense: the MFMA kernels (V1 / V3)
+    wall, step_ms = timed_run(eng, csr, B, steps, warmup, 10 ** 9, 1, names=eng.replicated_names)
+    step_s = step_ms * 1e-3 / steps
+    bytes_ = B * (2 * 4 * dc * 2 + 48.0 * kh + 56) + 16.0 * dc * kh       # feature rows (V1 + V3) + the sparse rows + dense optimizer traffic
+    res['dense_dc128'] = {'value': steps * B / wall, 'unit': 'triplets/s', 'steps': steps, 'ms_per_step': wall * 1e3 / steps,
+                          'config': {'workload': 'VBPR ML-10M shape, k=%d, DENSE content features d_c=%d, batch_size=%d' % (k, dc, B)},
+                          'roofline': {'kernels': 'tkr::vbpr_project/reduce/occur/pair/rows/dense (6 launches per batch)', 'bound': 'hbm',
+                                       'achieved': bytes_ / step_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': bytes_ / step_s / 1e9 / HBM_PEAK_GBS,
+                                       'mfma_TFLOPs': 4.0 * dc * kh * B / step_s / 1e12, 'step_us': step_s * 1e6, 'traffic': None}}
+    del eng
     return res
 
 

@@ -182,11 +182,16 @@ sync.end()
 assert torch.allclose(e.t['V'][0], V0 + 0.5 * sum(range(1, world + 1)))        # P0 + sum of deltas
 assert torch.allclose(e.t['V'][1], torch.full((6, 4), sum(range(1, world + 1)) / world))   # slots: mean
 assert torch.allclose(e.t['b'][0][:world], torch.ones(world))
-U0 = torch.zeros(5, 2); U = U0.clone(); U[rank::world] += rank + 1
-out = tdist.combine_user_rows(U, U0)
-exp = torch.zeros(5, 2)
-for r in range(world): exp[r::world] += r + 1
-assert torch.allclose(out, exp)
+# user rows: every rank holds ONLY the rows of its users (5 users dealt round-robin -> shards of 3 and 2) and they are gathered once
+owned = tdist.shard_users(list(range(5)), rank, world)
+rows = torch.full((len(owned), 2), float(rank + 1)); slots = rows * 10
+full, full_ms = np.zeros((5, 2), np.float32), np.zeros((5, 2), np.float32)
+for ids, r_, m_ in tdist.gather_owned_rows(owned, rows, slots):
+    full[ids], full_ms[ids] = r_, m_
+exp = np.zeros((5, 2), np.float32)
+for r in range(world): exp[r::world] = r + 1
+assert np.array_equal(full, exp) and np.array_equal(full_ms, exp * 10)
+assert tdist.shared_seed(None if rank else 12345) == 12345 and tdist.shared_seed(7 + rank) == 7      # rank 0's seed wins
 dist.barrier(); dist.destroy_process_group()
 print('ok', rank)
 '''

@@ -5,7 +5,7 @@ replicated and reconciled by ONE all-reduce per epoch (RCCL over xGMI; backend '
 Reduction rule: parameters  P <- P0 + sum_g (P_g - P0)   (sum of per-replica deltas:
 tracks the single-stream trajectory to first order, whereas a plain mean divides the item
 displacement by the world size); RMSProp slots  ms <- mean_g ms_g.
-User rows are only ever updated by their owning rank; they are combined once, after training.
+Each rank allocates only the rows of the users it owns; they are gathered once, after training.
 """
 from __future__ import annotations
 
@@ -174,9 +174,27 @@ class ItemSync:
             cnt.zero_()                                       # buffer 0 is current again for every row
 
 
-def combine_user_rows(current: torch.Tensor, start: torch.Tensor) -> torch.Tensor:
-    """after training: every user row was changed by at most one rank -> sum of deltas is exact"""
+def gather_owned_rows(owned, rows: torch.Tensor, slots: torch.Tensor):
+    """After training: every rank contributes the user rows it owns.  -> [(global ids, rows, slots) per rank] as numpy arrays
+    on every rank.  One all-gather of the ids and one of [rows | slots]; shards differ in length by at most one user, the
+    shorter ones are padded.  (Round 1 kept the FULL user table on every rank and all-reduced it: 246 MB at the Netflix shape.)"""
     _, w = world()
-    if w == 1:
-        return current
-    return reduce_deltas(current, start)
+    n, width = int(rows.shape[0]), int(rows.shape[1])
+    on_dev = dist.get_backend() == 'nccl'                            # RCCL moves device tensors, gloo host tensors
+    dev = rows.device if on_dev else torch.device('cpu')
+    sizes = torch.zeros(w, dtype=torch.int64, device=dev)
+    mine = torch.tensor([n], dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, mine)
+    cap = int(sizes.max())
+    ids = torch.full((cap,), -1, dtype=torch.int64, device=dev)
+    ids[:n] = torch.as_tensor(np.asarray(owned, dtype=np.int64)).to(dev)
+    body = torch.zeros((cap, 2 * width), dtype=torch.float32, device=dev)
+    body[:n, :width] = rows.to(dev)
+    body[:n, width:] = slots.to(dev)
+    all_ids = torch.empty((w * cap,), dtype=torch.int64, device=dev)
+    all_body = torch.empty((w * cap, 2 * width), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(all_ids, ids)
+    dist.all_gather_into_tensor(all_body, body)
+    all_ids, all_body, sizes = all_ids.cpu().numpy(), all_body.cpu().numpy(), sizes.cpu().numpy()
+    return [(all_ids[r * cap:r * cap + sizes[r]], all_body[r * cap:r * cap + sizes[r], :width], all_body[r * cap:r * cap + sizes[r], width:])
+            for r in range(w)]

@@ -41,6 +41,20 @@ class TrainingCSR:
                      np.asarray(tr_users, dtype=np.int32), device)
         return self
 
+    @classmethod
+    def shard(cls, row_ptr, pos_cols, owned, device):
+        """CSR of the users `owned` (global indices) in the shard's own numbering: row q = user owned[q].  The engine of a
+        rank allocates only these rows (multi-GPU: SURVEY.md §8e)."""
+        row_ptr = np.asarray(row_ptr, dtype=np.int64)
+        owned = np.asarray(owned, dtype=np.int64)
+        deg = row_ptr[owned + 1] - row_ptr[owned]
+        local_ptr = np.zeros(len(owned) + 1, dtype=np.int64)
+        np.cumsum(deg, out=local_ptr[1:])
+        take = np.repeat(row_ptr[owned] - local_ptr[:-1], deg) + np.arange(int(local_ptr[-1]), dtype=np.int64)
+        self = cls.from_arrays(local_ptr, np.asarray(pos_cols)[take], np.flatnonzero(deg > 0).astype(np.int32), device)
+        self.local = True
+        return self
+
     def _finish(self, row_ptr, pos, tr_users, device):
         assert row_ptr[-1] < 2 ** 31
         owner = np.repeat(np.arange(len(row_ptr) - 1, dtype=np.int64), np.diff(row_ptr))
@@ -326,6 +340,19 @@ class DoubleTable:
             self.ms[0].copy_(ms)
 
 
+def _generators(device, seed, user_seed):
+    """(generator of the replicated tables, generator of the user rows).  One process: the same object, users first, as
+    ever.  A user shard: two generators, so that every rank draws the same item tables whatever its number of users."""
+    gen = torch.Generator(device=device)
+    if user_seed is None:
+        gen.manual_seed(seed & 0x7FFFFFFFFFFFFFFF)
+        return gen, gen
+    gen.manual_seed((seed ^ 0x5BD1E9955BD1E995) & 0x7FFFFFFFFFFFFFFF)
+    gen_u = torch.Generator(device=device)
+    gen_u.manual_seed(int(user_seed) & 0x7FFFFFFFFFFFFFFF)
+    return gen, gen_u
+
+
 FLOW_MAX_BATCH = int(__import__('os').environ.get('TKR_FLOW_MAX_BATCH', 1024))    # batch sizes up to this take the persistent dataflow step (K2f)
 FLOW_WAVES_PER_CU = int(__import__('os').environ.get('TKR_FLOW_WAVES_PER_CU', 0))    # 0 = the library default
 
@@ -390,17 +417,19 @@ class BprEngine(PlanMixin):
     up to FLOW_MAX_BATCH, where a launch per batch is latency-bound).  run_batches picks by batch size and converts the
     tables when it changes; get / set work on either."""
 
-    def __init__(self, n_users, n_items, k, hp, device=None, seed=None):
+    def __init__(self, n_users, n_items, k, hp, device=None, seed=None, user_seed=None):
+        """``user_seed``: this engine holds ONE SHARD of the users (multi-GPU: n_users = rows owned by the rank): the user
+        rows are drawn from their own generator (a different one per rank), the replicated item tables from ``seed`` alone
+        (identical on every rank)."""
         self.device = device or default_device()
         self.n_users, self.n_items, self.k = n_users, n_items, k
         self.hp = hp
         self.seed = int(seed if seed is not None else np.random.SeedSequence().entropy % (2 ** 63))
-        gen = torch.Generator(device=self.device)
-        gen.manual_seed(self.seed & 0x7FFFFFFFFFFFFFFF)
+        gen, gen_u = _generators(self.device, self.seed, user_seed)
         # single/bpr.py:77-79: U, V ~ N(0, 0.01); b = 0.  RMSProp `rms` slots start at one.
         self.layout = 'bulk'
         self.layout_epoch = 0           # bumped whenever the tables are re-allocated (dist.ItemSync re-binds)
-        self.U = DoubleTable(n_users, k, self.device, 0.01, gen)
+        self.U = DoubleTable(n_users, k, self.device, 0.01, gen_u)
         self.V = DoubleTable(n_items, k, self.device, 0.01, gen)
         self.b = DoubleTable(n_items, 0, self.device)
         self.tailU = self.tailV = self.ctl = None
@@ -547,15 +576,14 @@ class VbprEngine(PlanMixin):
 
     SPARSE_DENSITY = 0.25      # below this fraction of nonzeros the step uses the CSR/CSC view of feat (csrc/vbpr_step.hip S1/S3)
 
-    def __init__(self, n_users, n_items, k, d, feat, hp, device=None, seed=None, sparse=None):
+    def __init__(self, n_users, n_items, k, d, feat, hp, device=None, seed=None, sparse=None, user_seed=None):
         self.device = device or default_device()
         self.n_users, self.n_items, self.k, self.kh, self.d = n_users, n_items, k, k // 2, d
         self.hp = hp
         self.seed = int(seed if seed is not None else np.random.SeedSequence().entropy % (2 ** 63))
-        gen = torch.Generator(device=self.device)
-        gen.manual_seed(self.seed & 0x7FFFFFFFFFFFFFFF)
+        gen, gen_u = _generators(self.device, self.seed, user_seed)
         kh = self.kh
-        self.U = DoubleTable(n_users, 2 * kh, self.device, 0.01, gen)          # vbpr.py:37-40
+        self.U = DoubleTable(n_users, 2 * kh, self.device, 0.01, gen_u)        # vbpr.py:37-40
         self.I = DoubleTable(n_items, kh, self.device, 0.01, gen)              # vbpr.py:41
         self.irb = DoubleTable(n_items, 0, self.device)                        # vbpr.py:43
         f32 = dict(dtype=torch.float32, device=self.device)

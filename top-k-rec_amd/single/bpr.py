@@ -49,6 +49,8 @@ class BPR(REC):
         self.fue = self.fie = self.fib = None
         self._eng = None        # device tables (the reference's tf.Session + variables)
         self._csr = None        # device CSR of tr_data
+        self._owned = None      # multi-GPU: global indices of the users whose rows this rank holds
+        self._global_users = None
         self.last_epoch_loss = None
 
     # ------------------------------------------------------------------ data (bpr.py:51-69)
@@ -110,24 +112,50 @@ class BPR(REC):
     def _hyper(self):
         return dict(lu=self.lu, li=self.li, lj=self.lj, lb=self.lb, lr=self.lr, mode=self.mode)
 
-    def _make_engine(self, device, seed):
-        return _engine.BprEngine(self.n_users, self.n_items, self.k, self._hyper(), device, seed)
+    def _make_engine(self, device, seed, n_users=None, user_seed=None):
+        return _engine.BprEngine(n_users or self.n_users, self.n_items, self.k, self._hyper(), device, seed, user_seed=user_seed)
 
-    def build_graph(self, *, device=None, seed=None):
+    def build_graph(self, *, device=None, seed=None, owned=None):
         """Allocate and initialise the model tables in HBM (user_embed / item_embed ~ N(0, 0.01),
         item_bias = 0, RMSProp slots = 1; bpr.py:77-79,100).  The reference returns the three
-        feed placeholders; there is nothing to feed here, so the engine is returned instead."""
-        self._eng = self._make_engine(device, seed)
-        if self._csr is None or self._csr.row_ptr.device != self._eng.device:
-            self._csr = self._make_csr(self.tr_users, self._eng.device)
+        feed placeholders; there is nothing to feed here, so the engine is returned instead.
+
+        ``owned`` (multi-GPU): the global indices of the users this rank trains.  Only THEIR rows are allocated -- local
+        row q is user owned[q], the training CSR is re-indexed to match -- while the item-side tables are full replicas."""
+        self._owned = None if owned is None else np.asarray(owned, dtype=np.int64)
+        if self._owned is None:
+            self._eng = self._make_engine(device, seed)
+            if self._csr is None or self._csr.row_ptr.device != self._eng.device or getattr(self._csr, 'local', False):
+                self._csr = self._make_csr(self.tr_users, self._eng.device)
+            return self._eng
+        import dist as tdist
+        rank, _ = tdist.world()
+        self._eng = self._make_engine(device, seed, n_users=len(self._owned), user_seed=(seed or 0) * 1000003 + 7919 * (rank + 1))
+        self._csr = self._make_local_csr(self._owned, self._eng.device)
         return self._eng
+
+    def _make_local_csr(self, owned, device):
+        """training CSR of a user shard in the shard's own row numbering (row q = user owned[q])"""
+        row_ptr, pos, _ = self._csr_arrays if getattr(self, '_csr_arrays', None) is not None else (None, None, None)
+        if row_ptr is None or row_ptr[-1] != sum(len(v) for v in self.tr_data.values()):      # tr_data assigned by hand
+            row_ptr = np.zeros(self.n_users + 1, dtype=np.int64)
+            for u, items in self.tr_data.items():
+                row_ptr[u + 1] = len(items)
+            np.cumsum(row_ptr, out=row_ptr)
+            pos = np.fromiter((it for u in sorted(self.tr_data) for it in self.tr_data[u]), dtype=np.int32, count=int(row_ptr[-1]))
+        return _engine.TrainingCSR.shard(row_ptr, pos, owned, device)
+
+    def _user_rows(self, table):
+        """the rows of a [n_users, ...] host array this rank's engine holds (all of them in a single process)"""
+        table = np.asarray(table)
+        return table if getattr(self, '_owned', None) is None else np.ascontiguousarray(table[self._owned])
 
     # ------------------------------------------------------------------ train (bpr.py:103-153)
     def _warm_start(self):
         """bpr.py:127-135: text-imported (or previous) fue/fie/fib override the fresh init."""
         if self.fue is not None:
             tprint('Initialize user embeddings')
-            self._eng.set_users(U=self.fue)
+            self._eng.set_users(U=self._user_rows(self.fue))
         if self.fie is not None:
             tprint('Initialize item embeddings')
             self._eng.set_items(V=self.fie)
@@ -135,9 +163,31 @@ class BPR(REC):
             tprint('Initialize item biases')
             self._eng.set_items(b=np.asarray(self.fib).ravel())
 
+    def _collect_users(self, width):
+        """fue of the whole model.  One process: the engine's table.  Sharded: every rank contributes the rows it owns
+        (parameters and slots, one all-gather each -- no rank ever held or exchanged the full table during training); users
+        nobody trains keep their start: the warm-start value, else N(0, 0.01) drawn from the shared seed."""
+        p, ms = self._eng.get('U')
+        if getattr(self, '_owned', None) is None:
+            self._global_users = None
+            return p.cpu().numpy()
+        import dist as tdist
+        if self.fue is not None and np.asarray(self.fue).shape == (self.n_users, width):
+            base = np.array(self.fue, dtype=np.float32)
+        else:
+            base = (np.random.Generator(np.random.PCG64(self._eng.seed)).standard_normal((self.n_users, width)) * 0.01).astype(np.float32)
+        base_ms = np.ones_like(base)
+        old = getattr(self, '_global_users', None)
+        if old is not None and old[1].shape == base_ms.shape:
+            base_ms = old[1].numpy().copy()
+        for ids, rows, slots in tdist.gather_owned_rows(self._owned, p, ms):
+            base[ids], base_ms[ids] = rows, slots
+        self._global_users = (torch.from_numpy(base.copy()), torch.from_numpy(base_ms))       # what export_model writes
+        return base
+
     def _collect(self):
         """bpr.py:151-153"""
-        self.fue = self._eng.get('U')[0].cpu().numpy()
+        self.fue = self._collect_users(self.k)
         self.fie = self._eng.get('V')[0].cpu().numpy()
         self.fib = self._eng.get('b')[0].reshape(-1, 1).cpu().numpy()
 
@@ -159,7 +209,8 @@ class BPR(REC):
         import dist as tdist
         rank, world = tdist.world()
         seed = tdist.shared_seed(seed)                   # one init and one sample-stream key for every rank
-        self.build_graph(device=device, seed=seed)
+        sharded = world > 1 and streams == 1
+        self.build_graph(device=device, seed=seed, owned=tdist.shard_users(self.tr_users, rank, world) if sharded else None)
         if model_path is not None:
             assert isinstance(model_path, str)
             tprint("Initialize weights with the previous trained model")
@@ -182,13 +233,12 @@ class BPR(REC):
             self._collect()
             return
         if world > 1:
-            shard = tdist.shard_users(self.tr_users, rank, world)
-            self._csr = self._make_csr(shard, self._eng.device)
+            # each rank owns the rows of its users (build_graph allocated only those and re-indexed the CSR); the item-side
+            # tables are replicas, reconciled once per epoch; the user rows are gathered once, after training (_collect)
             n_batches = tdist.batches_per_rank(n_batches, world)
             self._eng.triplets_drawn = rank * epochs * n_batches * batch_size      # disjoint stream positions
             tdist.assert_replicated(self._eng)             # same seed, same warm start: the replicas must start equal
             sync = tdist.ItemSync(self._eng)
-            users_start = self._eng.get('U')[0].clone()
         for eid in range(epochs):
             t0 = time.time()
             if world > 1:
@@ -204,10 +254,6 @@ class BPR(REC):
                 sys.stderr.write(' ... total time collapse %8.4fs' % spent)
                 sys.stderr.flush()
                 print()
-        if world > 1:
-            p, ms = self._eng.get('U')
-            self._eng.set_users(U=tdist.combine_user_rows(p, users_start), msU=ms)
-            self._csr = None                     # the sharded CSR is not the model's full training set
         self._collect()
 
     def _train_streams(self, epochs, n_batches, batch_size, S, verbose):
@@ -286,11 +332,15 @@ class BPR(REC):
         for name in ('U', 'V', 'b'):
             p, ms = e.get(name)
             out[name], out['ms_' + name] = p.cpu(), ms.cpu()
+        if getattr(self, '_global_users', None) is not None:           # sharded run: the gathered table, not this rank's rows
+            out['U'], out['ms_U'] = self._global_users
         return out
 
     def _restore_tensors(self, blob):
         e = self._eng
-        e.set_users(U=blob['U'], msU=blob['ms_U'])
+        e.set_users(U=self._user_rows(blob['U']), msU=self._user_rows(blob['ms_U']))
+        if getattr(self, '_owned', None) is not None:
+            self._global_users = (torch.as_tensor(np.asarray(blob['U'])).clone(), torch.as_tensor(np.asarray(blob['ms_U'])).clone())
         e.set_items(V=blob['V'], b=blob['b'], msV=blob['ms_V'], msb=blob['ms_b'])
 
     def import_model(self, model_path: str) -> None:

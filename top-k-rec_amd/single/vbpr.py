@@ -47,16 +47,17 @@ class VBPR(BPR):
         hp['le'] = self.le
         return hp
 
-    def _make_engine(self, device, seed):
+    def _make_engine(self, device, seed, n_users=None, user_seed=None):
         assert getattr(self, 'feat', None) is not None, 'call load_content_data() before train()'
-        return _engine.VbprEngine(self.n_users, self.n_items, self.k, self.d, self.feat, self._hyper(), device, seed)
+        return _engine.VbprEngine(n_users or self.n_users, self.n_items, self.k, self.d, self.feat, self._hyper(), device, seed,
+                                  user_seed=user_seed)
 
     def _warm_start(self):
         """vbpr.py:99-108: fue splits into ure|uce, the first half of fie is ire, fib goes to irb."""
         kh = self.k // 2
         if self.fue is not None:
             tprint('Initialize user embeddings')
-            self._eng.set_users(U=np.ascontiguousarray(np.asarray(self.fue)[:, :2 * kh]))
+            self._eng.set_users(U=np.ascontiguousarray(self._user_rows(self.fue)[:, :2 * kh]))
         if self.fie is not None:
             tprint('Initialize item embeddings')
             self._eng.set_items(I=np.ascontiguousarray(np.asarray(self.fie)[:, :kh]))
@@ -67,7 +68,7 @@ class VBPR(BPR):
     def _collect(self):
         """vbpr.py:124-126 (two [n_items, d] x [d, .] products, once per train(): torch matmul)"""
         e = self._eng
-        self.fue = e.get('U')[0].cpu().numpy()
+        self.fue = self._collect_users(2 * (self.k // 2))
         ire, irb = e.get('I')[0], e.get('irb')[0]
         self.fie = torch.cat([ire, e.feat @ e.cem], dim=1).cpu().numpy()
         self.fib = (irb + e.feat @ e.icb).reshape(-1, 1).cpu().numpy()
@@ -78,10 +79,14 @@ class VBPR(BPR):
         for name in ('U', 'I', 'irb', 'cem', 'icb'):
             p, ms = e.get(name)
             out[name], out['ms_' + name] = p.cpu(), ms.cpu()
+        if getattr(self, '_global_users', None) is not None:
+            out['U'], out['ms_U'] = self._global_users
         return out
 
     def _restore_tensors(self, blob):
         e = self._eng
-        e.set_users(U=blob['U'], msU=blob['ms_U'])
+        e.set_users(U=self._user_rows(blob['U']), msU=self._user_rows(blob['ms_U']))
+        if getattr(self, '_owned', None) is not None:
+            self._global_users = (torch.as_tensor(np.asarray(blob['U'])).clone(), torch.as_tensor(np.asarray(blob['ms_U'])).clone())
         e.set_items(I=blob['I'], irb=blob['irb'], msI=blob['ms_I'], msirb=blob['ms_irb'])
         e.set_dense(cem=blob['cem'], icb=blob['icb'], mscem=blob['ms_cem'], msicb=blob['ms_icb'])
