@@ -465,6 +465,19 @@ def main():
                                                'frac': a2 / HBM_PEAK_GBS, 'launch_us': s2 * 1e3 / T2,
                                                'traffic': None,
                                                'traffic_from_profile': pmc_traffic('bpr_step_B8192') if (k == 128 and args.shape == 'ml10m') else None}}
+        del eng2
+        # batch_size 65,536 and 1,048,576 (planned grid-wide: csrc/planner_big.hip)
+        for Bb, Tb in ((65536, 128), (1048576, 8)):
+            engb = _engine.BprEngine(eng.n_users, eng.n_items, k, eng.hp, device, seed=98)
+            wb, sb = timed_run(engb, csr, Bb, Tb, Tb, 10 ** 9, 1)
+            ab = Bb * algorithmic_bytes_per_triplet(k) / (sb * 1e-3 / Tb) / 1e9
+            out['throughput_mode_B%d' % Bb] = {'batch_size': Bb, 'steps': Tb, 'value': Tb * Bb / wb, 'unit': 'triplets/s', 'ms_per_step': wb * 1e3 / Tb,
+                                               'roofline': {'bound': 'hbm', 'achieved': ab, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ab / HBM_PEAK_GBS,
+                                                            'launch_us': sb * 1e3 / Tb, 'traffic': None,
+                                                            'note': 'algorithmic bytes give no credit for in-batch duplicates: %d item draws over %d items'
+                                                                    % (2 * Bb, eng.n_items)}}
+            del engb
+            torch.cuda.empty_cache()
         # legacy plain-SGD optimiser (old/methods/bpr.py:57-61): same path, no RMSProp slot traffic
         for Bs, key, steps_s in ((B, 'sgd_mode', 2048), (B2, 'sgd_throughput_mode', T2)):
             eng3 = _engine.BprEngine(eng.n_users, eng.n_items, k, dict(eng.hp, opt='sgd'), device, seed=77)

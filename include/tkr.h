@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TKR_VERSION 105 /* 0.1.5: K2f persistent dataflow step (tkr_bpr_flow_run), tkr_plan_rollback, no graph cache */
+#define TKR_VERSION 106 /* 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 (tkr_plan_workspace_bytes) */
 #define TKR_OK 0
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
@@ -59,7 +59,11 @@ int tkr_version(void);
  *                            version of b); prec [n_batches][3B][32]: one 128-byte record per task slot:
  *                            [0] row | kind<<31 (-1 = unused slot) [1] version of the row [2] occurrences [3] index of its
  *                            first occurrence in pocc counted from batch 0 [4] batch [8+4q..] pocc of occurrence q < 4
- * batch_size <= 8192, n_batches <= 512, ids < 2^30.  Output is bit-exact against oracle/plan_np.py. */
+ *   workspace                (batch_size > 8192 only, else NULL) tkr_plan_workspace_bytes(batch_size, n_batches) bytes of device
+ *                            scratch: such batches are planned grid-wide (device radix sort of batch|row|occurrence keys, scans)
+ *                            instead of one workgroup per batch -- single/bpr.py:103-113 accepts any batch_size
+ * n_batches <= 512, ids < 2^30, batch_size <= 2^20 (the dataflow form: batch_size <= 8192).  Output is bit-exact against
+ * oracle/plan_np.py for every batch size. */
 int tkr_plan_team(int32_t batch_size);        /* waves per step workgroup / heavy-row team: 4 (B <= 1024) or 16 */
 int tkr_plan_max_blocks(int32_t batch_size);  /* workgroups a batch can need */
 int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,
@@ -67,7 +71,10 @@ int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_pt
                     uint64_t first_triplet, const int64_t* ctl, int32_t n_batches, int32_t batch_size,
                     int32_t* ucnt, int32_t* icnt, uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u,
                     int32_t* out_i, int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr,
-                    int32_t* occt, int32_t* tpar, int32_t* prec, int32_t* pocc, void* stream);
+                    int32_t* occt, int32_t* tpar, int32_t* prec, int32_t* pocc, void* workspace, int64_t workspace_bytes,
+                    void* stream);
+/* device scratch tkr_sample_plan needs for batch_size > 8192 (sort keys, ranks, hipcub storage); 0 for smaller batches */
+int64_t tkr_plan_workspace_bytes(int32_t batch_size, int32_t n_batches);
 
 /* Take batches [first_batch, first_batch + n_batches) of a plan out of the update counters again.  tkr_sample_plan
  * advances ucnt / icnt for every batch it PLANS; a caller that drops the rest of a plan (BPR.train stopping inside a

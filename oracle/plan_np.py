@@ -272,8 +272,10 @@ def triplet_parity(u, i, j, ucnt, icnt):
 
 
 def _pack_t(ts):
-    ts = [int(x) for x in ts] + [0] * (4 - len(ts))
-    return ts[0] | (ts[1] << 16), ts[2] | (ts[3] << 16)
+    """two 16-bit triplet indices per word (what K3 reads; batches above 65,536 keep the low 16 bits, K3 stops at 8,192)"""
+    ts = [int(x) & 0xFFFF for x in ts] + [0] * (4 - len(ts))
+    words = np.array([ts[0] | (ts[1] << 16), ts[2] | (ts[3] << 16)], dtype=np.uint32).view(np.int32)
+    return int(words[0]), int(words[1])
 
 
 def launch_plan(task, occ, B, occt=None):

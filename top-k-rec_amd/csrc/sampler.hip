@@ -21,12 +21,12 @@
 // probes + 12 B triplet + 24 B occ + <=48 B task  ~= 0.1 KB; latency-bound, not on the
 // critical path (the step kernels of earlier batches run while later batches are planned).
 #include "tkr_common.h"
+#include "sampler_draw.h"
 
 namespace tkr {
 
 constexpr int kPlanThreads = 256;      // resolve/commit kernels, and sample_plan for B <= 1024
 constexpr int kPlanThreadsBig = 1024;  // sample_plan for larger batches (the LDS sort dominates there)
-constexpr int kMaxRounds = 64;   // oracle/plan_np.py MAX_ROUNDS
 constexpr int kLightMax = 4;     // oracle/plan_np.py LIGHT_MAX: occurrences one wave handles, B <= 4096
 constexpr int kLightMaxBig = 16; // ... LIGHT_MAX_BIG for larger batches
 __host__ __device__ inline int light_max(int B) { return B <= 4096 ? kLightMax : kLightMaxBig; }
@@ -36,41 +36,6 @@ __host__ __device__ inline int team_for(int B) { return B <= 1024 ? kTeamSmall :
 // light tasks per workgroup (oracle light_per_block): every wave slot (half-filled groups measured slower)
 __host__ __device__ inline int light_per_block(int B) { return team_for(B); }
 constexpr int kTouchWords = 16;  // bitmap words per row -> at most 512 batches per call
-
-__device__ __forceinline__ bool is_member(const int32_t* __restrict__ cols_sorted, int lo, int hi, int item) {
-    int a = lo, b = hi;
-    while (a < b) {
-        const int mid = (a + b) >> 1;
-        if (cols_sorted[mid] < item) a = mid + 1; else b = mid;
-    }
-    return a < hi && cols_sorted[a] == item;
-}
-
-__device__ __forceinline__ void draw_triplet(const int32_t* __restrict__ tr_users, uint32_t n_tr,
-                                             const int32_t* __restrict__ row_ptr,
-                                             const int32_t* __restrict__ pos_cols,
-                                             const int32_t* __restrict__ cols_sorted, uint32_t n_items,
-                                             uint32_t k0, uint32_t k1, uint64_t g, int& u, int& i, int& j) {
-    const uint32_t c0 = (uint32_t)g, c1 = (uint32_t)(g >> 32);
-    u32x4 w = philox4x32_10(c0, c1, 0u, 0u, k0, k1);
-    u = tr_users[mulhi64(w.x, w.y, n_tr)];
-    const int lo = row_ptr[u], hi = row_ptr[u + 1];
-    i = pos_cols[lo + (int)mulhi64(w.z, w.w, (uint32_t)(hi - lo))];
-    int cand = 0;
-    bool found = false;
-    for (uint32_t r = 1; r <= (uint32_t)kMaxRounds && !found; ++r) {
-        w = philox4x32_10(c0, c1, r, 0u, k0, k1);
-        cand = (int)mulhi64(w.x, w.y, n_items);
-        if (!is_member(cols_sorted, lo, hi, cand)) { found = true; break; }
-        cand = (int)mulhi64(w.z, w.w, n_items);
-        if (!is_member(cols_sorted, lo, hi, cand)) { found = true; break; }
-    }
-    if (!found) {   // cyclic scan fallback (user rated almost everything)
-        for (uint32_t s = 0; s < n_items && is_member(cols_sorted, lo, hi, cand); ++s)
-            cand = (cand + 1 == (int)n_items) ? 0 : cand + 1;
-    }
-    j = cand;
-}
 
 // In-LDS bitonic sort of n (power of two) 64-bit keys, ascending.
 template <int T>
@@ -414,21 +379,40 @@ extern "C" int tkr_plan_max_blocks(int32_t batch_size) {
     return (3 * batch_size + lpb - 1) / lpb + (3 * batch_size) / (tkr::light_max(batch_size) + 1);
 }
 
+extern "C" int tkr_sample_plan_big(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,
+                                   const int32_t* cols_sorted, int32_t n_users, int32_t n_items, uint64_t seed,
+                                   uint64_t first_triplet, const int64_t* ctl, int32_t n_batches, int32_t B, int32_t* ucnt,
+                                   int32_t* icnt, uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u, int32_t* out_i,
+                                   int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr, int32_t* occt,
+                                   int32_t* tpar, void* workspace, int64_t workspace_bytes, void* stream);      // csrc/planner_big.hip
+
 extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr,
                                const int32_t* pos_cols, const int32_t* cols_sorted, int32_t n_users,
                                int32_t n_items, uint64_t seed, uint64_t first_triplet, const int64_t* ctl,
                                int32_t n_batches, int32_t batch_size, int32_t* ucnt, int32_t* icnt,
                                uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u, int32_t* out_i,
                                int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr,
-                               int32_t* occt, int32_t* tpar, int32_t* prec, int32_t* pocc, void* stream) {
+                               int32_t* occt, int32_t* tpar, int32_t* prec, int32_t* pocc, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
     if (n_tr <= 0 || n_items <= 0 || n_users <= 0 || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
     if (n_users >= (1 << 30) || n_items >= (1 << 30)) return TKR_EUNSUPPORTED;   // id bits 30/31 carry flags
-    if (batch_size > 8192) return TKR_EUNSUPPORTED;   // 2B 64-bit keys must fit the 160 KiB LDS
     if (n_batches > 32 * tkr::kTouchWords) return TKR_EUNSUPPORTED;
     if (n_batches == 0) return TKR_OK;
     if (!ucnt || !icnt || !touch_u || !touch_i || !occt) return TKR_EINVAL;
     const bool flow = prec != nullptr;                      // dataflow form of the plan (csrc/bpr_flow.hip)
     if (flow ? !pocc : (!rec || !hdr)) return TKR_EINVAL;
+    if (batch_size > 8192) {                                // 2B 64-bit keys no longer fit one workgroup's LDS: grid-wide planner
+        if (flow) return TKR_EUNSUPPORTED;                  // the dataflow step is for small batches
+        const int rc = tkr_sample_plan_big(tr_users, n_tr, row_ptr, pos_cols, cols_sorted, n_users, n_items, seed, first_triplet, ctl,
+                                           n_batches, batch_size, ucnt, icnt, touch_u, touch_i, out_u, out_i, out_j, task, occ, rec,
+                                           hdr, occt, tpar, workspace, workspace_bytes, stream);
+        if (rc != TKR_OK) return rc;
+        const int rows_ = n_users + n_items;
+        hipLaunchKernelGGL(tkr::commit_kernel, dim3((rows_ + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_users, n_items, ucnt,
+                           icnt, touch_u, touch_i);
+        TKR_LAUNCH_CHECK();
+        return TKR_OK;
+    }
     int npad = 1;
     while (npad < 2 * batch_size) npad <<= 1;
     hipStream_t s = (hipStream_t)stream;

@@ -1,0 +1,45 @@
+// The (u, i, j) draw of K1, shared by the per-batch planner (sampler.hip) and the grid-wide one (planner_big.hip).
+// Replaces BPR._uniform_user_sampling (single/bpr.py:155-165); stream definition in oracle/plan_np.py.
+#pragma once
+#include "tkr_common.h"
+
+namespace tkr {
+
+constexpr int kMaxRounds = 64;   // oracle/plan_np.py MAX_ROUNDS
+
+__device__ __forceinline__ bool is_member(const int32_t* __restrict__ cols_sorted, int lo, int hi, int item) {
+    int a = lo, b = hi;
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (cols_sorted[mid] < item) a = mid + 1; else b = mid;
+    }
+    return a < hi && cols_sorted[a] == item;
+}
+
+__device__ __forceinline__ void draw_triplet(const int32_t* __restrict__ tr_users, uint32_t n_tr,
+                                             const int32_t* __restrict__ row_ptr,
+                                             const int32_t* __restrict__ pos_cols,
+                                             const int32_t* __restrict__ cols_sorted, uint32_t n_items,
+                                             uint32_t k0, uint32_t k1, uint64_t g, int& u, int& i, int& j) {
+    const uint32_t c0 = (uint32_t)g, c1 = (uint32_t)(g >> 32);
+    u32x4 w = philox4x32_10(c0, c1, 0u, 0u, k0, k1);
+    u = tr_users[mulhi64(w.x, w.y, n_tr)];
+    const int lo = row_ptr[u], hi = row_ptr[u + 1];
+    i = pos_cols[lo + (int)mulhi64(w.z, w.w, (uint32_t)(hi - lo))];
+    int cand = 0;
+    bool found = false;
+    for (uint32_t r = 1; r <= (uint32_t)kMaxRounds && !found; ++r) {
+        w = philox4x32_10(c0, c1, r, 0u, k0, k1);
+        cand = (int)mulhi64(w.x, w.y, n_items);
+        if (!is_member(cols_sorted, lo, hi, cand)) { found = true; break; }
+        cand = (int)mulhi64(w.z, w.w, n_items);
+        if (!is_member(cols_sorted, lo, hi, cand)) { found = true; break; }
+    }
+    if (!found) {   // cyclic scan fallback (user rated almost everything)
+        for (uint32_t s = 0; s < n_items && is_member(cols_sorted, lo, hi, cand); ++s)
+            cand = (cand + 1 == (int)n_items) ? 0 : cand + 1;
+    }
+    j = cand;
+}
+
+}  // namespace tkr

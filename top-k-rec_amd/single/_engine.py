@@ -89,6 +89,8 @@ class PlanBuffers:
             self.hdr = torch.empty(cap * 4, **i32)
             self.tpar = torch.empty(cap * B, **i32)          # per-triplet row parities (K3 sparse view)
         self.loss = torch.zeros(cap, dtype=torch.float32, device=device)
+        need = tkr_hip.plan_workspace_bytes(B, cap)                       # B > 8192: scratch of the grid-wide planner
+        self.ws = torch.empty(need, dtype=torch.uint8, device=device) if need else None
 
 
 class UpdateCounters:
@@ -159,7 +161,10 @@ OVERLAP_MIN_BATCH = int(__import__('os').environ.get('TKR_OVERLAP_MIN_BATCH', 20
 
 
 def _chunk_cap(B):
-    """batches planned per K1 call: <= 512 (bitmap words), <= 1M triplets of plan resident per buffer"""
+    """batches planned per K1 call: <= 512 (bitmap words), <= 1M triplets of plan resident per buffer (2M above batch 8192,
+    where a batch's wave records alone are 0.4 KB per triplet: two batches of 2^20)"""
+    if B > 8192:
+        return max(2, (1 << 21) // B)
     return min(MAX_PLAN_BATCHES, max(8, (1 << 20) // B))
 
 

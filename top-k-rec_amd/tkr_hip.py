@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtkr_hip.so')
 
 _lib = None
-VERSION = 105          # TKR_VERSION of include/tkr.h this binding was written against
+VERSION = 106          # TKR_VERSION of include/tkr.h this binding was written against
 
 
 class TkrError(RuntimeError):
@@ -52,7 +52,7 @@ EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_pl
            'tkr_ratings_destroy', 'tkr_matrix_read', 'tkr_matrix_sizes', 'tkr_matrix_copy', 'tkr_matrix_destroy',
            'tkr_matrix_write', 'tkr_raw_ranks', 'tkr_count_hits_rr', 'tkr_topk_set_math',
            'tkr_sync_snapshot', 'tkr_sync_pack', 'tkr_sync_unpack')
-EXPORTS_I64 = ('tkr_vbpr_workspace_floats', 'tkr_topk_workspace_bytes')
+EXPORTS_I64 = ('tkr_vbpr_workspace_floats', 'tkr_topk_workspace_bytes', 'tkr_plan_workspace_bytes')
 
 
 def lib():
@@ -111,6 +111,10 @@ def plan_team(B):
     return lib().tkr_plan_team(C.c_int32(B))
 
 
+def plan_workspace_bytes(B, n_batches):
+    return int(lib().tkr_plan_workspace_bytes(C.c_int32(B), C.c_int32(n_batches)))
+
+
 def plan_max_blocks(B):
     return lib().tkr_plan_max_blocks(C.c_int32(B))
 
@@ -122,6 +126,8 @@ def sample_plan(csr, n_users, n_items, seed, first_triplet, n_batches, B, cnt, p
     assert n_batches <= PLAN_MAX_BATCHES
     assert plan.u.numel() >= n_batches * B and plan.task.numel() >= n_batches * 3 * B * 4
     prec, pocc = getattr(plan, 'prec', None), getattr(plan, 'pocc', None)
+    ws = getattr(plan, 'ws', None)                      # device scratch of the grid-wide planner (B > 8192)
+    assert B <= 8192 or (ws is not None and ws.numel() >= plan_workspace_bytes(B, n_batches))
     if prec is not None:
         assert prec.numel() >= n_batches * 3 * B * 32 and pocc.numel() >= n_batches * 3 * B * 4
     else:
@@ -133,7 +139,8 @@ def sample_plan(csr, n_users, n_items, seed, first_triplet, n_batches, B, cnt, p
                                  C.c_uint64(first_triplet), _p(ctl), C.c_int32(n_batches), C.c_int32(B),
                                  _p(cnt.ucnt), _p(cnt.icnt), _p(cnt.touch_u), _p(cnt.touch_i),
                                  _p(plan.u), _p(plan.i), _p(plan.j), _p(plan.task), _p(plan.occ), _p(getattr(plan, 'rec', None)),
-                                 _p(getattr(plan, 'hdr', None)), _p(plan.occt), _p(getattr(plan, 'tpar', None)), _p(prec), _p(pocc))
+                                 _p(getattr(plan, 'hdr', None)), _p(plan.occt), _p(getattr(plan, 'tpar', None)), _p(prec), _p(pocc),
+                                 _p(ws), C.c_int64(ws.numel() if ws is not None else 0))
 
 
 def plan_rollback(plan, B, first_batch, n_batches, cnt):
