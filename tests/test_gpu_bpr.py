@@ -158,7 +158,8 @@ def test_bpr_step_parity(hip, k, B, nb, mode, lr):
         np.testing.assert_allclose(_current(T, name, cnt), ref[name], rtol=2e-4, atol=atol, err_msg=name)
         np.testing.assert_allclose(_current(T, 'ms' + name, cnt), ref['ms' + name], rtol=2e-4 if B < (1 << 20) else 5e-4, atol=1e-7,
                                    err_msg='ms' + name)
-    np.testing.assert_allclose(loss.cpu().numpy(), np.array(ref_loss), rtol=1e-4)
+    # the reported loss is one fp32 atomic add per row task: a million terms of ~0.7 keep 3-4 digits
+    np.testing.assert_allclose(loss.cpu().numpy(), np.array(ref_loss), rtol=1e-4 if B < (1 << 20) else 1e-3)
     # rows never sampled keep their initial value in buffer 0 and an untouched buffer 1
     assert np.all(T['U'][1].cpu().numpy()[ucnt == 0] == 0)
 

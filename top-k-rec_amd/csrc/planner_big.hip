@@ -8,12 +8,14 @@
 // resolve_kernel run one thread per task or occurrence with their per-batch ranks taken from two more scans.
 //
 //   draw      one thread per triplet: Philox stream of sampler.hip (draw_triplet), keys out
-//   sort      hipcub::DeviceRadixSort over 60-bit keys  batch:9 | row:30 | occurrence:21   (users: n*B keys, items: n*2B)
+//   sort      hipcub::DeviceRadixSort over keys  batch | row | occurrence, packed to the bits the sizes need (users: n*B keys, items: n*2B)
 //   heads     flag = first key of a (batch, row) group; exclusive scan -> group index; task = (row|kind, start, count, 0)
 //   resolve   parities from the touch bitmaps (as sampler.hip), light / heavy ranks by scan, 64-byte wave records, headers
 //
 // Integer work, HBM-bound streaming: ~150 B per triplet over all passes; it runs on the planner's side stream under the steps
 // of the previous chunk.  Every output word is defined by oracle/plan_np.py and must match it bit for bit (tests/test_gpu_bpr.py).
+#include <stdlib.h>
+
 #include <hipcub/hipcub.hpp>
 
 #include "tkr_common.h"
@@ -21,19 +23,21 @@
 
 namespace tkr {
 
-constexpr int kRowBits = 30, kOccBits = 21;
-constexpr uint64_t kOccMask = (1ull << kOccBits) - 1, kRowMask = (1ull << kRowBits) - 1;
-__host__ __device__ inline uint64_t big_key(uint32_t batch, uint32_t row, uint32_t o) {
-    return ((uint64_t)batch << (kRowBits + kOccBits)) | ((uint64_t)row << kOccBits) | o;
+// key = batch | row | occurrence, packed as tightly as the problem allows (the radix sort costs a pass per 8 bits):
+// `ob` bits of occurrence index, `rb` bits of row
+struct KeyBits { int ob, rb; };
+__host__ __device__ inline uint64_t big_key(KeyBits kb, uint32_t batch, uint32_t row, uint32_t o) {
+    return ((uint64_t)batch << (kb.rb + kb.ob)) | ((uint64_t)row << kb.ob) | o;
 }
-__device__ __forceinline__ uint32_t key_row(uint64_t k) { return (uint32_t)((k >> kOccBits) & kRowMask); }
-__device__ __forceinline__ uint32_t key_occ(uint64_t k) { return (uint32_t)(k & kOccMask); }
+__device__ __forceinline__ uint32_t key_row(KeyBits kb, uint64_t k) { return (uint32_t)((k >> kb.ob) & ((1ull << kb.rb) - 1)); }
+__device__ __forceinline__ uint32_t key_occ(KeyBits kb, uint64_t k) { return (uint32_t)(k & ((1ull << kb.ob) - 1)); }
+static int bits_for(uint64_t n) { int b = 1; while ((1ull << b) < n) ++b; return b; }        // values 0 .. n-1
 
 __global__ void big_draw_kernel(const int32_t* __restrict__ tr_users, uint32_t n_tr, const int32_t* __restrict__ row_ptr,
                                 const int32_t* __restrict__ pos_cols, const int32_t* __restrict__ cols_sorted, uint32_t n_items,
                                 uint64_t seed, uint64_t first_triplet, const int64_t* __restrict__ ctl, int B, size_t total,
                                 int32_t* __restrict__ out_u, int32_t* __restrict__ out_i, int32_t* __restrict__ out_j,
-                                uint64_t* __restrict__ ukeys, uint64_t* __restrict__ ikeys) {
+                                uint64_t* __restrict__ ukeys, uint64_t* __restrict__ ikeys, KeyBits ku, KeyBits ki) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
     const uint32_t b = (uint32_t)(g / B), t = (uint32_t)(g % B);
@@ -42,16 +46,16 @@ __global__ void big_draw_kernel(const int32_t* __restrict__ tr_users, uint32_t n
     draw_triplet(tr_users, n_tr, row_ptr, pos_cols, cols_sorted, n_items, (uint32_t)seed, (uint32_t)(seed >> 32),
                  first_triplet + batch0 * (uint64_t)B + g, u, i, j);
     out_u[g] = u; out_i[g] = i; out_j[g] = j;
-    ukeys[g] = big_key(b, (uint32_t)u, t);
-    ikeys[(size_t)b * 2 * B + t] = big_key(b, (uint32_t)i, t);
-    ikeys[(size_t)b * 2 * B + B + t] = big_key(b, (uint32_t)j, (uint32_t)B + t);
+    ukeys[g] = big_key(ku, b, (uint32_t)u, t);
+    ikeys[(size_t)b * 2 * B + t] = big_key(ki, b, (uint32_t)i, t);
+    ikeys[(size_t)b * 2 * B + B + t] = big_key(ki, b, (uint32_t)j, (uint32_t)B + t);
 }
 
 // flag[p] = 1 at the first key of every (batch, row) group; flag[total] = 0 (so that the exclusive scan's last entry is the count)
-__global__ void big_flag_kernel(const uint64_t* __restrict__ keys, size_t total, int per_batch, int32_t* __restrict__ flag) {
+__global__ void big_flag_kernel(const uint64_t* __restrict__ keys, size_t total, int per_batch, int32_t* __restrict__ flag, KeyBits kb) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p > total) return;
-    flag[p] = (p < total) && ((p % per_batch) == 0 || key_row(keys[p]) != key_row(keys[p - 1]));
+    flag[p] = (p < total) && ((p % per_batch) == 0 || key_row(kb, keys[p]) != key_row(kb, keys[p - 1]));
 }
 
 // heads write (row | kind<<31, start, -, 0), their position and the row's touch bit; every key writes its occurrence
@@ -60,14 +64,14 @@ __global__ void big_emit_kernel(const uint64_t* __restrict__ keys, const int32_t
                                 const int32_t* __restrict__ urank /*items: group counts of the users*/, size_t total, int B,
                                 const int32_t* __restrict__ bu, const int32_t* __restrict__ bi, const int32_t* __restrict__ bj,
                                 int4* __restrict__ task_all, int2* __restrict__ occ_all, int32_t* __restrict__ occt_all,
-                                int32_t* __restrict__ headpos, uint32_t* __restrict__ touch) {
+                                int32_t* __restrict__ headpos, uint32_t* __restrict__ touch, KeyBits kb) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= total) return;
     const int per = ITEM ? 2 * B : B;
     const size_t b = p / per;
     const int lp = (int)(p % per);
     const uint64_t key = keys[p];
-    const uint32_t row = key_row(key), o = key_occ(key);
+    const uint32_t row = key_row(kb, key), o = key_occ(kb, key);
     int2* occ = occ_all + b * 3 * B;
     int32_t* occt = occt_all + b * 3 * B;
     const int32_t* u_ = bu + b * B;
@@ -253,9 +257,13 @@ static BigLayout big_layout(char* base, size_t nB) {
 extern "C" int tkr_plan_team(int32_t batch_size);
 extern "C" int tkr_plan_max_blocks(int32_t batch_size);
 
-extern "C" int64_t tkr_plan_workspace_bytes(int32_t batch_size, int32_t n_batches) {
-    if (batch_size <= 8192 || n_batches <= 0) return 0;
+extern "C" int64_t tkr_plan_workspace_bytes_for(int32_t batch_size, int32_t n_batches) {
+    if (batch_size <= 0 || n_batches <= 0) return 0;
     return (int64_t)tkr::big_layout(nullptr, (size_t)batch_size * n_batches).total_bytes;
+}
+extern "C" int64_t tkr_plan_workspace_bytes(int32_t batch_size, int32_t n_batches) {
+    static const int big_from = [] { const char* e = getenv("TKR_PLAN_BIG_FROM"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();
+    return batch_size >= big_from ? tkr_plan_workspace_bytes_for(batch_size, n_batches) : 0;
 }
 
 // called by tkr_sample_plan for batch_size > 8192
@@ -266,10 +274,10 @@ extern "C" int tkr_sample_plan_big(const int32_t* tr_users, int32_t n_tr, const 
                                    int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr, int32_t* occt,
                                    int32_t* tpar, void* workspace, int64_t workspace_bytes, void* stream) {
     using namespace tkr;
-    if (B > (1 << 20)) return TKR_EUNSUPPORTED;                       // occurrence index: 21 bits
+    if (B > (1 << 20)) return TKR_EUNSUPPORTED;                       // 9 + 30 + 21 key bits at most
     const size_t nB = (size_t)B * n_batches;
     if (3 * nB + 1 >= (1ull << 31)) return TKR_EUNSUPPORTED;
-    if (!workspace || workspace_bytes < tkr_plan_workspace_bytes(B, n_batches)) return TKR_EINVAL;
+    if (!workspace || workspace_bytes < tkr_plan_workspace_bytes_for(B, n_batches)) return TKR_EINVAL;
     const BigLayout L = big_layout((char*)workspace, nB);
     hipStream_t s = (hipStream_t)stream;
     const int T = 256;
@@ -277,24 +285,26 @@ extern "C" int tkr_sample_plan_big(const int32_t* tr_users, int32_t n_tr, const 
     int4* task4 = reinterpret_cast<int4*>(task);
     int2* occ2 = reinterpret_cast<int2*>(occ);
 
+    const KeyBits ku = {bits_for((uint64_t)B), bits_for((uint64_t)n_users)}, ki = {bits_for(2 * (uint64_t)B), bits_for((uint64_t)n_items)};
+    const int end_u = ku.ob + ku.rb + bits_for((uint64_t)n_batches), end_i = ki.ob + ki.rb + bits_for((uint64_t)n_batches);
     hipLaunchKernelGGL(big_draw_kernel, blocks(nB), dim3(T), 0, s, tr_users, (uint32_t)n_tr, row_ptr, pos_cols, cols_sorted,
-                       (uint32_t)n_items, seed, first_triplet, ctl, B, nB, out_u, out_i, out_j, L.ukeys, L.ikeys);
+                       (uint32_t)n_items, seed, first_triplet, ctl, B, nB, out_u, out_i, out_j, L.ukeys, L.ikeys, ku, ki);
     TKR_LAUNCH_CHECK();
     size_t cb = L.cub_bytes;
-    TKR_CHECK(hipcub::DeviceRadixSort::SortKeys(L.cub, cb, (const uint64_t*)L.ukeys, L.ukeys2, (int)nB, 0, 60, s));
+    TKR_CHECK(hipcub::DeviceRadixSort::SortKeys(L.cub, cb, (const uint64_t*)L.ukeys, L.ukeys2, (int)nB, 0, end_u, s));
     cb = L.cub_bytes;
-    TKR_CHECK(hipcub::DeviceRadixSort::SortKeys(L.cub, cb, (const uint64_t*)L.ikeys, L.ikeys2, (int)(2 * nB), 0, 60, s));
-    hipLaunchKernelGGL(big_flag_kernel, blocks(nB + 1), dim3(T), 0, s, L.ukeys2, nB, B, L.uflag);
-    hipLaunchKernelGGL(big_flag_kernel, blocks(2 * nB + 1), dim3(T), 0, s, L.ikeys2, 2 * nB, 2 * B, L.iflag);
+    TKR_CHECK(hipcub::DeviceRadixSort::SortKeys(L.cub, cb, (const uint64_t*)L.ikeys, L.ikeys2, (int)(2 * nB), 0, end_i, s));
+    hipLaunchKernelGGL(big_flag_kernel, blocks(nB + 1), dim3(T), 0, s, L.ukeys2, nB, B, L.uflag, ku);
+    hipLaunchKernelGGL(big_flag_kernel, blocks(2 * nB + 1), dim3(T), 0, s, L.ikeys2, 2 * nB, 2 * B, L.iflag, ki);
     TKR_LAUNCH_CHECK();
     cb = L.cub_bytes;
     TKR_CHECK(hipcub::DeviceScan::ExclusiveSum(L.cub, cb, (const int32_t*)L.uflag, L.urank, (int)(nB + 1), s));
     cb = L.cub_bytes;
     TKR_CHECK(hipcub::DeviceScan::ExclusiveSum(L.cub, cb, (const int32_t*)L.iflag, L.irank, (int)(2 * nB + 1), s));
     hipLaunchKernelGGL((big_emit_kernel<false>), blocks(nB), dim3(T), 0, s, L.ukeys2, L.uflag, L.urank, L.urank, nB, B, out_u, out_i,
-                       out_j, task4, occ2, occt, L.uhead, touch_u);
+                       out_j, task4, occ2, occt, L.uhead, touch_u, ku);
     hipLaunchKernelGGL((big_emit_kernel<true>), blocks(2 * nB), dim3(T), 0, s, L.ikeys2, L.iflag, L.irank, L.urank, 2 * nB, B, out_u,
-                       out_i, out_j, task4, occ2, occt, L.ihead, touch_i);
+                       out_i, out_j, task4, occ2, occt, L.ihead, touch_i, ki);
     TKR_LAUNCH_CHECK();
     hipLaunchKernelGGL((big_count_kernel<false>), blocks(nB), dim3(T), 0, s, L.uflag, L.urank, L.urank, nB, B, L.uhead, task4);
     hipLaunchKernelGGL((big_count_kernel<true>), blocks(2 * nB), dim3(T), 0, s, L.iflag, L.irank, L.urank, 2 * nB, B, L.ihead, task4);

@@ -20,6 +20,8 @@
 // HBM traffic per triplet: 8 B row_ptr pair + 4 B positive + ~4*log2(deg) B membership
 // probes + 12 B triplet + 24 B occ + <=48 B task  ~= 0.1 KB; latency-bound, not on the
 // critical path (the step kernels of earlier batches run while later batches are planned).
+#include <stdlib.h>
+
 #include "tkr_common.h"
 #include "sampler_draw.h"
 
@@ -379,6 +381,7 @@ extern "C" int tkr_plan_max_blocks(int32_t batch_size) {
     return (3 * batch_size + lpb - 1) / lpb + (3 * batch_size) / (tkr::light_max(batch_size) + 1);
 }
 
+extern "C" int64_t tkr_plan_workspace_bytes_for(int32_t batch_size, int32_t n_batches);       // csrc/planner_big.hip, any batch size
 extern "C" int tkr_sample_plan_big(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,
                                    const int32_t* cols_sorted, int32_t n_users, int32_t n_items, uint64_t seed,
                                    uint64_t first_triplet, const int64_t* ctl, int32_t n_batches, int32_t B, int32_t* ucnt,
@@ -401,7 +404,11 @@ extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int3
     if (!ucnt || !icnt || !touch_u || !touch_i || !occt) return TKR_EINVAL;
     const bool flow = prec != nullptr;                      // dataflow form of the plan (csrc/bpr_flow.hip)
     if (flow ? !pocc : (!rec || !hdr)) return TKR_EINVAL;
-    if (batch_size > 8192) {                                // 2B 64-bit keys no longer fit one workgroup's LDS: grid-wide planner
+    static const int big_from = [] { const char* e = getenv("TKR_PLAN_BIG_FROM"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();
+    if (batch_size > 8192 || (batch_size >= big_from && !flow && workspace &&
+                              workspace_bytes >= tkr_plan_workspace_bytes_for(batch_size, n_batches))) {
+        // above 8192 the 2B 64-bit keys no longer fit one workgroup's LDS; from 4096 (TKR_PLAN_BIG_FROM) the grid-wide planner is
+        // simply faster (measured per batch: 4.7 vs 6.3 us at 4096, 7.6 vs 10.5 us at 8192) -- the two produce identical plans
         if (flow) return TKR_EUNSUPPORTED;                  // the dataflow step is for small batches
         const int rc = tkr_sample_plan_big(tr_users, n_tr, row_ptr, pos_cols, cols_sorted, n_users, n_items, seed, first_triplet, ctl,
                                            n_batches, batch_size, ucnt, icnt, touch_u, touch_i, out_u, out_i, out_j, task, occ, rec,

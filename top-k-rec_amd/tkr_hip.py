@@ -127,7 +127,8 @@ def sample_plan(csr, n_users, n_items, seed, first_triplet, n_batches, B, cnt, p
     assert plan.u.numel() >= n_batches * B and plan.task.numel() >= n_batches * 3 * B * 4
     prec, pocc = getattr(plan, 'prec', None), getattr(plan, 'pocc', None)
     ws = getattr(plan, 'ws', None)                      # device scratch of the grid-wide planner (B > 8192)
-    assert B <= 8192 or (ws is not None and ws.numel() >= plan_workspace_bytes(B, n_batches))
+    assert ws is None or ws.numel() >= plan_workspace_bytes(B, n_batches)
+    assert B <= 8192 or ws is not None
     if prec is not None:
         assert prec.numel() >= n_batches * 3 * B * 32 and pocc.numel() >= n_batches * 3 * B * 4
     else:
