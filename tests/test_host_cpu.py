@@ -286,18 +286,44 @@ def test_native_matrix_io_matches_reference_bytes(golden_dir, tmp_path, monkeypa
     path.write_text('1.0 x \n')
     with pytest.raises(textio.TextFormatError):
         textio.read_matrix(str(path))
-    # n1: the binary copy is what the TEXT says (6 decimals), is used while newer than the text, and goes stale with it
+    # n1: the binary copy is what the TEXT says (6 decimals); it is used only while the stamp inside it (size + mtime_ns of the text it
+    # was parsed from) equals the text file's -- an OLDER text put in its place (cp -p, rsync -t, tar) must not be served from the copy
     monkeypatch.setenv('TKR_NO_CACHE', '0')
     textio.write_matrix(str(path), m[:3])
     cached = np.load(str(path) + '.npy')
     np.testing.assert_array_equal(cached, want[:3])
-    np.save(str(path) + '.npy', np.full((3, 8), 7, np.float32))                            # a newer cache wins ...
-    os.utime(str(path) + '.npy', (os.path.getmtime(str(path)) + 5,) * 2)
+    np.save(str(path) + '.npy', np.full((3, 8), 7, np.float32))                            # same stamp: the copy is what is read ...
     assert np.all(textio.read_matrix(str(path)) == 7)
-    path.write_text('1.5 2.5 \n')                                                           # ... until the text changes
-    os.utime(str(path), (os.path.getmtime(str(path) + '.npy') + 5,) * 2)
+    old_stat = os.stat(str(path))
+    path.write_text('1.5 2.5 \n')                                                           # ... until the text changes,
+    os.utime(str(path), ns=(old_stat.st_atime_ns, old_stat.st_mtime_ns - 10 ** 10))         # even to a file with an OLDER timestamp
+    os.utime(str(path) + '.npy', None)                                                      # and a copy that is newer than it
     np.testing.assert_array_equal(textio.read_matrix(str(path)), np.array([[1.5, 2.5]], np.float32))
     np.testing.assert_array_equal(np.load(str(path) + '.npy'), np.array([[1.5, 2.5]], np.float32))
+    path.write_text('9.0 2.5 \n')                                                           # same size, same second, different content
+    np.testing.assert_array_equal(textio.read_matrix(str(path)), np.array([[9.0, 2.5]], np.float32))
+
+
+def test_ratings_cache_is_stamped(tmp_path, monkeypatch):
+    """n1 for the rating files: parse_ratings keeps its flat arrays beside the text (<file>.csr.npz) and uses them only for the same
+    text (size + mtime_ns) AND the same id tables"""
+    import textio
+    monkeypatch.setenv('TKR_NO_CACHE', '0')
+    path = tmp_path / 'f0tr.txt'
+    path.write_text('u1,a:1,b:0\nu2,b:1\nu9,a:1\n')
+    users, items = {'u1': 0, 'u2': 1}, {'a': 0, 'b': 1}
+    first = textio.parse_ratings(str(path), users, items)
+    assert os.path.exists(str(path) + '.csr.npz')
+    again = textio.parse_ratings(str(path), users, items)
+    for name in ('line_user', 'line_ptr', 'item', 'like'):
+        np.testing.assert_array_equal(getattr(first, name), getattr(again, name))
+    assert first.line_user.tolist() == [0, 1, -1] and first.item.tolist() == [0, 1, 1, 0] and first.like.tolist() == [1, 0, 1, 1]
+    swapped = textio.parse_ratings(str(path), users, {'a': 1, 'b': 0})                        # other id table: not served from the copy
+    assert swapped.item.tolist() == [1, 0, 0, 1]
+    st = os.stat(str(path))
+    path.write_text('u1,a:0,b:0\nu2,b:1\nu9,a:1\n')                                          # same size, older timestamp
+    os.utime(str(path), ns=(st.st_atime_ns, st.st_mtime_ns - 10 ** 10))
+    assert textio.parse_ratings(str(path), users, items).like.tolist() == [0, 0, 1, 1]
 
 
 def test_utils_history_and_ivt_match_reference(golden_dir):

@@ -621,7 +621,7 @@ class VbprEngine(PlanMixin):
         assert int(f_ptr[-1]) < 2 ** 31
         return dict(f_ptr=f_ptr.to(i32), f_col=rc[:, 1].to(i32).contiguous(), f_val=feat[rc[:, 0], rc[:, 1]].contiguous(),
                     c_ptr=c_ptr.to(i32), c_item=cr[:, 1].to(i32).contiguous(), c_val=feat[cr[:, 1], cr[:, 0]].contiguous(),
-                    item_tag=torch.zeros(n_items, dtype=torch.int64, device=feat.device))
+                    item_tag=torch.zeros(n_items + 8, dtype=torch.int64, device=feat.device))     # slots [n] int32 | two byte maps [ceil(n/4)*4] | counter: 8n + 16 bytes suffice, also for n <= 2
 
     def state(self):
         hp = self.hp

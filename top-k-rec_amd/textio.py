@@ -2,14 +2,17 @@
 libtkr_hip.so (csrc/textio.hip).  No GPU is needed for anything here.
 
     IdMap(dict)                       the reference's token -> index dict, handed to the parser
-    parse_ratings(path, users, items) "uid,iid:like,..." lines -> flat arrays (Ratings)
-    read_matrix(path)                 '%f ' text matrix -> fp32 [lines, cols]   (+ .npy cache)
+    parse_ratings(path, users, items) "uid,iid:like,..." lines -> flat arrays (Ratings)   (+ stamped .csr.npz copy)
+    read_matrix(path)                 '%f ' text matrix -> fp32 [lines, cols]   (+ stamped .npy copy)
     write_matrix(path, array)         fp32 array -> '%f ' text, byte-identical to utils.py:47-55
 
 The text files stay authoritative.  ``read_matrix`` keeps a binary copy ``<path>.npy`` of what
-it parsed (n1) and uses it only while it is newer than the text file and TKR_NO_CACHE is unset;
-``write_matrix`` refreshes the copy by parsing back the text it just wrote, so a cached read
-always returns exactly what a fresh parse of the text would.
+it parsed and ``parse_ratings`` a copy ``<path>.csr.npz`` of its flat arrays (n1).  A copy is used
+only when TKR_NO_CACHE is unset and the STAMP stored inside it -- byte size and mtime_ns of the
+text file it was made from (ratings: also a digest of the two id tables) -- equals the text file's
+current one; anything else (an older or newer text, a copy made with ``cp -p``, a coarse-mtime file
+system, other id lists) is a miss and the text is parsed again.  ``write_matrix`` refreshes the copy
+by parsing back the text it just wrote, so a cached read returns exactly what a fresh parse would.
 """
 from __future__ import annotations
 
@@ -44,13 +47,15 @@ class IdMap:
             raise TextFormatError('id tokens must be strings without newlines')
         blob = '\n'.join(keys).encode()
         index = np.fromiter(table.values(), dtype=np.int32, count=len(keys))
+        import zlib
+        self.digest = '%08x%08x%d' % (zlib.crc32(blob), zlib.crc32(index.tobytes()), len(keys))     # of tokens AND indices
         self._h = C.c_void_p()
         _check(tkr_hip.lib().tkr_idmap_create(blob, C.c_int64(len(blob)), index.ctypes.data_as(C.c_void_p),
                                               C.c_int64(len(keys)), C.byref(self._h)), 'tkr_idmap_create')
         self.size = len(keys)
 
     def __del__(self):
-        if getattr(self, '_h', None):
+        if getattr(self, '_h', None) and tkr_hip is not None:      # (module globals are gone at interpreter shutdown)
             tkr_hip.lib().tkr_idmap_destroy(self._h)
             self._h = None
 
@@ -71,9 +76,35 @@ class Ratings:
         return np.repeat(self.line_user, np.diff(self.line_ptr))
 
 
+def _stamp(path, extra=''):
+    st = os.stat(path)
+    return '%d:%d:%s' % (st.st_size, st.st_mtime_ns, extra)
+
+
 def parse_ratings(path: str, users, items) -> Ratings:
     users = users if isinstance(users, IdMap) else IdMap(users)
     items = items if isinstance(items, IdMap) else IdMap(items)
+    cache = path + '.csr.npz'
+    stamp = _stamp(path, users.digest + '/' + items.digest) if _cache_enabled() else None
+    if stamp is not None and os.path.isfile(cache):
+        try:
+            with np.load(cache, allow_pickle=False) as z:
+                if str(z['stamp']) == stamp:
+                    return Ratings(z['line_user'], z['line_ptr'], z['item'], z['like'])
+        except (OSError, ValueError, KeyError):
+            pass
+    out = _parse_ratings(path, users, items)
+    if stamp is not None:
+        try:
+            tmp = cache + '.tmp.%d.npz' % os.getpid()
+            np.savez(tmp, stamp=np.array(stamp), line_user=out.line_user, line_ptr=out.line_ptr, item=out.item, like=out.like)
+            os.replace(tmp, cache)
+        except OSError:
+            pass                               # read-only data directory: the text stays the only copy
+    return out
+
+
+def _parse_ratings(path, users, items) -> Ratings:
     lib = tkr_hip.lib()
     h = C.c_void_p()
     _check(lib.tkr_ratings_parse(os.fsencode(path), users._h, items._h, C.byref(h)), 'tkr_ratings_parse', path)
@@ -116,11 +147,12 @@ def _cache_enabled():
 def read_matrix(path: str) -> np.ndarray:
     """every line of a '%f ' text matrix -> fp32 [n_lines, n_cols]"""
     cache = _cache_path(path)
-    if _cache_enabled() and os.path.isfile(cache) and os.path.getmtime(cache) >= os.path.getmtime(path):
+    if _cache_enabled() and os.path.isfile(cache) and os.path.isfile(cache + '.stamp'):
         try:
-            got = np.load(cache)
-            if got.dtype == np.float32 and got.ndim == 2:
-                return got
+            if open(cache + '.stamp').read() == _stamp(path):
+                got = np.load(cache)
+                if got.dtype == np.float32 and got.ndim == 2:
+                    return got
         except (OSError, ValueError):
             pass
     out = _parse_matrix(path)
@@ -129,13 +161,20 @@ def read_matrix(path: str) -> np.ndarray:
 
 
 def _store_cache(path, parsed):
+    """binary copy + the stamp (size, mtime_ns) of the text it was parsed from; the stamp goes last, so a torn pair is a miss"""
     if not _cache_enabled():
         return
     try:
+        stamp = _stamp(path)
+        if os.path.exists(_cache_path(path) + '.stamp'):
+            os.remove(_cache_path(path) + '.stamp')
         tmp = _cache_path(path) + '.tmp.%d' % os.getpid()
         with open(tmp, 'wb') as fh:
             np.save(fh, parsed)
         os.replace(tmp, _cache_path(path))
+        with open(tmp, 'w') as fh:
+            fh.write(stamp)
+        os.replace(tmp, _cache_path(path) + '.stamp')
     except OSError:
         pass                                   # read-only data directory: the text stays the only copy
 
