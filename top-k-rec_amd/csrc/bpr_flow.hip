@@ -264,7 +264,23 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
             }
         }
         if (o.ok && part_ok) break;
-        if (spin_fail(waited, ctl, (part_ok && !(T.tune & 2u)) ? 0 : 4)) {      // only the own row missing: three loads per pass, poll at the round-trip rate
+        // How far away is what we wait for?  The buffer of version v holds v, v-2, v-4, ...: a tag of v-2 means the producer is
+        // one or two updates away (poll), v-4 or older at least three -- two whole hand-offs, ~2 us each: sleep through that
+        // (a waiting wave that polls costs everybody's loads latency, a sleeping one nothing)
+        bool far = false;
+        if (!(T.tune & 2u)) {
+            if (!o.ok) far = (int)(own_ver - (uint32_t)bcast_i((int)xt.y, 0)) >= 4;
+            if (!part_ok) {
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    const int src = (q < n) ? q : 0;
+                    far = far || (int)((uint32_t)bcast_i(d.y, src) - (uint32_t)bcast_i((int)xa[q][0].y, 0)) >= 4 ||
+                          (int)((uint32_t)bcast_i(d.w, src) - (uint32_t)bcast_i((int)xb[q][0].y, 0)) >= 4;
+                }
+            }
+        }
+        if (far) __builtin_amdgcn_s_sleep(127);      // 127 x 64 clocks = 3.4 us
+        if (spin_fail(waited, ctl, part_ok ? 0 : 4)) {      // only the own row missing: three loads per pass, poll at the round-trip rate
             if (waited >= kSpinLimit && lane == 0 &&                     // post-mortem of the first wave that gave up
                 atomicCAS(ctl + kCtlDebug, 0u, 1u) == 0u) {
                 ctl[kCtlDebug + 1] = o.ok;
@@ -411,7 +427,7 @@ __device__ __forceinline__ uint32_t grab_index(uint32_t ticket, int home, uint32
 }
 
 template <int NP, bool PROF = false>
-__global__ __launch_bounds__(256, (NP == 1 ? 3 : 1)) void bpr_flow_kernel(tkr_flow_state st, const int4* __restrict__ prec,
+__global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_flow_state st, const int4* __restrict__ prec,
                                                        const int4* __restrict__ pocc, uint32_t total,
                                                        uint32_t* __restrict__ ctl, float* __restrict__ loss_out, uint32_t tune) {
     constexpr int NE = 2 * NP;
