@@ -3,7 +3,9 @@ under profiles/: <round>_bench_kernel_stats.csv, <round>_kernel_summary.csv, <ro
 import csv, json, os, re, sys
 import pandas as pd
 src, tag = sys.argv[1], sys.argv[2]
-KERN = ('bpr_step_kernel', 'sample_plan_kernel', 'resolve_kernel', 'commit_kernel', 'score_topk_bf16_kernel', 'score_topk_kernel', 'merge_topk_kernel',
+KERN = ('bpr_flow_kernel', 'bpr_step_kernel', 'sample_plan_kernel', 'resolve_flow_kernel', 'resolve_kernel', 'commit_kernel', 'rollback_kernel',
+        'big_draw_kernel', 'big_flag_kernel', 'big_emit_kernel', 'big_count_kernel', 'big_fill_kernel', 'big_parity_kernel', 'big_record_kernel',
+        'DeviceRadixSort', 'radix_sort', 'DeviceScan', 'scan', 'vbpr_pair_kernel', 'score_topk_bf16_kernel', 'score_topk_kernel', 'merge_topk_kernel',
         'raw_rank_kernel', 'count_hits_rr_kernel',
         'build_mask_kernel', 'vbpr_sproject_kernel', 'vbpr_sdense_kernel', 'vbpr_project_kernel', 'vbpr_reduce_kernel', 'vbpr_occur_kernel', 'vbpr_rows_kernel', 'vbpr_dense_kernel',
         'calib_rowcopy_kernel')
@@ -32,38 +34,55 @@ df = pd.DataFrame(out, columns=['kernel', 'grid_threads', 'wg', 'calls', 'avg_us
 df.to_csv('profiles/%s_kernel_summary.csv' % tag, index=False)
 print(df.to_string())
 def counter(tagdir, C, pat):
-    d = pd.read_csv(find('%s_%s' % (tagdir, C), '%s_counter_collection.csv*' % tagdir[0]))
+    d = pd.read_csv(find('%s_%s' % (tagdir, C), '%s_counter_collection.csv*' % ('c' if tagdir == 'calib' else 'b')))
     return d[d.Kernel_Name.str.contains(pat)]
 known_r, known_w = 541065216, 536870912
 cf = counter('calib', 'FETCH_SIZE', 'calib_rowcopy').Counter_Value.mean()
 cw = counter('calib', 'WRITE_SIZE', 'calib_rowcopy').Counter_Value.mean()
 fr, fw = known_r / (cf * 1024), known_w / (cw * 1024)
-res = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around `python bench.py --no-cpu-baseline --steps 2048 '
-                 '--warmup 256`; corrected by the factors measured with scripts/pmc_calibrate.py (known-byte gather copy, same access '
-                 'pattern); bytes = KB * 1024 * factor',
+res = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) around `python bench.py --no-cpu-baseline '
+                 '--no-extras --steps 2048 --warmup 256` (headline: the persistent kernel, 2,304 batches of 256) and `... --batch-size 8192 --steps 256 '
+                 '--warmup 128` (one launch per batch); corrected by the factors measured with scripts/pmc_calibrate.py (known-byte gather copy); '
+                 'bytes = KB * 1024 * factor',
        'calibration': {'known_read_bytes': known_r, 'known_write_bytes': known_w, 'FETCH_SIZE_KB': cf, 'WRITE_SIZE_KB': cw,
                        'read_factor': fr, 'write_factor': fw}}
-f = counter('bench', 'FETCH_SIZE', 'bpr_step_kernel|score_topk')
-w = counter('bench', 'WRITE_SIZE', 'bpr_step_kernel|score_topk')
-f = f.assign(k=f.Kernel_Name.map(short))
-w = w.assign(k=w.Kernel_Name.map(short))
-raw = {}
-for (k, g), ff in f.groupby(['k', 'Grid_Size']):
-    ww = w[(w.k == k) & (w.Grid_Size == g)]
-    raw[(k, int(g))] = {'FETCH_SIZE_KB': float(ff.Counter_Value.mean()), 'WRITE_SIZE_KB': float(ww.Counter_Value.mean()), 'launches': int(len(ff)),
-                        'hbm_bytes_per_launch_corrected': float(ff.Counter_Value.mean() * 1024 * fr + ww.Counter_Value.mean() * 1024 * fw)}
-    print(k, g, raw[(k, int(g))])
-def pick(kernel, which):
-    grids = sorted(g for (k, g) in raw if k == kernel)
-    return raw[(kernel, grids[0] if which == 'small' else grids[-1])] if grids else None
-topk = 'tkr::score_topk_bf16_kernel' if any(k == 'tkr::score_topk_bf16_kernel' for k, _ in raw) else 'tkr::score_topk_kernel'
-for key, val in (('bpr_step_B256', pick('tkr::bpr_step_kernel', 'small')), ('bpr_step_B8192', pick('tkr::bpr_step_kernel', 'large')),
-                 ('bpr_step_sgd_B256', pick('tkr::bpr_step_kernel<SGD>', 'small')), ('bpr_step_sgd_B8192', pick('tkr::bpr_step_kernel<SGD>', 'large')),
-                 ('score_topk_ml10m_k128', pick(topk, 'small')), ('score_topk_netflix_k128', pick(topk, 'large'))):
-    if val is not None:
-        res[key] = val
-res['by_kernel_and_grid'] = {'%s grid %d' % k: v for k, v in raw.items()}
+def total(tagdir, pat):
+    f, w = counter(tagdir, 'FETCH_SIZE', pat), counter(tagdir, 'WRITE_SIZE', pat)
+    return float(f.Counter_Value.sum()) * 1024 * fr, float(w.Counter_Value.sum()) * 1024 * fw, len(f)
+rd, wr, n = total('headline', 'bpr_flow_kernel')
+batches = 2048 + 256
+res['bpr_flow_B256'] = {'launches': n, 'batches': batches, 'hbm_read_bytes_per_batch': rd / batches, 'hbm_write_bytes_per_batch': wr / batches,
+                        'hbm_bytes_per_launch_corrected': (rd + wr) / batches,
+                        'note': 'per BATCH (a launch of the persistent kernel covers up to 512 batches); algorithmic 1,587,200 B; the granule '
+                                'tables move 8 bytes per fp32 (value + version tag)'}
+res['bpr_step_B256'] = res['bpr_flow_B256']          # the key bench.py looks up for the headline
+rd, wr, n = total('b8192', 'bpr_step_kernel')
+res['bpr_step_B8192'] = {'launches': n, 'hbm_bytes_per_launch_corrected': (rd + wr) / max(n, 1), 'hbm_read_bytes_per_launch': rd / max(n, 1),
+                         'hbm_write_bytes_per_launch': wr / max(n, 1)}
+for key in ('bpr_flow_B256', 'bpr_step_B8192'):
+    print(key, res[key])
 json.dump(res, open('profiles/%s_pmc_traffic.json' % tag, 'w'), indent=1)
 if os.path.exists(os.path.join(src, 'bench_under_rocprof.json')):
     import shutil
     shutil.copy(os.path.join(src, 'bench_under_rocprof.json'), 'profiles/%s_bench_under_rocprof.json' % tag)
+# the driver's exact command: which HIP calls and kernels the process made (the timed 20 steps must be launches only)
+try:
+    hs = pd.read_csv(find('driver', 'd_hip_api_stats.csv'))
+    hs.to_csv('profiles/%s_driver_cmd_hip_api_stats.csv' % tag, index=False)
+    ks = pd.read_csv(find('driver', 'd_kernel_stats.csv'))
+    ks['Name'] = ks['Name'].str.slice(0, 110)
+    ks.to_csv('profiles/%s_driver_cmd_kernel_stats.csv' % tag, index=False)
+    shutil.copy(os.path.join(src, 'driver_cmd.json'), 'profiles/%s_driver_cmd.json' % tag)
+    ht = pd.read_csv(find('driver', 'd_hip_api_trace.csv*'))
+    kt = pd.read_csv(find('driver', 'd_kernel_trace.csv*'))
+    flow = kt[kt.Kernel_Name.str.contains('bpr_flow_kernel')].sort_values('Start_Timestamp')
+    last = flow.iloc[-1]                                            # the timed 20 batches = the last persistent launch
+    prev_end = flow.iloc[-2].End_Timestamp if len(flow) > 1 else 0
+    win = ht[(ht.Start_Timestamp > prev_end) & (ht.Start_Timestamp < last.End_Timestamp)]
+    calls = win.Function.value_counts().to_dict()
+    json.dump({'window': 'HIP API calls between the end of the warm-up launch and the end of the timed launch of `bench.py --steps 20 --warmup 5`',
+               'calls': calls, 'timed_kernel_us': float(last.End_Timestamp - last.Start_Timestamp) / 1e3},
+              open('profiles/%s_driver_cmd_timed_region.json' % tag, 'w'), indent=1)
+    print('timed region HIP calls:', calls)
+except Exception as e:       # noqa
+    print('driver trace not summarised:', repr(e))

@@ -52,7 +52,7 @@ def test_integration_md_sequence():
     assert lib.tkr_sample_plan(ptr(tr_users), len(tr_users_l), ptr(row_ptr), ptr(pos_cols), ptr(cols_sorted), n_users, n_items,
                                C.c_uint64(seed), C.c_uint64(0), None, nb, B, ptr(ucnt), ptr(icnt), ptr(touch_u), ptr(touch_i),
                                ptr(out_u), ptr(out_i), ptr(out_j), ptr(task), ptr(occ), ptr(rec), ptr(hdr), ptr(occt), None, None, None,
-                               stream) == 0                                # tpar, prec, pocc unused: one launch per batch (K2)
+                               None, C.c_int64(0), stream) == 0             # tpar, prec, pocc, workspace unused: one launch per batch (K2), B <= 4096
     assert lib.tkr_bpr_run(C.byref(st), ptr(rec), ptr(occ), ptr(hdr), B, nb, ptr(loss), stream) == 0
     torch.cuda.synchronize()
     u, i, j = P.sample_triplets(tr_users_l, row_ptr_n, pos_n, srt_n, n_items, seed, 0, nb * B)
