@@ -170,3 +170,52 @@ def test_netflix_shape_chunk_matches_oracle():
     untouched = np.setdiff1d(np.arange(n_users), u)
     np.testing.assert_array_equal(got['U'][untouched], init['U'][untouched])
     assert np.abs(got['V'] - init['V']).max() > 1e-4
+
+
+def test_topk_full_netflix_shape_properties():
+    """BASELINE.json configs[4] at FULL size on one GPU: top-30 of all 17,770 items for all 480,189 users (k = 128), every user with a
+    rated mask.  Size-independent properties on EVERY row (sorted, no rated column, no duplicate, no padding), the checksum of the
+    result against a second run (the kernel is deterministic) and against the fp32 arithmetic mode on the rows where that is decided
+    (gap above 1e-6 relative), and 1,200 sampled rows against the fp64 oracle."""
+    import tkr_hip
+    n_users, n_items, k, K, deg = 480189, 17770, 128, 30, 60
+    dev = torch.device('cuda')
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    U = (torch.randn((n_users, k), device=dev, generator=g) * 0.01 * 1e6).round() / 1e6       # '%f'-rounded factors, like the CLI's input
+    V = (torch.randn((n_items, k), device=dev, generator=g) * 0.01 * 1e6).round() / 1e6
+    ptr = torch.arange(0, (n_users + 1) * deg, deg, dtype=torch.int64, device=dev)
+    cols = torch.randint(0, n_items, (n_users * deg,), device=dev, generator=g, dtype=torch.int32)
+    cols = torch.sort(cols.view(n_users, deg), dim=1).values.contiguous().view(-1)
+    mask, pitch = tkr_hip.build_rated_mask(ptr, cols, n_users, n_items)
+    ids, scores = tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch, want_scores=True)
+    ids2 = tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch)
+    assert torch.equal(ids, ids2)                                                       # run-to-run identical
+    assert bool((ids >= 0).all()) and bool((ids < n_items).all())
+    assert bool((scores[:, 1:] <= scores[:, :-1]).all())                                # descending on every row
+    srt = torch.sort(ids, dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())                                      # no duplicate column in any row
+    rated = cols.view(n_users, deg).long()
+    hit = torch.zeros(n_users, dtype=torch.bool, device=dev)
+    for c in range(K):                                                                  # no rated column in any row: searchsorted per position
+        at = torch.searchsorted(rated, ids[:, c:c + 1].long()).clamp(max=deg - 1)
+        hit |= rated.gather(1, at).squeeze(1) == ids[:, c].long()
+    assert not bool(hit.any())
+    # sampled rows against fp64
+    sample = torch.arange(0, n_users, 401, device=dev)
+    s64 = U[sample].double() @ V.double().T
+    s64.scatter_(1, rated[sample], float('-inf'))
+    top_s, top_i = torch.topk(s64, K + 1, dim=1)
+    got = ids[sample].long()
+    np.testing.assert_allclose(scores[sample].cpu().numpy(), s64.gather(1, got).cpu().numpy(), rtol=2e-5, atol=1e-9)
+    decided = ((top_s[:, :-1] - top_s[:, 1:]) > 1e-6 * top_s[:, :-1].abs()).all(1)      # rows without a near-tie inside or at the cut
+    assert int(decided.sum()) > len(sample) // 2
+    assert torch.equal(got[decided], top_i[decided, :K])
+    # and the fp32-MFMA arithmetic agrees on those rows too (the two modes differ only in summation order)
+    tkr_hip.set_topk_math('fp32')
+    try:
+        ids_f = tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch)
+    finally:
+        tkr_hip.set_topk_math('bf16x3')
+    assert torch.equal(ids_f[sample][decided], got[decided])
+    assert float((ids_f == ids).all(1).float().mean()) > 0.97
