@@ -20,7 +20,6 @@ Prints ONE JSON line (rank 0).  Extra objects beside the contract fields:
                   np.random sampler + numpy step), bounded sample, rank 0, N = 1 only
   throughput_mode the same path at batch_size 8192 (a legal train() argument; NOT the headline)
   sgd_mode / sgd_throughput_mode  the legacy plain-SGD optimiser (old/methods/bpr.py:57-61) at batch 256 / 8192
-  streams_mode    opt-in train(streams=4): four user shards on four HIP streams of the one GPU (extra, not headline)
   bpr_netflix_shape  the headline path at BASELINE.json configs[3]'s shape (480,189 x 17,770) on one GPU
   topk            the other half of BASELINE.json's metric: full-catalogue top-30 scored users/s (K4)
                   with its own MFMA roofline (bf16 dense peak / 6 split products; fp32 MFMA peak under TKR_TOPK_MATH=fp32) and cpu_baseline
@@ -291,13 +290,14 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
     featd = torch.rand((n_items, dc), device=device, generator=g) + 0.1
     featd /= featd.norm(dim=1, keepdim=True)
     eng = _engine.VbprEngine(n_users, n_items, k, dc, featd, hp, device, seed=3)
-    assert eng.sparse is None                                            # fully dense: the MFMA kernels (V1 / V3)
+    assert eng.sparse is not None            # this narrow, even a fully dense matrix goes through the gather kernels (S1 / S3): the MFMA kernels
+                                             # tile d by 64 / 128 columns and would run on 2 workgroups (measured 55 us per batch)
     wall, step_ms = timed_run(eng, csr, B, steps, warmup, 10 ** 9, 1, names=eng.replicated_names)
     step_s = step_ms * 1e-3 / steps
-    bytes_ = B * (2 * 4 * dc * 2 + 48.0 * kh + 56) + 16.0 * dc * kh       # feature rows (V1 + V3) + the sparse rows + dense optimizer traffic
+    bytes_ = B * (2 * dc * (4.0 * kh + 12.0) + 48.0 * kh + 56) + 16.0 * dc * kh + 8.0 * n_items * dc       # gathered cem rows + the sparse rows + dense optimizer traffic + the CSC walk
     res['dense_dc128'] = {'value': steps * B / wall, 'unit': 'triplets/s', 'steps': steps, 'ms_per_step': wall * 1e3 / steps,
                           'config': {'workload': 'VBPR ML-10M shape, k=%d, DENSE content features d_c=%d, batch_size=%d' % (k, dc, B)},
-                          'roofline': {'kernels': 'tkr::vbpr_project/reduce/occur/pair/rows/dense (6 launches per batch)', 'bound': 'hbm',
+                          'roofline': {'kernels': 'tkr::vbpr_sproject / pair / rows / sdense (4 launches per batch)', 'bound': 'hbm',
                                        'achieved': bytes_ / step_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': bytes_ / step_s / 1e9 / HBM_PEAK_GBS,
                                        'mfma_TFLOPs': 4.0 * dc * kh * B / step_s / 1e12, 'step_us': step_s * 1e6, 'traffic': None}}
     del eng
@@ -322,48 +322,6 @@ def netflix_train_bench(k, device, B=256, steps=2048, warmup=512):
                                    % (n_users, n_items, int(row_ptr[-1]), k, B)},
             'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'launch_us': us,
                          'traffic': None}}
-
-
-def streams_bench(r, k, device, B=256, S=4, steps=2048, warmup=2048):   # warm-up = run: plan buffers and graphs cached
-    """opt-in train(streams=S): S user shards with replicated item tables on S HIP streams of ONE GPU (per-epoch
-    exchange as in the multi-GPU layout; the exchange itself is outside this timed region like in the N>1 bench
-    it happens every (limit//B)//S steps).  Aggregate triplets/s over the S streams."""
-    import synth
-    import dist as tdist
-    from single import _engine
-    row_ptr, pos, _, tr_users = synth.positives_csr(r)
-    n_users, n_items = r['n_users'], r['n_in'] + r['n_out']
-    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=1e-4, mode='l2')
-    engs = [_engine.BprEngine(n_users, n_items, k, hp, device, seed=50) for _ in range(S)]
-    csrs = [_engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tdist.shard_users(tr_users, i, S), dtype=np.int32), device)
-            for i in range(S)]
-    hs = [torch.cuda.Stream(device=device) for _ in range(S)]
-
-    phase = {}
-
-    def run(n):                                  # as BPR._train_streams: plan all shards first, then step concurrently
-        t_a = time.perf_counter()
-        planned = [_engine.plan_ahead(e, c, n, B) for e, c in zip(engs, csrs)]
-        torch.cuda.synchronize()
-        t_b = time.perf_counter()
-        fns = [e.step_fn(B) for e in engs]
-        for chunk in range(max(len(pl) for pl in planned)):            # round-robin over streams, one chunk each
-            for e, pl, st, fn in zip(engs, planned, hs, fns):
-                if chunk < len(pl):
-                    with torch.cuda.stream(st):
-                        _engine.run_planned(e, pl[chunk:chunk + 1], B, False, fn)
-        torch.cuda.synchronize()
-        phase['plan_ms'], phase['step_ms'] = (t_b - t_a) * 1e3, (time.perf_counter() - t_b) * 1e3
-    run(warmup)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(steps)
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    return {'streams': S, 'batch_size': B, 'steps_per_stream': steps, 'value': S * steps * B / wall, 'unit': 'triplets/s',
-            'us_per_batch_per_stream': wall / steps * 1e6, 'plan_ms': phase['plan_ms'], 'step_ms': phase['step_ms'],
-            'semantics': 'user-sharded data parallel inside one GPU (same per-epoch sum-of-deltas exchange as multi-GPU); '
-                         'NOT the single-stream reference semantics of the headline value'}
 
 
 def topk_cpu_baseline(r, k, K=30, budget_s=12.0, slice_users=2000):
@@ -497,7 +455,6 @@ def main():
             out['topk_netflix_shape'] = topk_bench_netflix(k, device)
             out['vbpr'] = vbpr_bench(r, csr, k, device)
             out['bpr_netflix_shape'] = netflix_train_bench(k, device)
-            out['streams_mode'] = streams_bench(r, k, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(r, k, B)
     if rank == 0:

@@ -358,7 +358,8 @@ def _generators(device, seed, user_seed):
     return gen, gen_u
 
 
-FLOW_MAX_BATCH = int(__import__('os').environ.get('TKR_FLOW_MAX_BATCH', 1024))    # batch sizes up to this take the persistent dataflow step (K2f)
+FLOW_MAX_BATCH = int(__import__('os').environ.get('TKR_FLOW_MAX_BATCH', 256))     # batch sizes up to this take the persistent dataflow step (K2f);
+                                   # measured per batch, K2f vs K2: 64: 1.6 vs 3.9 us, 128: 2.4 vs 4.2, 256: 3.3 vs 4.5, 512: 7.3 vs 5.2, 1024: 12.1 vs 6.5
 FLOW_WAVES_PER_CU = int(__import__('os').environ.get('TKR_FLOW_WAVES_PER_CU', 0))    # 0 = the library default
 
 
@@ -580,6 +581,7 @@ class VbprEngine(PlanMixin):
     cem / icb are dense and single-buffered (their update is its own launch, after every read)."""
 
     SPARSE_DENSITY = 0.25      # below this fraction of nonzeros the step uses the CSR/CSC view of feat (csrc/vbpr_step.hip S1/S3)
+    SPARSE_MAX_NARROW_D = 1024 # ... and so does any feature matrix this narrow
 
     def __init__(self, n_users, n_items, k, d, feat, hp, device=None, seed=None, sparse=None, user_seed=None):
         self.device = device or default_device()
@@ -603,7 +605,9 @@ class VbprEngine(PlanMixin):
         self.ws = None
         self.sparse = None
         nnz = int(torch.count_nonzero(self.feat))
-        if sparse or (sparse is None and nnz <= self.SPARSE_DENSITY * n_items * d):
+        # narrow feature matrices take the gather view too, dense or not: the MFMA kernels tile d in slices of 128 / 64 columns and
+        # leave the chip empty below a few thousand columns (d = 128: 55 us per batch against ~35 through the CSR / CSC walk)
+        if sparse or (sparse is None and (nnz <= self.SPARSE_DENSITY * n_items * d or d <= self.SPARSE_MAX_NARROW_D)):
             self.sparse = self._sparse_view(self.feat)
 
     @staticmethod
