@@ -290,14 +290,15 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
     featd = torch.rand((n_items, dc), device=device, generator=g) + 0.1
     featd /= featd.norm(dim=1, keepdim=True)
     eng = _engine.VbprEngine(n_users, n_items, k, dc, featd, hp, device, seed=3)
-    assert eng.sparse is not None            # this narrow, even a fully dense matrix goes through the gather kernels (S1 / S3): the MFMA kernels
-                                             # tile d by 64 / 128 columns and would run on 2 workgroups (measured 55 us per batch)
+    assert eng.sparse is None                # fully dense: the MFMA kernels (V1 / V3).  They tile d by 128 / 64 columns: at d_c = 128 the projection
+                                             # and the dense update run on 1-2 workgroups (55 us per batch; the gather view is worse, 244 us: its
+                                             # column walk gives one wave a whole 10,380-entry column)
     wall, step_ms = timed_run(eng, csr, B, steps, warmup, 10 ** 9, 1, names=eng.replicated_names)
     step_s = step_ms * 1e-3 / steps
-    bytes_ = B * (2 * dc * (4.0 * kh + 12.0) + 48.0 * kh + 56) + 16.0 * dc * kh + 8.0 * n_items * dc       # gathered cem rows + the sparse rows + dense optimizer traffic + the CSC walk
+    bytes_ = B * (2 * 4 * dc * 2 + 48.0 * kh + 56) + 16.0 * dc * kh       # feature rows (V1 + V3) + the sparse rows + dense optimizer traffic
     res['dense_dc128'] = {'value': steps * B / wall, 'unit': 'triplets/s', 'steps': steps, 'ms_per_step': wall * 1e3 / steps,
                           'config': {'workload': 'VBPR ML-10M shape, k=%d, DENSE content features d_c=%d, batch_size=%d' % (k, dc, B)},
-                          'roofline': {'kernels': 'tkr::vbpr_sproject / pair / rows / sdense (4 launches per batch)', 'bound': 'hbm',
+                          'roofline': {'kernels': 'tkr::vbpr_project/reduce/occur/pair/rows/dense (6 launches per batch)', 'bound': 'hbm',
                                        'achieved': bytes_ / step_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': bytes_ / step_s / 1e9 / HBM_PEAK_GBS,
                                        'mfma_TFLOPs': 4.0 * dc * kh * B / step_s / 1e12, 'step_us': step_s * 1e6, 'traffic': None}}
     del eng

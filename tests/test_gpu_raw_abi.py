@@ -92,3 +92,80 @@ def test_integration_md_sequence():
     for uu in range(n_users):
         hits += np.array(R.bucket_hits([int(c) for c in got[uu] if c >= 0], set(likes[uu]), step, total // step))
     np.testing.assert_array_equal(torch.cumsum(first, 0).cpu().numpy(), hits)
+
+
+class tkr_flow_state(C.Structure):                # include/tkr.h
+    _fields_ = [(n, C.c_void_p) for n in ('U', 'msU', 'tailU', 'rdU', 'V', 'msV', 'tailV', 'rdV')] + \
+               [(n, C.c_int32) for n in ('n_users', 'n_items', 'k', 'mode')] + \
+               [(n, C.c_float) for n in ('lu', 'li', 'lj', 'lb', 'lr', 'rho', 'eps')] + [('opt', C.c_int32)]
+
+
+def test_integration_md_persistent_sequence():
+    """INTEGRATION.md §B.1b with raw ctypes: granule tables, the dataflow form of the plan, ONE persistent launch for the chunk, a
+    second launch for the rest of the plan, rollback of what was planned but not run -- against the oracle"""
+    lib = C.CDLL(os.path.join(ROOT, 'top-k-rec_amd', 'libtkr_hip.so'))
+    lib.tkr_flow_row_granules.restype = C.c_int32
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    dev = 'cuda'
+    rng = np.random.Generator(np.random.PCG64(1))
+    n_users, n_items, k, B, nb, run, seed = 500, 200, 50, 128, 8, 6, 4242
+    tr = {u: [int(x) for x in rng.integers(0, n_items, int(rng.integers(1, 9)))] for u in range(n_users)}
+    tr_users_l = list(tr.keys())
+    row_ptr_n, pos_n, srt_n = P.build_csr(tr, n_users)
+    i32 = dict(dtype=torch.int32, device=dev)
+    tr_users, row_ptr = torch.tensor(tr_users_l, **i32), torch.from_numpy(row_ptr_n).to(dev)
+    pos_cols, cols_sorted = torch.from_numpy(pos_n).to(dev), torch.from_numpy(srt_n).to(dev)
+    ref = R.init_bpr_state(n_users, n_items, k, rng)
+    kp = lib.tkr_flow_row_granules(k)
+    assert kp == 128
+
+    def granules(n, w, init=None, pad=0.0):         # [2][n][w] x {fp32 value, uint32 tag}: version 0 in buffer 0, no version in buffer 1
+        t = torch.zeros(2, n, w, 2, device=dev)
+        t[0, :, :, 0] = pad
+        if init is not None:
+            t[0, :, :init.shape[1], 0] = torch.from_numpy(init).to(dev)
+        t.view(torch.int32)[1, :, :, 1] = -1
+        return t
+    U, msU = granules(n_users, kp, ref['U']), granules(n_users, kp, ref['msU'], pad=1.0)
+    V, msV = granules(n_items, kp, ref['V']), granules(n_items, kp, ref['msV'], pad=1.0)
+    tailU, tailV = granules(n_users, 4), granules(n_items, 4)
+    tailV[0, :, 1, 0] = 1.0                         # the slot of the (zero) bias
+    rdU, rdV = torch.zeros(2 * n_users, **i32), torch.zeros(2 * n_items, **i32)
+    lib.tkr_flow_ctl_words.restype = C.c_int32
+    ctl = torch.zeros(lib.tkr_flow_ctl_words(), **i32)
+    ucnt, icnt = torch.zeros(n_users, **i32), torch.zeros(n_items, **i32)
+    touch_u, touch_i = torch.zeros(n_users * 16, **i32), torch.zeros(n_items * 16, **i32)
+    out_u, out_i, out_j = (torch.empty(nb * B, **i32) for _ in range(3))
+    task, occ, occt = torch.empty(nb * 3 * B * 4, **i32), torch.empty(nb * 3 * B * 2, **i32), torch.empty(nb * 3 * B, **i32)
+    prec, pocc = torch.empty(nb * 3 * B * 32, **i32), torch.empty(nb * 3 * B * 4, **i32)
+    loss = torch.zeros(nb, device=dev)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.05, mode='l2')
+    st = tkr_flow_state(ptr(U), ptr(msU), ptr(tailU), ptr(rdU), ptr(V), ptr(msV), ptr(tailV), ptr(rdV), n_users, n_items, k, 0,
+                        hp['lu'], hp['li'], hp['lj'], hp['lb'], hp['lr'], 0.9, 1e-10, 0)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.tkr_sample_plan(ptr(tr_users), len(tr_users_l), ptr(row_ptr), ptr(pos_cols), ptr(cols_sorted), n_users, n_items,
+                               C.c_uint64(seed), C.c_uint64(0), None, nb, B, ptr(ucnt), ptr(icnt), ptr(touch_u), ptr(touch_i),
+                               ptr(out_u), ptr(out_i), ptr(out_j), ptr(task), ptr(occ), None, None, ptr(occt), None, ptr(prec), ptr(pocc),
+                               None, C.c_int64(0), stream) == 0
+    at = lambda first: C.c_void_p(prec.data_ptr() + first * 3 * B * 32 * 4)              # the record of the first task of batch `first`
+    assert lib.tkr_bpr_flow_run(C.byref(st), at(0), ptr(pocc), B, 2, ptr(ctl), ptr(loss), 0, stream) == 0          # batches 0, 1
+    assert lib.tkr_bpr_flow_run(C.byref(st), at(2), ptr(pocc), B, run - 2, ptr(ctl), ptr(loss), 0, stream) == 0    # batches 2 .. 5
+    assert lib.tkr_plan_rollback(ptr(task), B, run, nb - run, ptr(ucnt), ptr(icnt), stream) == 0                            # 6, 7 never run
+    torch.cuda.synchronize()
+    assert int(ctl[1026]) == 0                      # TKR_FLOW_CTL_STATUS
+    u, i, j = P.sample_triplets(tr_users_l, row_ptr_n, pos_n, srt_n, n_items, seed, 0, nb * B)
+    np.testing.assert_array_equal(out_u.cpu().numpy(), u)
+    ref_loss = [R.bpr_step(ref, u[q * B:(q + 1) * B], i[q * B:(q + 1) * B], j[q * B:(q + 1) * B], hp) for q in range(run)]
+    cu, ci = np.zeros(n_users, np.int32), np.zeros(n_items, np.int32)
+    for q in range(run):
+        cu[np.unique(u[q * B:(q + 1) * B])] += 1
+        ci[np.unique(np.concatenate([i[q * B:(q + 1) * B], j[q * B:(q + 1) * B]]))] += 1
+    np.testing.assert_array_equal(ucnt.cpu().numpy(), cu)                                  # counters = batches that RAN
+    np.testing.assert_array_equal(icnt.cpu().numpy(), ci)
+    fue = U[(ucnt & 1).long(), torch.arange(n_users, device=dev), :k, 0].cpu().numpy()     # bpr.py:151: the current buffer's values
+    fie = V[(icnt & 1).long(), torch.arange(n_items, device=dev), :k, 0].cpu().numpy()
+    fib = tailV[(icnt & 1).long(), torch.arange(n_items, device=dev), 0, 0].cpu().numpy()
+    np.testing.assert_allclose(fue, ref['U'], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(fie, ref['V'], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(fib, ref['b'], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(loss.cpu().numpy()[:run], np.array(ref_loss), rtol=1e-4)

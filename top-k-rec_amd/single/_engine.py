@@ -581,7 +581,6 @@ class VbprEngine(PlanMixin):
     cem / icb are dense and single-buffered (their update is its own launch, after every read)."""
 
     SPARSE_DENSITY = 0.25      # below this fraction of nonzeros the step uses the CSR/CSC view of feat (csrc/vbpr_step.hip S1/S3)
-    SPARSE_MAX_NARROW_D = 1024 # ... and so does any feature matrix this narrow
 
     def __init__(self, n_users, n_items, k, d, feat, hp, device=None, seed=None, sparse=None, user_seed=None):
         self.device = device or default_device()
@@ -605,9 +604,7 @@ class VbprEngine(PlanMixin):
         self.ws = None
         self.sparse = None
         nnz = int(torch.count_nonzero(self.feat))
-        # narrow feature matrices take the gather view too, dense or not: the MFMA kernels tile d in slices of 128 / 64 columns and
-        # leave the chip empty below a few thousand columns (d = 128: 55 us per batch against ~35 through the CSR / CSC walk)
-        if sparse or (sparse is None and (nnz <= self.SPARSE_DENSITY * n_items * d or d <= self.SPARSE_MAX_NARROW_D)):
+        if sparse or (sparse is None and nnz <= self.SPARSE_DENSITY * n_items * d):
             self.sparse = self._sparse_view(self.feat)
 
     @staticmethod
