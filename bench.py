@@ -91,6 +91,12 @@ def build_problem(shape, k, rank, world, device, seed=42):
     return r, csr, eng, int(row_ptr[-1])
 
 
+def _chunk_crossings(steps, B):
+    """upper bound of the extra step calls a run of `steps` batches makes because it crosses plan chunks"""
+    from single import _engine
+    return steps // _engine._chunk_cap(B) + 1
+
+
 def timed_run(eng, csr, B, steps, warmup, sync_every, world, names=None):
     """warmup untimed, then exactly `steps` batches between barriers; returns (wall_s, step_kernel_ms)"""
     import dist as tdist
@@ -108,6 +114,7 @@ def timed_run(eng, csr, B, steps, warmup, sync_every, world, names=None):
             done += m
 
     run(warmup)
+    eng.reserve_events(-(-steps // sync_every) + _chunk_crossings(steps, B))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

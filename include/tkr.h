@@ -123,9 +123,10 @@ int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ,
  * A freshly assigned table holds version 0 in buffer 0 (all tags 0, expects 0, rd 0) and tags 0xffffffff in buffer 1.
  * The plan is tkr_sample_plan's dataflow form (prec / pocc non-NULL there): `prec` points at the record of the first
  * task of the first batch to run, `pocc` and `loss_out` (nullable, pre-zeroed) at batch 0 of that plan call.
- * ctl: tkr_flow_ctl_words() uint32 of caller-owned device memory, zeroed once by the caller (the call itself re-zeroes
- * the ticket counters on the stream before the launch); ctl[status word] != 0 after a launch means a bounded spin ran
- * out (results invalid).
+ * ctl: tkr_flow_ctl_words() uint32 of caller-owned device memory, zeroed once by the caller; every launch leaves its
+ * ticket words at zero again (the last workgroup out does it), so calls on one stream follow each other without a
+ * memset between them.  One ctl serves one launch at a time.  ctl[status word] != 0 after a launch means a bounded spin
+ * ran out (results invalid; zero ctl again before anything else runs on it).
  * waves_per_cu: 0 = default.  k <= 256, 3 * batch_size * n_batches < 2^29. */
 typedef struct {
     void* U;

@@ -128,7 +128,7 @@ def _check(F, ref, ucnt, icnt, uocc, iocc, tol=dict(rtol=2e-4, atol=1e-5), slots
     status, ctl = F.status()
     assert status == 0, 'a bounded spin ran out'
     A = F.hip.FLOW_CTL_ARRIVE
-    assert ctl[:A].reshape(32, 32)[:, 1:].sum() == 0 and ctl[:A:32].sum() >= 3 * len(ucnt) // len(ucnt)     # only the 32 ticket words are touched
+    assert not ctl[:A + 2].any()        # the ticket, arrival and leave words are back at zero: the next launch needs no memset
     got = F.current(ucnt, icnt)
     for name in ('U', 'V', 'b'):
         np.testing.assert_allclose(got[name], ref[name], err_msg=name, **tol)

@@ -51,6 +51,7 @@ typedef unsigned long long u64;
 constexpr int kQueues = 32;
 constexpr int kQueueStride = 32;          // uint32 words between ticket counters (one 128-byte line each)
 constexpr int kCtlArrive = kQueues * kQueueStride;
+constexpr int kCtlLeave = kCtlArrive + 1;     // workgroups that have taken their last ticket
 constexpr int kCtlStatus = kCtlArrive + 2;
 constexpr int kCtlSpins = kCtlArrive + 3;     // diagnostics: spin passes taken
 constexpr int kCtlDebug = kCtlArrive + 8;     // 16 words: what the first wave that gave up was waiting for
@@ -592,6 +593,18 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
     }
 
     if (lane == 0 && spins) atomicAdd(ctl + kCtlSpins, spins);
+
+    // The last workgroup out puts the ticket words back to zero: the next launch starts from a clean ctl without a memset in
+    // front of it (a launch of its own: ~8 us of a 20-batch call).  Every wave has its last ticket back by now -- it broke
+    // out on the value (the vmcnt covers the give-up path, where the prefetched ticket is never looked at).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 &&
+        __hip_atomic_fetch_add(ctl + kCtlLeave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+        for (int q = 0; q < kQueues; ++q) ctl[q * kQueueStride] = 0u;
+        ctl[kCtlArrive] = 0u;
+        ctl[kCtlLeave] = 0u;
+    }
 }
 
 }  // namespace tkr
@@ -638,7 +651,6 @@ extern "C" int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, c
     if (grid > need) grid = need;
     if (grid < 8) grid = 8;                                          // >= 32 waves: every queue has a wave
     hipStream_t s = (hipStream_t)stream;
-    TKR_CHECK(hipMemsetAsync(ctl, 0, (size_t)(tkr::kCtlArrive + 1) * sizeof(uint32_t), s));      // ticket counters + arrival counter
     const int4* r4 = reinterpret_cast<const int4*>(prec);
     const int4* o4 = reinterpret_cast<const int4*>(pocc);
     static const bool prof = getenv("TKR_FLOW_PROFILE") && getenv("TKR_FLOW_PROFILE")[0] == '1';     // cycle sums into ctl (scripts/probe_flow_bench.py)

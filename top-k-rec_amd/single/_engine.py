@@ -176,6 +176,10 @@ class _Chunk:
         self.idx, self.nb, self.used, self.B, self.first, self.csr = idx, nb, 0, B, first, csr
 
 
+def _event_pair():
+    return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+
 class PlanMixin:
     """Sample stream position + plans of an engine.
 
@@ -205,6 +209,7 @@ class PlanMixin:
         self.plan = None                # the plan buffer of the last chunk that ran
         self.pipe = None
         self.step_events = None         # list of (start, end, n_launches) when a bench wants kernel time
+        self._event_pool = []           # event pairs that already exist on the device (reserve_events)
 
     @property
     def cnt(self):
@@ -219,6 +224,15 @@ class PlanMixin:
     def triplets_drawn(self, value):
         self.settle()
         self._drawn = int(value)
+
+    def reserve_events(self, n):
+        """n event pairs for step_events, created NOW: a torch event is only created on the device by its first record(),
+        tens of microseconds that would otherwise land between the launches of a short timed run"""
+        while len(self._event_pool) < n:
+            pair = _event_pair()
+            for e in pair:
+                e.record()
+            self._event_pool.append(pair)
 
     def settle(self):
         """drop what is planned but has not run; afterwards the counters describe the tables"""
@@ -269,7 +283,7 @@ class PlanMixin:
             if want_loss:
                 plan.loss[lo:lo + m].zero_()
             if self.step_events is not None:          # bench: HIP events around the step launches
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = self._event_pool.pop() if self._event_pool else _event_pair()
                 e0.record()
             step_fn(plan, lo, m, plan.loss if want_loss else None)
             if self.step_events is not None:
@@ -569,8 +583,7 @@ class BprEngine(PlanMixin):
     def step_fn(self, B):
         state = self.state()
         if self.layout == 'flow':
-            return lambda plan, lo, nb, loss: tkr_hip.bpr_flow_run(state, plan, B, nb, self.ctl, loss, first=lo,
-                                                                   waves_per_cu=FLOW_WAVES_PER_CU)
+            return tkr_hip.flow_stepper(state, B, self.ctl, FLOW_WAVES_PER_CU)
         return lambda plan, lo, nb, loss: tkr_hip.bpr_run(state, plan, B, nb, loss, first=lo)
 
 
