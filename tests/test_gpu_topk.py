@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 from oracle import ref_np as R
 
 
-@pytest.fixture(scope='module', params=['bf16x3', 'fp32'])
+@pytest.fixture(scope='module', params=['bf16x3', 'fp32', 'refine'])
 def hip(request):
     """every test runs under both score arithmetics of K4 (include/tkr.h, tkr_topk_set_math)"""
     import tkr_hip

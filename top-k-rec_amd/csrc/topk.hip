@@ -37,6 +37,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kTopkMaxWaves = 8;
 constexpr int kCap = 64;                 // candidate slots per user (= wave width: one entry per lane in a trim)
 constexpr int kMaxK = 32;                // K + 32 (largest per-tile inflow) <= kCap
+constexpr int TKR_EAGAIN_EXACT = -100;   // internal: the bound-and-refine launch cannot run here (no workspace for its flags)
 
 __device__ __forceinline__ uint32_t ordered_bits(float s) {      // monotone float -> uint
     const uint32_t f = __float_as_uint(s);
@@ -61,6 +62,25 @@ __device__ __forceinline__ float share_threshold(uint32_t* thr_shared, int row, 
     if (publish && thr > -INFINITY) seen = atomicMax(&thr_shared[row], ordered_bits(thr));
     seen = max(seen, (uint32_t)__shfl_xor((int)seen, 32, 64));  // the h = 1 lane of the user gets it too
     return fmaxf(thr, unordered_bits(seen));
+}
+// Bound-and-refine arithmetic: the filter runs on approximate scores with `thr` = (lower bound of the K-th best EXACT score)
+// - margin; what the item ranges of a block tell each other is the bound itself.
+// thr and margin are in the user's scaled units (scale = a power of two), the shared word is not.
+__device__ __forceinline__ float share_bound(uint32_t* thr_shared, int row, bool publish, float thr, float margin, float scale,
+                                             float inv_scale) {
+    if (!thr_shared) return thr;
+    uint32_t seen = 0u;
+    if (publish && thr > -INFINITY) seen = atomicMax(&thr_shared[row], ordered_bits((thr + margin) * inv_scale));
+    seen = max(seen, (uint32_t)__shfl_xor((int)seen, 32, 64));
+    return fmaxf(thr, unordered_bits(seen) * scale - margin);
+}
+
+// 2^e with amax * 2^e in [2^13, 2^14) (|e| <= 60; 1 for amax = 0): the power-of-two scaling of the fp16 pass
+__device__ __forceinline__ float pow2_scale(float amax) {
+    if (!(amax > 0.f)) return 1.f;
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
+    const int sft = max(-60, min(60, 13 - e));
+    return __uint_as_float((uint32_t)(127 + sft) << 23);
 }
 
 template <int STRIDE>
@@ -126,13 +146,24 @@ struct TopkSmem {
 
 // Sort user `uw`'s candidate list, keep the best K, return the new threshold (K-th best, or -inf
 // while fewer than K candidates exist).  Wave-uniform call.
-template <typename IdT>
-__device__ __forceinline__ float trim_user(const TopkSmem<IdT>& sm, int uw, int K, int lane, uint64_t* sorted_out) {
+// REFINE (bound-and-refine arithmetic): the scores are approximations within `m2`/2 of the exact ones, so everything within
+// m2 of the K-th best stays: returns max(thr_in, K-th best - m2), keeps what reaches it.
+template <typename IdT, bool REFINE = false>
+__device__ __forceinline__ float trim_user(const TopkSmem<IdT>& sm, int uw, int K, int lane, uint64_t* sorted_out,
+                                           float thr_in = -INFINITY, float m2 = 0.f) {
     const int n = min(sm.cnt[uw], kCap);                         // a reservation past the capacity wrote nothing
     uint64_t key = 0;                                            // below every real key (real keys have idx+1 > 0)
     if (lane < n) key = ((uint64_t)ordered_bits(sm.cs[lane * sm.users + uw]) << 32) | ((uint32_t)sm.ci[lane * sm.users + uw] + 1u);
     key = wave_sort_desc(key, lane);
-    const int keep = min(n, K);
+    int keep = min(n, K);
+    float refined = thr_in;
+    if constexpr (REFINE) {
+        if (n >= K) {
+            const uint32_t kb = __builtin_amdgcn_readlane((uint32_t)(key >> 32), K - 1);
+            refined = fmaxf(thr_in, unordered_bits(kb) - m2);
+            keep = __popcll(__ballot(lane < n && unordered_bits((uint32_t)(key >> 32)) >= refined));     // sorted: a prefix of the lanes
+        }
+    }
     if (lane < keep) {
         const uint32_t ob = (uint32_t)(key >> 32);
         const uint32_t f = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
@@ -141,6 +172,7 @@ __device__ __forceinline__ float trim_user(const TopkSmem<IdT>& sm, int uw, int 
     }
     if (lane == 0) sm.cnt[uw] = keep;
     if (sorted_out) *sorted_out = key;
+    if constexpr (REFINE) return refined;
     const uint32_t kb = __builtin_amdgcn_readlane((uint32_t)(key >> 32), K - 1);
     const uint32_t kf = (kb & 0x80000000u) ? (kb & 0x7fffffffu) : ~kb;
     return (n >= K) ? __uint_as_float(kf) : -INFINITY;
@@ -151,8 +183,9 @@ __device__ __forceinline__ float trim_user(const TopkSmem<IdT>& sm, int uw, int 
 // stay; order and exact cut come from the final sort), so the search runs on the upper 16 bits of the ordered
 // score: 16 bitwise steps over 32 keys packed two per register, then in-place compaction of the entries whose
 // 16-bit key reaches the bound.  A list that does not shrink enough is caught by the on-demand exact trim.
-template <typename IdT>
-__device__ __forceinline__ float trim_all_users(const TopkSmem<IdT>& sm, int uw, int h, int K, float thr) {
+// REFINE: approximate scores, see trim_user -- the bound found is lowered by m2 before it becomes the threshold and the cut.
+template <typename IdT, bool REFINE = false>
+__device__ __forceinline__ float trim_all_users(const TopkSmem<IdT>& sm, int uw, int h, int K, float thr, float m2 = 0.f) {
     const int n = sm.cnt[uw];
     uint32_t kp[16];                                         // entries 2e (low half) and 2e+1 (high half); 0 = absent
 #pragma unroll
@@ -174,6 +207,11 @@ __device__ __forceinline__ float trim_all_users(const TopkSmem<IdT>& sm, int uw,
         if (c >= K) prefix = cand;
     }
     const bool active = n >= K && prefix != 0;               // fewer than K candidates: keep all, threshold unchanged
+    float refined = thr;
+    if constexpr (REFINE) {
+        refined = fmaxf(thr, unordered_bits(prefix << 16) - m2);
+        prefix = min(prefix, ordered_bits(refined) >> 16);   // every entry >= refined has a 16-bit key >= this one
+    }
     int mine = 0;
 #pragma unroll
     for (int e = 0; e < 16; ++e) mine += ((kp[e] & 0xffffu) >= prefix) + ((kp[e] >> 16) >= prefix);
@@ -198,6 +236,7 @@ __device__ __forceinline__ float trim_all_users(const TopkSmem<IdT>& sm, int uw,
         __builtin_amdgcn_wave_barrier();
     }
     if (active && h == 0) sm.cnt[uw] = mine + other;
+    if constexpr (REFINE) return active ? refined : thr;
     const uint32_t ob = prefix << 16;                        // smallest ordered score with this 16-bit key
     const uint32_t f = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
     return active ? fmaxf(thr, __uint_as_float(f)) : thr;
@@ -210,9 +249,11 @@ __device__ __forceinline__ float trim_all_users(const TopkSmem<IdT>& sm, int uw,
 // reaches my user's threshold" and lives in SGPRs; registers without a single candidate are skipped by a scalar
 // branch, the rated/tail/no-user bits (maskw) are consulted only when a lane has one.
 // BIASED: `acc` already holds fl(fl(dot) + bias) (add_bias_inplace), tbias is not read
-template <typename IdT, bool BIASED = false>
+// REFINE: approximate scores (see trim_user); a list whose exact trim leaves no room for this tile's candidates loses them and
+// says so in `lost` (the exact arithmetic redoes the block).
+template <typename IdT, bool BIASED = false, bool REFINE = false>
 __device__ __forceinline__ void filter_tile(const TopkSmem<IdT>& sm, const f32x16& acc, const float* tbias, uint32_t maskw,
-                                            int t, int K, float& thr) {
+                                            int t, int K, float& thr, float m2 = 0.f, bool* lost = nullptr, float bscale = 1.f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ul = lane & 31, h = lane >> 5, users = sm.users;
     const int uw = wave * 32 + ul;
@@ -225,10 +266,17 @@ __device__ __forceinline__ void filter_tile(const TopkSmem<IdT>& sm, const f32x1
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                            // rows 8g+4h .. 8g+4h+3 are registers 4g..4g+3
             const float4 bq = *reinterpret_cast<const float4*>(tbias + 8 * g + 4 * h);
-            sc[4 * g + 0] = acc[4 * g + 0] + bq.x;               // fl(fl(dot)+b)
-            sc[4 * g + 1] = acc[4 * g + 1] + bq.y;
-            sc[4 * g + 2] = acc[4 * g + 2] + bq.z;
-            sc[4 * g + 3] = acc[4 * g + 3] + bq.w;
+            if constexpr (REFINE) {                              // scores in the user's scaled units
+                sc[4 * g + 0] = fmaf(bq.x, bscale, acc[4 * g + 0]);
+                sc[4 * g + 1] = fmaf(bq.y, bscale, acc[4 * g + 1]);
+                sc[4 * g + 2] = fmaf(bq.z, bscale, acc[4 * g + 2]);
+                sc[4 * g + 3] = fmaf(bq.w, bscale, acc[4 * g + 3]);
+            } else {
+                sc[4 * g + 0] = acc[4 * g + 0] + bq.x;           // fl(fl(dot)+b)
+                sc[4 * g + 1] = acc[4 * g + 1] + bq.y;
+                sc[4 * g + 2] = acc[4 * g + 2] + bq.z;
+                sc[4 * g + 3] = acc[4 * g + 3] + bq.w;
+            }
         }
     }
     uint64_t hr[16], any = 0;
@@ -263,15 +311,21 @@ __device__ __forceinline__ void filter_tile(const TopkSmem<IdT>& sm, const f32x1
     uint64_t ov = __ballot(unplaced != 0);
     while (ov) {
         const int u = (__ffsll((long long)ov) - 1) & 31;
-        const float nt = trim_user<IdT>(sm, wave * 32 + u, K, lane, nullptr);
+        float nt;
+        if constexpr (REFINE) nt = trim_user<IdT, true>(sm, wave * 32 + u, K, lane, nullptr, __shfl(thr, u, 64), __shfl(m2, u, 64));
+        else nt = trim_user<IdT>(sm, wave * 32 + u, K, lane, nullptr);
         if (ul == u) {
             thr = fmaxf(thr, nt);                                // never below what another item range published
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if ((unplaced & (1u << r)) && sc[r] >= thr) {
                     const int p2 = atomicAdd(&sm.cnt[uw], 1);
-                    sm.cs[p2 * users + uw] = sc[r] + 0.0f;
-                    sm.ci[p2 * users + uw] = (IdT)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                    if (!REFINE || p2 < kCap) {
+                        sm.cs[p2 * users + uw] = sc[r] + 0.0f;
+                        sm.ci[p2 * users + uw] = (IdT)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                    } else {
+                        *lost = true;
+                    }
                 }
             unplaced = 0;
         }
@@ -288,6 +342,15 @@ __device__ __forceinline__ void add_bias_inplace(f32x16& acc, const float* tbias
     for (int g = 0; g < 4; ++g) {
         const float4 bq = *reinterpret_cast<const float4*>(tbias + 8 * g + 4 * h);
         acc[4 * g + 0] += bq.x; acc[4 * g + 1] += bq.y; acc[4 * g + 2] += bq.z; acc[4 * g + 3] += bq.w;
+    }
+}
+
+__device__ __forceinline__ void add_scaled_bias_inplace(f32x16& acc, const float* tbias, int h, float bscale) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 bq = *reinterpret_cast<const float4*>(tbias + 8 * g + 4 * h);
+        acc[4 * g + 0] = fmaf(bq.x, bscale, acc[4 * g + 0]); acc[4 * g + 1] = fmaf(bq.y, bscale, acc[4 * g + 1]);
+        acc[4 * g + 2] = fmaf(bq.z, bscale, acc[4 * g + 2]); acc[4 * g + 3] = fmaf(bq.w, bscale, acc[4 * g + 3]);
     }
 }
 
@@ -346,6 +409,82 @@ __device__ __forceinline__ void write_rows(const TopkSmem<IdT>& sm, const TopkSl
     }
 }
 
+// ---- bound-and-refine: the exact score of one candidate ------------------------------------------------------------------
+// The fp32 dot product of the fp32-MFMA kernel, bit for bit: v_mfma_f32_32x32x2_f32 adds the product of k-half 0, then the
+// product of k-half 1, one fused multiply-add each (measured: scripts/probe_mfma_order.py, 100 % of 7,680 scores at k = 50,
+// 64, 100, 128) -- so acc <- fma(v[kk], u[kk], acc); acc <- fma(v[KH+kk], u[KH+kk], acc) for kk = 0 .. KH-1, then fl(acc + bias)
+// and -0.0 -> +0.0 as the filter of that kernel does.
+__device__ __forceinline__ float exact_score(const float* __restrict__ up, const float* __restrict__ vp, int k, const float* bias, int col) {
+    const int KH = (k + 1) >> 1;
+    float acc = 0.f;
+    if ((k & 7) == 0) {                                         // both halves 16-byte aligned
+#pragma unroll 2
+        for (int kk = 0; kk < KH; kk += 4) {
+            const float4 a0 = *reinterpret_cast<const float4*>(vp + kk), a1 = *reinterpret_cast<const float4*>(vp + KH + kk);
+            const float4 b0 = *reinterpret_cast<const float4*>(up + kk), b1 = *reinterpret_cast<const float4*>(up + KH + kk);
+            acc = fmaf(a0.x, b0.x, acc); acc = fmaf(a1.x, b1.x, acc);
+            acc = fmaf(a0.y, b0.y, acc); acc = fmaf(a1.y, b1.y, acc);
+            acc = fmaf(a0.z, b0.z, acc); acc = fmaf(a1.z, b1.z, acc);
+            acc = fmaf(a0.w, b0.w, acc); acc = fmaf(a1.w, b1.w, acc);
+        }
+    } else {
+        for (int kk = 0; kk < KH; ++kk) {
+            acc = fmaf(vp[kk], up[kk], acc);
+            if (KH + kk < k) acc = fmaf(vp[KH + kk], up[KH + kk], acc);
+        }
+    }
+    acc = acc + (bias ? bias[col] : 0.f);
+    return acc + 0.0f;
+}
+
+// Final stage of the bound-and-refine kernel: every list holds a superset of its user's best K (by exact score) among the
+// tiles of this workgroup; the candidates are scored exactly, one per lane, and sorted on (exact score, column).
+template <typename IdT>
+__device__ __forceinline__ void write_rows_refine(const TopkSmem<IdT>& sm, const TopkSlot& ws, int n_rows, int K, float thr, float m2,
+                                                  const float* __restrict__ U, const int32_t* __restrict__ uidx,
+                                                  const float* __restrict__ Vt, const float* __restrict__ bias, int k,
+                                                  int32_t* __restrict__ out_ids, float* __restrict__ out_scores,
+                                                  uint64_t* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int me = lane & 31, half = lane >> 5;
+    if (__ballot(sm.cnt[wave * 32 + me] > 32) != 0) {
+        (void)trim_all_users<IdT, true>(sm, wave * 32 + me, half, K, thr, m2);
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int j = 0; j < 16; ++j) {
+        const int u0 = wave * 32 + 2 * j, r0 = ws.block * sm.users + u0;
+        if (r0 >= n_rows) break;                                 // wave-uniform
+        const int n0 = min(sm.cnt[u0], kCap);
+        const int n1 = (r0 + 1 < n_rows) ? min(sm.cnt[u0 + 1], kCap) : 0;
+        if (n0 <= 32 && n1 <= 32) {                              // two users at once, one per half of the wave
+            const int uu = u0 + half, nn = half ? n1 : n0, r = r0 + half;
+            uint64_t key = 0;
+            if (me < nn) {
+                const int col = (int)sm.ci[me * sm.users + uu];
+                const float sx = exact_score(U + (size_t)(uidx ? uidx[r] : r) * k, Vt + (size_t)col * k, k, bias, col);
+                key = ((uint64_t)ordered_bits(sx) << 32) | ((uint32_t)col + 1u);
+            }
+            key = wave_sort_halves(key, lane);
+            const int p = half ? 31 - me : me;                   // the upper half comes out ascending
+            if (r < n_rows && p < K) emit_row<IdT>(ws, r, p, p < nn, key, K, out_ids, out_scores, part);
+            continue;
+        }
+        for (int q = 0; q < 2; ++q) {
+            const int r = r0 + q;
+            if (r >= n_rows) break;
+            const int n = q ? n1 : n0;
+            uint64_t key = 0;
+            if (lane < n) {
+                const int col = (int)sm.ci[lane * sm.users + u0 + q];
+                const float sx = exact_score(U + (size_t)(uidx ? uidx[r] : r) * k, Vt + (size_t)col * k, k, bias, col);
+                key = ((uint64_t)ordered_bits(sx) << 32) | ((uint32_t)col + 1u);
+            }
+            key = wave_sort_desc(key, lane);
+            if (lane < K) emit_row<IdT>(ws, r, lane, lane < n, key, K, out_ids, out_scores, part);
+        }
+    }
+}
+
 // waves per workgroup of an instantiation: 8 (two per SIMD: one wave's filter overlaps the other's MFMA
 // chain); 6 when candidate ids need 32 bits (LDS); 4 for wide factor rows (100+ operand registers)
 template <int KHP, typename IdT>
@@ -358,7 +497,9 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
     int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int tiles_per_split,
     uint64_t* __restrict__ part /*[n_rows][gridDim.y][K] sorted keys, when gridDim.y > 1*/,
     uint32_t* __restrict__ thr_shared /*[n_rows] ordered bits of a lower bound of the row's K-th best score, or null*/,
-    const int4* __restrict__ items /*balanced item table (block, t_begin, t_end, slot | stride << 16), or null: the grid*/) {
+    const int4* __restrict__ items /*balanced item table (block, t_begin, t_end, slot | stride << 16), or null: the grid*/,
+    const uint32_t* __restrict__ only_flagged /*per user block, or null: rank every block.  Set by the bound-and-refine kernel
+                                                for blocks it could not finish*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int KP = 2 * KHP + 4;                              // padded LDS row (floats): conflict-free b128 reads
     const int W = blockDim.x >> 6;
@@ -376,6 +517,7 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
     const int uw = wave * 32 + ul;                               // user slot inside the workgroup
     int4 it = make_int4((int)blockIdx.x, (int)blockIdx.y * tiles_per_split, 0, (int)blockIdx.y | ((int)gridDim.y << 16));
     if (items) it = items[blockIdx.x];
+    if (only_flagged && only_flagged[it.x] == 0u) return;
     const TopkSlot ws = {it.x, it.w & 0xffff, it.w >> 16};
     const int row = ws.block * users + uw;                       // row of the output / index into uidx
     const bool user_ok = row < n_rows;
@@ -507,6 +649,8 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
 // gfx950 the fp32 MFMA does not overlap other work of the SIMD at all.  Finite inputs only (inf - inf in the split).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split3(float a, __bf16& p1, __bf16& p2, __bf16& p3) {
     p1 = (__bf16)a;
@@ -518,15 +662,29 @@ __device__ __forceinline__ void split3(float a, __bf16& p1, __bf16& p2, __bf16& 
 template <int KS, typename IdT>
 constexpr int topk_waves_bf16() { return sizeof(IdT) == 2 ? kTopkMaxWaves : 6; }
 
-template <int KS, typename IdT>
+// REFINE = bound-and-refine arithmetic (tkr_topk_set_math(2)): ONE fp16 product per element instead of six bf16 ones
+// (v_mfma_f32_32x32x16_f16, the same rate).  fp16 has 11 significant bits but a narrow exponent range, so both sides are
+// scaled by powers of two first: the item factors by sv (max |V| lands in [2^13, 2^14)), each user's row by its own su;
+// the filter, the lists and the thresholds of a user live in these scaled units (scale = su * sv; the bias enters as
+// fma(bias, scale, acc)).  In them the approximate score is within
+//   margin = scale * (1.05 * 2^-10 * |u| * max_i |v_i| + 2^-18 * (|u| * max|v| + max|bias|)) + 2.01 * k
+// of the exact fp32 score of exact_score(): each factor is rounded by <= 2^-11 relative -- or, below fp16's normal range,
+// by <= 2^-14 absolute even if the matrix pipe flushes subnormals (the 2.01 * k term: 2 * k * 2^14 * 2^-14) --, Cauchy-Schwarz
+// bounds the sum, and the 2^-18 term covers the fp32 roundings of both accumulations and of the bias add.  A list that keeps
+// everything within 2 * margin of the K-th best approximate score therefore holds the exact best K; they are rescored exactly
+// at the end.  `extra`: bits of [0] max |v_i|, [1] max |bias|, [2] max |V element| (topk_bounds_kernel); [4 + block] = 1
+// when a list of the block overflowed.
+template <int KS, typename IdT, bool REFINE = false>
 __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score_topk_bf16_kernel(
     const float* __restrict__ U, const int32_t* __restrict__ uidx, int n_rows, const float* __restrict__ Vt,
     const float* __restrict__ bias, int n_cols, int k, const uint32_t* __restrict__ mask, int mask_pitch, int K,
     int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int tiles_per_split, uint64_t* __restrict__ part,
-    uint32_t* __restrict__ thr_shared, const int4* __restrict__ items /*(block, t_begin, t_end, slot | stride << 16) or null*/) {
+    uint32_t* __restrict__ thr_shared, const int4* __restrict__ items /*(block, t_begin, t_end, slot | stride << 16) or null*/,
+    uint32_t* __restrict__ extra) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NPART = REFINE ? 1 : 3;
     constexpr int PARTB = KS * 32;                               // bytes of one bf16 part of an item row (KS*16 elements)
-    constexpr int ROWB = 3 * PARTB + 16;                         // padded row: conflict-free ds_read_b128 (ROWB/4 = 4 mod 8)
+    constexpr int ROWB = NPART * PARTB + 16;                     // padded row: conflict-free ds_read_b128 (ROWB/4 = 4 mod 8)
     constexpr int KPAD = KS * 16;
     const int W = blockDim.x >> 6;
     const int users = W * 32;
@@ -550,7 +708,9 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
     const bool user_ok = row < n_rows;
 
     // ---- B operand: lane (user ul, k-group h) holds elements 16s + 8h .. +7 of its user's row, three parts each
-    bf16x8 breg[KS][3];
+    bf16x8 breg[REFINE ? 1 : KS][NPART];
+    f16x8 hreg[REFINE ? KS : 1];
+    float margin = 0.f, bscale = 1.f, inv_bscale = 1.f, sv = 1.f;
     {
         const int urow = user_ok ? (uidx ? uidx[row] : row) : 0;
         const float* up = U + (size_t)urow * k;
@@ -575,17 +735,44 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
                     uv[s][i] = (user_ok && e < k) ? v : 0.f;
                 }
         }
+        if constexpr (REFINE) {
+            float nu = 0.f, amax = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
+            for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __bf16 p1, p2, p3;
-                split3(uv[s][i], p1, p2, p3);
-                breg[s][0][i] = p1; breg[s][1][i] = p2; breg[s][2][i] = p3;
-            }
+                for (int i = 0; i < 8; ++i) {
+                    nu = fmaf(uv[s][i], uv[s][i], nu);
+                    amax = fmaxf(amax, fabsf(uv[s][i]));
+                }
+            nu += __shfl_xor(nu, 32, 64);                          // the other k-group of the same user
+            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+            const float su = pow2_scale(amax);
+            sv = pow2_scale(__uint_as_float(extra[2]));
+            bscale = su * sv;
+            inv_bscale = __uint_as_float((254u - ((__float_as_uint(bscale) >> 23) & 0xffu)) << 23);
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) hreg[s][i] = (_Float16)(uv[s][i] * su);
+            const float reach = sqrtf(nu) * 1.001f * __uint_as_float(extra[0]);      // >= |u| * max |v_i|
+            margin = (fmaf(1.05f * 0.0009765625f, reach, 3.8146973e-6f * (reach + __uint_as_float(extra[1]))) + 7.7e-34f) * bscale +
+                     2.01f * (float)KPAD;
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __bf16 p1, p2, p3;
+                    split3(uv[s][i], p1, p2, p3);
+                    breg[s][0][i] = p1; breg[s][NPART > 1 ? 1 : 0][i] = p2; breg[s][NPART > 2 ? 2 : 0][i] = p3;
+                }
+        }
     }
+    const float m2 = 2.f * margin;
+    bool lost = false;
     for (int s = tid; s < users; s += blockDim.x) sm.cnt[s] = 0;
     float thr = (thr_shared && user_ok) ? unordered_bits(thr_shared[row]) : -INFINITY;   // what other item ranges found so far
+    if constexpr (REFINE) thr = thr * bscale - margin;
     const int n_tiles_all = (n_cols + 31) >> 5;
     const int t_begin = it.y;
     const int n_tiles = items ? it.z : min(n_tiles_all, t_begin + tiles_per_split);
@@ -629,26 +816,37 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
             for (int q = 0; q < NC; ++q)
                 if (src_off[q] >= 0) {
                     const float a[4] = {stg[q].x, stg[q].y, stg[q].z, stg[q].w};
-                    bf16x4 p1, p2, p3;
+                    if constexpr (REFINE) {
+                        f16x4 p1;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        __bf16 x1, x2, x3;
-                        split3(a[i], x1, x2, x3);
-                        p1[i] = x1; p2[i] = x2; p3[i] = x3;
+                        for (int i = 0; i < 4; ++i) p1[i] = (_Float16)(a[i] * sv);
+                        *reinterpret_cast<f16x4*>(dst + dst_off[q]) = p1;
+                    } else {
+                        bf16x4 p1, p2, p3;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            __bf16 x1, x2, x3;
+                            split3(a[i], x1, x2, x3);
+                            p1[i] = x1; p2[i] = x2; p3[i] = x3;
+                        }
+                        *reinterpret_cast<bf16x4*>(dst + dst_off[q]) = p1;
+                        *reinterpret_cast<bf16x4*>(dst + dst_off[q] + (NPART - 1) / 2 * PARTB) = p2;
+                        *reinterpret_cast<bf16x4*>(dst + dst_off[q] + (NPART - 1) * PARTB) = p3;
                     }
-                    *reinterpret_cast<bf16x4*>(dst + dst_off[q]) = p1;
-                    *reinterpret_cast<bf16x4*>(dst + dst_off[q] + PARTB) = p2;
-                    *reinterpret_cast<bf16x4*>(dst + dst_off[q] + 2 * PARTB) = p3;
                 }
         } else {
             for (int c = tid; c < 32 * KPAD; c += nthreads) {
                 const int item = c / KPAD, e = c % KPAD, col = t * 32 + item;
                 float v = 0.f;
                 if (e < k && col < n_cols) v = Vt[(size_t)col * k + e];
-                __bf16 x1, x2, x3;
-                split3(v, x1, x2, x3);
                 __bf16* rowp = reinterpret_cast<__bf16*>(dst + item * ROWB);
-                rowp[e] = x1; rowp[KPAD + e] = x2; rowp[2 * KPAD + e] = x3;
+                if constexpr (REFINE) {
+                    reinterpret_cast<_Float16*>(rowp)[e] = (_Float16)(v * sv);
+                } else {
+                    __bf16 x1, x2, x3;
+                    split3(v, x1, x2, x3);
+                    rowp[e] = x1; rowp[(NPART - 1) / 2 * KPAD + e] = x2; rowp[(NPART - 1) * KPAD + e] = x3;
+                }
             }
         }
         if (tid < 32) sm.tbias[buf * 32 + tid] = stg_bias;
@@ -673,15 +871,20 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
         const unsigned char* arow = tile + buf * 32 * ROWB + ul * ROWB + h * 16;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(arow + s * 32);
-            const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(arow + PARTB + s * 32);
-            const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(arow + 2 * PARTB + s * 32);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, breg[s][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, breg[s][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[s][2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, breg[s][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[s][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[s][0], acc, 0, 0, 0);
+            if constexpr (REFINE) {
+                const f16x8 a = *reinterpret_cast<const f16x8*>(arow + s * 32);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, hreg[s], acc, 0, 0, 0);
+            } else {
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(arow + s * 32);
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(arow + (NPART - 1) / 2 * PARTB + s * 32);
+                const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(arow + (NPART - 1) * PARTB + s * 32);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, breg[s][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, breg[s][NPART > 1 ? 1 : 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[s][NPART > 2 ? 2 : 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, breg[s][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[s][NPART > 1 ? 1 : 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[s][0], acc, 0, 0, 0);
+            }
         }
         // Where the one barrier of the tile sits.  k <= 64: EARLY, right after the staging -- tile t+1 is in LDS, every wave
         // is done reading tile t, and the filter touches only the wave's own lists, so a wave whose filter is short starts
@@ -691,7 +894,10 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
         // interleave them best when they start together (a lone dependent chain issues at ~44 instead of 32 cycles per
         // MFMA); there the barrier stays behind the filter.
         constexpr bool kEarlyBarrier = KS <= 4;
-        if constexpr (kEarlyBarrier) add_bias_inplace(acc, sm.tbias + buf * 32, h);
+        if constexpr (kEarlyBarrier) {
+            if constexpr (REFINE) add_scaled_bias_inplace(acc, sm.tbias + buf * 32, h, bscale);
+            else add_bias_inplace(acc, sm.tbias + buf * 32, h);
+        }
         if (t + 1 < n_tiles) stage_store(t + 1, buf ^ 1);
         if (t + 2 < n_tiles) stage_load(t + 2);
         if constexpr (kEarlyBarrier) __syncthreads();
@@ -699,15 +905,47 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
         if (t == n_tiles_all - 1) maskw |= tail_mask;
         if (t == next_sched) {
             if (__ballot(sm.cnt[uw] > kCap / 2) != 0) {            // lists still short (thresholds shared by earlier ranges): nothing to gain
-                thr = trim_all_users<IdT>(sm, uw, h, K, thr);
-                thr = share_threshold(thr_shared, row, user_ok && h == 0, thr);
+                if constexpr (REFINE) {
+                    thr = trim_all_users<IdT, true>(sm, uw, h, K, thr, m2);
+                    thr = share_bound(thr_shared, row, user_ok && h == 0, thr, margin, bscale, inv_bscale);
+                } else {
+                    thr = trim_all_users<IdT>(sm, uw, h, K, thr);
+                    thr = share_threshold(thr_shared, row, user_ok && h == 0, thr);
+                }
             }
             next_sched = t + ((t - t_begin + 1) >> 1);
         }
-        filter_tile<IdT, kEarlyBarrier>(sm, acc, sm.tbias + buf * 32, maskw, t, K, thr);
+        filter_tile<IdT, kEarlyBarrier, REFINE>(sm, acc, sm.tbias + buf * 32, maskw, t, K, thr, m2, &lost, bscale);
         if constexpr (!kEarlyBarrier) __syncthreads();
     }
-    write_rows<IdT>(sm, ws, n_rows, K, thr, out_ids, out_scores, part);
+    if constexpr (REFINE) {
+        if (__ballot(lost) != 0 && lane == 0) extra[4 + ws.block] = 1u;       // the exact kernel redoes this block
+        write_rows_refine<IdT>(sm, ws, n_rows, K, thr, m2, U, uidx, Vt, bias, k, out_ids, out_scores, part);
+    } else {
+        write_rows<IdT>(sm, ws, n_rows, K, thr, out_ids, out_scores, part);
+    }
+}
+
+// max_i |v_i| (2-norm, rounded up) and max_i |bias_i| for the margin of the bound-and-refine kernel; bounds[] zeroed before
+__global__ __launch_bounds__(256) void topk_bounds_kernel(const float* __restrict__ Vt, const float* __restrict__ bias, int n_cols,
+                                                         int k, uint32_t* __restrict__ bounds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float vmax = 0.f, bmax = 0.f, emax = 0.f;
+    for (int col = blockIdx.x * 4 + wave; col < n_cols; col += gridDim.x * 4) {
+        float ss = 0.f;
+        for (int e = lane; e < k; e += 64) { const float v = Vt[(size_t)col * k + e]; ss = fmaf(v, v, ss); emax = fmaxf(emax, fabsf(v)); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        vmax = fmaxf(vmax, sqrtf(ss) * 1.001f);
+        if (bias) bmax = fmaxf(bmax, fabsf(bias[col]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) emax = fmaxf(emax, __shfl_xor(emax, o, 64));
+    if (lane == 0) {                                             // non-negative floats order like their bits
+        atomicMax(&bounds[0], __float_as_uint(vmax));
+        if (bias) atomicMax(&bounds[1], __float_as_uint(bmax));
+        atomicMax(&bounds[2], __float_as_uint(emax));
+    }
 }
 
 // ---- merge of the per-item-range partial lists: one wave per row ----------------------------------
@@ -887,125 +1125,186 @@ static int topk_spans_per_cu() {
     return m;
 }
 
-template <int KHP, typename IdT>
-static int launch_topk(int W, const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias,
-                       int n_cols, int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
-                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    constexpr int KP = 2 * KHP + 4;
-    const int users = W * 32;
-    const size_t lds = (size_t)(2 * 32 * KP + 64) * 4 + (size_t)users * 4 + (size_t)users * kCap * (4 + sizeof(IdT));
-    if (lds > 160 * 1024) return TKR_EUNSUPPORTED;
-    auto kern = score_topk_kernel<KHP, IdT>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) return (int)e;
+// How one K4 call covers the (user block, tile) space and where its scratch lives in the workspace:
+//   [lists x n_rows x K sorted keys][n_rows shared threshold words][extra words]
+struct TopkPlan {
+    dim3 grid;
+    int tps;                  // tiles per item range of the plain grid (0 with the item table)
+    uint64_t* part;           // partial lists
+    uint32_t* thr_shared;     // or null
+    const int4* items;        // item table, or null: the plain (block, range) grid
+    int merge_lists;          // > 1: merge_topk_kernel over this many slots per row
+    const int32_t* nslots;
+    uint32_t* extra;          // `extra_words` zeroed uint32 behind the thresholds, or null when they did not fit
+};
+
+static int plan_topk(int users, int n_rows, int n_cols, int K, void* workspace, size_t workspace_bytes, size_t extra_words,
+                     hipStream_t stream, TopkPlan& p) {
     const int grid = (n_rows + users - 1) / users;
     const int n_tiles = (n_cols + 31) / 32;
     const size_t per_split = (size_t)n_rows * K * sizeof(uint64_t);
-    const size_t thr_bytes = (size_t)n_rows * sizeof(uint32_t);
+    const size_t thr_bytes = (size_t)n_rows * sizeof(uint32_t), extra_bytes = extra_words * sizeof(uint32_t);
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    p = TopkPlan{};
     const int G = topk_span_count((long long)grid * n_tiles);
     if (workspace && G > 0) {
         const ItemTable* tab = item_table(n_rows, users, n_tiles, G);
         if (tab && workspace_bytes >= (size_t)tab->stride * per_split + thr_bytes) {
-            uint32_t* thr_shared = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(workspace) + (size_t)tab->stride * per_split);
-            TKR_CHECK(hipMemsetAsync(thr_shared, 0, thr_bytes, stream));
-            hipLaunchKernelGGL(kern, dim3(tab->n_items), dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch,
-                               K, out_ids, out_scores, 0, reinterpret_cast<uint64_t*>(workspace), thr_shared, tab->d_items);
-            if (tab->stride > 1)
-                hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream,
-                                   reinterpret_cast<const uint64_t*>(workspace), n_rows, tab->stride, K, out_ids, out_scores,
-                                   tab->d_nslots, users);
-            return (int)hipGetLastError();
+            const size_t lists_bytes = (size_t)tab->stride * per_split;
+            const bool fits = workspace_bytes >= lists_bytes + thr_bytes + extra_bytes;
+            p.grid = dim3(tab->n_items);
+            p.part = reinterpret_cast<uint64_t*>(ws);
+            p.thr_shared = reinterpret_cast<uint32_t*>(ws + lists_bytes);
+            p.items = tab->d_items;
+            p.merge_lists = tab->stride;
+            p.nslots = tab->d_nslots;
+            p.extra = (fits && extra_words) ? p.thr_shared + n_rows : nullptr;
+            TKR_CHECK(hipMemsetAsync(p.thr_shared, 0, thr_bytes + (p.extra ? extra_bytes : 0), stream));
+            return TKR_OK;
         }
     }
-    const int max_splits = (workspace && workspace_bytes > thr_bytes)
-                               ? (int)std::min<size_t>(kMaxSplits, (workspace_bytes - thr_bytes) / (per_split ? per_split : 1)) : 1;
+    const size_t fixed = thr_bytes + extra_bytes;
+    const int max_splits = (workspace && workspace_bytes > fixed)
+                               ? (int)std::min<size_t>(kMaxSplits, (workspace_bytes - fixed) / (per_split ? per_split : 1)) : 1;
     int S = pick_splits(n_rows, users, n_tiles, max_splits < 1 ? 1 : max_splits);
     const int tps = (n_tiles + S - 1) / S;
     S = (n_tiles + tps - 1) / tps;
-    uint32_t* thr_shared = nullptr;
-    if (S > 1) {                                                 // thresholds live behind the S partial lists
-        thr_shared = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(workspace) + (size_t)S * per_split);
-        TKR_CHECK(hipMemsetAsync(thr_shared, 0, thr_bytes, stream));
+    p.grid = dim3(grid, S);
+    p.tps = tps;
+    p.part = reinterpret_cast<uint64_t*>(ws);
+    p.merge_lists = S;
+    const size_t lists_bytes = S > 1 ? (size_t)S * per_split : 0;
+    const bool fits = workspace && workspace_bytes >= lists_bytes + fixed;
+    if (S > 1 || (fits && extra_words)) {                        // thresholds live behind the S partial lists
+        p.thr_shared = reinterpret_cast<uint32_t*>(ws + lists_bytes);
+        p.extra = (fits && extra_words) ? p.thr_shared + n_rows : nullptr;
+        TKR_CHECK(hipMemsetAsync(p.thr_shared, 0, thr_bytes + (p.extra ? extra_bytes : 0), stream));
     }
-    hipLaunchKernelGGL(kern, dim3(grid, S), dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,
-                       out_ids, out_scores, tps, reinterpret_cast<uint64_t*>(workspace), thr_shared, nullptr);
-    if (S > 1)
-        hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream,
-                           reinterpret_cast<const uint64_t*>(workspace), n_rows, S, K, out_ids, out_scores, nullptr, users);
+    return TKR_OK;
+}
+
+static int merge_planned(const TopkPlan& p, int users, int n_rows, int K, int32_t* out_ids, float* out_scores, hipStream_t stream) {
+    if (p.merge_lists > 1)
+        hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, reinterpret_cast<const uint64_t*>(p.part),
+                           n_rows, p.merge_lists, K, out_ids, out_scores, p.nslots, users);
     return (int)hipGetLastError();
 }
 
-template <int KS, typename IdT>
+template <int KHP, typename IdT>
+static int launch_topk_planned(const TopkPlan& p, const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias,
+                               int n_cols, int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
+                               const uint32_t* only_flagged, hipStream_t stream) {
+    constexpr int KP = 2 * KHP + 4;
+    const int W = topk_waves<KHP, IdT>(), users = W * 32;
+    const size_t lds = (size_t)(2 * 32 * KP + 64) * 4 + (size_t)users * 4 + (size_t)users * kCap * (4 + sizeof(IdT));
+    if (lds > 160 * 1024) return TKR_EUNSUPPORTED;
+    auto kern = score_topk_kernel<KHP, IdT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, p.grid, dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids,
+                       out_scores, p.tps, p.part, p.thr_shared, p.items, only_flagged);
+    return (int)hipGetLastError();
+}
+
+template <int KHP, typename IdT>
+static int launch_topk(const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias, int n_cols, int k,
+                       const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores, void* workspace,
+                       size_t workspace_bytes, hipStream_t stream) {
+    const int users = topk_waves<KHP, IdT>() * 32;
+    TopkPlan p;
+    int rc = plan_topk(users, n_rows, n_cols, K, workspace, workspace_bytes, 0, stream, p);
+    if (rc != TKR_OK) return rc;
+    rc = launch_topk_planned<KHP, IdT>(p, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores, nullptr, stream);
+    if (rc != TKR_OK) return rc;
+    return merge_planned(p, users, n_rows, K, out_ids, out_scores, stream);
+}
+
+// the fp32-MFMA kernel for the factor width k (k <= 128 here: same workgroup shape as the bf16 kernels)
+template <typename IdT>
+static int launch_fp32_planned(const TopkPlan& p, const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias,
+                               int n_cols, int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
+                               const uint32_t* only_flagged, hipStream_t stream) {
+    const int kh = (k + 1) / 2;
+#define TKR_TOPK_CASE(KHP)                                                                                                    \
+    if (kh <= KHP)                                                                                                            \
+        return launch_topk_planned<KHP, IdT>(p, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores,    \
+                                             only_flagged, stream);
+    TKR_TOPK_CASE(16)
+    TKR_TOPK_CASE(28)
+    TKR_TOPK_CASE(32)
+    TKR_TOPK_CASE(52)
+    TKR_TOPK_CASE(64)
+#undef TKR_TOPK_CASE
+    return TKR_EUNSUPPORTED;
+}
+
+template <int KS, typename IdT, bool REFINE>
 static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias, int n_cols,
                             int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
                             void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    constexpr int ROWB = 3 * KS * 32 + 16;
+    constexpr int ROWB = (REFINE ? 1 : 3) * KS * 32 + 16;
     const int W = topk_waves_bf16<KS, IdT>();
     const int users = W * 32;
     const size_t lds = (size_t)2 * 32 * ROWB + 64 * 4 + (size_t)users * 4 + (size_t)users * kCap * (4 + sizeof(IdT));
     if (lds > 160 * 1024) return TKR_EUNSUPPORTED;
-    auto kern = score_topk_bf16_kernel<KS, IdT>;
+    auto kern = score_topk_bf16_kernel<KS, IdT, REFINE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return (int)e;
-    const int grid = (n_rows + users - 1) / users;
-    const int n_tiles = (n_cols + 31) / 32;
-    const size_t per_split = (size_t)n_rows * K * sizeof(uint64_t);
-    const size_t thr_bytes = (size_t)n_rows * sizeof(uint32_t);
-    const int G = topk_span_count((long long)grid * n_tiles);
-    if (workspace && G > 0) {
-        const ItemTable* tab = item_table(n_rows, users, n_tiles, G);
-        if (tab && workspace_bytes >= (size_t)tab->stride * per_split + thr_bytes) {
-            uint32_t* thr_shared = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(workspace) + (size_t)tab->stride * per_split);
-            TKR_CHECK(hipMemsetAsync(thr_shared, 0, thr_bytes, stream));
-            hipLaunchKernelGGL(kern, dim3(tab->n_items), dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch,
-                               K, out_ids, out_scores, 0, reinterpret_cast<uint64_t*>(workspace), thr_shared, tab->d_items);
-            if (tab->stride > 1)
-                hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream,
-                                   reinterpret_cast<const uint64_t*>(workspace), n_rows, tab->stride, K, out_ids, out_scores,
-                                   tab->d_nslots, users);
-            return (int)hipGetLastError();
-        }
+    const int n_blocks = (n_rows + users - 1) / users;
+    TopkPlan p;
+    int rc = plan_topk(users, n_rows, n_cols, K, workspace, workspace_bytes, REFINE ? (size_t)(4 + n_blocks) : 0, stream, p);
+    if (rc != TKR_OK) return rc;
+    if constexpr (REFINE) {
+        if (!p.extra) return TKR_EAGAIN_EXACT;                    // no room for the block flags: the caller runs the fp32 kernel
+        hipLaunchKernelGGL(topk_bounds_kernel, dim3(std::min(256, (n_cols + 3) / 4)), dim3(256), 0, stream, Vt, bias, n_cols, k, p.extra);
     }
-    const int max_splits = (workspace && workspace_bytes > thr_bytes)
-                               ? (int)std::min<size_t>(kMaxSplits, (workspace_bytes - thr_bytes) / (per_split ? per_split : 1)) : 1;
-    int S = pick_splits(n_rows, users, n_tiles, max_splits < 1 ? 1 : max_splits);
-    const int tps = (n_tiles + S - 1) / S;
-    S = (n_tiles + tps - 1) / tps;
-    uint32_t* thr_shared = nullptr;
-    if (S > 1) {                                                 // thresholds live behind the S partial lists
-        thr_shared = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(workspace) + (size_t)S * per_split);
-        TKR_CHECK(hipMemsetAsync(thr_shared, 0, thr_bytes, stream));
+    hipLaunchKernelGGL(kern, p.grid, dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids,
+                       out_scores, p.tps, p.part, p.thr_shared, p.items, p.extra);
+    rc = (int)hipGetLastError();
+    if (rc != TKR_OK) return rc;
+    if constexpr (REFINE) {                                       // blocks with an overflowed list: the fp32 kernel, same work items
+        rc = launch_fp32_planned<IdT>(p, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores, p.extra + 4, stream);
+        if (rc != TKR_OK) return rc;
     }
-    hipLaunchKernelGGL(kern, dim3(grid, S), dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,
-                       out_ids, out_scores, tps, reinterpret_cast<uint64_t*>(workspace), thr_shared, nullptr);
-    if (S > 1)
-        hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream,
-                           reinterpret_cast<const uint64_t*>(workspace), n_rows, S, K, out_ids, out_scores, nullptr, users);
-    return (int)hipGetLastError();
+    return merge_planned(p, users, n_rows, K, out_ids, out_scores, stream);
 }
 
 // arithmetic of the score block: 0 = bf16-split products on the dense matrix pipe (k <= 128), 1 = fp32 MFMA for every k.
 // Initial value from TKR_TOPK_MATH=fp32|bf16x3; tkr_topk_set_math changes it for the process.
 static int g_topk_math = -1;
-static bool topk_bf16_enabled() {
+static int topk_math() {
     if (g_topk_math < 0) {
         const char* e = getenv("TKR_TOPK_MATH");
-        g_topk_math = (e && strcmp(e, "fp32") == 0) ? 1 : 0;
+        g_topk_math = (e && strcmp(e, "fp32") == 0) ? 1 : (e && strcmp(e, "refine") == 0) ? 2 : 0;
     }
-    return g_topk_math == 0;
+    return g_topk_math;
 }
 
 template <typename IdT>
 static int dispatch_topk(const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias, int n_cols,
                          int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
                          void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    if (k <= 128 && topk_bf16_enabled()) {
+    if (k <= 128 && topk_math() == 2) {                          // bound-and-refine; without room for its flags: the fp32 kernel (same results)
+        int rc = TKR_EAGAIN_EXACT;
+#define TKR_TOPK_REFINE_CASE(KS)                                                                                        \
+    if (rc == TKR_EAGAIN_EXACT && k <= 16 * KS) {                                                                       \
+        rc = launch_topk_bf16<KS, IdT, true>(U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores, \
+                                             workspace, workspace_bytes, stream);                                      \
+        if (rc != TKR_EAGAIN_EXACT) return rc;                                                                          \
+        rc = TKR_OK;                                                                                                    \
+    }
+        TKR_TOPK_REFINE_CASE(1)
+        TKR_TOPK_REFINE_CASE(2)
+        TKR_TOPK_REFINE_CASE(4)
+        TKR_TOPK_REFINE_CASE(8)
+#undef TKR_TOPK_REFINE_CASE
+    }
+    if (k <= 128 && topk_math() == 0) {
 #define TKR_TOPK_BF16_CASE(KS)                                                                                          \
     if (k <= 16 * KS)                                                                                                   \
-        return launch_topk_bf16<KS, IdT>(U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores, workspace, \
-                                         workspace_bytes, stream);
+        return launch_topk_bf16<KS, IdT, false>(U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores, \
+                                                workspace, workspace_bytes, stream);
         TKR_TOPK_BF16_CASE(1)
         TKR_TOPK_BF16_CASE(2)
         TKR_TOPK_BF16_CASE(4)
@@ -1015,7 +1314,7 @@ static int dispatch_topk(const float* U, const int32_t* uidx, int n_rows, const 
     const int kh = (k + 1) / 2;
 #define TKR_TOPK_CASE(KHP)                                                                                   \
     if (kh <= KHP)                                                                                           \
-        return launch_topk<KHP, IdT>(topk_waves<KHP, IdT>(), U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, \
+        return launch_topk<KHP, IdT>(U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,                   \
                                      out_ids, out_scores, workspace, workspace_bytes, stream);
     TKR_TOPK_CASE(16)
     TKR_TOPK_CASE(28)
@@ -1040,7 +1339,7 @@ extern "C" int tkr_build_rated_mask(const int64_t* rated_ptr, const int32_t* rat
 }
 
 extern "C" int tkr_topk_set_math(int32_t mode) {
-    if (mode != 0 && mode != 1) return TKR_EINVAL;
+    if (mode < 0 || mode > 2) return TKR_EINVAL;
     tkr::g_topk_math = mode;
     return TKR_OK;
 }
@@ -1055,7 +1354,8 @@ extern "C" int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K) {
     if (splits < 2) splits = 2;
     const int64_t pieces = (512 + blocks - 1) / blocks + 1;      // 256 x (spans per CU <= 2)
     const int64_t lists = splits > pieces ? splits : pieces;
-    return lists * n_rows * K * (int64_t)sizeof(uint64_t) + (int64_t)n_rows * (int64_t)sizeof(uint32_t);
+    const int64_t refine_words = 4 + ((int64_t)n_rows + 191) / 192;      // bounds + one flag per user block (>= 192 users each)
+    return lists * n_rows * K * (int64_t)sizeof(uint64_t) + (int64_t)n_rows * (int64_t)sizeof(uint32_t) + refine_words * 4;
 }
 
 extern "C" int tkr_score_topk(const float* U, const int32_t* user_idx, int32_t n_rows, const float* Vt,

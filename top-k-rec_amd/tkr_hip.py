@@ -253,8 +253,10 @@ def _score_topk_once(U, Vt, K, bias, user_idx, mask, mask_pitch, want_scores, sp
 
 
 def set_topk_math(mode):
-    """'bf16x3' (default: split products on the dense matrix pipe, k <= 128) or 'fp32' (fp32 MFMA) -- see include/tkr.h"""
-    _check(lib().tkr_topk_set_math(C.c_int32({'bf16x3': 0, 'fp32': 1}[mode])), 'tkr_topk_set_math')
+    """'bf16x3' (split products on the dense matrix pipe, k <= 128), 'fp32' (fp32 MFMA) or 'refine' (one bf16 pass with a
+    rigorous error bound picks the candidates, the fp32 arithmetic of 'fp32' ranks them: same lists and scores as 'fp32',
+    k <= 128) -- see include/tkr.h"""
+    _check(lib().tkr_topk_set_math(C.c_int32({'bf16x3': 0, 'fp32': 1, 'refine': 2}[mode])), 'tkr_topk_set_math')
 
 
 def score_topk(U, Vt, K, bias=None, user_idx=None, mask=None, mask_pitch=0, want_scores=False, split=True):
