@@ -22,7 +22,7 @@ Prints ONE JSON line (rank 0).  Extra objects beside the contract fields:
   sgd_mode / sgd_throughput_mode  the legacy plain-SGD optimiser (old/methods/bpr.py:57-61) at batch 256 / 8192
   bpr_netflix_shape  the headline path at BASELINE.json configs[3]'s shape (480,189 x 17,770) on one GPU
   topk            the other half of BASELINE.json's metric: full-catalogue top-30 scored users/s (K4)
-                  with its own MFMA roofline (bf16 dense peak / 6 split products; fp32 MFMA peak under TKR_TOPK_MATH=fp32) and cpu_baseline
+                  with its own MFMA roofline (fp16 dense peak for the default bound-and-refine arithmetic; TKR_TOPK_MATH=bf16x3|fp32 the others) and cpu_baseline
 """
 import argparse
 import json
@@ -42,17 +42,53 @@ MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA, dense
 MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense (no sparsity)
 
 
+MFMA_F16_PEAK_TF = 2500.0      # MI355X_MICROARCH.md: fp16 MFMA, dense (same rate as bf16)
+
+
+def topk_math(k):
+    """the score arithmetic K4 runs a width-k problem in (include/tkr.h tkr_topk_set_math)"""
+    mode = os.environ.get('TKR_TOPK_MATH', 'refine')
+    return 'fp32' if (k > 128 or mode == 'fp32') else ('bf16x3' if mode == 'bf16x3' else 'refine')
+
+
 def topk_roofline(tf, k):
     """K4 against the pipe it runs on.  `achieved` is always ALGORITHMIC fp32 flops (2*k*n_items per user) per
-    second.  Default arithmetic (k <= 128): every fp32 product is six bf16 partial products on the dense matrix pipe, so
-    the ceiling for algorithmic flops is the bf16 dense peak / 6; TKR_TOPK_MATH=fp32 (and k > 128): the fp32 MFMA peak."""
-    split = k <= 128 and os.environ.get('TKR_TOPK_MATH', 'bf16x3') != 'fp32'
-    peak = MFMA_BF16_PEAK_TF / 6.0 if split else MFMA_F32_PEAK_TF
-    return {'kernel': 'tkr::score_topk_bf16_kernel' if split else 'tkr::score_topk_kernel', 'bound': 'mfma', 'achieved': tf,
-            'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
-            'arithmetic': ('bf16x3 split, 6 x v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulate: executed bf16 rate %.0f TFLOP/s '
-                           'of %.0f dense' % (6 * tf, MFMA_BF16_PEAK_TF)) if split else 'v_mfma_f32_32x32x2_f32',
-            'vs_fp32_mfma_peak': tf / MFMA_F32_PEAK_TF}
+    second.  refine (default, k <= 128): ONE fp16 product per element on the dense matrix pipe proposes the candidates (the
+    fp32 rescoring of ~33 of them per user is 0.2 % of the flops), ceiling = the fp16 dense peak; bf16x3: six bf16 partial
+    products per element, ceiling = bf16 dense peak / 6; fp32 (and k > 128): the fp32 MFMA peak."""
+    math = topk_math(k)
+    peak = {'refine': MFMA_F16_PEAK_TF, 'bf16x3': MFMA_BF16_PEAK_TF / 6.0, 'fp32': MFMA_F32_PEAK_TF}[math]
+    what = {'refine': 'bound-and-refine: 1 x v_mfma_f32_32x32x16_f16 per 16 k (scaled fp16, rigorous margin) + exact fp32 fma-chain '
+                      'rescoring of the candidates; results = the fp32 arithmetic bit for bit',
+            'bf16x3': 'bf16x3 split, 6 x v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulate: executed bf16 rate %.0f TFLOP/s of %.0f '
+                      'dense' % (6 * tf, MFMA_BF16_PEAK_TF),
+            'fp32': 'v_mfma_f32_32x32x2_f32'}[math]
+    return {'kernel': 'tkr::score_topk_kernel' if math == 'fp32' else 'tkr::score_topk_bf16_kernel', 'bound': 'mfma', 'achieved': tf,
+            'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak, 'arithmetic': what, 'vs_fp32_mfma_peak': tf / MFMA_F32_PEAK_TF}
+
+
+def topk_other_arithmetics(run, k):
+    """ms per pass of the same launch under the other two score arithmetics (all on the bench line)"""
+    import tkr_hip
+    out = {}
+    if k > 128:
+        return out
+    try:
+        for mode in ('refine', 'bf16x3', 'fp32'):
+            if mode == topk_math(k):
+                continue
+            tkr_hip.set_topk_math(mode)
+            run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run(); run()
+            e1.record()
+            torch.cuda.synchronize()
+            out[mode] = e0.elapsed_time(e1) / 2
+    finally:
+        tkr_hip.set_topk_math(topk_math(k))
+    return out
 
 
 def pmc_traffic(key):
@@ -199,6 +235,7 @@ def topk_bench(r, k, device, rank, world, K=30, reps=5):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     launch_ms = e0.elapsed_time(e1) / reps
+    others = topk_other_arithmetics(lambda: tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch), k) if world == 1 else {}
     n_items = V.shape[0]
     flops = 2.0 * k * n_items * U.shape[0]
     tf = flops / (launch_ms * 1e-3) / 1e12
@@ -208,7 +245,8 @@ def topk_bench(r, k, device, rank, world, K=30, reps=5):
             'roofline': dict(topk_roofline(tf, k),
                              traffic=None,
                              traffic_from_profile=pmc_traffic('score_topk_ml10m_k128') if (k == 128 and n_items == 10380 and world == 1) else None,
-                             launch_ms=launch_ms, algorithmic_flops_per_launch=flops)}
+                             launch_ms=launch_ms, algorithmic_flops_per_launch=flops),
+            'ms_per_pass_other_arithmetics': others}
 
 
 def topk_bench_netflix(k, device, K=30, reps=3):
@@ -234,11 +272,12 @@ def topk_bench_netflix(k, device, K=30, reps=3):
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     ms = e0.elapsed_time(e1) / reps
+    others = topk_other_arithmetics(lambda: tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch), k)
     flops = 2.0 * k * n_items * n_users
     tf = flops / (ms * 1e-3) / 1e12
     return {'value': n_users * reps / wall, 'unit': 'users/s', 'ms_per_pass': wall * 1e3 / reps,
             'config': {'workload': '%d users x %d items, k=%d, top-%d, %d rated items per user masked' % (n_users, n_items, k, K, deg)},
-            'roofline': dict(topk_roofline(tf, k), launch_ms=ms)}
+            'roofline': dict(topk_roofline(tf, k), launch_ms=ms), 'ms_per_pass_other_arithmetics': others}
 
 
 def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):

@@ -213,13 +213,22 @@ int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* 
  *   workspace (nullable, device, workspace_bytes): scratch for per-item-range partial lists; with
  *     tkr_topk_workspace_bytes(n_rows, K) bytes the launch splits the catalogue so that the grid fills
  *     the 256 CUs in whole rounds (results are identical with or without it)
- * Arithmetic of the scores (tkr_topk_set_math, initial value from TKR_TOPK_MATH=bf16x3|fp32):
- *   0 "bf16x3" (default, k <= 128): each fp32 factor is split exactly into three bf16 parts and a product is the six
+ * Arithmetic of the scores (tkr_topk_set_math, initial value from TKR_TOPK_MATH=refine|bf16x3|fp32):
+ *   2 "refine" (default; k <= 128, needs the workspace, n_cols < 2^27): bound-and-refine.  ONE fp16 product per element
+ *     (factors scaled by powers of two, v_mfma_f32_32x32x16_f16) scores the catalogue within a rigorous margin
+ *     (2^-10 * 1.05 * |u| * max|v_i| + roundings, see csrc/topk.hip); the candidate lists keep everything within twice the
+ *     margin of the K-th best approximate score, and the survivors are rescored with the arithmetic of mode 1, which
+ *     decides the order: ids and score bits are those of mode 1, at 2.1x its speed.  A list that cannot hold its margin
+ *     (massive near-ties) sends its user block through the mode-1 kernel.  Without a workspace the call runs as mode 1.
+ *   0 "bf16x3" (k <= 128): each fp32 factor is split exactly into three bf16 parts and a product is the six
  *     leading partial products (each exact in fp32, the dropped ones < 2^-23 |ab|) accumulated in fp32 by
  *     v_mfma_f32_32x32x16_bf16 -- an fp32 dot product with yet another summation order: same error against fp64 as
  *     np.dot / the fp32 kernel, identical results whenever the partial sums are representable; finite inputs only;
- *   1 "fp32": v_mfma_f32_32x32x2_f32 (a bitwise fmaf chain), used for every k and always for k > 128.
- *   On gfx950 the fp32 MFMA runs at the vector-ALU rate and overlaps nothing; mode 0 is 1.4-1.6x faster.
+ *   1 "fp32": v_mfma_f32_32x32x2_f32, used for every k and always for k > 128: per score the fma chain
+ *     acc <- fma(v[j], u[j], acc); acc <- fma(v[KH+j], u[KH+j], acc), j = 0 .. KH-1, KH = ceil(k/2), then fl(acc + bias)
+ *     (oracle/ref_np.py mfma_chain_scores restates it; bit-exact on generic inputs).
+ *   On gfx950 the fp32 MFMA runs at the vector-ALU rate and overlaps nothing; mode 0 is 1.4-1.6x faster than mode 1,
+ *   mode 2 1.5-2.1x.
  * K <= 32 per launch (larger K: rank 32, add the found columns to the mask with tkr_build_rated_mask, rank
  * again -- top-k-rec_amd/tkr_hip.py score_topk does this), k <= 256. */
 int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K);

@@ -425,6 +425,27 @@ def scenario_scores(umat, vmat, bmat, vids, teids):
     return scores
 
 
+def mfma_chain_scores(umat, temat, tebias=None):
+    """The fp32 dot product of evaluate.py:78-80 (``np.dot(umat, temat.T)`` + bias: BLAS picks the summation order there) in
+    the ONE order the build's fp32 arithmetic uses (include/tkr.h tkr_topk_set_math modes 1 and 2): the two halves of the factor
+    vector interleaved -- ``acc = fma(v[j], u[j], acc); acc = fma(v[KH+j], u[KH+j], acc)`` for j = 0..KH-1, KH = ceil(k/2) --
+    one rounding per fused multiply-add, then ``fl(acc + bias)``.  Products are exact in float64 (24 x 24 bits); the sum is rounded
+    to 53 and then to 24 bits, which differs from a single rounding only when the float64 sum lands exactly on a float32 tie --
+    the comparing tests allow for a 1e-4 fraction of such scores.  Any order is a valid reading of the reference line; this one is
+    what the kernels are held to, bit for bit."""
+    u64, v64 = np.asarray(umat, dtype=np.float64), np.asarray(temat, dtype=np.float64)
+    k = u64.shape[1]
+    kh = (k + 1) // 2
+    acc = np.zeros((u64.shape[0], v64.shape[0]), dtype=F32)
+    for j in range(kh):
+        acc = (np.outer(u64[:, j], v64[:, j]) + acc).astype(F32)
+        if kh + j < k:
+            acc = (np.outer(u64[:, kh + j], v64[:, kh + j]) + acc).astype(F32)
+    if tebias is not None:
+        acc = (acc + np.asarray(tebias, dtype=F32).reshape(1, -1)).astype(F32)
+    return acc + F32(0.0)
+
+
 def filtered_topk(scores_row, rated_cols, total, canonical=True):
     """evaluate.py:96-105 ranking part for one user: walk the ascending argsort from the
     end, skip rated columns, stop after ``total`` kept.  ``canonical=True`` uses the

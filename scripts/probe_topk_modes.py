@@ -1,11 +1,12 @@
 """K4 under its three score arithmetics at the two benchmark shapes: time per pass, agreement of 'refine' with 'fp32'.
-python scripts/probe_topk_modes.py [ml10m|netflix|both]"""
+python scripts/probe_topk_modes.py [ml10m|netflix|both] [mode,mode,...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'top-k-rec_amd')]
 import numpy as np, torch
 import tkr_hip
 which = sys.argv[1] if len(sys.argv) > 1 else 'both'
+modes = sys.argv[2].split(',') if len(sys.argv) > 2 else ['bf16x3', 'fp32', 'refine']
 dev = torch.device('cuda', 0)
 shapes = [('ml10m', 69878, 10380, 130), ('netflix', 480189, 17770, 150)]
 for name, n_users, n_items, deg in shapes:
@@ -19,7 +20,7 @@ for name, n_users, n_items, deg in shapes:
     cols = torch.randint(0, n_items, (n_users * deg,), device=dev, generator=g, dtype=torch.int32)
     mask, pitch = tkr_hip.build_rated_mask(ptr, cols, n_users, n_items)
     out = {}
-    for mode in ('bf16x3', 'fp32', 'refine'):
+    for mode in modes:
         tkr_hip.set_topk_math(mode)
         out[mode] = tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch, want_scores=True)
         torch.cuda.synchronize()
@@ -30,6 +31,8 @@ for name, n_users, n_items, deg in shapes:
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 3
         print('%-8s %-7s %7.2f ms per pass = %5.1f M users/s' % (name, mode, ms, n_users / ms / 1e3), flush=True)
+    if len(modes) < 3:
+        continue
     same_ids = torch.equal(out['refine'][0], out['fp32'][0])
     same_sc = torch.equal(out['refine'][1].view(torch.int32), out['fp32'][1].view(torch.int32))
     print('%-8s refine == fp32: ids %s, score bits %s;  bf16x3 ids equal fp32 in %.2f %% of rows' %

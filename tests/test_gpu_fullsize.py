@@ -211,11 +211,15 @@ def test_topk_full_netflix_shape_properties():
     decided = ((top_s[:, :-1] - top_s[:, 1:]) > 1e-6 * top_s[:, :-1].abs()).all(1)      # rows without a near-tie inside or at the cut
     assert int(decided.sum()) > len(sample) // 2
     assert torch.equal(got[decided], top_i[decided, :K])
-    # and the fp32-MFMA arithmetic agrees on those rows too (the two modes differ only in summation order)
-    tkr_hip.set_topk_math('fp32')
+    # the default arithmetic (bound-and-refine) IS the fp32-MFMA arithmetic: all 480,189 x 30 ids and score bits
+    # agree; the bf16-split arithmetic differs only in summation order (same rows wherever the cut is decided)
     try:
-        ids_f = tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch)
-    finally:
+        tkr_hip.set_topk_math('fp32')
+        ids_f, sc_f = tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch, want_scores=True)
         tkr_hip.set_topk_math('bf16x3')
-    assert torch.equal(ids_f[sample][decided], got[decided])
-    assert float((ids_f == ids).all(1).float().mean()) > 0.97
+        ids_b = tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch)
+    finally:
+        tkr_hip.set_topk_math(tkr_hip.TOPK_MATH_DEFAULT)
+    assert torch.equal(ids_f, ids) and torch.equal(sc_f.view(torch.int32), scores.view(torch.int32))
+    assert torch.equal(ids_b[sample][decided], got[decided])
+    assert float((ids_b == ids).all(1).float().mean()) > 0.97

@@ -5,8 +5,9 @@ Index work: bit-exact.  Ranked id lists are compared
   * exactly against the oracle on exact-arithmetic inputs (every partial sum representable ->
     summation order cannot matter) including deliberate score ties (canonical tie rule),
   * on generic fp32 inputs wherever the oracle's adjacent score gap exceeds 1e-6 relative.
-Every test runs under both score arithmetics (bf16-split products on the dense matrix pipe = default, and fp32 MFMA);
-test_score_error_against_fp64 states the floating-point tolerance of each."""
+Every test runs under the three score arithmetics (bound-and-refine = default, bf16-split products on the dense matrix pipe,
+fp32 MFMA); test_score_error_against_fp64 states the floating-point tolerance of each, test_refine_is_the_fp32_arithmetic
+that the first reproduces the third bit for bit and that both are the fma chain the oracle restates."""
 import json
 import os
 
@@ -21,13 +22,13 @@ from oracle import ref_np as R
 
 @pytest.fixture(scope='module', params=['bf16x3', 'fp32', 'refine'])
 def hip(request):
-    """every test runs under both score arithmetics of K4 (include/tkr.h, tkr_topk_set_math)"""
+    """every test runs under all score arithmetics of K4 (include/tkr.h, tkr_topk_set_math)"""
     import tkr_hip
     assert torch.cuda.is_available()
     tkr_hip.lib()
     tkr_hip.set_topk_math(request.param)
     yield tkr_hip
-    tkr_hip.set_topk_math('bf16x3')
+    tkr_hip.set_topk_math(tkr_hip.TOPK_MATH_DEFAULT)
 
 
 def _dev(a):
@@ -122,6 +123,47 @@ def test_generic_fp32_lists_match_outside_near_ties(hip):
             assert np.all(ids[r][gap_ok] == np.array(ref)[gap_ok]), 'row %d' % r
         same += int(ids[r].tolist() == ref)
     assert same > 0.95 * n_rows
+
+
+@pytest.mark.parametrize('n_rows,n_cols,k,bias,wide', [(300, 2000, 128, True, False), (1000, 700, 64, False, False),
+                                                       (513, 1500, 100, True, False), (200, 900, 50, True, True),
+                                                       (3000, 5000, 128, True, False), (64, 70000, 32, False, False)])
+def test_refine_is_the_fp32_arithmetic(n_rows, n_cols, k, bias, wide):
+    """Bound-and-refine (the default) returns the ids AND the score bits of the fp32-MFMA arithmetic on generic inputs -- the fp16
+    pass only proposes, the fp32 fma chain decides -- and both are the chain oracle/ref_np.mfma_chain_scores restates.  'wide':
+    factors over nine decades (the power-of-two scaling of the fp16 pass and its margin must hold there too)."""
+    import tkr_hip
+    rng = np.random.Generator(np.random.PCG64(n_rows + 3 * n_cols + k))
+    U = (rng.standard_normal((n_rows, k)) * 0.01).astype(np.float32)
+    V = (rng.standard_normal((n_cols, k)) * 0.01).astype(np.float32)
+    if wide:
+        U *= (10.0 ** rng.uniform(-4, 5, (n_rows, 1))).astype(np.float32)
+        V *= (10.0 ** rng.uniform(-5, 4, (n_cols, k))).astype(np.float32)
+    b = (rng.standard_normal(n_cols) * 0.002).astype(np.float32) if bias else None
+    K = 30
+    rated = [rng.choice(n_cols, 40, replace=False).tolist() for _ in range(n_rows)]
+    out = {}
+    try:
+        for mode in ('refine', 'fp32'):
+            tkr_hip.set_topk_math(mode)
+            ids, sc = _gpu_lists(tkr_hip, U, V, b, rated, K, want_scores=True)
+            out[mode] = (ids.cpu().numpy(), sc.cpu().numpy())
+    finally:
+        tkr_hip.set_topk_math(tkr_hip.TOPK_MATH_DEFAULT)
+    np.testing.assert_array_equal(out['refine'][0], out['fp32'][0])
+    np.testing.assert_array_equal(out['refine'][1].view(np.int32), out['fp32'][1].view(np.int32))
+    if n_rows * n_cols <= 2_000_000:                          # the oracle's chain, on every returned score
+        chain = R.mfma_chain_scores(U, V, b)
+        ids, sc = out['fp32']
+        exp = np.take_along_axis(chain, ids.astype(np.int64), axis=1)
+        same = exp.view(np.int32) == sc.view(np.int32)
+        assert same.mean() > 1 - 1e-4                         # float64 double rounding in the oracle, see its docstring
+        np.testing.assert_allclose(sc, exp, rtol=3e-7, atol=0)
+        # ... and the lists are the oracle's ranking of the chain scores wherever it is free of exact ties at the cut
+        for r in range(0, n_rows, 7):
+            ref = R.filtered_topk(chain[r], set(rated[r]), K, canonical=True)
+            if same[r].all():
+                assert ids[r].tolist() == ref, 'row %d' % r
 
 
 def test_item_range_split_is_invisible(hip):

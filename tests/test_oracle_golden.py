@@ -144,3 +144,22 @@ def test_g9_utils_evaluate(golden_dir):
                                                  run['total'] // run['step'], canonical=canonical)
             assert hits == run['hits'] and count == run['count']
             assert trrs == run['trrs']                               # same additions in the same order
+
+
+def test_mfma_chain_scores_is_an_fp32_dot_product():
+    """oracle/ref_np.mfma_chain_scores (the summation order the K4 kernels are held to): exact where every partial sum is
+    representable, within the fp32 dot-product error bound of float64 otherwise, bias added last, -0.0 canonicalised"""
+    rng = np.random.Generator(np.random.PCG64(17))
+    for k in (1, 7, 50, 128):
+        U = rng.integers(-8, 9, (6, k)).astype(np.float32) / 8
+        V = rng.integers(-8, 9, (9, k)).astype(np.float32) / 8
+        b = rng.integers(-8, 9, 9).astype(np.float32) / 8
+        np.testing.assert_array_equal(R.mfma_chain_scores(U, V, b), U @ V.T + b)
+        U = (rng.standard_normal((6, k)) * 0.01).astype(np.float32)
+        V = (rng.standard_normal((9, k)) * 0.01).astype(np.float32)
+        got = R.mfma_chain_scores(U, V, None)
+        s64 = U.astype(np.float64) @ V.astype(np.float64).T
+        bound = k * 2.0 ** -24 * (np.abs(U).astype(np.float64) @ np.abs(V).astype(np.float64).T)
+        assert got.dtype == np.float32 and np.all(np.abs(got - s64) <= bound + 1e-45)
+    z = R.mfma_chain_scores(np.zeros((1, 4), np.float32), -np.ones((1, 4), np.float32), None)
+    assert not np.signbit(z).any()

@@ -30,6 +30,10 @@
 #include "tkr_common.h"
 #include "../../include/tkr.h"
 
+#ifndef TKR_ABL
+#define TKR_ABL 0      // timing experiments only (scripts/ablate_topk.sh): 1 no filter, 2 no staging, 4 no per-tile barrier, 8 no on-demand trims, 16 no scheduled trims, 32 no appends
+#endif
+
 namespace tkr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -283,6 +287,9 @@ __device__ __forceinline__ void filter_tile(const TopkSmem<IdT>& sm, const f32x1
 #pragma unroll
     for (int r = 0; r < 16; ++r) { hr[r] = __ballot(sc[r] >= thr); any |= hr[r]; }
     if (!any) return;
+#if TKR_ABL & 32
+    if (any != 12345u) return;
+#endif
     uint32_t hits = 0;                                           // bit r: register r of this lane is a candidate
 #pragma unroll
     for (int r = 0; r < 16; ++r) hits |= (sc[r] >= thr) ? (1u << r) : 0u;
@@ -309,6 +316,9 @@ __device__ __forceinline__ void filter_tile(const TopkSmem<IdT>& sm, const f32x1
     // rare: some user's list overflowed.  Exact trim of that user (keeps K, raises the threshold), then its
     // lanes append what still qualifies: at most 32 per user and tile, K + 32 <= kCap.
     uint64_t ov = __ballot(unplaced != 0);
+#if TKR_ABL & 8
+    ov = 0;
+#endif
     while (ov) {
         const int u = (__ffsll((long long)ov) - 1) & 31;
         float nt;
@@ -869,12 +879,18 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
         // A operand: lane (item ul, k-group h) reads elements 16s + 8h .. +7 of each part; small terms first.
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const unsigned char* arow = tile + buf * 32 * ROWB + ul * ROWB + h * 16;
+        if constexpr (REFINE) {                                   // one MFMA per fragment: all the LDS reads go out first
+            f16x8 afrag[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) afrag[s] = *reinterpret_cast<const f16x8*>(arow + s * 32);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[s], hreg[s], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);   // the scheduler otherwise reloads one fragment register before every MFMA
+            __builtin_amdgcn_sched_group_barrier(0x008, KS, 0);
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            if constexpr (REFINE) {
-                const f16x8 a = *reinterpret_cast<const f16x8*>(arow + s * 32);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, hreg[s], acc, 0, 0, 0);
-            } else {
+            if constexpr (!REFINE) {
                 const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(arow + s * 32);
                 const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(arow + (NPART - 1) / 2 * PARTB + s * 32);
                 const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(arow + (NPART - 1) * PARTB + s * 32);
@@ -898,12 +914,14 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
             if constexpr (REFINE) add_scaled_bias_inplace(acc, sm.tbias + buf * 32, h, bscale);
             else add_bias_inplace(acc, sm.tbias + buf * 32, h);
         }
+#if !(TKR_ABL & 2)
         if (t + 1 < n_tiles) stage_store(t + 1, buf ^ 1);
         if (t + 2 < n_tiles) stage_load(t + 2);
+#endif
         if constexpr (kEarlyBarrier) __syncthreads();
         if (!user_ok) maskw = 0xffffffffu;
         if (t == n_tiles_all - 1) maskw |= tail_mask;
-        if (t == next_sched) {
+        if (t == next_sched && !(TKR_ABL & 16)) {
             if (__ballot(sm.cnt[uw] > kCap / 2) != 0) {            // lists still short (thresholds shared by earlier ranges): nothing to gain
                 if constexpr (REFINE) {
                     thr = trim_all_users<IdT, true>(sm, uw, h, K, thr, m2);
@@ -915,8 +933,14 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
             }
             next_sched = t + ((t - t_begin + 1) >> 1);
         }
+#if !(TKR_ABL & 1)
         filter_tile<IdT, kEarlyBarrier, REFINE>(sm, acc, sm.tbias + buf * 32, maskw, t, K, thr, m2, &lost, bscale);
+#else
+        if (acc[0] + acc[5] + acc[10] + acc[15] == 12345.678f) sm.cnt[uw] = 1;     // keeps the chain alive
+#endif
+#if !(TKR_ABL & 4)
         if constexpr (!kEarlyBarrier) __syncthreads();
+#endif
     }
     if constexpr (REFINE) {
         if (__ballot(lost) != 0 && lane == 0) extra[4 + ws.block] = 1u;       // the exact kernel redoes this block
@@ -1270,13 +1294,14 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
     return merge_planned(p, users, n_rows, K, out_ids, out_scores, stream);
 }
 
-// arithmetic of the score block: 0 = bf16-split products on the dense matrix pipe (k <= 128), 1 = fp32 MFMA for every k.
-// Initial value from TKR_TOPK_MATH=fp32|bf16x3; tkr_topk_set_math changes it for the process.
+// arithmetic of the score block: 2 = bound-and-refine (default; k <= 128 and a workspace, else it runs as 1), 0 = bf16-split
+// products on the dense matrix pipe (k <= 128), 1 = fp32 MFMA for every k.
+// Initial value from TKR_TOPK_MATH=refine|bf16x3|fp32; tkr_topk_set_math changes it for the process.
 static int g_topk_math = -1;
 static int topk_math() {
     if (g_topk_math < 0) {
         const char* e = getenv("TKR_TOPK_MATH");
-        g_topk_math = (e && strcmp(e, "fp32") == 0) ? 1 : (e && strcmp(e, "refine") == 0) ? 2 : 0;
+        g_topk_math = (e && strcmp(e, "fp32") == 0) ? 1 : (e && strcmp(e, "bf16x3") == 0) ? 0 : 2;
     }
     return g_topk_math;
 }

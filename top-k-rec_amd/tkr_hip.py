@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libtkr_hip.so')
+LIB_PATH = os.environ.get('TKR_HIP_LIB') or os.path.join(_HERE, 'libtkr_hip.so')      # the override is for A/B builds of the kernels (scripts/)
 
 _lib = None
 VERSION = 106          # TKR_VERSION of include/tkr.h this binding was written against
@@ -252,10 +252,13 @@ def _score_topk_once(U, Vt, K, bias, user_idx, mask, mask_pitch, want_scores, sp
     return ids, scores
 
 
+TOPK_MATH_DEFAULT = 'refine'
+
+
 def set_topk_math(mode):
-    """'bf16x3' (split products on the dense matrix pipe, k <= 128), 'fp32' (fp32 MFMA) or 'refine' (one bf16 pass with a
-    rigorous error bound picks the candidates, the fp32 arithmetic of 'fp32' ranks them: same lists and scores as 'fp32',
-    k <= 128) -- see include/tkr.h"""
+    """'refine' (default: one scaled fp16 pass with a rigorous error bound picks the candidates, the arithmetic of 'fp32' ranks
+    them -- same lists and score bits as 'fp32'; k <= 128), 'bf16x3' (split products on the dense matrix pipe, k <= 128) or
+    'fp32' (fp32 MFMA) -- see include/tkr.h"""
     _check(lib().tkr_topk_set_math(C.c_int32({'bf16x3': 0, 'fp32': 1, 'refine': 2}[mode])), 'tkr_topk_set_math')
 
 
