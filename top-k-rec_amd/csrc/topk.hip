@@ -31,7 +31,7 @@
 #include "../../include/tkr.h"
 
 #ifndef TKR_ABL
-#define TKR_ABL 0      // timing experiments only (scripts/ablate_topk.sh): 1 no filter, 2 no staging, 4 no per-tile barrier, 8 no on-demand trims, 16 no scheduled trims, 32 no appends
+#define TKR_ABL 0      // timing experiments only (scripts/ablate_topk.sh): 1 no filter, 2 no staging, 4 no per-tile barrier, 8 no on-demand trims, 16 no scheduled trims, 32 no appends, 64 no final stage of the refine kernel
 #endif
 
 namespace tkr {
@@ -428,7 +428,7 @@ __device__ __forceinline__ float exact_score(const float* __restrict__ up, const
     const int KH = (k + 1) >> 1;
     float acc = 0.f;
     if ((k & 7) == 0) {                                         // both halves 16-byte aligned
-#pragma unroll 2
+#pragma unroll 8                                                // 32 loads in flight: two memory round trips per 128 factors
         for (int kk = 0; kk < KH; kk += 4) {
             const float4 a0 = *reinterpret_cast<const float4*>(vp + kk), a1 = *reinterpret_cast<const float4*>(vp + KH + kk);
             const float4 b0 = *reinterpret_cast<const float4*>(up + kk), b1 = *reinterpret_cast<const float4*>(up + KH + kk);
@@ -448,51 +448,47 @@ __device__ __forceinline__ float exact_score(const float* __restrict__ up, const
 }
 
 // Final stage of the bound-and-refine kernel: every list holds a superset of its user's best K (by exact score) among the
-// tiles of this workgroup; the candidates are scored exactly, one per lane, and sorted on (exact score, column).
+// tiles of this workgroup.  Phase 1 scores the candidates exactly, one per lane, over the FLAT sequence of the wave's 32
+// lists (a rescoring is four dependent memory round trips of 16 loads -- ~5 us whether 34 lanes work or 64; per list that
+// was 32 passes per wave, flat it is ~17) and writes the exact score over the approximate one; phase 2 is the final
+// stage of the exact kernels (lower-bound trim to K..32 entries, two users per sort).  `offs`: 33 ints of LDS of this wave.
 template <typename IdT>
 __device__ __forceinline__ void write_rows_refine(const TopkSmem<IdT>& sm, const TopkSlot& ws, int n_rows, int K, float thr, float m2,
                                                   const float* __restrict__ U, const int32_t* __restrict__ uidx,
                                                   const float* __restrict__ Vt, const float* __restrict__ bias, int k,
                                                   int32_t* __restrict__ out_ids, float* __restrict__ out_scores,
-                                                  uint64_t* __restrict__ part) {
+                                                  uint64_t* __restrict__ part, int* offs) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int me = lane & 31, half = lane >> 5;
     if (__ballot(sm.cnt[wave * 32 + me] > 32) != 0) {
         (void)trim_all_users<IdT, true>(sm, wave * 32 + me, half, K, thr, m2);
         __builtin_amdgcn_wave_barrier();
     }
-    for (int j = 0; j < 16; ++j) {
-        const int u0 = wave * 32 + 2 * j, r0 = ws.block * sm.users + u0;
-        if (r0 >= n_rows) break;                                 // wave-uniform
-        const int n0 = min(sm.cnt[u0], kCap);
-        const int n1 = (r0 + 1 < n_rows) ? min(sm.cnt[u0 + 1], kCap) : 0;
-        if (n0 <= 32 && n1 <= 32) {                              // two users at once, one per half of the wave
-            const int uu = u0 + half, nn = half ? n1 : n0, r = r0 + half;
-            uint64_t key = 0;
-            if (me < nn) {
-                const int col = (int)sm.ci[me * sm.users + uu];
-                const float sx = exact_score(U + (size_t)(uidx ? uidx[r] : r) * k, Vt + (size_t)col * k, k, bias, col);
-                key = ((uint64_t)ordered_bits(sx) << 32) | ((uint32_t)col + 1u);
-            }
-            key = wave_sort_halves(key, lane);
-            const int p = half ? 31 - me : me;                   // the upper half comes out ascending
-            if (r < n_rows && p < K) emit_row<IdT>(ws, r, p, p < nn, key, K, out_ids, out_scores, part);
-            continue;
-        }
-        for (int q = 0; q < 2; ++q) {
-            const int r = r0 + q;
-            if (r >= n_rows) break;
-            const int n = q ? n1 : n0;
-            uint64_t key = 0;
-            if (lane < n) {
-                const int col = (int)sm.ci[lane * sm.users + u0 + q];
-                const float sx = exact_score(U + (size_t)(uidx ? uidx[r] : r) * k, Vt + (size_t)col * k, k, bias, col);
-                key = ((uint64_t)ordered_bits(sx) << 32) | ((uint32_t)col + 1u);
-            }
-            key = wave_sort_desc(key, lane);
-            if (lane < K) emit_row<IdT>(ws, r, lane, lane < n, key, K, out_ids, out_scores, part);
+    const int n = lane < 32 ? min(sm.cnt[wave * 32 + lane], kCap) : 0;
+    if (lane < 32) sm.cnt[wave * 32 + lane] = n;                 // a reservation past the capacity wrote nothing
+    int incl = n;                                                // inclusive scan over the 32 lists
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const int total = __shfl(incl, 31, 64);
+    if (lane < 32) offs[lane] = incl - n;
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < total; base += 64) {               // wave-uniform
+        const int f = base + lane;
+        int u = 0;                                               // the last list that starts at or before f (empty lists share a start)
+#pragma unroll
+        for (int step = 16; step > 0; step >>= 1)
+            if (offs[u + step] <= f) u += step;
+        if (f < total) {
+            const int e = f - offs[u], uq = wave * 32 + u, r = ws.block * sm.users + uq;
+            const int col = (int)sm.ci[e * sm.users + uq];
+            sm.cs[e * sm.users + uq] = exact_score(U + (size_t)(uidx ? uidx[r] : r) * k, Vt + (size_t)col * k, k, bias, col);
         }
     }
+    __builtin_amdgcn_wave_barrier();
+    write_rows<IdT>(sm, ws, n_rows, K, -INFINITY, out_ids, out_scores, part);
 }
 
 // waves per workgroup of an instantiation: 8 (two per SIMD: one wave's filter overlaps the other's MFMA
@@ -944,7 +940,10 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
     }
     if constexpr (REFINE) {
         if (__ballot(lost) != 0 && lane == 0) extra[4 + ws.block] = 1u;       // the exact kernel redoes this block
-        write_rows_refine<IdT>(sm, ws, n_rows, K, thr, m2, U, uidx, Vt, bias, k, out_ids, out_scores, part);
+#if !(TKR_ABL & 64)
+        write_rows_refine<IdT>(sm, ws, n_rows, K, thr, m2, U, uidx, Vt, bias, k, out_ids, out_scores, part,
+                               reinterpret_cast<int*>(tile) + wave * 64);      // the tile buffers are free now
+#endif
     } else {
         write_rows<IdT>(sm, ws, n_rows, K, thr, out_ids, out_scores, part);
     }
