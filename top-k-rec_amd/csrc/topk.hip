@@ -31,7 +31,21 @@
 #include "../../include/tkr.h"
 
 #ifndef TKR_ABL
-#define TKR_ABL 0      // timing experiments only (scripts/ablate_topk.sh): 1 no filter, 2 no staging, 4 no per-tile barrier, 8 no on-demand trims, 16 no scheduled trims, 32 no appends, 64 no final stage of the refine kernel
+#define TKR_ABL 0      // timing experiments only (scripts/ablate_topk.sh): 1 no filter, 2 no staging, 4 no per-tile barrier, 8 no on-demand trims, 16 no scheduled trims, 32 no appends, 64 no final stage of the refine kernel, 256 per-phase cycle counters (tkr_k4_prof_read)
+#endif
+
+#if TKR_ABL & 256
+// cycle sums per phase of the bf16 / refine tile loop, all waves: [0] MFMA chain + bias, [1] staging, [2] barrier, [3] scheduled
+// trims, [4] filter, [5] prologue (operands, first tile), [6] final stage, [7] wave-tiles.  scripts/probe_topk_phases.py reads them.
+__device__ unsigned long long g_k4_prof[8];
+#define K4_MARK(i)                                                           \
+    {                                                                        \
+        const unsigned long long n_ = __builtin_amdgcn_s_memtime();          \
+        k4p[i] += n_ - k4t;                                                  \
+        k4t = n_;                                                            \
+    }
+#else
+#define K4_MARK(i)
 #endif
 
 namespace tkr {
@@ -688,6 +702,9 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
     uint32_t* __restrict__ thr_shared, const int4* __restrict__ items /*(block, t_begin, t_end, slot | stride << 16) or null*/,
     uint32_t* __restrict__ extra) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+#if TKR_ABL & 256
+    const unsigned long long k4_start = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int NPART = REFINE ? 1 : 3;
     constexpr int PARTB = KS * 32;                               // bytes of one bf16 part of an item row (KS*16 elements)
     constexpr int ROWB = NPART * PARTB + 16;                     // padded row: conflict-free ds_read_b128 (ROWB/4 = 4 mod 8)
@@ -868,6 +885,10 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
 
     const uint32_t tail_mask = (n_cols & 31) ? (0xffffffffu << (n_cols & 31)) : 0u;
     int next_sched = t_begin + 2;
+#if TKR_ABL & 256
+    unsigned long long k4p[8] = {0, 0, 0, 0, 0, 0, 0, 0}, k4t = k4_start;
+    K4_MARK(5)
+#endif
     for (int t = t_begin; t < n_tiles; ++t) {
         const int buf = t & 1;
         uint32_t maskw = (mask && user_ok) ? mask[(size_t)t * mask_pitch + row] : 0u;
@@ -905,16 +926,22 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
         // k = 128: measured slower that way (14.4 -> 17.7 ms) -- the MFMA chains dominate there and the two waves of a SIMD
         // interleave them best when they start together (a lone dependent chain issues at ~44 instead of 32 cycles per
         // MFMA); there the barrier stays behind the filter.
-        constexpr bool kEarlyBarrier = KS <= 4;
+        constexpr bool kEarlyBarrier = REFINE || KS <= 4;    // refine: the chain is 8 MFMAs at every width, the filter dominates
         if constexpr (kEarlyBarrier) {
             if constexpr (REFINE) add_scaled_bias_inplace(acc, sm.tbias + buf * 32, h, bscale);
             else add_bias_inplace(acc, sm.tbias + buf * 32, h);
         }
+#if TKR_ABL & 256
+        asm volatile("" : "+v"(acc));
+        K4_MARK(0)
+#endif
 #if !(TKR_ABL & 2)
         if (t + 1 < n_tiles) stage_store(t + 1, buf ^ 1);
         if (t + 2 < n_tiles) stage_load(t + 2);
 #endif
+        K4_MARK(1)
         if constexpr (kEarlyBarrier) __syncthreads();
+        K4_MARK(2)
         if (!user_ok) maskw = 0xffffffffu;
         if (t == n_tiles_all - 1) maskw |= tail_mask;
         if (t == next_sched && !(TKR_ABL & 16)) {
@@ -929,6 +956,7 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
             }
             next_sched = t + ((t - t_begin + 1) >> 1);
         }
+        K4_MARK(3)
 #if !(TKR_ABL & 1)
         filter_tile<IdT, kEarlyBarrier, REFINE>(sm, acc, sm.tbias + buf * 32, maskw, t, K, thr, m2, &lost, bscale);
 #else
@@ -936,6 +964,11 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
 #endif
 #if !(TKR_ABL & 4)
         if constexpr (!kEarlyBarrier) __syncthreads();
+#endif
+#if TKR_ABL & 256
+        asm volatile("" : "+v"(thr));
+        K4_MARK(4)
+        k4p[7] += 1;
 #endif
     }
     if constexpr (REFINE) {
@@ -947,6 +980,11 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
     } else {
         write_rows<IdT>(sm, ws, n_rows, K, thr, out_ids, out_scores, part);
     }
+#if TKR_ABL & 256
+    K4_MARK(6)
+    if (lane == 0)
+        for (int q = 0; q < 8; ++q) atomicAdd(&g_k4_prof[q], k4p[q]);
+#endif
 }
 
 // max_i |v_i| (2-norm, rounded up) and max_i |bias_i| for the margin of the bound-and-refine kernel; bounds[] zeroed before
@@ -1361,6 +1399,15 @@ extern "C" int tkr_build_rated_mask(const int64_t* rated_ptr, const int32_t* rat
     TKR_LAUNCH_CHECK();
     return TKR_OK;
 }
+
+#if TKR_ABL & 256
+extern "C" int tkr_k4_prof_read(unsigned long long* out8) {      // timing builds only: read and reset the phase counters
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_k4_prof), sizeof(zero));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_k4_prof), zero, sizeof(zero));
+    return (int)e;
+}
+#endif
 
 extern "C" int tkr_topk_set_math(int32_t mode) {
     if (mode < 0 || mode > 2) return TKR_EINVAL;
