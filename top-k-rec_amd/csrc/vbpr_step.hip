@@ -743,17 +743,31 @@ __global__ __launch_bounds__(256) void vbpr_sdense_kernel(tkr_vbpr_state st, con
         const int slot_l = hit ? x.slots[item] : 0;
         uint64_t m = __ballot(hit);
         while (m) {                                     // ascending lane = ascending item: a fixed summation order
-            const int l = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int slot = __builtin_amdgcn_readlane(slot_l, l);
-            const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val), l));
-            const float* arow = Aw + (size_t)slot * kh;
+            // four hits per round: their A rows are gathered together (one memory round trip per round, not per hit -- a column
+            // has ~4 hits at batch 256); a round with fewer hits repeats the first slot with value 0
+            int slot[4];
+            float v[4];
 #pragma unroll
-            for (int hh = 0; hh < NH; ++hh) {
-                const int n2 = lane + hh * 64;
-                if (n2 < kh) g[hh] = fmaf(v, arow[n2], g[hh]);
+            for (int u = 0; u < 4; ++u) {
+                const int l = m ? __ffsll((long long)m) - 1 : 0;
+                const bool have = m != 0;
+                m &= m - 1;
+                slot[u] = have ? __builtin_amdgcn_readlane(slot_l, l) : slot[0];
+                v[u] = have ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(val), l)) : 0.f;
             }
-            gi = fmaf(v, ab[slot], gi);
+            float arow[4][NH], av[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int hh = 0; hh < NH; ++hh) arow[u][hh] = Aw[(size_t)slot[u] * kh + min(lane + hh * 64, kh - 1)];
+                av[u] = ab[slot[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int hh = 0; hh < NH; ++hh) g[hh] = fmaf(v[u], arow[u][hh], g[hh]);
+                gi = fmaf(v[u], av[u], gi);
+            }
         }
     }
     const bool l2 = st.mode == 0;
