@@ -149,8 +149,8 @@ def timed_run(eng, csr, B, steps, warmup, sync_every, world, names=None):
                 isync.end()
             done += m
 
+    eng.reserve_events(-(-steps // sync_every) + _chunk_crossings(steps, B))      # created now, not between the timed launches
     run(warmup)
-    eng.reserve_events(-(-steps // sync_every) + _chunk_crossings(steps, B))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -5,7 +5,7 @@ import pandas as pd
 src, tag = sys.argv[1], sys.argv[2]
 KERN = ('bpr_flow_kernel', 'bpr_step_kernel', 'sample_plan_kernel', 'resolve_flow_kernel', 'resolve_kernel', 'commit_kernel', 'rollback_kernel',
         'big_draw_kernel', 'big_flag_kernel', 'big_emit_kernel', 'big_count_kernel', 'big_fill_kernel', 'big_parity_kernel', 'big_record_kernel',
-        'DeviceRadixSort', 'radix_sort', 'DeviceScan', 'scan', 'vbpr_pair_kernel', 'score_topk_bf16_kernel', 'score_topk_kernel', 'merge_topk_kernel',
+        'DeviceRadixSort', 'radix_sort', 'DeviceScan', 'scan', 'vbpr_pair_kernel', 'score_topk_bf16_kernel', 'score_topk_kernel', 'merge_topk_kernel', 'topk_bounds_kernel',
         'raw_rank_kernel', 'count_hits_rr_kernel',
         'build_mask_kernel', 'vbpr_sproject_kernel', 'vbpr_sdense_kernel', 'vbpr_project_kernel', 'vbpr_reduce_kernel', 'vbpr_occur_kernel', 'vbpr_rows_kernel', 'vbpr_dense_kernel',
         'calib_rowcopy_kernel')
@@ -14,6 +14,10 @@ def short(n):
         if k in n:
             if k == 'bpr_step_kernel' and re.search(r'bpr_step_kernel<\d+, (?:true|false), \d+, true>', n):
                 return 'tkr::bpr_step_kernel<SGD>'
+            if k == 'score_topk_bf16_kernel':           # <KS, IdT, REFINE>: the bound-and-refine arithmetic is its own line
+                return 'tkr::score_topk_bf16_kernel<refine>' if re.search(r'score_topk_bf16_kernel<\d+, [a-z ]+, true>', n) else 'tkr::score_topk_bf16_kernel<bf16x3>'
+            if k == 'score_topk_kernel':
+                return 'tkr::score_topk_kernel (fp32 MFMA; ~5-8 us calls: the no-op fallback pass behind a refine launch)'
             return 'tkr::' + k
     return None
 import glob

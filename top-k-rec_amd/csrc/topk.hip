@@ -992,20 +992,48 @@ __global__ __launch_bounds__(256) void topk_bounds_kernel(const float* __restric
                                                          int k, uint32_t* __restrict__ bounds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float vmax = 0.f, bmax = 0.f, emax = 0.f;
-    for (int col = blockIdx.x * 4 + wave; col < n_cols; col += gridDim.x * 4) {
-        float ss = 0.f;
-        for (int e = lane; e < k; e += 64) { const float v = Vt[(size_t)col * k + e]; ss = fmaf(v, v, ss); emax = fmaxf(emax, fabsf(v)); }
+    if ((k & 3) == 0 && k <= 128) {                              // a column per half-wave, one float4 per lane, four columns in flight
+        const int half = lane >> 5, l = lane & 31;
+        const int stride = gridDim.x * 8;
+        for (int c0 = (blockIdx.x * 4 + wave) * 2 + half; c0 < n_cols; c0 += 4 * stride) {
+            float4 v[4];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        vmax = fmaxf(vmax, sqrtf(ss) * 1.001f);
-        if (bias) bmax = fmaxf(bmax, fabsf(bias[col]));
+            for (int u = 0; u < 4; ++u) {
+                const int col = c0 + u * stride;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (col < n_cols && 4 * l < k) v[u] = *reinterpret_cast<const float4*>(Vt + (size_t)col * k + 4 * l);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int col = c0 + u * stride;
+                float ss = fmaf(v[u].x, v[u].x, fmaf(v[u].y, v[u].y, fmaf(v[u].z, v[u].z, v[u].w * v[u].w)));
+                emax = fmaxf(emax, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                vmax = fmaxf(vmax, sqrtf(ss) * 1.001f);
+                if (bias && col < n_cols && l == 0) bmax = fmaxf(bmax, fabsf(bias[col]));
+            }
+        }
+        vmax = fmaxf(vmax, __shfl_xor(vmax, 32, 64));
+        bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+    } else {
+        for (int col = blockIdx.x * 4 + wave; col < n_cols; col += gridDim.x * 4) {
+            float ss = 0.f;
+            for (int e = lane; e < k; e += 64) { const float v = Vt[(size_t)col * k + e]; ss = fmaf(v, v, ss); emax = fmaxf(emax, fabsf(v)); }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            vmax = fmaxf(vmax, sqrtf(ss) * 1.001f);
+            if (bias) bmax = fmaxf(bmax, fabsf(bias[col]));
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) emax = fmaxf(emax, __shfl_xor(emax, o, 64));
-    if (lane == 0) {                                             // non-negative floats order like their bits
-        atomicMax(&bounds[0], __float_as_uint(vmax));
-        if (bias) atomicMax(&bounds[1], __float_as_uint(bmax));
-        atomicMax(&bounds[2], __float_as_uint(emax));
+    __shared__ float red[3][4];                                  // one atomic per workgroup and word: 3,072 atomics on one line took 18 us
+    if (lane == 0) { red[0][wave] = vmax; red[1][wave] = bmax; red[2][wave] = emax; }
+    __syncthreads();
+    if (threadIdx.x < 3) {                                       // non-negative floats order like their bits
+        const float m = fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]), fmaxf(red[threadIdx.x][2], red[threadIdx.x][3]));
+        if (m > 0.f) atomicMax(&bounds[threadIdx.x], __float_as_uint(m));
     }
 }
 
