@@ -171,6 +171,9 @@ struct Own {                              // a task's own row while it is proces
     float b, msb;
     uint32_t exp_even, exp_odd, rd;       // expect[0], expect[1] as carried by the version read; rd[(version + 1) & 1]
     bool ok;
+#ifdef TKR_FLOW_TRACE
+    unsigned long long t_valid, t_part;   // when the own row / the partner rows validated
+#endif
 };
 
 __device__ __forceinline__ bool spin_fail(uint32_t& spins, uint32_t* ctl, int nap = 4) {
@@ -235,6 +238,9 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
             if (!sgd) lane_own = lane_own && row_tagged<NP>(xm, own_ver);
             if (__all(lane_own)) {
                 o.ok = true;
+#ifdef TKR_FLOW_TRACE
+                o.t_valid = __builtin_amdgcn_s_memrealtime();
+#endif
                 row_values<NP>(xo, own);
                 if (!sgd) row_values<NP>(xm, ms);
                 o.b = bcast_f(__uint_as_float(xt.x), 0);
@@ -253,6 +259,9 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
             }
             if (__all(lane_part)) {
                 part_ok = true;
+#ifdef TKR_FLOW_TRACE
+                o.t_part = __builtin_amdgcn_s_memrealtime();
+#endif
                 // The partner rows are in registers: acknowledge the reads NOW (lane q: one add on rd[version & 1] of both
                 // partner rows of occurrence q), not after this task's own row has arrived too -- the next writers of those
                 // rows are waiting for exactly this.
@@ -264,7 +273,13 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
                 }
             }
         }
-        if (o.ok && part_ok) break;
+        if (o.ok && part_ok) {
+            // the acknowledge count once more, NOW: the copy of this pass was loaded before the row it came with was written, i.e.
+            // before the last readers of the version underneath acknowledged -- it cost a round trip behind the gradients on every
+            // chain link; this load returns while they are computed
+            o.rd = ld_u32(own_rd);
+            break;
+        }
         // How far away is what we wait for?  The buffer of version v holds v, v-2, v-4, ...: a tag of v-2 means the producer is
         // one or two updates away (poll), v-4 or older at least three -- two whole hand-offs, ~2 us each: sleep through that
         // (a waiting wave that polls costs everybody's loads latency, a sleeping one nothing)
@@ -427,6 +442,15 @@ __device__ __forceinline__ uint32_t grab_index(uint32_t ticket, int home, uint32
     return idx < total ? (uint32_t)idx : 0xffffffffu;
 }
 
+#ifdef TKR_FLOW_TRACE
+// timing builds only (scripts/probe_flow_timeline.py): per batch, the 100 MHz time stamps of the task of ITEM 0 --
+// [0] record in hand, [1] rows valid + gradients done, [2] readers acknowledged, [3] stores issued
+__device__ unsigned long long* g_flow_trace;
+#define TKR_TRACE(i) if (trace_buf && is_item && row == 0 && lane == 0) trace_buf[(size_t)batch * 8 + (i)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define TKR_TRACE(i)
+#endif
+
 template <int NP, bool PROF = false>
 __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_flow_state st, const int4* __restrict__ prec,
                                                        const int4* __restrict__ pocc, uint32_t total,
@@ -443,6 +467,9 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
     T.rdU = st.rdU; T.rdV = st.rdV;
     const bool sgd = st.opt == 1;
     const bool want_loss = loss_out != nullptr;
+#ifdef TKR_FLOW_TRACE
+    unsigned long long* const trace_buf = g_flow_trace;           // read once: a load per mark would drain the memory pipe before the stamp
+#endif
 
     // queue of this wave = (arrival number of its workgroup * 4 + wave) & 31: one atomic per workgroup (a word takes ~12 ns
     // per atomic: per wave that was 12 us of start-up), and still independent of block index, placement and residency
@@ -484,6 +511,7 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
         const bool is_item = rowk < 0;
         const int row = rowk & 0x7fffffff;
 
+        TKR_TRACE(0)
         const size_t n_rows = is_item ? st.n_items : st.n_users;
         const size_t roff = (size_t)(ver & 1u) * (is_item ? T.istride : T.ustride) + (size_t)row * T.kp;
         const size_t woff = (size_t)((ver + 1u) & 1u) * (is_item ? T.istride : T.ustride) + (size_t)row * T.kp;
@@ -495,7 +523,7 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
         float own[NE], ms[NE], g[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) { g[e] = 0.f; ms[e] = 0.f; }
-        Own o = {0.f, 0.f, 0u, 0u, 0u, false};
+        Own o = {};
         float gb = 0.f, loss_lane = 0.f, loss_x = 0.f;
 
         const u64* own_tail = tabT + ((size_t)(ver & 1u) * n_rows + row) * 4;
@@ -527,29 +555,17 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
 #undef TKR_FLOW_GROUP
         if (!alive) break;
         TKR_PROF_MARK(2)
+        TKR_TRACE(1)
+#ifdef TKR_FLOW_TRACE
+        if (trace_buf && is_item && row == 0 && lane == 0) { trace_buf[(size_t)batch * 8 + 4] = o.t_valid; trace_buf[(size_t)batch * 8 + 5] = o.t_part; trace_buf[(size_t)batch * 8 + 6] = spins; }
+#endif
 
         if (!is_item && want_loss) {
             const float tot = wave_sum(loss_lane) + loss_x;
             if (lane == 0) atomicAdd(loss_out + batch, tot);
         }
 
-        // version ver+1 lands on the buffer that held ver-1: wait until every reader of ver-1 has acknowledged
-        const uint32_t expect = (ver & 1u) ? o.exp_even : o.exp_odd;        // readers of version ver-1
-        uint32_t waited = 0;
-        while ((int32_t)(o.rd - expect) < 0) {
-            if (spin_fail(waited, ctl)) {
-                if (waited >= kSpinLimit && lane == 0 && atomicCAS(ctl + kCtlDebug, 0u, 2u) == 0u) {
-                    ctl[kCtlDebug + 1] = o.rd; ctl[kCtlDebug + 2] = expect; ctl[kCtlDebug + 3] = ver; ctl[kCtlDebug + 4] = (uint32_t)rowk;
-                }
-                alive = false;
-                break;
-            }
-            o.rd = ld_u32(own_rd);
-        }
-        spins += waited;
-        if (!alive) break;
-        TKR_PROF_MARK(3)
-
+        // the new row first (nothing in it depends on the acknowledgements): behind the wait only the stores are left
         const uint32_t nv = ver + 1u;
         float pn[NE], mn[NE];
 #pragma unroll
@@ -569,6 +585,25 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
             mbn = st.rho * o.msb + (1.f - st.rho) * gb * gb;
             bn = o.b - st.lr * gb * __builtin_amdgcn_rsqf(mbn + st.eps);
         }
+
+        // version ver+1 lands on the buffer that held ver-1: wait until every reader of ver-1 has acknowledged
+        const uint32_t expect = (ver & 1u) ? o.exp_even : o.exp_odd;        // readers of version ver-1
+        uint32_t waited = 0;
+        while ((int32_t)(o.rd - expect) < 0) {
+            if (spin_fail(waited, ctl)) {
+                if (waited >= kSpinLimit && lane == 0 && atomicCAS(ctl + kCtlDebug, 0u, 2u) == 0u) {
+                    ctl[kCtlDebug + 1] = o.rd; ctl[kCtlDebug + 2] = expect; ctl[kCtlDebug + 3] = ver; ctl[kCtlDebug + 4] = (uint32_t)rowk;
+                }
+                alive = false;
+                break;
+            }
+            o.rd = ld_u32(own_rd);
+        }
+        spins += waited;
+        if (!alive) break;
+        TKR_PROF_MARK(3)
+        TKR_TRACE(2)
+
         store_row<NP>(tabP + woff, lane, pn, nv);
         if (!sgd) store_row<NP>(tabM + woff, lane, mn, nv);
         if (lane < 2) {                             // tail = {bias, its slot | expect[0], expect[1]}
@@ -583,6 +618,7 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
             }
             __builtin_amdgcn_raw_buffer_store_b128(tv, row_rsrc(tabT + ((size_t)(nv & 1u) * n_rows + row) * 4, 32), lane * 16, 0, kAuxStore);
         }
+        TKR_TRACE(3)
         if constexpr (PROF) prof[5] += 1;
         TKR_PROF_MARK(4)
     }
@@ -608,6 +644,12 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
 }
 
 }  // namespace tkr
+
+#ifdef TKR_FLOW_TRACE
+extern "C" int tkr_flow_trace_buffer(unsigned long long* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(tkr::g_flow_trace), &p, sizeof(p));
+}
+#endif
 
 extern "C" int32_t tkr_flow_row_granules(int32_t k) { return (k + 127) / 128 * 128; }
 extern "C" int32_t tkr_flow_ctl_words(void) { return tkr::kCtlArrive + 64; }
