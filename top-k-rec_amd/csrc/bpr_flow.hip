@@ -443,7 +443,8 @@ __device__ __forceinline__ uint32_t grab_index(uint32_t ticket, int home, uint32
 }
 
 #ifdef TKR_FLOW_TRACE
-// timing builds only (scripts/probe_flow_timeline.py): per batch, the 100 MHz time stamps of the task of ITEM 0 --
+// timing builds only (scripts/probe_flow_timeline.py; a stamp that is stored at once waits ~0.2 us for s_memrealtime, so the segments
+// are upper bounds and a build with one more stamp runs slower): per batch, the 100 MHz time stamps of the task of ITEM 0 --
 // [0] record in hand, [1] rows valid + gradients done, [2] readers acknowledged, [3] stores issued
 __device__ unsigned long long* g_flow_trace;
 #define TKR_TRACE(i) if (trace_buf && is_item && row == 0 && lane == 0) trace_buf[(size_t)batch * 8 + (i)] = __builtin_amdgcn_s_memrealtime();
