@@ -166,6 +166,35 @@ def test_refine_is_the_fp32_arithmetic(n_rows, n_cols, k, bias, wide):
                 assert ids[r].tolist() == ref, 'row %d' % r
 
 
+def test_refine_overflowing_lists_fall_back():
+    """Lists that cannot hold their margin: 400 exact copies of the row every user likes best (far more than the 64 slots of a
+    list) plus 300 near-copies inside the fp16 margin.  The bound-and-refine kernel has to give those user blocks up and the fp32
+    kernel redoes them: the result is the oracle's (ties -> higher column first), with and without item-range splitting."""
+    import tkr_hip
+    rng = np.random.Generator(np.random.PCG64(77))
+    n_rows, n_cols, k, K = 700, 3000, 64, 30
+    U = (np.abs(rng.standard_normal((n_rows, k))) * 0.01 + 0.001).astype(np.float32)
+    V = (rng.standard_normal((n_cols, k)) * 0.002).astype(np.float32)
+    best = np.full(k, 0.03, dtype=np.float32)                       # positive against every (positive) user row
+    dup = rng.choice(n_cols, 700, replace=False)
+    V[dup[:400]] = best
+    V[dup[400:]] = best * (1.0 - rng.uniform(0, 2e-4, (300, 1)).astype(np.float32))      # within 2^-10 * |u||v| of the copies
+    rated = [rng.choice(n_cols, 20, replace=False).tolist() for _ in range(n_rows)]
+    exp, s = _oracle_lists(U, V, None, rated, K)
+    chain = R.mfma_chain_scores(U, V, None)
+    try:
+        tkr_hip.set_topk_math('refine')
+        ids = _gpu_lists(tkr_hip, U, V, None, rated, K).cpu().numpy()
+        tkr_hip.set_topk_math('fp32')
+        ids_f = _gpu_lists(tkr_hip, U, V, None, rated, K).cpu().numpy()
+    finally:
+        tkr_hip.set_topk_math(tkr_hip.TOPK_MATH_DEFAULT)
+    np.testing.assert_array_equal(ids, ids_f)
+    for r in range(0, n_rows, 9):                                   # the fma chain's ranking (exact copies tie exactly in any order of summation)
+        assert ids[r].tolist() == R.filtered_topk(chain[r], set(rated[r]), K, canonical=True), 'row %d' % r
+        assert set(ids[r].tolist()) <= set(dup[:400].tolist())
+
+
 def test_item_range_split_is_invisible(hip):
     """the launch may split the catalogue into item ranges and merge: identical ids and scores either way"""
     rng = np.random.Generator(np.random.PCG64(21))
