@@ -33,6 +33,52 @@ __device__ __forceinline__ bool poll(const uint32_t* row, int lane, uint32_t tag
     }
     return false;
 }
+// the link as K2f builds it: two full rows and a 32-byte tail (two lanes), all three polled and validated per pass
+template <int TAIL_LANES>
+__device__ __forceinline__ void put3(uint32_t* base, int lane, uint32_t tag) {
+    v4u x; x.x = lane; x.y = tag; x.z = lane + 64; x.w = tag;
+    __builtin_amdgcn_raw_buffer_store_b128(x, rsrc(base, 1024), lane * 16, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(x, rsrc(base + 1024, 1024), lane * 16, 0, 16);
+    if (lane < TAIL_LANES) __builtin_amdgcn_raw_buffer_store_b128(x, rsrc(base + 2048, 1024), lane * 16, 0, 16);
+}
+template <int TAIL_LANES>
+__device__ __forceinline__ bool poll3(const uint32_t* base, int lane, uint32_t tag, uint32_t& spins) {
+    for (uint32_t it = 0; it < 2000000u; ++it) {
+        const v4u a = __builtin_amdgcn_raw_buffer_load_b128(rsrc(base, 1024), lane * 16, 0, 16);
+        const v4u b = __builtin_amdgcn_raw_buffer_load_b128(rsrc(base + 1024, 1024), lane * 16, 0, 16);
+        const v4u c = __builtin_amdgcn_raw_buffer_load_b128(rsrc(base + 2048, 1024), (lane % TAIL_LANES) * 16, 0, 16);
+        asm volatile("" ::: "memory");
+        if (__all(a.y == tag && a.w == tag && b.y == tag && b.w == tag && c.y == tag && c.w == tag)) { spins += it; return true; }
+    }
+    return false;
+}
+template <int TAIL_LANES>
+__global__ void pingpong3(uint32_t* rows, int a_block, int b_block, int n, unsigned long long* out) {
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x != a_block && (int)blockIdx.x != b_block) return;
+    uint32_t* r0 = rows; uint32_t* r1 = rows + 4096;
+    uint32_t spins = 0;
+    bool ok = true;
+    if ((int)blockIdx.x == a_block) {
+        for (int i = 1; i <= n && ok; ++i) { put3<TAIL_LANES>(r0, lane, i); ok = poll3<TAIL_LANES>(r1, lane, i, spins); }
+    } else {
+        for (int i = 1; i <= n && ok; ++i) { ok = poll3<TAIL_LANES>(r0, lane, i, spins); put3<TAIL_LANES>(r1, lane, i); }
+    }
+    if (lane == 0) { out[(blockIdx.x == a_block ? 0 : 2)] = ok; out[(blockIdx.x == a_block ? 1 : 3)] = spins; }
+}
+template <int TAIL_LANES>
+static void run3(const char* what, uint32_t* rows, int a, int b, unsigned long long* out, int n) {
+    hipMemset(rows, 0, 16384 * 4); hipMemset(out, 0, 32);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((pingpong3<TAIL_LANES>), dim3(64), dim3(64), 0, 0, rows, a, b, n, out);
+    hipEventRecord(e1); hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[4]; hipMemcpy(h, out, 32, hipMemcpyDeviceToHost);
+    printf("  %-44s %7.3f us per hop (%s; %.1f polls per hop)\n", what, ms * 1e3 / (2.0 * n), h[0] && h[2] ? "ok" : "TIMED OUT",
+           (double)(h[1] + h[3]) / (2.0 * n));
+}
+
 // blocks: every block reports its XCC; the host picked roles (block ids of A and B) from a census run
 template <int STORE, int LOAD>
 __global__ void pingpong(uint32_t* rows, int a_block, int b_block, int n, unsigned long long* out, uint32_t* xcc) {
@@ -54,7 +100,7 @@ __global__ void pingpong(uint32_t* rows, int a_block, int b_block, int n, unsign
 
 template <int STORE, int LOAD>
 static void run(const char* what, uint32_t* rows, int a, int b, unsigned long long* out, uint32_t* xcc, int n) {
-    hipMemset(rows, 0, 8192 * 4); hipMemset(out, 0, 32);
+    hipMemset(rows, 0, 16384 * 4); hipMemset(out, 0, 32);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
     hipLaunchKernelGGL((pingpong<STORE, LOAD>), dim3(64), dim3(64), 0, 0, rows, a, b, n, out, xcc);
@@ -67,7 +113,7 @@ static void run(const char* what, uint32_t* rows, int a, int b, unsigned long lo
 
 int main() {
     uint32_t *rows, *xcc; unsigned long long* out;
-    hipMalloc(&rows, 8192 * 4); hipMalloc(&xcc, 64 * 4); hipMalloc(&out, 32);
+    hipMalloc(&rows, 16384 * 4); hipMalloc(&xcc, 64 * 4); hipMalloc(&out, 32);
     hipMemset(xcc, 0xff, 64 * 4);
     hipLaunchKernelGGL((pingpong<0, 16>), dim3(64), dim3(64), 0, 0, rows, -1, -1, 0, out, xcc);      // census
     hipDeviceSynchronize();
@@ -84,8 +130,8 @@ int main() {
         run<3, 16>("store sc0 sc1, load sc1", rows, 0, b, out, xcc, n);
         run<3, 17>("store sc0 sc1, load sc0 sc1", rows, 0, b, out, xcc, n);
         if (!pass) run<2, 16>("store plain, load sc1", rows, 0, b, out, xcc, n);
-        if (!pass) run<2, 1>("store plain, load sc0", rows, 0, b, out, xcc, n);
-        run<1, 1>("store sc1 + plain, load sc0", rows, 0, b, out, xcc, n);
+        run3<64>("two rows + a full third row", rows, 0, b, out, n);
+        run3<2>("two rows + a 32-byte tail (K2f's link)", rows, 0, b, out, n);
     }
     return 0;
 }

@@ -215,7 +215,6 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
             if (!sgd) issue_row<NP>(own_ms, lane, xm);
             xt = issue_tail(own_tail, lane & 1);
         }
-        o.rd = ld_u32(own_rd);                      // every pass: as fresh as the rows when the last one validates
         if (!part_ok) {
 #pragma unroll
             for (int q = 0; q < G; ++q) {
@@ -273,13 +272,7 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
                 }
             }
         }
-        if (o.ok && part_ok) {
-            // the acknowledge count once more, NOW: the copy of this pass was loaded before the row it came with was written, i.e.
-            // before the last readers of the version underneath acknowledged -- it cost a round trip behind the gradients on every
-            // chain link; this load returns while they are computed
-            o.rd = ld_u32(own_rd);
-            break;
-        }
+        if (part_ok) break;                         // the own row alone is waited for in the tight loop below
         // How far away is what we wait for?  The buffer of version v holds v, v-2, v-4, ...: a tag of v-2 means the producer is
         // one or two updates away (poll), v-4 or older at least three -- two whole hand-offs, ~2 us each: sleep through that
         // (a waiting wave that polls costs everybody's loads latency, a sleeping one nothing)
@@ -318,7 +311,52 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
             return false;
         }
     }
+    // Only the own row is missing -- the state of every task on a chain through a popular row, and what the chain's period is
+    // made of.  A pass of the general loop above is ~300 instructions of one wave with a SIMD to itself (which rows are still
+    // missing, which of them are far away, ...): ~0.4 us on top of the loads' round trip, and a link was 1.7 us even with its
+    // arithmetic compiled out, against 0.6-0.8 us for the same three stores and loads in a bare ping-pong
+    // (scripts/ubench/hop_xcd.hip).  This loop is the bare ping-pong: three loads, the tags, one branch.
+    if (!o.ok) {
+        for (;;) {
+            issue_row<NP>(own_p, lane, xo);
+            if (!sgd) issue_row<NP>(own_ms, lane, xm);
+            xt = issue_tail(own_tail, lane & 1);
+            bool lane_own = row_tagged<NP>(xo, own_ver) && xt.y == own_ver && xt.w == own_ver;
+            if (!sgd) lane_own = lane_own && row_tagged<NP>(xm, own_ver);
+            if (__all(lane_own)) break;
+            // a tag two versions of this buffer back: the producer is at least three updates away -- sleep through two hand-offs
+            if (!(T.tune & 2u) && (int)(own_ver - (uint32_t)bcast_i((int)xt.y, 0)) >= 4) __builtin_amdgcn_s_sleep(127);
+            if (spin_fail(waited, ctl, 0)) {
+                if (waited >= kSpinLimit && lane == 0 && atomicCAS(ctl + kCtlDebug, 0u, 1u) == 0u) {
+                    ctl[kCtlDebug + 1] = 0u;
+                    ctl[kCtlDebug + 2] = 1u;
+                    ctl[kCtlDebug + 3] = own_ver;
+                    ctl[kCtlDebug + 4] = xo[0].y;
+                    ctl[kCtlDebug + 5] = xt.y;
+                    ctl[kCtlDebug + 13] = ITEM;
+                    ctl[kCtlDebug + 14] = (uint32_t)n;
+                }
+                return false;
+            }
+        }
+        o.ok = true;
+#ifdef TKR_FLOW_TRACE
+        o.t_valid = __builtin_amdgcn_s_memrealtime();
+#endif
+        row_values<NP>(xo, own);
+        if (!sgd) row_values<NP>(xm, ms);
+        o.b = bcast_f(__uint_as_float(xt.x), 0);
+        o.msb = bcast_f(__uint_as_float(xt.z), 0);
+        o.exp_even = (uint32_t)bcast_i((int)xt.x, 1);
+        o.exp_odd = (uint32_t)bcast_i((int)xt.z, 1);
+    }
+    // the acknowledge count is loaded NOW, once, and returns while the gradients are computed (not in every pass: the word is
+    // under atomic update by the readers, and the copy of an earlier pass predates the last acknowledgements anyway)
+    o.rd = ld_u32(own_rd);
     spins += waited;
+#ifdef TKR_FLOW_TRACE
+    if (T.tune & 4u) return true;                 // experiment: no gradients at all (what is the link without its arithmetic?)
+#endif
 
     // x_t of every occurrence: one dot product each (user row: <u, v_i - v_j>; item row: <u, v_row - v_other>,
     // single/bpr.py:87-89), all reduced together; lane L then holds occurrence L >> SH and the sigmoids run side by side
@@ -590,6 +628,9 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
         // version ver+1 lands on the buffer that held ver-1: wait until every reader of ver-1 has acknowledged
         const uint32_t expect = (ver & 1u) ? o.exp_even : o.exp_odd;        // readers of version ver-1
         uint32_t waited = 0;
+#ifdef TKR_FLOW_TRACE
+        if (T.tune & 8u) o.rd = expect;             // experiment: no acknowledge wait
+#endif
         while ((int32_t)(o.rd - expect) < 0) {
             if (spin_fail(waited, ctl)) {
                 if (waited >= kSpinLimit && lane == 0 && atomicCAS(ctl + kCtlDebug, 0u, 2u) == 0u) {
