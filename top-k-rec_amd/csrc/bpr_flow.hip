@@ -130,25 +130,39 @@ __device__ __forceinline__ void dotf2(const float (&a)[NE], const float (&b1)[NE
 }
 
 // Sums of M per-lane values over the wave by recursive halving: lane L ends up with the total of value L >> SH,
-// SH = 6 - log2(M) (M = 16: L >> 2).  M - 1 exchanges + SH butterflies instead of 6 M: the reductions of a popular
-// item's dozen occurrences sit on the chain that limits the batch.  Fixed pattern, so results are repeatable.
+// SH = 6 - log2(M) (M = 4: L >> 4, M = 8: L >> 3).  The reductions of a popular item's occurrences sit on the chain that limits
+// the batch, and a cross-lane move through the LDS crossbar (what __shfl_xor compiles to) is ~70 cycles of latency per level,
+// six levels deep.  gfx950 exchanges half-waves and 16-lane rows in the vector ALU (v_permlane32_swap / v_permlane16_swap: one
+// instruction swaps the upper half of a with the lower half of b, so a' + b' holds value i's partial sums in the lower lanes and
+// value i+half's in the upper ones); inside a row DPP does the rest.  Fixed pattern, so results are repeatable.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <int M>
 __device__ __forceinline__ float reduce_multi(float (&v)[M], int lane) {
-    int D = 32;
+    static_assert(M == 4 || M == 8, "4 or 8 values");
 #pragma unroll
-    for (int m = M; m > 1; m >>= 1, D >>= 1) {
-        const int half = m >> 1;
-        const bool upper = (lane & D) != 0;
+    for (int i = 0; i < M / 2; ++i) {                               // lanes l and l + 32
+        const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + M / 2]), false, false);
+        v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
 #pragma unroll
-        for (int i = 0; i < half; ++i) {
-            const float send = upper ? v[i] : v[i + half];
-            const float keep = upper ? v[i + half] : v[i];
-            v[i] = keep + __shfl_xor(send, D);
-        }
+    for (int i = 0; i < M / 4; ++i) {                               // rows r and r + 1
+        const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + M / 4]), false, false);
+        v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
     }
     float r = v[0];
-#pragma unroll
-    for (; D >= 1; D >>= 1) r += __shfl_xor(r, D);
+    if constexpr (M == 8) {                                         // lanes l and l ^ 8 (= a rotation by 8 inside the row)
+        const bool upper = (lane & 8) != 0;
+        const float send = upper ? v[0] : v[1], keep = upper ? v[1] : v[0];
+        r = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128, 0xf, 0xf, false));
+        r = dpp_add<0x141>(r);            // row_half_mirror: lane i + lane 7 - i of its group of eight
+        r = dpp_add<0xb1>(r);             // quad_perm [1,0,3,2]
+        r = dpp_add<0x4e>(r);             // quad_perm [2,3,0,1] -> all eight lanes hold the total
+    } else {
+        r = dpp_add<0xb1>(r);             // the sixteen lanes of a row
+        r = dpp_add<0x4e>(r);
+        r = dpp_add<0x124>(r);            // row_ror:4
+        r = dpp_add<0x128>(r);            // row_ror:8
+    }
     return r;
 }
 
@@ -385,15 +399,13 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
     }
     float dotv;
     const int myq = lane >> SH;
-    if constexpr (G <= 4) {                      // few values: DPP trees (cross-lane permutes cost ~100 cycles per stage)
-        dotv = 0.f;
+    if constexpr (G == 1) {
+        dotv = wave_sum(part[0]);                // every lane
+    } else if constexpr (G <= 4) {               // two to four values ride one reduction of four (lane L: value L >> 4)
+        float p4[4];
 #pragma unroll
-        for (int q = 0; q < G; ++q) {
-            if (q < n) {
-                const float t = wave_sum(part[q]);
-                if (myq == q) dotv = t;
-            }
-        }
+        for (int q = 0; q < 4; ++q) p4[q] = q < G ? part[q] : 0.f;
+        dotv = reduce_multi<4>(p4, lane);
     } else {
         dotv = reduce_multi<G>(part, lane);
     }
@@ -610,6 +622,13 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
 #pragma unroll
         for (int e = 0; e < NE; ++e) mn[e] = 0.f;
         float bn, mbn = 0.f;
+#ifdef TKR_FLOW_TRACE
+        if (T.tune & 16u) {                         // experiment: the row goes back unchanged
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { pn[e] = own[e]; mn[e] = ms[e]; }
+            bn = o.b; mbn = o.msb;
+        } else
+#endif
         if (sgd) {                                  // old/methods/bpr.py:57-61: P <- P - lr * dcost/dP
 #pragma unroll
             for (int e = 0; e < NE; ++e) pn[e] = own[e] - st.lr * g[e];
