@@ -262,7 +262,9 @@ class PlanMixin:
         if self.pipe is None:
             self.pipe = PlanPipeline(self.device)
         self.pipe.ensure(_chunk_cap(B), B, self._plan_flow())
-        overlap = B >= OVERLAP_MIN_BATCH
+        # K1 of the chunk after this one on the side stream: behind the per-batch launches of a large batch, or behind the ONE
+        # persistent launch of a dataflow chunk (100 us of planner per 512 batches that otherwise sit in front of every 1.4 ms launch)
+        overlap = B >= OVERLAP_MIN_BATCH or self._plan_flow()
         if cur is not None and self._ahead is not None:
             nxt, self._ahead = self._ahead, None
         else:
