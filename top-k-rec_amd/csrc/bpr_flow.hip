@@ -432,6 +432,9 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
             loss_lane += l2 ? 0.5f * (ta_me * ta_me + tb_me * tb_me) * st.lb : (fabsf(ta_me) + fabsf(tb_me)) * st.lb;
         }
     }
+    // data terms per occurrence; the regulariser of the own row once for all of them (n * lambda * own: every occurrence adds the
+    // same term -- one multiply-add per element instead of one per occurrence on the chain through the popular rows)
+    float lam_sum = 0.f;
 #pragma unroll
     for (int q = 0; q < G; ++q) {
         if (q < n) {
@@ -440,35 +443,26 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
             const float s = bcast_f(s_me, q << SH);
             if constexpr (!ITEM) {
                 row_values<NP>(xb[q], pb);
-                if (l2) {
 #pragma unroll
-                    for (int e = 0; e < NE; ++e) {
-                        g[e] += -s * (pa[e] - pb[e]) + st.lu * own[e];
-                        if (want_loss) loss_lane += 0.5f * (own[e] * own[e] * st.lu + pa[e] * pa[e] * st.li + pb[e] * pb[e] * st.lj);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) {
-                        g[e] += -s * (pa[e] - pb[e]) + st.lu * sgn(own[e]);
-                        if (want_loss) loss_lane += fabsf(own[e]) * st.lu + fabsf(pa[e]) * st.li + fabsf(pb[e]) * st.lj;
-                    }
+                for (int e = 0; e < NE; ++e) {
+                    g[e] = fmaf(-s, pa[e] - pb[e], g[e]);
+                    if (want_loss) loss_lane += l2 ? 0.5f * (own[e] * own[e] * st.lu + pa[e] * pa[e] * st.li + pb[e] * pb[e] * st.lj)
+                                                   : fabsf(own[e]) * st.lu + fabsf(pa[e]) * st.li + fabsf(pb[e]) * st.lj;
                 }
+                lam_sum += st.lu;
             } else {
                 const bool role_j = bcast_i(d.z, q) < 0;
                 const float sg = role_j ? s : -s;
-                const float lam = role_j ? st.lj : st.li;
-                if (l2) {
 #pragma unroll
-                    for (int e = 0; e < NE; ++e) g[e] += sg * pa[e] + lam * own[e];
-                    gb += sg + st.lb * o.b;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) g[e] += sg * pa[e] + lam * sgn(own[e]);
-                    gb += sg + st.lb * sgn(o.b);
-                }
+                for (int e = 0; e < NE; ++e) g[e] = fmaf(sg, pa[e], g[e]);
+                gb += sg;
+                lam_sum += role_j ? st.lj : st.li;
             }
         }
     }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) g[e] = fmaf(lam_sum, l2 ? own[e] : sgn(own[e]), g[e]);
+    if constexpr (ITEM) gb = fmaf((float)n * st.lb, l2 ? o.b : sgn(o.b), gb);
 
     if ((T.tune & 1u) && lane < n) {
         uint32_t* pa_rd = (ITEM ? T.rdU : T.rdV) + 2 * (size_t)d.x + (d.y & 1);
