@@ -181,6 +181,12 @@ struct FlowTables {                       // device view of tkr_flow_state
     uint32_t tune;                        // experiment switches (scripts/probe_flow_bench.py): bit 0 late acks, bit 1 nap while only the own row is missing
 };
 
+struct NextTask {                         // the task after the current one, fetched while the current one waits for its rows
+    uint32_t idx;                         // its index (0xffffffff: the queue is exhausted)
+    int4 w;                               // its record (one int4 per lane, lanes 0..7)
+    bool have;
+};
+
 struct Own {                              // a task's own row while it is processed
     float b, msb;
     uint32_t exp_even, exp_odd, rd;       // expect[0], expect[1] as carried by the version read; rd[(version + 1) & 1]
@@ -202,6 +208,19 @@ __device__ __forceinline__ bool spin_fail(uint32_t& spins, uint32_t* ctl, int na
     return false;
 }
 
+// next task index of this wave, or 0xffffffff when its queue is exhausted: ONE returning atomic per task on the wave's
+// home counter.  (A first version also read all counters to steal from a lagging queue: 768 tasks x 8 loads per batch on
+// 8 lines that are being atomically updated serialise at the atomic rate -- measured 10 us per grab.)
+__device__ __forceinline__ uint32_t grab_issue(uint32_t* ctl, int lane, int home) {     // lane 0 holds the ticket when it lands
+    uint32_t t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(ctl + home * kQueueStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t;
+}
+__device__ __forceinline__ uint32_t grab_index(uint32_t ticket, int home, uint32_t total) {
+    const u64 idx = (u64)(uint32_t)bcast_i((int)ticket, 0) * kQueues + home;
+    return idx < total ? (uint32_t)idx : 0xffffffffu;
+}
+
 // One group of n <= G occurrences of a task; lane q < n holds occurrence q in `d` = (a, version of a, b | role<<31,
 // version of b).  ITEM = false: the row is a user; a = positive item, b = negative item.  ITEM = true: the row is an item;
 // a = user, b = the other item (bit 31: this row is the NEGATIVE item).  All 2G partner rows are in flight at once -- a
@@ -215,7 +234,8 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
                                            const u64* own_p, const u64* own_ms, const u64* own_tail, const uint32_t* own_rd,
                                            uint32_t own_ver, float (&own)[2 * NP], float (&ms)[2 * NP], Own& o,
                                            float (&g)[2 * NP], float& gb, float& loss_lane, float& loss_x, bool want_loss,
-                                           bool sgd, uint32_t* ctl, uint32_t& spins) {
+                                           bool sgd, uint32_t* ctl, uint32_t& spins, NextTask& nx, uint32_t ticket, int home,
+                                           uint32_t total, const int4* __restrict__ prec) {
     constexpr int NE = 2 * NP;
     v4u xo[NP], xm[NP], xt = {0u, 0u, 0u, 0u};
     v4u xa[G][NP], xb[G][NP];
@@ -285,6 +305,16 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
                     __hip_atomic_fetch_add(pb_rd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+        }
+        // The first pass has waited for its loads, so the ticket taken before them is back too: the record of the NEXT task is
+        // fetched now and lands while this task validates, waits and computes -- a task used to start with the round trip of its
+        // ticket behind the previous task's write-through stores (0.4 us) and then the round trip of its record (0.55 us),
+        // a quarter of a wave's time per task.
+        if (!nx.have) {
+            nx.idx = grab_index(ticket, home, total);
+            nx.w = make_int4(0, 0, 0, 0);
+            if (nx.idx != 0xffffffffu && lane < 8) nx.w = prec[(size_t)nx.idx * 8 + lane];
+            nx.have = true;
         }
         if (part_ok) break;                         // the own row alone is waited for in the tight loop below
         // How far away is what we wait for?  The buffer of version v holds v, v-2, v-4, ...: a tag of v-2 means the producer is
@@ -473,19 +503,6 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
     return true;
 }
 
-// next task index of this wave, or 0xffffffff when its queue is exhausted: ONE returning atomic per task on the wave's
-// home counter.  (A first version also read all counters to steal from a lagging queue: 768 tasks x 8 loads per batch on
-// 8 lines that are being atomically updated serialise at the atomic rate -- measured 10 us per grab.)
-__device__ __forceinline__ uint32_t grab_issue(uint32_t* ctl, int lane, int home) {     // lane 0 holds the ticket when it lands
-    uint32_t t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(ctl + home * kQueueStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return t;
-}
-__device__ __forceinline__ uint32_t grab_index(uint32_t ticket, int home, uint32_t total) {
-    const u64 idx = (u64)(uint32_t)bcast_i((int)ticket, 0) * kQueues + home;
-    return idx < total ? (uint32_t)idx : 0xffffffffu;
-}
-
 #ifdef TKR_FLOW_TRACE
 // timing builds only (scripts/probe_flow_timeline.py; a stamp that is stored at once waits ~0.2 us for s_memrealtime, so the segments
 // are upper bounds and a build with one more stamp runs slower): per batch, the 100 MHz time stamps of the task of ITEM 0 --
@@ -537,15 +554,27 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
     // The ticket of the NEXT task is taken while the current one runs (its round trip is off the wave's cycle).  Safe: a
     // wave's next ticket is higher than its current one and a task only ever waits for lower ones.
     uint32_t ticket = grab_issue(ctl, lane, home);
+    NextTask nx;
+    nx.idx = 0u; nx.w = make_int4(0, 0, 0, 0); nx.have = false;
     while (alive) {
-        const uint32_t idx = grab_index(ticket, home, total);
-        TKR_PROF_MARK(0)
-        if (idx == 0xffffffffu) break;
-        const int4* r = prec + (size_t)idx * 8;
-        int4 w = make_int4(0, 0, 0, 0);
-        if (lane < 8) w = r[lane];                                          // 128-byte record, one int4 per lane (an L2 hit: K1 just wrote it)
-        asm volatile("" : "+v"(w.x), "+v"(w.y), "+v"(w.z), "+v"(w.w) :: "memory");   // the record lands BEFORE the atomic is issued: memory
-        ticket = grab_issue(ctl, lane, home);                               // returns in order, and the record must not queue behind its round trip
+        uint32_t idx;
+        int4 w;
+        if (nx.have) {                                                      // fetched while the previous task ran (flow_group)
+            idx = nx.idx;
+            w = nx.w;
+            TKR_PROF_MARK(0)
+            if (idx == 0xffffffffu) break;
+        } else {                                                            // first task of the wave, or the previous slot was unused
+            idx = grab_index(ticket, home, total);
+            TKR_PROF_MARK(0)
+            if (idx == 0xffffffffu) break;
+            const int4* r = prec + (size_t)idx * 8;
+            w = make_int4(0, 0, 0, 0);
+            if (lane < 8) w = r[lane];                                      // 128-byte record, one int4 per lane (an L2 hit: K1 just wrote it)
+            asm volatile("" : "+v"(w.x), "+v"(w.y), "+v"(w.z), "+v"(w.w) :: "memory");   // the record lands BEFORE the atomic is issued: memory
+        }                                                                   // returns in order, and the record must not queue behind its round trip
+        nx.have = false;
+        ticket = grab_issue(ctl, lane, home);                               // the ticket of the task after this one
         const int rowk = bcast_i(w.x, 0);
         TKR_PROF_MARK(1)
         if (rowk == -1) { if constexpr (PROF) prof[6] += 1; continue; }    // unused slot of its batch
@@ -574,9 +603,9 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
         const u64* own_tail = tabT + ((size_t)(ver & 1u) * n_rows + row) * 4;
 #define TKR_FLOW_GROUP(GG, nn, dd)                                                                                             \
     (is_item ? flow_group<NP, GG, true>(st, T, lane, nn, dd, tabP + roff, tabM + roff, own_tail, own_rd, ver, own, ms, o, g, gb,   \
-                                        loss_lane, loss_x, false, sgd, ctl, spins)                                              \
+                                        loss_lane, loss_x, false, sgd, ctl, spins, nx, ticket, home, total, prec)                \
              : flow_group<NP, GG, false>(st, T, lane, nn, dd, tabP + roff, tabM + roff, own_tail, own_rd, ver, own, ms, o, g, gb,  \
-                                         loss_lane, loss_x, want_loss, sgd, ctl, spins))
+                                         loss_lane, loss_x, want_loss, sgd, ctl, spins, nx, ticket, home, total, prec))
         if (n_occ <= 4) {                         // the common case: its occurrences sit in the record (lanes 2..5)
             const int src = (lane + 2) & 7;
             const int4 d = make_int4(__shfl(w.x, src), __shfl(w.y, src), __shfl(w.z, src), __shfl(w.w, src));
@@ -659,6 +688,8 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
         TKR_PROF_MARK(3)
         TKR_TRACE(2)
 
+        // the next task's record is consumed BEFORE the stores go out: a wait behind them would include their write-through
+        asm volatile("" : "+v"(nx.w.x), "+v"(nx.w.y), "+v"(nx.w.z), "+v"(nx.w.w));
         store_row<NP>(tabP + woff, lane, pn, nv);
         if (!sgd) store_row<NP>(tabM + woff, lane, mn, nv);
         if (lane < 2) {                             // tail = {bias, its slot | expect[0], expect[1]}
