@@ -928,7 +928,9 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
         // MFMA); there the barrier stays behind the filter.
         constexpr bool kEarlyBarrier = REFINE || KS <= 4;    // refine: the chain is 8 MFMAs at every width, the filter dominates
         if constexpr (kEarlyBarrier) {
-            if constexpr (REFINE) add_scaled_bias_inplace(acc, sm.tbias + buf * 32, h, bscale);
+            if constexpr (REFINE) {
+                if (bias) add_scaled_bias_inplace(acc, sm.tbias + buf * 32, h, bscale);     // VBPR models have no item bias: 16 fma per tile less
+            }
             else add_bias_inplace(acc, sm.tbias + buf * 32, h);
         }
 #if TKR_ABL & 256
