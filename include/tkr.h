@@ -271,6 +271,14 @@ int tkr_count_hits_rr(const int32_t* ids, const int32_t* raw_rank, int32_t n_row
  *   (the caller all-reduces flat_delta | flat_ms with SUM: RCCL over xGMI through torch.distributed)
  *   tkr_sync_unpack    P[0][r] = start[r] + flat_delta[r];  ms[0][r] = flat_ms[r];  the caller then zeroes cnt */
 int tkr_sync_snapshot(const float* P, const int32_t* cnt, float* start, int64_t n, int32_t w, void* stream);
+/* the same exchange for the granule tables of tkr_flow_state (item side: V, msV, tailV, rdV; n = n_items): start / flat_delta /
+ * flat_ms hold the n*k elements of V followed by the n item biases.  tkr_sync_flow_unpack leaves the tables as a fresh assignment
+ * does (version 0 in buffer 0, none in buffer 1, expect = rd = 0) and zeroes the update counters itself. */
+int tkr_sync_flow_snapshot(const void* V, const void* tailV, const int32_t* icnt, float* start, int32_t n, int32_t k, void* stream);
+int tkr_sync_flow_pack(const void* V, const void* msV, const void* tailV, const int32_t* icnt, const float* start, float* flat_delta,
+                       float* flat_ms, int32_t n, int32_t k, float inv_world, void* stream);
+int tkr_sync_flow_unpack(void* V, void* msV, void* tailV, uint32_t* rdV, int32_t* icnt, const float* start, const float* flat_delta,
+                         const float* flat_ms, int32_t n, int32_t k, void* stream);
 int tkr_sync_pack(const float* P, const float* ms, const int32_t* cnt, const float* start, float* flat_delta, float* flat_ms,
                   int64_t n, int32_t w, float inv_world, void* stream);
 int tkr_sync_unpack(float* P, float* ms, const float* start, const float* flat_delta, const float* flat_ms, int64_t n, int32_t w,

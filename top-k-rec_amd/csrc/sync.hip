@@ -42,7 +42,100 @@ __global__ void sync_unpack_kernel(float* __restrict__ P, float* __restrict__ ms
     ms[i] = flat_ms[i];
 }
 
+// ---- the same three steps for the GRANULE tables of the dataflow step (csrc/bpr_flow.hip) -----------------------------
+// V / msV: [2][n][kp] granules {fp32 value, uint32 version tag}; the item bias and its slot are granules 0 and 1 of the row's
+// tail [2][n][4].  "Current" is buffer (cnt[r] & 1).  The flat vectors hold the n*k elements of V followed by the n biases.
+// unpack re-creates what a fresh assignment of the tables looks like: version 0 of every row in buffer 0 (tags 0, padding 0 / slot
+// padding 1), no version in buffer 1 (tags 0xffffffff), expect = 0, rd = 0, update counters 0 -- one launch instead of ~20
+// framework ops (fills, strided copies, tag resets) on 2 x 21 MB: measured 464 -> ~60 us per exchange at the ML-10M shape.
+__global__ void sync_flow_snapshot_kernel(const float2* __restrict__ P, const float2* __restrict__ tail, const int32_t* __restrict__ cnt,
+                                          float* __restrict__ start, int n, int k, int kp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * (k + 1)) return;
+    const int r = (int)(i / (k + 1)), c = (int)(i % (k + 1));
+    const int64_t par = cnt[r] & 1;
+    if (c < k) start[(int64_t)r * k + c] = P[(par * n + r) * kp + c].x;
+    else start[(int64_t)n * k + r] = tail[(par * n + r) * 4 + 0].x;
+}
+
+__global__ void sync_flow_pack_kernel(const float2* __restrict__ P, const float2* __restrict__ M, const float2* __restrict__ tail,
+                                      const int32_t* __restrict__ cnt, const float* __restrict__ start, float* __restrict__ flat_delta,
+                                      float* __restrict__ flat_ms, int n, int k, int kp, float inv_world) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * (k + 1)) return;
+    const int r = (int)(i / (k + 1)), c = (int)(i % (k + 1));
+    const int64_t par = cnt[r] & 1;
+    if (c < k) {
+        const int64_t o = (int64_t)r * k + c, g = (par * n + r) * kp + c;
+        flat_delta[o] = P[g].x - start[o];
+        flat_ms[o] = M[g].x * inv_world;
+    } else {
+        const int64_t o = (int64_t)n * k + r, g = (par * n + r) * 4;
+        flat_delta[o] = tail[g + 0].x - start[o];
+        flat_ms[o] = tail[g + 1].x * inv_world;
+    }
+}
+
+__global__ void sync_flow_unpack_kernel(float2* __restrict__ P, float2* __restrict__ M, float2* __restrict__ tail,
+                                        uint32_t* __restrict__ rd, int32_t* __restrict__ cnt, const float* __restrict__ start,
+                                        const float* __restrict__ flat_delta, const float* __restrict__ flat_ms, int n, int k, int kp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * kp) return;
+    const int r = (int)(i / kp), c = (int)(i % kp);
+    const float none = __uint_as_float(0xffffffffu), zero_tag = __uint_as_float(0u);
+    const int64_t g0 = (int64_t)r * kp + c, g1 = ((int64_t)n + r) * kp + c;
+    const int64_t o = (int64_t)r * k + c;
+    P[g0] = make_float2(c < k ? start[o] + flat_delta[o] : 0.f, zero_tag);
+    M[g0] = make_float2(c < k ? flat_ms[o] : 1.f, zero_tag);
+    P[g1] = make_float2(0.f, none);
+    M[g1] = make_float2(0.f, none);
+    if (c < 4) {
+        const int64_t ob = (int64_t)n * k + r;
+        float v = 0.f;
+        if (c == 0) v = start[ob] + flat_delta[ob];
+        if (c == 1) v = flat_ms[ob];
+        tail[(int64_t)r * 4 + c] = make_float2(v, zero_tag);
+        tail[((int64_t)n + r) * 4 + c] = make_float2(0.f, none);
+    }
+    if (c == 0) { rd[2 * (int64_t)r] = 0u; rd[2 * (int64_t)r + 1] = 0u; cnt[r] = 0; }
+}
+
 }  // namespace tkr
+
+extern "C" int tkr_sync_flow_snapshot(const void* P, const void* tail, const int32_t* cnt, float* start, int32_t n, int32_t k,
+                                      void* stream) {
+    if (!P || !tail || !cnt || !start || n <= 0 || k <= 0) return TKR_EINVAL;
+    const int kp = (k + 127) / 128 * 128;
+    const int64_t tot = (int64_t)n * (k + 1);
+    hipLaunchKernelGGL(tkr::sync_flow_snapshot_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const float2*>(P), static_cast<const float2*>(tail), cnt, start, n, k, kp);
+    TKR_LAUNCH_CHECK();
+    return TKR_OK;
+}
+
+extern "C" int tkr_sync_flow_pack(const void* P, const void* M, const void* tail, const int32_t* cnt, const float* start,
+                                  float* flat_delta, float* flat_ms, int32_t n, int32_t k, float inv_world, void* stream) {
+    if (!P || !M || !tail || !cnt || !start || !flat_delta || !flat_ms || n <= 0 || k <= 0) return TKR_EINVAL;
+    const int kp = (k + 127) / 128 * 128;
+    const int64_t tot = (int64_t)n * (k + 1);
+    hipLaunchKernelGGL(tkr::sync_flow_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const float2*>(P), static_cast<const float2*>(M), static_cast<const float2*>(tail), cnt, start,
+                       flat_delta, flat_ms, n, k, kp, inv_world);
+    TKR_LAUNCH_CHECK();
+    return TKR_OK;
+}
+
+extern "C" int tkr_sync_flow_unpack(void* P, void* M, void* tail, uint32_t* rd, int32_t* cnt, const float* start,
+                                    const float* flat_delta, const float* flat_ms, int32_t n, int32_t k, void* stream) {
+    if (!P || !M || !tail || !rd || !cnt || !start || !flat_delta || !flat_ms || n <= 0 || k <= 0) return TKR_EINVAL;
+    const int kp = (k + 127) / 128 * 128;
+    const int64_t tot = (int64_t)n * kp;
+    hipLaunchKernelGGL(tkr::sync_flow_unpack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<float2*>(P), static_cast<float2*>(M), static_cast<float2*>(tail), rd, cnt, start, flat_delta,
+                       flat_ms, n, k, kp);
+    TKR_LAUNCH_CHECK();
+    return TKR_OK;
+}
 
 extern "C" int tkr_sync_snapshot(const float* P, const int32_t* cnt, float* start, int64_t n, int32_t w, void* stream) {
     if (!P || !start || n <= 0 || w <= 0) return TKR_EINVAL;

@@ -552,10 +552,16 @@ class BprEngine(PlanMixin):
 
     def replicated_tables(self):
         """(name, P, ms, update counter or None) of every table all ranks update: dist.ItemSync packs them with
-        csrc/sync.hip.  The granule layout is exchanged through get / set_replicated instead (empty list)."""
+        csrc/sync.hip.  The granule layout has its own fused kernels (flow_sync_tables): empty list here."""
         if self.layout == 'flow':
             return []
         return [('V', self.V.p, self.V.ms, self.cnt.icnt), ('b', self.b.p, self.b.ms, self.cnt.icnt)]
+
+    def flow_sync_tables(self):
+        """the item-side granule tables for dist.ItemSync's fused exchange (csrc/sync.hip tkr_sync_flow_*), or None in the plain layout"""
+        if self.layout != 'flow':
+            return None
+        return self.V.p, self.V.ms, self.tailV.t, self.tailV.rd, self._cnt.icnt, self.n_items, self.k
 
     def copy_model_from(self, other):
         """start from another engine's current parameters and slots (shards of one model)"""

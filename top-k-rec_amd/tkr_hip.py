@@ -51,7 +51,8 @@ EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_pl
            'tkr_idmap_create', 'tkr_idmap_destroy', 'tkr_ratings_parse', 'tkr_ratings_sizes', 'tkr_ratings_copy',
            'tkr_ratings_destroy', 'tkr_matrix_read', 'tkr_matrix_sizes', 'tkr_matrix_copy', 'tkr_matrix_destroy',
            'tkr_matrix_write', 'tkr_raw_ranks', 'tkr_count_hits_rr', 'tkr_topk_set_math',
-           'tkr_sync_snapshot', 'tkr_sync_pack', 'tkr_sync_unpack')
+           'tkr_sync_snapshot', 'tkr_sync_pack', 'tkr_sync_unpack', 'tkr_sync_flow_snapshot', 'tkr_sync_flow_pack',
+           'tkr_sync_flow_unpack')
 EXPORTS_I64 = ('tkr_vbpr_workspace_floats', 'tkr_topk_workspace_bytes', 'tkr_plan_workspace_bytes')
 
 
@@ -334,6 +335,20 @@ def sync_snapshot(P, cnt, start, n, w):
 def sync_pack(P, ms, cnt, start, flat_delta, flat_ms, n, w, inv_world):
     _call('tkr_sync_pack', P, _p(P), _p(ms), _p(cnt), _p(start), _p(flat_delta), _p(flat_ms), C.c_int64(n), C.c_int32(w),
                                C.c_float(inv_world))
+
+
+def sync_flow_snapshot(V, tailV, icnt, start, n, k):
+    _call('tkr_sync_flow_snapshot', V, _p(V), _p(tailV), _p(icnt), _p(start), C.c_int32(n), C.c_int32(k))
+
+
+def sync_flow_pack(V, msV, tailV, icnt, start, flat_delta, flat_ms, n, k, inv_world):
+    _call('tkr_sync_flow_pack', V, _p(V), _p(msV), _p(tailV), _p(icnt), _p(start), _p(flat_delta), _p(flat_ms), C.c_int32(n),
+          C.c_int32(k), C.c_float(inv_world))
+
+
+def sync_flow_unpack(V, msV, tailV, rdV, icnt, start, flat_delta, flat_ms, n, k):
+    _call('tkr_sync_flow_unpack', V, _p(V), _p(msV), _p(tailV), _p(rdV), _p(icnt), _p(start), _p(flat_delta), _p(flat_ms),
+          C.c_int32(n), C.c_int32(k))
 
 
 def sync_unpack(P, ms, start, flat_delta, flat_ms, n, w):
