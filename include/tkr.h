@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define TKR_VERSION 107 /* 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
+#define TKR_VERSION 108 /* 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
 #define TKR_OK 0
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
