@@ -278,3 +278,47 @@ def test_engine_layouts_and_piecewise_plans():
         R.bpr_step(ref, u2[lo:lo + B_], i2[lo:lo + B_], j2[lo:lo + B_], hp)
     for n in ('U', 'V', 'b'):
         np.testing.assert_allclose(a.get(n)[0].cpu().numpy(), ref[n], rtol=3e-4, atol=2e-5, err_msg=n)
+
+
+def test_fused_exchange_of_the_granule_tables(monkeypatch):
+    """dist.ItemSync on the dataflow layout (tkr_sync_flow_snapshot / pack / unpack) against the same exchange through get /
+    set_replicated: two 'ranks' that did the same work (the all-reduce doubles the packed vector) must leave V = start + 2 * delta,
+    b alike, the slots unchanged, and the tables in the freshly assigned state -- bit for bit, and training goes on from there
+    exactly as from tables assigned the slow way."""
+    from single import _engine
+    import dist as tdist
+    n_users, n_items, k = 700, 300, 64
+    tr, tr_users = _toy(n_users, n_items, seed=5)
+    row_ptr, pos, srt = P.build_csr(tr, n_users)
+    dev = torch.device('cuda')
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.02, mode='l2')
+    monkeypatch.setattr(tdist, 'world', lambda: (0, 2))
+    monkeypatch.setattr(tdist.dist, 'all_reduce', lambda t, op=None, group=None: t.mul_(2.0))     # two ranks with identical deltas
+
+    def run(fused):
+        eng = _engine.BprEngine(n_users, n_items, k, hp, dev, seed=9)
+        eng.run_batches(csr, 7, 256, want_loss=False)
+        if not fused:
+            monkeypatch.setattr(eng, 'flow_sync_tables', lambda: None)
+        sync = tdist.ItemSync(eng)
+        assert (sync.flow is not None) == fused
+        sync.begin()
+        start = {n: [t.clone() for t in eng.get(n)] for n in ('V', 'b')}
+        eng.run_batches(csr, 9, 256, want_loss=False)
+        cur = {n: [t.clone() for t in eng.get(n)] for n in ('V', 'b')}
+        sync.end()
+        eng.check()
+        for n in ('V', 'b'):
+            got_p, got_ms = eng.get(n)
+            assert torch.equal(got_p, start[n][0] + 2.0 * (cur[n][0] - start[n][0])), n
+            assert torch.equal(got_ms, 2.0 * (cur[n][1] * 0.5)), n
+        assert int(eng.cnt.icnt.abs().sum()) == 0
+        eng.run_batches(csr, 11, 256, want_loss=False)
+        eng.check()
+        return eng
+
+    a, b = run(True), run(False)
+    for x, y in ((a.V.p, b.V.p), (a.V.ms, b.V.ms), (a.tailV.t, b.tailV.t), (a.U.p, b.U.p)):       # granules incl. tags, both buffers
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    assert torch.equal(a.tailV.rd, b.tailV.rd) and torch.equal(a.cnt.icnt, b.cnt.icnt)
