@@ -374,8 +374,8 @@ def _generators(device, seed, user_seed):
     return gen, gen_u
 
 
-FLOW_MAX_BATCH = int(__import__('os').environ.get('TKR_FLOW_MAX_BATCH', 256))     # batch sizes up to this take the persistent dataflow step (K2f);
-                                   # measured per batch, K2f vs K2: 64: 1.6 vs 3.9 us, 128: 2.4 vs 4.2, 256: 3.3 vs 4.5, 512: 7.3 vs 5.2, 1024: 12.1 vs 6.5
+FLOW_MAX_BATCH = int(__import__('os').environ.get('TKR_FLOW_MAX_BATCH', 512))     # batch sizes up to this take the persistent dataflow step (K2f);
+                                   # measured per batch, K2f vs K2: 64: 1.3 vs 3.9 us, 128: 1.8 vs 4.1, 256: 2.6 vs 4.5, 512: 5.1 vs 5.2, 1024: 8.8 vs 6.8
 FLOW_WAVES_PER_CU = int(__import__('os').environ.get('TKR_FLOW_WAVES_PER_CU', 0))    # 0 = the library default
 
 
