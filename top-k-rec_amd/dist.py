@@ -81,7 +81,7 @@ class ItemSync:
     On the GPU the snapshot / pack / unpack are one HIP launch per table (csrc/sync.hip) around ONE collective
     on a flat buffer: xGMI all-reduces of a few MB are latency-bound, and ~25 framework ops per exchange cost
     240 us against a 2.1 ms epoch at 8 GPUs.  Engines without ``replicated_tables`` (the CPU stand-ins of the gloo
-    tests) take the same arithmetic through plain tensor ops; the granule tables of the dataflow step (batch <= 256) have their
+    tests) take the same arithmetic through plain tensor ops; the granule tables of the dataflow step (batch <= 512) have their
     own fused kernels (tkr_sync_flow_*: 464 -> ~60 us per exchange at the ML-10M shape, against a 1.25 ms epoch at 8 GPUs)."""
 
     def __init__(self, engine, names=None):
