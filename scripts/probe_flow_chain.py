@@ -14,7 +14,7 @@ pos = np.zeros(n_users, dtype=np.int32)
 csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.arange(n_users, dtype=np.int32), dev)
 hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=1e-4, mode='l2')
 eng = _engine.BprEngine(n_users, n_items, 128, hp, dev, seed=5)
-for B in (1, 2, 4):
+for B in (1, 4, 8, 12, 16):
     for w in waves:
         _engine.FLOW_WAVES_PER_CU = w
         eng.run_batches(csr, 512, B, want_loss=False); torch.cuda.synchronize()

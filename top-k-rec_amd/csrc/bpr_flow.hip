@@ -221,26 +221,48 @@ __device__ __forceinline__ uint32_t grab_index(uint32_t ticket, int home, uint32
     return idx < total ? (uint32_t)idx : 0xffffffffu;
 }
 
-// One group of n <= G occurrences of a task; lane q < n holds occurrence q in `d` = (a, version of a, b | role<<31,
-// version of b).  ITEM = false: the row is a user; a = positive item, b = negative item.  ITEM = true: the row is an item;
-// a = user, b = the other item (bit 31: this row is the NEGATIVE item).  All 2G partner rows are in flight at once -- a
-// popular item occurs a dozen times in a 256-batch, and every extra group is a memory round trip on the chain that
-// limits the whole batch.  The loads are STRAIGHT-LINE code: slots q >= n repeat occurrence 0 (hits in L2, ignored by
-// the arithmetic) -- a branch per slot makes the compiler drain the memory pipe (s_waitcnt vmcnt(0)) at every join, one
-// round trip per occurrence instead of one per group (seen in the ISA, and as 5.3 instead of 3.9 us per batch).
-// Returns false when a spin ran out.
+// ---- a task in three steps --------------------------------------------------------------------------------------------------
+// flow_fetch   the partner rows of one group of n <= G occurrences: issue, re-issue until their tags are right, acknowledge, and
+//              PACK what the task's arithmetic needs from them (Packed).  The own row is asked for in the same passes.
+// flow_own     only the own row is missing -- the state of every task on a chain through a popular row: the bare poll loop.
+// flow_apply   gradients of the group from Packed + the own row.
+// Everything that does not need the own row happens in flow_fetch, i.e. while a task on a chain waits: what follows the arrival
+// of the own row is that chain's period (measured: 1.65 us per link up to four occurrences, 2.2 us with eight when the partner
+// rows were only turned into dot products and gradients afterwards, 4.9 us with twelve, whose second group of partner rows was
+// not even asked for before the first group was done -- and the most popular item of a 256-batch has 5-8 occurrences in 81 % of
+// the batches and more in 12 %).
+//
+// Lane q < n of `d` holds occurrence q = (a, version of a, b | role<<31, version of b).  User row: a = positive item, b = negative
+// item.  Item row: a = user, b = the other item (bit 31: this row is the NEGATIVE item).  All 2G partner rows are in flight at
+// once; the loads are STRAIGHT-LINE code: slots q >= n repeat occurrence 0 (hits in L2, masked out of the arithmetic) -- a branch
+// per slot makes the compiler drain the memory pipe (s_waitcnt vmcnt(0)) at every join, one round trip per occurrence instead of
+// one per group (seen in the ISA, and as 5.3 instead of 3.9 us per batch).
+template <int G>
+constexpr int group_shift() { return G <= 4 ? 4 : 3; }      // lane L speaks for occurrence L >> shift in the reductions
+
+template <int NP, int G>
+struct Packed {
+    float pa[G][2 * NP];     // item row: the user rows u_q;  user row: v_i - v_j of occurrence q  (0 for q >= n)
+    float c[G];              // item row: this lane's share of <u_q, v_other>;  user row: 0
+    float bias_me;           // of "my" occurrence (lane >> shift): item row: the other item's bias;  user row: b_i - b_j
+    bool role_me;            // item row: my occurrence has this row as the NEGATIVE item
+    uint32_t roles;          // item row: bit q = occurrence q has this row as the negative item
+    float lam_sum;           // the own row's regulariser weight summed over the occurrences
+    float loss_part;         // user row, loss wanted: the partner-only regulariser terms of this lane
+    int n;
+};
+
 template <int NP, int G, bool ITEM>
-__device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowTables& T, int lane, int n, const int4 d,
-                                           const u64* own_p, const u64* own_ms, const u64* own_tail, const uint32_t* own_rd,
-                                           uint32_t own_ver, float (&own)[2 * NP], float (&ms)[2 * NP], Own& o,
-                                           float (&g)[2 * NP], float& gb, float& loss_lane, float& loss_x, bool want_loss,
-                                           bool sgd, uint32_t* ctl, uint32_t& spins, NextTask& nx, uint32_t ticket, int home,
-                                           uint32_t total, const int4* __restrict__ prec) {
+__device__ __forceinline__ bool flow_fetch(const tkr_flow_state& st, const FlowTables& T, int lane, int n, const int4 d,
+                                           const u64* own_p, const u64* own_ms, const u64* own_tail, uint32_t own_ver,
+                                           float (&own)[2 * NP], float (&ms)[2 * NP], Own& o, bool want_loss, bool sgd,
+                                           uint32_t* ctl, uint32_t& spins, NextTask& nx, uint32_t ticket, int home,
+                                           uint32_t total, const int4* __restrict__ prec, Packed<NP, G>& pk) {
     constexpr int NE = 2 * NP;
+    static_assert(G <= 4 || G == 8, "group width");
     v4u xo[NP], xm[NP], xt = {0u, 0u, 0u, 0u};
     v4u xa[G][NP], xb[G][NP];
     v2u xta[G], xtb[G];
-    bool part_ok = false;
     uint32_t waited = 0;
     for (;;) {
         // a pass first ISSUES every load it still needs and only then looks at tags: one round trip per pass, not per row
@@ -249,22 +271,20 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
             if (!sgd) issue_row<NP>(own_ms, lane, xm);
             xt = issue_tail(own_tail, lane & 1);
         }
-        if (!part_ok) {
 #pragma unroll
-            for (int q = 0; q < G; ++q) {
-                const int src = (q < n) ? q : 0;
-                const int a = bcast_i(d.x, src), b = bcast_i(d.z, src) & 0x3fffffff;
-                const uint32_t va = (uint32_t)bcast_i(d.y, src), vb = (uint32_t)bcast_i(d.w, src);
-                if constexpr (ITEM) {
-                    issue_row<NP>(T.U + (va & 1u) * T.ustride + (size_t)a * T.kp, lane, xa[q]);
-                    xta[q] = v2u{0u, va};
-                } else {
-                    issue_row<NP>(T.V + (va & 1u) * T.istride + (size_t)a * T.kp, lane, xa[q]);
-                    xta[q] = issue_bias(T.tailV + ((size_t)(va & 1u) * st.n_items + a) * 4);
-                }
-                issue_row<NP>(T.V + (vb & 1u) * T.istride + (size_t)b * T.kp, lane, xb[q]);
-                xtb[q] = issue_bias(T.tailV + ((size_t)(vb & 1u) * st.n_items + b) * 4);
+        for (int q = 0; q < G; ++q) {
+            const int src = (q < n) ? q : 0;
+            const int a = bcast_i(d.x, src), b = bcast_i(d.z, src) & 0x3fffffff;
+            const uint32_t va = (uint32_t)bcast_i(d.y, src), vb = (uint32_t)bcast_i(d.w, src);
+            if constexpr (ITEM) {
+                issue_row<NP>(T.U + (va & 1u) * T.ustride + (size_t)a * T.kp, lane, xa[q]);
+                xta[q] = v2u{0u, va};
+            } else {
+                issue_row<NP>(T.V + (va & 1u) * T.istride + (size_t)a * T.kp, lane, xa[q]);
+                xta[q] = issue_bias(T.tailV + ((size_t)(va & 1u) * st.n_items + a) * 4);
             }
+            issue_row<NP>(T.V + (vb & 1u) * T.istride + (size_t)b * T.kp, lane, xb[q]);
+            xtb[q] = issue_bias(T.tailV + ((size_t)(vb & 1u) * st.n_items + b) * 4);
         }
         if (!o.ok) {
             bool lane_own = row_tagged<NP>(xo, own_ver) && xt.y == own_ver && xt.w == own_ver;
@@ -282,30 +302,14 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
                 o.exp_odd = (uint32_t)bcast_i((int)xt.z, 1);
             }
         }
-        if (!part_ok) {
-            bool lane_part = true;
+        bool lane_part = true;
 #pragma unroll
-            for (int q = 0; q < G; ++q) {
-                const int src = (q < n) ? q : 0;
-                const uint32_t va = (uint32_t)bcast_i(d.y, src), vb = (uint32_t)bcast_i(d.w, src);
-                lane_part = lane_part && row_tagged<NP>(xa[q], va) && row_tagged<NP>(xb[q], vb) && xtb[q].y == vb && xta[q].y == va;
-            }
-            if (__all(lane_part)) {
-                part_ok = true;
-#ifdef TKR_FLOW_TRACE
-                o.t_part = __builtin_amdgcn_s_memrealtime();
-#endif
-                // The partner rows are in registers: acknowledge the reads NOW (lane q: one add on rd[version & 1] of both
-                // partner rows of occurrence q), not after this task's own row has arrived too -- the next writers of those
-                // rows are waiting for exactly this.
-                if (!(T.tune & 1u) && lane < n) {
-                    uint32_t* pa_rd = (ITEM ? T.rdU : T.rdV) + 2 * (size_t)d.x + (d.y & 1);
-                    uint32_t* pb_rd = T.rdV + 2 * (size_t)(d.z & 0x3fffffff) + (d.w & 1);
-                    __hip_atomic_fetch_add(pa_rd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(pb_rd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+        for (int q = 0; q < G; ++q) {
+            const int src = (q < n) ? q : 0;
+            const uint32_t va = (uint32_t)bcast_i(d.y, src), vb = (uint32_t)bcast_i(d.w, src);
+            lane_part = lane_part && row_tagged<NP>(xa[q], va) && row_tagged<NP>(xb[q], vb) && xtb[q].y == vb && xta[q].y == va;
         }
+        const bool part_ok = __all(lane_part);
         // The first pass has waited for its loads, so the ticket taken before them is back too: the record of the NEXT task is
         // fetched now and lands while this task validates, waits and computes -- a task used to start with the round trip of its
         // ticket behind the previous task's write-through stores (0.4 us) and then the round trip of its record (0.55 us),
@@ -316,28 +320,25 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
             if (nx.idx != 0xffffffffu && lane < 8) nx.w = prec[(size_t)nx.idx * 8 + lane];
             nx.have = true;
         }
-        if (part_ok) break;                         // the own row alone is waited for in the tight loop below
+        if (part_ok) break;
         // How far away is what we wait for?  The buffer of version v holds v, v-2, v-4, ...: a tag of v-2 means the producer is
-        // one or two updates away (poll), v-4 or older at least three -- two whole hand-offs, ~2 us each: sleep through that
-        // (a waiting wave that polls costs everybody's loads latency, a sleeping one nothing)
+        // one or two updates away (poll), v-4 or older at least three -- two whole hand-offs: sleep through that (a waiting
+        // wave that polls costs everybody's loads latency, a sleeping one nothing)
         bool far = false;
         if (!(T.tune & 2u)) {
-            if (!o.ok) far = (int)(own_ver - (uint32_t)bcast_i((int)xt.y, 0)) >= 4;
-            if (!part_ok) {
 #pragma unroll
-                for (int q = 0; q < G; ++q) {
-                    const int src = (q < n) ? q : 0;
-                    far = far || (int)((uint32_t)bcast_i(d.y, src) - (uint32_t)bcast_i((int)xa[q][0].y, 0)) >= 4 ||
-                          (int)((uint32_t)bcast_i(d.w, src) - (uint32_t)bcast_i((int)xb[q][0].y, 0)) >= 4;
-                }
+            for (int q = 0; q < G; ++q) {
+                const int src = (q < n) ? q : 0;
+                far = far || (int)((uint32_t)bcast_i(d.y, src) - (uint32_t)bcast_i((int)xa[q][0].y, 0)) >= 4 ||
+                      (int)((uint32_t)bcast_i(d.w, src) - (uint32_t)bcast_i((int)xb[q][0].y, 0)) >= 4;
             }
         }
         if (far) __builtin_amdgcn_s_sleep(127);      // 127 x 64 clocks = 3.4 us
-        if (spin_fail(waited, ctl, part_ok ? 0 : 4)) {      // only the own row missing: three loads per pass, poll at the round-trip rate
+        if (spin_fail(waited, ctl, 4)) {
             if (waited >= kSpinLimit && lane == 0 &&                     // post-mortem of the first wave that gave up
                 atomicCAS(ctl + kCtlDebug, 0u, 1u) == 0u) {
                 ctl[kCtlDebug + 1] = o.ok;
-                ctl[kCtlDebug + 2] = part_ok;
+                ctl[kCtlDebug + 2] = 0u;
                 ctl[kCtlDebug + 3] = own_ver;
                 ctl[kCtlDebug + 4] = xo[0].y;
                 ctl[kCtlDebug + 5] = xt.y;
@@ -355,12 +356,67 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
             return false;
         }
     }
-    // Only the own row is missing -- the state of every task on a chain through a popular row, and what the chain's period is
-    // made of.  A pass of the general loop above is ~300 instructions of one wave with a SIMD to itself (which rows are still
-    // missing, which of them are far away, ...): ~0.4 us on top of the loads' round trip, and a link was 1.7 us even with its
-    // arithmetic compiled out, against 0.6-0.8 us for the same three stores and loads in a bare ping-pong
-    // (scripts/ubench/hop_xcd.hip).  This loop is the bare ping-pong: three loads, the tags, one branch.
+    spins += waited;
+#ifdef TKR_FLOW_TRACE
+    o.t_part = __builtin_amdgcn_s_memrealtime();
+#endif
+    // The partner rows are in registers: acknowledge the reads NOW (lane q: one add on rd[version & 1] of both partner rows of
+    // occurrence q), not after this task's own row has arrived too -- the next writers of those rows are waiting for exactly this.
+    if (lane < n) {
+        uint32_t* pa_rd = (ITEM ? T.rdU : T.rdV) + 2 * (size_t)d.x + (d.y & 1);
+        uint32_t* pb_rd = T.rdV + 2 * (size_t)(d.z & 0x3fffffff) + (d.w & 1);
+        __hip_atomic_fetch_add(pa_rd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(pb_rd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // pack: everything the arithmetic needs from the partner rows, 3 registers per occurrence instead of 12
+    constexpr int SH = group_shift<G>();
+    const int myq = lane >> SH;
+    const bool l2 = (st.mode == 0);
+    pk.n = n; pk.roles = 0u; pk.lam_sum = 0.f; pk.loss_part = 0.f; pk.bias_me = 0.f; pk.role_me = false;
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        float av[NE], bv[NE];
+        row_values<NP>(xa[q], av);
+        row_values<NP>(xb[q], bv);
+        const bool live = q < n;
+        const float ta = __uint_as_float(xta[q].x), tb = __uint_as_float(xtb[q].x);
+        if constexpr (ITEM) {
+            float c = 0.f;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { c = fmaf(av[e], bv[e], c); pk.pa[q][e] = live ? av[e] : 0.f; }
+            pk.c[q] = live ? c : 0.f;
+            const bool role_j = live && bcast_i(d.z, live ? q : 0) < 0;
+            if (live) { pk.roles |= (role_j ? 1u : 0u) << q; pk.lam_sum += role_j ? st.lj : st.li; }
+            if (myq == q) { pk.bias_me = tb; pk.role_me = role_j; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) pk.pa[q][e] = live ? av[e] - bv[e] : 0.f;
+            pk.c[q] = 0.f;
+            if (live) pk.lam_sum += st.lu;
+            if (myq == q) pk.bias_me = ta - tb;
+            if (want_loss && live) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    pk.loss_part += l2 ? 0.5f * (av[e] * av[e] * st.li + bv[e] * bv[e] * st.lj) : fabsf(av[e]) * st.li + fabsf(bv[e]) * st.lj;
+                if (myq == q && (lane & ((1 << SH) - 1)) == 0)
+                    pk.loss_part += l2 ? 0.5f * (ta * ta + tb * tb) * st.lb : (fabsf(ta) + fabsf(tb)) * st.lb;
+            }
+        }
+    }
+    return true;
+}
+
+// Only the own row is missing -- the state of every task on a chain through a popular row, and what the chain's period is made
+// of.  A pass of the general loop of flow_fetch is ~300 instructions of one wave with a SIMD to itself: ~0.4 us on top of the
+// loads' round trip, and a link was 1.7 us even with its arithmetic compiled out, against 0.6-0.8 us for the same three stores
+// and loads in a bare ping-pong (scripts/ubench/hop_xcd.hip).  This loop is the bare ping-pong: three loads, the tags, one branch.
+template <int NP>
+__device__ __forceinline__ bool flow_own(const FlowTables& T, int lane, const u64* own_p, const u64* own_ms, const u64* own_tail,
+                                         const uint32_t* own_rd, uint32_t own_ver, float (&own)[2 * NP], float (&ms)[2 * NP], Own& o,
+                                         bool sgd, uint32_t* ctl, uint32_t& spins) {
     if (!o.ok) {
+        v4u xo[NP], xm[NP], xt = {0u, 0u, 0u, 0u};
+        uint32_t waited = 0;
         for (;;) {
             issue_row<NP>(own_p, lane, xo);
             if (!sgd) issue_row<NP>(own_ms, lane, xm);
@@ -371,18 +427,17 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
             // a tag two versions of this buffer back: the producer is at least three updates away -- sleep through two hand-offs
             if (!(T.tune & 2u) && (int)(own_ver - (uint32_t)bcast_i((int)xt.y, 0)) >= 4) __builtin_amdgcn_s_sleep(127);
             if (spin_fail(waited, ctl, 0)) {
-                if (waited >= kSpinLimit && lane == 0 && atomicCAS(ctl + kCtlDebug, 0u, 1u) == 0u) {
+                if (waited >= kSpinLimit && lane == 0 && atomicCAS(ctl + kCtlDebug, 0u, 3u) == 0u) {
                     ctl[kCtlDebug + 1] = 0u;
                     ctl[kCtlDebug + 2] = 1u;
                     ctl[kCtlDebug + 3] = own_ver;
                     ctl[kCtlDebug + 4] = xo[0].y;
                     ctl[kCtlDebug + 5] = xt.y;
-                    ctl[kCtlDebug + 13] = ITEM;
-                    ctl[kCtlDebug + 14] = (uint32_t)n;
                 }
                 return false;
             }
         }
+        spins += waited;
         o.ok = true;
 #ifdef TKR_FLOW_TRACE
         o.t_valid = __builtin_amdgcn_s_memrealtime();
@@ -397,34 +452,28 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
     // the acknowledge count is loaded NOW, once, and returns while the gradients are computed (not in every pass: the word is
     // under atomic update by the readers, and the copy of an earlier pass predates the last acknowledgements anyway)
     o.rd = ld_u32(own_rd);
-    spins += waited;
-#ifdef TKR_FLOW_TRACE
-    if (T.tune & 4u) return true;                 // experiment: no gradients at all (what is the link without its arithmetic?)
-#endif
+    return true;
+}
 
-    // x_t of every occurrence: one dot product each (user row: <u, v_i - v_j>; item row: <u, v_row - v_other>,
-    // single/bpr.py:87-89), all reduced together; lane L then holds occurrence L >> SH and the sigmoids run side by side
-    constexpr int SH = G <= 4 ? 4 : (G == 8 ? 3 : 2);
-    static_assert(G <= 4 || G == 8 || G == 16, "group width");
+// x_t of every occurrence: one dot product each (user row: <u, v_i - v_j>; item row: <u, v_row - v_other>, single/bpr.py:87-89),
+// all reduced together; lane L then holds occurrence L >> shift and the sigmoids run side by side.  Then the data terms of the
+// gradient per occurrence and the regulariser of the own row once for all of them (n * lambda * own).
+template <int NP, int G, bool ITEM>
+__device__ __forceinline__ void flow_apply(const tkr_flow_state& st, const FlowTables& T, int lane, const Packed<NP, G>& pk,
+                                           const float (&own)[2 * NP], const Own& o, float (&g)[2 * NP], float& gb,
+                                           float& loss_lane, bool want_loss) {
+    constexpr int NE = 2 * NP;
+    constexpr int SH = group_shift<G>();
+#ifdef TKR_FLOW_TRACE
+    if (T.tune & 4u) return;                      // experiment: no gradients at all (what is the link without its arithmetic?)
+#endif
     const bool l2 = (st.mode == 0);
     float part[G];
 #pragma unroll
     for (int q = 0; q < G; ++q) {
-        float acc = 0.f;
-        if (q < n) {
+        float acc = -pk.c[q];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const float a0 = __uint_as_float(xa[q][p].x), a1 = __uint_as_float(xa[q][p].z);
-                const float b0 = __uint_as_float(xb[q][p].x), b1 = __uint_as_float(xb[q][p].z);
-                if constexpr (ITEM) {
-                    acc = fmaf(a0, own[2 * p] - b0, acc);
-                    acc = fmaf(a1, own[2 * p + 1] - b1, acc);
-                } else {
-                    acc = fmaf(own[2 * p], a0 - b0, acc);
-                    acc = fmaf(own[2 * p + 1], a1 - b1, acc);
-                }
-            }
-        }
+        for (int e = 0; e < NE; ++e) acc = fmaf(pk.pa[q][e], own[e], acc);
         part[q] = acc;
     }
     float dotv;
@@ -439,68 +488,92 @@ __device__ __forceinline__ bool flow_group(const tkr_flow_state& st, const FlowT
     } else {
         dotv = reduce_multi<G>(part, lane);
     }
-    float bd = 0.f, ta_me = 0.f, tb_me = 0.f;
-    bool role_me = false;
-#pragma unroll
-    for (int q = 0; q < G; ++q) {
-        if (myq == q) {
-            ta_me = __uint_as_float(xta[q].x);
-            tb_me = __uint_as_float(xtb[q].x);
-        }
-    }
-    if constexpr (ITEM) {
-        role_me = __shfl(d.z, myq) < 0;
-        bd = o.b - tb_me;
-    } else {
-        bd = ta_me - tb_me;
-    }
-    const float x_me = (ITEM && role_me) ? -(bd + dotv) : (bd + dotv);
+    const float bd = ITEM ? o.b - pk.bias_me : pk.bias_me;
+    const float x_me = (ITEM && pk.role_me) ? -(bd + dotv) : (bd + dotv);
     const float s_me = fast_sigmoid_neg(x_me);
     if constexpr (!ITEM) {
-        if (want_loss && myq < n && (lane & ((1 << SH) - 1)) == 0) {
-            loss_lane += softplus_neg(x_me);
-            loss_lane += l2 ? 0.5f * (ta_me * ta_me + tb_me * tb_me) * st.lb : (fabsf(ta_me) + fabsf(tb_me)) * st.lb;
+        if (want_loss) {
+            if (myq < pk.n && (lane & ((1 << SH) - 1)) == 0) loss_lane += softplus_neg(x_me);
+            float own_part = 0.f;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) own_part += l2 ? 0.5f * own[e] * own[e] * st.lu : fabsf(own[e]) * st.lu;
+            loss_lane += pk.loss_part + (float)pk.n * own_part;
         }
     }
-    // data terms per occurrence; the regulariser of the own row once for all of them (n * lambda * own: every occurrence adds the
-    // same term -- one multiply-add per element instead of one per occurrence on the chain through the popular rows)
-    float lam_sum = 0.f;
 #pragma unroll
     for (int q = 0; q < G; ++q) {
-        if (q < n) {
-            float pa[NE], pb[NE];
-            row_values<NP>(xa[q], pa);
+        if (q < pk.n) {
             const float s = bcast_f(s_me, q << SH);
-            if constexpr (!ITEM) {
-                row_values<NP>(xb[q], pb);
-#pragma unroll
-                for (int e = 0; e < NE; ++e) {
-                    g[e] = fmaf(-s, pa[e] - pb[e], g[e]);
-                    if (want_loss) loss_lane += l2 ? 0.5f * (own[e] * own[e] * st.lu + pa[e] * pa[e] * st.li + pb[e] * pb[e] * st.lj)
-                                                   : fabsf(own[e]) * st.lu + fabsf(pa[e]) * st.li + fabsf(pb[e]) * st.lj;
-                }
-                lam_sum += st.lu;
-            } else {
-                const bool role_j = bcast_i(d.z, q) < 0;
-                const float sg = role_j ? s : -s;
-#pragma unroll
-                for (int e = 0; e < NE; ++e) g[e] = fmaf(sg, pa[e], g[e]);
+            float sg = -s;
+            if constexpr (ITEM) {
+                if ((pk.roles >> q) & 1u) sg = s;
                 gb += sg;
-                lam_sum += role_j ? st.lj : st.li;
             }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) g[e] = fmaf(sg, pk.pa[q][e], g[e]);
         }
     }
 #pragma unroll
-    for (int e = 0; e < NE; ++e) g[e] = fmaf(lam_sum, l2 ? own[e] : sgn(own[e]), g[e]);
-    if constexpr (ITEM) gb = fmaf((float)n * st.lb, l2 ? o.b : sgn(o.b), gb);
+    for (int e = 0; e < NE; ++e) g[e] = fmaf(pk.lam_sum, l2 ? own[e] : sgn(own[e]), g[e]);
+    if constexpr (ITEM) gb = fmaf((float)pk.n * st.lb, l2 ? o.b : sgn(o.b), gb);
+}
 
-    if ((T.tune & 1u) && lane < n) {
-        uint32_t* pa_rd = (ITEM ? T.rdU : T.rdV) + 2 * (size_t)d.x + (d.y & 1);
-        uint32_t* pb_rd = T.rdV + 2 * (size_t)(d.z & 0x3fffffff) + (d.w & 1);
-        __hip_atomic_fetch_add(pa_rd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(pb_rd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// All the occurrences of one task.  Up to four sit in the record; five to sixteen come from the occurrence list in groups of
+// eight, and the partner rows of BOTH groups are fetched before the own row is waited for; beyond that, group after group.
+template <int NP, bool ITEM>
+__device__ __forceinline__ bool run_task(const tkr_flow_state& st, const FlowTables& T, int lane, int n_occ, int first, const int4 w,
+                                         const int4* __restrict__ pocc, const u64* own_p, const u64* own_ms, const u64* own_tail,
+                                         const uint32_t* own_rd, uint32_t ver, float (&own)[2 * NP], float (&ms)[2 * NP], Own& o,
+                                         float (&g)[2 * NP], float& gb, float& loss_lane, bool want_loss, bool sgd, uint32_t* ctl,
+                                         uint32_t& spins, NextTask& nx, uint32_t ticket, int home, uint32_t total,
+                                         const int4* __restrict__ prec) {
+#define TKR_FETCH(GG, nn, dd, PK)                                                                                                  \
+    flow_fetch<NP, GG, ITEM>(st, T, lane, nn, dd, own_p, own_ms, own_tail, ver, own, ms, o, want_loss, sgd, ctl, spins, nx, ticket, \
+                             home, total, prec, PK)
+#define TKR_ONE(GG, nn, dd)                                                                                    \
+    {                                                                                                          \
+        Packed<NP, GG> pk;                                                                                     \
+        if (!TKR_FETCH(GG, nn, dd, pk)) return false;                                                          \
+        if (!flow_own<NP>(T, lane, own_p, own_ms, own_tail, own_rd, ver, own, ms, o, sgd, ctl, spins)) return false; \
+        flow_apply<NP, GG, ITEM>(st, T, lane, pk, own, o, g, gb, loss_lane, want_loss);                          \
+        return true;                                                                                           \
+    }
+    if (n_occ <= 4) {                             // the common case: its occurrences sit in the record (lanes 2..5)
+        const int src = (lane + 2) & 7;
+        const int4 d = make_int4(__shfl(w.x, src), __shfl(w.y, src), __shfl(w.z, src), __shfl(w.w, src));
+        switch (n_occ) {
+            case 1: TKR_ONE(1, 1, d)
+            case 2: TKR_ONE(2, 2, d)
+            case 3: TKR_ONE(3, 3, d)
+            default: TKR_ONE(4, 4, d)
+        }
+    }
+    constexpr int kBig = 8;
+    if (n_occ <= 2 * kBig) {
+        const int n0 = min(kBig, n_occ), n1 = n_occ - n0;
+        int4 d0 = make_int4(0, 0, 0, 0), d1 = make_int4(0, 0, 0, 0);
+        if (lane < n0) d0 = pocc[first + lane];
+        if (lane < n1) d1 = pocc[first + kBig + lane];
+        Packed<NP, kBig> p0, p1;
+        if (!TKR_FETCH(kBig, n0, d0, p0)) return false;
+        if (n1 > 0 && !TKR_FETCH(kBig, n1, d1, p1)) return false;
+        if (!flow_own<NP>(T, lane, own_p, own_ms, own_tail, own_rd, ver, own, ms, o, sgd, ctl, spins)) return false;
+        flow_apply<NP, kBig, ITEM>(st, T, lane, p0, own, o, g, gb, loss_lane, want_loss);
+        if (n1 > 0) flow_apply<NP, kBig, ITEM>(st, T, lane, p1, own, o, g, gb, loss_lane, want_loss);
+        return true;
+    }
+    for (int done = 0; done < n_occ; done += kBig) {          // (no batch of 256 has such a row; batches of thousands do)
+        const int n = min(kBig, n_occ - done);
+        int4 d = make_int4(0, 0, 0, 0);
+        if (lane < n) d = pocc[first + done + lane];
+        Packed<NP, kBig> pk;
+        if (!TKR_FETCH(kBig, n, d, pk)) return false;
+        if (done == 0 && !flow_own<NP>(T, lane, own_p, own_ms, own_tail, own_rd, ver, own, ms, o, sgd, ctl, spins)) return false;
+        flow_apply<NP, kBig, ITEM>(st, T, lane, pk, own, o, g, gb, loss_lane, want_loss);
     }
     return true;
+#undef TKR_ONE
+#undef TKR_FETCH
 }
 
 #ifdef TKR_FLOW_TRACE
@@ -601,32 +674,10 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
         float gb = 0.f, loss_lane = 0.f, loss_x = 0.f;
 
         const u64* own_tail = tabT + ((size_t)(ver & 1u) * n_rows + row) * 4;
-#define TKR_FLOW_GROUP(GG, nn, dd)                                                                                             \
-    (is_item ? flow_group<NP, GG, true>(st, T, lane, nn, dd, tabP + roff, tabM + roff, own_tail, own_rd, ver, own, ms, o, g, gb,   \
-                                        loss_lane, loss_x, false, sgd, ctl, spins, nx, ticket, home, total, prec)                \
-             : flow_group<NP, GG, false>(st, T, lane, nn, dd, tabP + roff, tabM + roff, own_tail, own_rd, ver, own, ms, o, g, gb,  \
-                                         loss_lane, loss_x, want_loss, sgd, ctl, spins, nx, ticket, home, total, prec))
-        if (n_occ <= 4) {                         // the common case: its occurrences sit in the record (lanes 2..5)
-            const int src = (lane + 2) & 7;
-            const int4 d = make_int4(__shfl(w.x, src), __shfl(w.y, src), __shfl(w.z, src), __shfl(w.w, src));
-            switch (n_occ) {
-                case 1: alive = TKR_FLOW_GROUP(1, 1, d); break;
-                case 2: alive = TKR_FLOW_GROUP(2, 2, d); break;
-                case 3: alive = TKR_FLOW_GROUP(3, 3, d); break;
-                default: alive = TKR_FLOW_GROUP(4, 4, d); break;
-            }
-        } else {                                  // popular rows: up to kBig occurrences per pass from the occurrence list
-            // (8 per pass: at the ML-10M shape the most popular item occurs ~7 times in a 256-batch; wider groups cost
-            // registers -- 16 slots are 192 VGPRs of loads in flight -- and with them the waves that hide everything else)
-            constexpr int kBig = 8;
-            for (int done = 0; done < n_occ && alive; done += kBig) {
-                const int n = min(kBig, n_occ - done);
-                int4 d = make_int4(0, 0, 0, 0);
-                if (lane < n) d = pocc[first + done + lane];
-                alive = TKR_FLOW_GROUP(kBig, n, d);
-            }
-        }
-#undef TKR_FLOW_GROUP
+        alive = is_item ? run_task<NP, true>(st, T, lane, n_occ, first, w, pocc, tabP + roff, tabM + roff, own_tail, own_rd, ver, own, ms, o,
+                                             g, gb, loss_lane, false, sgd, ctl, spins, nx, ticket, home, total, prec)
+                        : run_task<NP, false>(st, T, lane, n_occ, first, w, pocc, tabP + roff, tabM + roff, own_tail, own_rd, ver, own, ms,
+                                              o, g, gb, loss_lane, want_loss, sgd, ctl, spins, nx, ticket, home, total, prec);
         if (!alive) break;
         TKR_PROF_MARK(2)
         TKR_TRACE(1)
