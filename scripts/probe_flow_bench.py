@@ -33,3 +33,4 @@ for w in waves:
         tasks = max(int(pr[5]), 1)
         print('   cycles per task: grab %.0f  record %.0f  rows+math %.0f  war %.0f  finish %.0f   (tasks %d, idle slots %d; 2.4 GHz: 2400 cycles = 1 us)'
               % (pr[0] / tasks, pr[1] / tasks, pr[2] / tasks, pr[3] / tasks, pr[4] / tasks, tasks, int(pr[6])), flush=True)
+        print('   acknowledge wait: %.0f %% of it in item tasks' % (100.0 * pr[7] / max(int(pr[3]), 1)), flush=True)

@@ -55,7 +55,7 @@ constexpr int kCtlLeave = kCtlArrive + 1;     // workgroups that have taken thei
 constexpr int kCtlStatus = kCtlArrive + 2;
 constexpr int kCtlSpins = kCtlArrive + 3;     // diagnostics: spin passes taken
 constexpr int kCtlDebug = kCtlArrive + 8;     // 16 words: what the first wave that gave up was waiting for
-constexpr int kCtlProf = kCtlArrive + 32;     // TKR_FLOW_PROFILE=1: 8 x uint64 cycle sums (grab, record, rows, war, finish, tasks, idle slots, -)
+constexpr int kCtlProf = kCtlArrive + 32;     // TKR_FLOW_PROFILE=1: 8 x uint64 cycle sums (grab, record, rows, war, finish, tasks, idle slots, war of item tasks)
 constexpr uint32_t kSpinLimit = 1u << 20;     // passes of ONE wait (each >= ~0.3 us) before a wave gives up
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));      // two granules: {value0, tag0, value1, tag1}
@@ -736,6 +736,7 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
         }
         spins += waited;
         if (!alive) break;
+        if constexpr (PROF) { if (is_item) prof[7] += __builtin_amdgcn_s_memtime() - tq; }      // the item tasks' share of the acknowledge wait
         TKR_PROF_MARK(3)
         TKR_TRACE(2)
 
