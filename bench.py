@@ -133,41 +133,104 @@ def _chunk_crossings(steps, B):
     return steps // _engine._chunk_cap(B) + 1
 
 
-def timed_run(eng, csr, B, steps, warmup, sync_every, world, names=None):
-    """warmup untimed, then exactly `steps` batches between barriers; returns (wall_s, step_kernel_ms)"""
-    import dist as tdist
-    isync = tdist.ItemSync(eng, names)
+class Loop:
+    """The loop of single/bpr.py:136-147 as BPR.train runs it on this rank: batches in stream order and, at N > 1, the exchange
+    of the item-side tables at its REAL cadence -- every `sync_every` batches, counted across run() calls (round 2 wrapped
+    every call in begin()/end(): a 20-step timed call then paid one whole exchange that belongs to an epoch of 488 batches)."""
 
-    def run(n):
+    def __init__(self, eng, csr, B, sync_every, world, names=None):
+        import dist as tdist
+        self.eng, self.csr, self.B, self.sync_every, self.world = eng, csr, B, sync_every, world
+        self.isync = tdist.ItemSync(eng, names) if world > 1 else None
+        self.since = 0                   # batches since the last exchange
+        self.exchanges = 0
+
+    def run(self, n):
         done = 0
         while done < n:
-            m = min(n - done, sync_every)
-            if world > 1:
-                isync.begin()
-            eng.run_batches(csr, m, B, want_loss=False)
-            if world > 1:
-                isync.end()
+            if self.isync is not None and self.since == 0:
+                self.isync.begin()
+            m = min(n - done, self.sync_every - self.since)
+            self.eng.run_batches(self.csr, m, self.B, want_loss=False)
             done += m
+            self.since += m
+            if self.since == self.sync_every:
+                self.since = 0
+                if self.isync is not None:
+                    self.isync.end()
+                    self.exchanges += 1
 
-    eng.reserve_events(-(-steps // sync_every) + _chunk_crossings(steps, B))      # created now, not between the timed launches
-    run(warmup)
+
+def _fence(world):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+
+
+def timed_run(eng, csr, B, steps, warmup, sync_every, world, names=None, loop=None):
+    """warmup untimed, then exactly `steps` batches between barriers; returns (wall_s, step_kernel_ms, loop).
+    What the timed region contains: for each batch its (u, i, j) draw + plan (K1) AND its step -- settle() drops
+    whatever an earlier call planned but did not run, and run_batches plans exactly what it is asked to run."""
+    loop = loop or Loop(eng, csr, B, sync_every, world, names)
+    eng.reserve_events(-(-(steps + warmup) // sync_every) + _chunk_crossings(steps, B) + 2)      # created now, not between the timed launches
+    loop.run(warmup)
+    eng.settle()                 # nothing planned ahead: the timed batches sample and plan themselves (also reports a failed step)
+    _fence(world)
     eng.step_events = []
+    before = loop.exchanges
     t0 = time.perf_counter()
-    run(steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    loop.run(steps)
+    _fence(world)
     wall = time.perf_counter() - t0
     step_ms = sum(a.elapsed_time(b) for a, b, _ in eng.step_events)
     launches = sum(n for _, _, n in eng.step_events)
     eng.step_events = None
+    eng.check()
     assert launches == steps
-    return wall, step_ms
+    loop.timed_exchanges = loop.exchanges - before
+    return wall, step_ms, loop
+
+
+def max_over_ranks(x, device, world):
+    if world == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def epoch_mode(eng, csr, B, k, world, device, loop, epochs=2):
+    """Whole reference epochs: `epochs` x sync_every batches per rank (sync_every = (epoch_sample_limit // B) // N, what
+    BPR.train gives a rank per epoch), each followed by its exchange at N > 1.  At N = 1 this is the steady state of the
+    headline configuration (2 x 3906 = 7812 batches, K1 of every batch inside the timed region)."""
+    per = loop.sync_every
+    loop.run((per - loop.since) % per)           # to an epoch boundary
+    if loop.isync is not None:
+        loop.isync.timing = []
+    wall, step_ms, _ = timed_run(eng, csr, B, epochs * per, 0, per, world, loop=loop)
+    wall = max_over_ranks(wall, device, world)
+    us = step_ms * 1e3 / (epochs * per)
+    gbs = B * algorithmic_bytes_per_triplet(k) / (us * 1e-6) / 1e9
+    out = {'epochs': epochs, 'batches_per_rank_per_epoch': per, 'steps': epochs * per, 'value': world * epochs * per * B / wall,
+           'unit': 'triplets/s', 'ms_per_step': wall * 1e3 / (epochs * per), 'ms_per_epoch': wall * 1e3 / epochs,
+           'timed_region': 'per batch: K1 (draw + plan) and the step; per epoch: the exchange of the item tables' if world > 1
+                           else 'per batch: K1 (draw + plan, side stream behind the previous chunk) and the step',
+           'roofline': {'kernel': 'tkr::bpr_flow_kernel' if eng.layout == 'flow' else 'tkr::bpr_step_kernel', 'bound': 'hbm', 'achieved': gbs,
+                        'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'launch_us': us,
+                        'algorithmic_bytes_per_launch': B * algorithmic_bytes_per_triplet(k), 'traffic': None,
+                        'traffic_from_profile': pmc_traffic('bpr_flow_B%d' % B) if (k == 128 and eng.layout == 'flow') else None}}
+    if loop.isync is not None:
+        t = loop.isync.timing
+        loop.isync.timing = None
+        if t:
+            parts = [(a.elapsed_time(b), b.elapsed_time(c), c.elapsed_time(d)) for a, b, c, d in t]
+            n = len(parts)
+            out['exchanges'] = n
+            out['exchange_us'] = {'pack': 1e3 * sum(p[0] for p in parts) / n, 'collective': 1e3 * sum(p[1] for p in parts) / n,
+                                  'unpack': 1e3 * sum(p[2] for p in parts) / n,
+                                  'note': 'HIP events on the training stream around tkr_sync_*pack / all_reduce / tkr_sync_*unpack, mean per exchange, rank 0'}
+    return out
 
 
 def cpu_baseline(r, k, B, budget_s=12.0):
@@ -299,7 +362,7 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
     out = {}
     for key, sparse in (('sparse_view', None), ('dense_view', False)):
         eng = _engine.VbprEngine(n_users, n_items, k, d, feat, hp, device, seed=3, sparse=sparse)
-        wall, step_ms = timed_run(eng, csr, B, steps, warmup, 10 ** 9, 1, names=eng.replicated_names)
+        wall, step_ms, _ = timed_run(eng, csr, B, steps, warmup, 10 ** 9, 1, names=eng.replicated_names)
         step_s = step_ms * 1e-3 / steps
         if eng.sparse is not None:
             # dense optimizer traffic + the CSC walk + one cem row and one icb value per nonzero of the 2B gathered items
@@ -324,7 +387,7 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
     # throughput mode of the same model: batch_size 8192 (a legal train() argument), sparse view
     eng = _engine.VbprEngine(n_users, n_items, k, d, feat, hp, device, seed=3)
     Bt, st_ = 8192, 48
-    wall, step_ms = timed_run(eng, csr, Bt, st_, st_, 10 ** 9, 1, names=eng.replicated_names)
+    wall, step_ms, _ = timed_run(eng, csr, Bt, st_, st_, 10 ** 9, 1, names=eng.replicated_names)
     step_s = step_ms * 1e-3 / st_
     bytes_ = 16.0 * d * kh + 8.0 * nnz + 2.0 * Bt * (nnz / n_items) * (4.0 * kh + 12.0) + Bt * (48.0 * kh + 56)
     res['throughput_mode'] = {'batch_size': Bt, 'steps': st_, 'value': st_ * Bt / wall, 'unit': 'triplets/s', 'ms_per_step': wall * 1e3 / st_,
@@ -339,7 +402,7 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
     assert eng.sparse is None                # fully dense: the MFMA kernels (V1 / V3).  They tile d by 128 / 64 columns: at d_c = 128 the projection
                                              # and the dense update run on 1-2 workgroups (55 us per batch; the gather view is worse, 244 us: its
                                              # column walk gives one wave a whole 10,380-entry column)
-    wall, step_ms = timed_run(eng, csr, B, steps, warmup, 10 ** 9, 1, names=eng.replicated_names)
+    wall, step_ms, _ = timed_run(eng, csr, B, steps, warmup, 10 ** 9, 1, names=eng.replicated_names)
     step_s = step_ms * 1e-3 / steps
     bytes_ = B * (2 * 4 * dc * 2 + 48.0 * kh + 56) + 16.0 * dc * kh       # feature rows (V1 + V3) + the sparse rows + dense optimizer traffic
     res['dense_dc128'] = {'value': steps * B / wall, 'unit': 'triplets/s', 'steps': steps, 'ms_per_step': wall * 1e3 / steps,
@@ -361,7 +424,7 @@ def netflix_train_bench(k, device, B=256, steps=2048, warmup=512):
     csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, tr_users, device)
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=1e-4, mode='l2')
     eng = _engine.BprEngine(n_users, n_items, k, hp, device, seed=4321)
-    wall, step_ms = timed_run(eng, csr, B, steps, warmup, 10 ** 9, 1)
+    wall, step_ms, _ = timed_run(eng, csr, B, steps, warmup, 10 ** 9, 1)
     us = step_ms * 1e3 / steps
     gbs = B * algorithmic_bytes_per_triplet(k) / (us * 1e-6) / 1e9
     return {'value': steps * B / wall, 'unit': 'triplets/s', 'steps': steps, 'ms_per_step': wall * 1e3 / steps,
@@ -430,12 +493,9 @@ def main():
 
     B, k = args.batch_size, args.k
     r, csr, eng, nnz = build_problem(args.shape, k, rank, world, device)
-    sync_every = max(1, (args.epoch_sample_limit // B) // world) if world > 1 else args.steps + args.warmup
-    wall, step_ms = timed_run(eng, csr, B, args.steps, args.warmup, sync_every, world)
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    sync_every = max(1, (args.epoch_sample_limit // B) // world)       # batches per rank and epoch, as BPR.train deals them (dist.batches_per_rank)
+    wall, step_ms, loop = timed_run(eng, csr, B, args.steps, args.warmup, sync_every, world)
+    wall = max_over_ranks(wall, device, world)
     value = world * args.steps * B / wall
     launch_us = step_ms * 1e3 / args.steps
     achieved = B * algorithmic_bytes_per_triplet(k) / (launch_us * 1e-6) / 1e9
@@ -449,6 +509,11 @@ def main():
                                                                         r['n_users'], r['n_in'] + r['n_out'], nnz, k, B),
                    'batch_size': B, 'k': k, 'sharding': 'users sharded over %d GPU(s), item tables replicated, '
                                                         'all-reduce every %d steps' % (world, sync_every) if world > 1 else 'single GPU'},
+        'timed_region': {'per_batch': ['K1 tkr_sample_plan: (u,i,j) draw + plan of the timed batches (planned inside the region: nothing is left over '
+                                       'from the warm-up)', 'K2f tkr_bpr_flow_run' if eng.layout == 'flow' else 'K2 tkr_bpr_run'],
+                         'exchanges_inside': loop.timed_exchanges,
+                         'note': 'exactly --steps batches; at N > 1 the exchange keeps its per-epoch cadence (every %d batches, counted from the first '
+                                 'warm-up batch), see epoch_mode for whole epochs' % sync_every},
         'roofline': {'kernel': 'tkr::bpr_flow_kernel (one persistent launch per chunk of batches)' if eng.layout == 'flow' else 'tkr::bpr_step_kernel',
                      'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
@@ -456,13 +521,18 @@ def main():
                      'launch_us': launch_us,          # per BATCH: the persistent kernel's launch covers many batches, duration / batches
                      'algorithmic_bytes_per_launch': B * algorithmic_bytes_per_triplet(k)},
     }
+    # whole epochs with K1 of every batch (and, at N > 1, every exchange) inside the timed region: at N = 1 the steady state of the headline
+    em = epoch_mode(eng, csr, B, k, world, device, loop)
+    out['epoch_mode'] = em
+    if world == 1:
+        out['steady_state'] = em
     if rank == 0 and world == 1 and not args.no_extras:
         # throughput mode: same kernels, batch_size 8192 (fresh tables)
         from single import _engine
         B2 = 8192
         eng2 = _engine.BprEngine(eng.n_users, eng.n_items, k, eng.hp, device, seed=99)
         T2 = 1024     # 8 plan chunks of 128: the first chunk's planning is the only one the steps do not hide (with 2 chunks it is half)
-        w2, s2 = timed_run(eng2, csr, B2, T2, T2, 10 ** 9, 1)       # warm-up as long as the run: same chunking, side stream warm
+        w2, s2, _ = timed_run(eng2, csr, B2, T2, T2, 10 ** 9, 1)       # warm-up as long as the run: same chunking, side stream warm
         a2 = B2 * algorithmic_bytes_per_triplet(k) / (s2 * 1e-3 / T2) / 1e9
         out['throughput_mode'] = {'batch_size': B2, 'steps': T2, 'value': T2 * B2 / w2, 'unit': 'triplets/s',
                                   'ms_per_step': w2 * 1e3 / T2,
@@ -474,7 +544,7 @@ def main():
         # batch_size 65,536 and 1,048,576 (planned grid-wide: csrc/planner_big.hip)
         for Bb, Tb in ((65536, 128), (1048576, 8)):
             engb = _engine.BprEngine(eng.n_users, eng.n_items, k, eng.hp, device, seed=98)
-            wb, sb = timed_run(engb, csr, Bb, Tb, Tb, 10 ** 9, 1)
+            wb, sb, _ = timed_run(engb, csr, Bb, Tb, Tb, 10 ** 9, 1)
             ab = Bb * algorithmic_bytes_per_triplet(k) / (sb * 1e-3 / Tb) / 1e9
             out['throughput_mode_B%d' % Bb] = {'batch_size': Bb, 'steps': Tb, 'value': Tb * Bb / wb, 'unit': 'triplets/s', 'ms_per_step': wb * 1e3 / Tb,
                                                'roofline': {'bound': 'hbm', 'achieved': ab, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ab / HBM_PEAK_GBS,
@@ -486,7 +556,7 @@ def main():
         # legacy plain-SGD optimiser (old/methods/bpr.py:57-61): same path, no RMSProp slot traffic
         for Bs, key, steps_s in ((B, 'sgd_mode', 2048), (B2, 'sgd_throughput_mode', T2)):
             eng3 = _engine.BprEngine(eng.n_users, eng.n_items, k, dict(eng.hp, opt='sgd'), device, seed=77)
-            w3, s3 = timed_run(eng3, csr, Bs, steps_s, steps_s, 10 ** 9, 1)
+            w3, s3, _ = timed_run(eng3, csr, Bs, steps_s, steps_s, 10 ** 9, 1)
             a3 = Bs * (24 * k + 40) / (s3 * 1e-3 / steps_s) / 1e9        # 3 rows x (read+write) + biases + ids
             out[key] = {'batch_size': Bs, 'steps': steps_s, 'value': steps_s * Bs / w3, 'unit': 'triplets/s',
                         'ms_per_step': w3 * 1e3 / steps_s,

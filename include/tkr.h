@@ -11,6 +11,10 @@
  *   - all buffers are caller-owned DEVICE pointers (e.g. torch tensor.data_ptr()) with explicit
  *     sizes; the library keeps no device memory of its own, with one stated exception: K4's per-shape
  *     work-item table (a few KB, cached per device for the 8 most recent shapes)
+ *   - NOT thread-safe: the reference is a single Python thread and so is the caller this
+ *     library is written for.  Process-global state without locks: K4's work-item table cache and its
+ *     arithmetic mode (tkr_topk_set_math), per-device attributes cached by K1 and K2f on first use.  One host
+ *     thread per process calls in; one process per GPU.
  *   - `stream` is a hipStream_t passed as void*; all calls are asynchronous and stream-ordered;
  *     scalar results are written to device memory
  *   - ids are int32, parameters fp32

