@@ -141,6 +141,7 @@ class Loop:
     def __init__(self, eng, csr, B, sync_every, world, names=None):
         import dist as tdist
         self.eng, self.csr, self.B, self.sync_every, self.world = eng, csr, B, sync_every, world
+        eng.prepare(B)                   # the table layout of this batch size BEFORE the exchange binds to the tables (as BPR.train does)
         self.isync = tdist.ItemSync(eng, names) if world > 1 else None
         self.since = 0                   # batches since the last exchange
         self.exchanges = 0

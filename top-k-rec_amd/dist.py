@@ -165,6 +165,12 @@ class ItemSync:
         if w == 1:
             return
         self._settle()
+        if getattr(self.eng, 'layout_epoch', 0) != self._bound:
+            # the engine re-allocated its tables after begin() (a different batch size -> a different layout): the snapshot and the
+            # counters this object holds belong to tables that no longer exist.  Round 2's bench.py did exactly that in its warm-up
+            # (begin() before the first run_batches) and zeroed the live update counters through the stale binding.
+            raise RuntimeError('ItemSync.end(): the engine changed its table layout since begin(); call engine.prepare(batch_size) '
+                               'before the first begin()')
         marks = []
         if self.flow is not None:
             import tkr_hip

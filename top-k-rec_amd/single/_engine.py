@@ -111,16 +111,21 @@ class PlanPipeline:
     everything the main stream holds at that moment (the steps that last read the buffer, an in-order K1 that owns
     the counters); the steps of a chunk wait for the event of its plan."""
 
+    _side_streams = {}                   # one planner stream per device and process: creating a HIP stream costs milliseconds
+
     def __init__(self, device):
         self.device = device
-        self._side = None                # created on first overlapped use: an idle second queue is not free
+        self._side = None                # taken on first overlapped use: an idle second queue is not free
         self.bufs = [None, None]
         self.planned = [None, None]      # event: plan in bufs[i] complete (side stream)
 
     @property
     def side(self):
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            key = (self.device.type, self.device.index)
+            if key not in PlanPipeline._side_streams:
+                PlanPipeline._side_streams[key] = torch.cuda.Stream(device=self.device)
+            self._side = PlanPipeline._side_streams[key]
         return self._side
 
     def ensure(self, cap, B, flow=False):
@@ -275,6 +280,8 @@ class PlanMixin:
         # K1 of the chunk after this one on the side stream: behind the per-batch launches of a large batch, or behind the ONE
         # persistent launch of a dataflow chunk (100 us of planner per 512 batches that otherwise sit in front of every 1.4 ms launch)
         overlap = B >= OVERLAP_MIN_BATCH or self._plan_flow()
+        if overlap:
+            self.pipe.side                            # exists from the first call on (a warm-up then pays for its creation, not a later call)
         if cur is not None and self._ahead is not None:
             nxt, self._ahead = self._ahead, None
         else:
@@ -515,9 +522,11 @@ class BprEngine(PlanMixin):
         self._cnt.icnt.zero_()
 
     def _failed(self, code):
+        post = self.ctl[tkr_hip.FLOW_CTL_DEBUG:tkr_hip.FLOW_CTL_DEBUG + 16].cpu().tolist()      # what the first wave that gave up waited for
         self.ctl.zero_()
         self._flow_ran = False
-        raise tkr_hip.TkrError('persistent BPR step gave up waiting for a row version (status %d): tables are invalid' % code)
+        raise tkr_hip.TkrError('persistent BPR step gave up waiting for a row version (status %d): tables are invalid; '
+                               'post-mortem words (csrc/bpr_flow.hip kCtlDebug) %r' % (code, post))
 
     def _raise_pending(self):
         ev, self._status_event = self._status_event, None
