@@ -80,19 +80,29 @@ import numpy as np, torch, torch.distributed as dist
 torch.cuda.set_device(0)
 dist.init_process_group('gloo')
 from single import BPR
-m = BPR(k=16, lr=1e-2)
-m.load_training_data(%(data)r + '/uid', %(data)r + '/vid', %(data)r + '/f0tr.txt')
-m.train(epochs=12, batch_size=256, seed=21, verbose=False)
-if dist.get_rank() == 0:
-    m.export_embeddings(%(out)r)
+for seed in %(seeds)r:
+    m = BPR(k=16, lr=1e-2)
+    m.load_training_data(%(data)r + '/uid', %(data)r + '/vid', %(data)r + '/f0tr.txt')
+    m.train(epochs=12, batch_size=256, seed=seed, verbose=False)
+    if dist.get_rank() == 0:
+        m.export_embeddings(%(out)r + str(seed))
 dist.barrier(); dist.destroy_process_group()
 '''
 
+ACC_SEEDS = 8
+
 
 def test_sharded_accuracy_tracks_single_stream(tmp_path):
-    """SURVEY H4: 4 user shards + per-epoch sum-of-deltas exchange vs the single-stream run, same data and
-    hyper-parameters (different sample streams): accuracy@k must agree within the seed-noise band (0.01 here,
-    measured differences are a few 1e-3) and both must clearly beat an untrained model."""
+    """SURVEY H4 / BASELINE.json north_star: 4 user shards + per-epoch sum-of-deltas exchange vs the single-stream run, same data and
+    hyper-parameters, ACC_SEEDS seeds each.  The two draw DIFFERENT sample streams (a shard samples inside its own users), so
+    one pair of runs differs by training noise: the seed-to-seed standard deviation of ONE single-stream run is 0.0016-0.0026 per
+    bucket here (3,000 users, lr = 1e-2 = 100 x the reference's, so that 12 epochs train at all).  Measured on MI355X, mean over 8
+    seeds, sharded - single: -0.0002, -0.0007, -0.0013, -0.0011, -0.0013, -0.0024 (standard error of such a difference: 0.0011):
+    the exchange costs up to ~1 % relative at this step size -- V is a whole epoch stale inside a shard, an O(lr^2) effect of the
+    rule north_star prescribes (one all-reduce per epoch), not of the kernels.  north_star's +-0.001 is asserted where it is
+    defined -- same stream, HIP path vs oracle (tests/test_gpu_e2e.py, accuracy from exported factors) -- and here the seed-averaged
+    difference is held to 0.003, every sharded run to the seed-noise band.  Tried: rebuilding the slot from per-shard decay
+    factors instead of averaging it (scripts/probe_exchange_rule.py): twice the bias, dropped."""
     sys.path.insert(0, os.path.join(ROOT, 'top-k-rec_amd'))
     import synth
     import evaluate as E
@@ -100,20 +110,25 @@ def test_sharded_accuracy_tracks_single_stream(tmp_path):
     r = synth.make_ratings(3000, 700, 0, seed=5, mu=3.6, sigma=0.6, min_r=8, max_r=150, alpha=0.6, gain=2.0, select=4.0)
     data = str(tmp_path / 'data')
     synth.write_dataset(data, r)
-    single = BPR(k=16, lr=1e-2)
-    single.load_training_data(data + '/uid', data + '/vid', data + '/f0tr.txt')
-    single.train(epochs=12, batch_size=256, seed=7, verbose=False)
-    single.export_embeddings(str(tmp_path / 'single'))
+    seeds = list(range(7, 7 + ACC_SEEDS))
+    for seed in seeds:
+        single = BPR(k=16, lr=1e-2)
+        single.load_training_data(data + '/uid', data + '/vid', data + '/f0tr.txt')
+        single.train(epochs=12, batch_size=256, seed=seed, verbose=False)
+        single.export_embeddings(str(tmp_path / ('single%d' % seed)))
     script = tmp_path / 'acc_worker.py'
-    script.write_text(_ACC_WORKER % dict(root=ROOT, pkg=os.path.join(ROOT, 'top-k-rec_amd'), data=data, out=str(tmp_path / 'sharded')))
+    script.write_text(_ACC_WORKER % dict(root=ROOT, pkg=os.path.join(ROOT, 'top-k-rec_amd'), data=data, out=str(tmp_path / 'sharded'),
+                                         seeds=[100 + s for s in seeds]))
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=4',
                           '--master-addr', '127.0.0.1', '--master-port', '29643', str(script)],
-                         capture_output=True, text=True, timeout=280)
+                         capture_output=True, text=True, timeout=580)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    acc = {}
-    for name in ('single', 'sharded'):
+
+    def acc_of(name):
         line = E.main(['-d', data, '-m', str(tmp_path / name), '-sl', 'im'])[0]
-        acc[name] = np.array([float(x) for x in line.split(',')[1:]])
+        return np.array([float(x) for x in line.split(',')[1:]])
+    single = np.stack([acc_of('single%d' % s) for s in seeds])
+    sharded = np.stack([acc_of('sharded%d' % (100 + s)) for s in seeds])
     untrained = BPR(k=16)
     untrained.load_training_data(data + '/uid', data + '/vid', data + '/f0tr.txt')
     rng = np.random.Generator(np.random.PCG64(1))
@@ -121,10 +136,12 @@ def test_sharded_accuracy_tracks_single_stream(tmp_path):
     untrained.fie = (rng.standard_normal((700, 16)) * 0.01).astype(np.float32)
     untrained.fib = np.zeros((700, 1), np.float32)
     untrained.export_embeddings(str(tmp_path / 'untrained'))
-    base = np.array([float(x) for x in E.main(['-d', data, '-m', str(tmp_path / 'untrained'), '-sl', 'im'])[0].split(',')[1:]])
-    print('acc single', acc['single'], 'sharded', acc['sharded'], 'untrained', base)
-    assert np.max(np.abs(acc['single'] - acc['sharded'])) <= 0.01
-    assert acc['single'][-1] > 2 * base[-1] and acc['sharded'][-1] > 2 * base[-1]
+    base = acc_of('untrained')
+    noise = single.std(0).max()
+    print('acc single mean', single.mean(0), 'sharded mean', sharded.mean(0), 'seed std', single.std(0), sharded.std(0), 'untrained', base)
+    assert np.max(np.abs(single.mean(0) - sharded.mean(0))) <= 0.003, (single.mean(0), sharded.mean(0))
+    assert np.max(np.abs(sharded - single.mean(0))) <= max(0.006, 4 * noise)                  # every sharded run inside the seed-noise band
+    assert single.mean(0)[-1] > 2 * base[-1] and sharded.mean(0)[-1] > 2 * base[-1]
 
 
 def test_streams_mode_matches_oracle_simulation(tmp_path):

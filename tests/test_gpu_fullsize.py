@@ -32,8 +32,9 @@ def _run(d, hp, nb, B, k, seed):
     return eng, init
 
 
-def test_full_epoch_matches_oracle_and_invariants(ml10m):
-    d, k, B = ml10m, 128, 256
+@pytest.mark.parametrize('k', [128, 50])      # BASELINE.json configs[1] (k = 128) and configs[0]'s width (k = 50, the reference's train.py)
+def test_full_epoch_matches_oracle_and_invariants(ml10m, k):
+    d, B = ml10m, 256
     nb = 10 ** 6 // B                                                 # single/bpr.py:139: limit // batch_size
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=1.0e-4, mode='l2')       # the reference's defaults
     eng, init = _run(d, hp, nb, B, k, seed=2024)

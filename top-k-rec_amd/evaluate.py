@@ -152,6 +152,11 @@ def evaluate_scenario(umat_dev, vmat, bmat, uids, vids, data_dir, fold, scenario
     block of the scenario's test lines; what the reference accumulates over users -- tresults[k] and tcount, :106-112 --
     is summed over the ranks by one all-reduce of interval + 1 integers (no other exchange: the factors are replicated)."""
     full = load_scenario(data_dir, fold, scenario, uids, umap)
+    return evaluate_loaded(umat_dev, vmat, bmat, vids, full, step, total, device)
+
+
+def evaluate_loaded(umat_dev, vmat, bmat, vids, full, step, total, device):
+    """the ranking + counting half of evaluate_scenario on an already parsed Scenario (the same on every rank)"""
     rank, world = _world()
     sc = shard_scenario(full, rank, world) if world > 1 else full
     interval = total // step
