@@ -127,10 +127,9 @@ def build_problem(shape, k, rank, world, device, seed=42):
     return r, csr, eng, int(row_ptr[-1])
 
 
-def _chunk_crossings(steps, B):
+def _chunk_crossings(eng, steps, B):
     """upper bound of the extra step calls a run of `steps` batches makes because it crosses plan chunks"""
-    from single import _engine
-    return steps // _engine._chunk_cap(B) + 1
+    return steps // eng._cap(B) + 1
 
 
 class Loop:
@@ -174,7 +173,7 @@ def timed_run(eng, csr, B, steps, warmup, sync_every, world, names=None, loop=No
     What the timed region contains: for each batch its (u, i, j) draw + plan (K1) AND its step -- settle() drops
     whatever an earlier call planned but did not run, and run_batches plans exactly what it is asked to run."""
     loop = loop or Loop(eng, csr, B, sync_every, world, names)
-    eng.reserve_events(-(-(steps + warmup) // sync_every) + _chunk_crossings(steps, B) + 2)      # created now, not between the timed launches
+    eng.reserve_events(-(-(steps + warmup) // sync_every) + _chunk_crossings(eng, steps, B) + 2)      # created now, not between the timed launches
     loop.run(warmup)
     eng.settle()                 # nothing planned ahead: the timed batches sample and plan themselves (also reports a failed step)
     _fence(world)
@@ -366,10 +365,15 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
         wall, step_ms, _ = timed_run(eng, csr, B, steps, warmup, 10 ** 9, 1, names=eng.replicated_names)
         step_s = step_ms * 1e-3 / steps
         if eng.sparse is not None:
-            # dense optimizer traffic + the CSC walk + one cem row and one icb value per nonzero of the 2B gathered items
-            bytes_ = 16.0 * d * kh + 8.0 * nnz + 2.0 * B * (nnz / n_items) * (4.0 * kh + 12.0)
+            # dense optimizer traffic (cem and its slot, read + written: TF's dense RMSProp moves every element every batch) + the
+            # column plan of the batch (a header per column, 16 B per nonzero of the 2B feature rows) + one cem row and one icb value per
+            # such nonzero.  (Round 2 also walked the whole CSC of feat per batch, 8 B per nonzero of feat: gone with the column plan.)
+            ent = 2.0 * B * (nnz / n_items)
+            bytes_ = 16.0 * d * kh + 32.0 * d + 16.0 * ent + ent * (4.0 * kh + 12.0)
             gbs = bytes_ / step_s / 1e9
-            roof = {'kernels': 'tkr::vbpr_sproject (project + alpha, beta) / pair / rows / sdense (4 launches per batch)', 'bound': 'hbm', 'achieved': gbs,
+            roof = {'kernels': 'tkr::vbpr_tproject (project + alpha, beta) / pairsum / update (row tasks + column tasks): 3 launches per batch; '
+                               'tkr::vbpr_colplan beside K1' if eng.wants_cols(B) else
+                               'tkr::vbpr_sproject / pair / rows / sdense (4 launches per batch)', 'bound': 'hbm', 'achieved': gbs,
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch_chain': bytes_,
                     'step_us': step_s * 1e6, 'traffic': None}
         else:
@@ -400,15 +404,15 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
     featd = torch.rand((n_items, dc), device=device, generator=g) + 0.1
     featd /= featd.norm(dim=1, keepdim=True)
     eng = _engine.VbprEngine(n_users, n_items, k, dc, featd, hp, device, seed=3)
-    assert eng.sparse is None                # fully dense: the MFMA kernels (V1 / V3).  They tile d by 128 / 64 columns: at d_c = 128 the projection
-                                             # and the dense update run on 1-2 workgroups (55 us per batch; the gather view is worse, 244 us: its
-                                             # column walk gives one wave a whole 10,380-entry column)
+    assert eng.wants_cols(B)                 # a narrow feat takes the gather view + column plan whatever its density (the fp32-MFMA kernels V1 / V3
+                                             # tile d by 128 / 64 columns: 1-2 workgroups at d_c = 128, 55 us per batch in round 2); every column meets
+                                             # every triplet, so a column's run (2B entries) is split over the 16 groups of its workgroup
     wall, step_ms, _ = timed_run(eng, csr, B, steps, warmup, 10 ** 9, 1, names=eng.replicated_names)
     step_s = step_ms * 1e-3 / steps
     bytes_ = B * (2 * 4 * dc * 2 + 48.0 * kh + 56) + 16.0 * dc * kh       # feature rows (V1 + V3) + the sparse rows + dense optimizer traffic
     res['dense_dc128'] = {'value': steps * B / wall, 'unit': 'triplets/s', 'steps': steps, 'ms_per_step': wall * 1e3 / steps,
                           'config': {'workload': 'VBPR ML-10M shape, k=%d, DENSE content features d_c=%d, batch_size=%d' % (k, dc, B)},
-                          'roofline': {'kernels': 'tkr::vbpr_project/reduce/occur/pair/rows/dense (6 launches per batch)', 'bound': 'hbm',
+                          'roofline': {'kernels': 'tkr::vbpr_tproject / pairsum / update (3 launches per batch)', 'bound': 'hbm',
                                        'achieved': bytes_ / step_s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': bytes_ / step_s / 1e9 / HBM_PEAK_GBS,
                                        'mfma_TFLOPs': 4.0 * dc * kh * B / step_s / 1e12, 'step_us': step_s * 1e6, 'traffic': None}}
     del eng

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TKR_VERSION 108 /* 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
+#define TKR_VERSION 109 /* 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
 #define TKR_OK 0
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
@@ -202,6 +202,33 @@ int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* 
                  const int32_t* occ, const int32_t* hdr, const int32_t* occt, const int32_t* tri_u /*nullable*/,
                  const int32_t* tpar /*nullable*/, int32_t batch_size,
                  int32_t n_batches, float* workspace, float* loss_out, void* stream);
+
+/* Column-plan form of the same step (batch_size <= 1024, kh % 4 == 0, CSR view of feat): three launches per batch
+ * (project + score / pair sums / row tasks and column tasks side by side) instead of four to six, csrc/vbpr_cols.hip.
+ * Which (triplet, feature column) pairs a batch touches depends on the sampled triplets and on the structure of feat only,
+ * so it is prepared beside K1, off the step's critical path:
+ *   tkr_vbpr_colplan   for each of n_batches batches (tri_i / tri_j = tkr_sample_plan's out_i / out_j), from the CSR
+ *                      f_ptr / f_col / f_val of feat, with tcap = 2 * row_cap and row_cap >= the longest row of feat:
+ *                      tcnt [n_batches][B], tent [n_batches][B][tcap][2]   per triplet the (column, value bits) of f_i's nonzeros
+ *                                          (+value) followed by f_j's (-value): the gather list of the projection
+ *                      cent [n_batches][B * tcap][2]   the same entries as (t, +-value bits) grouped by feature column, every
+ *                                          column's run in (t, side) order
+ *                      colh [n_batches][d][8]   per column (entries, first entry in cent, then its first three entries inline)
+ *                      One workgroup per batch keeps the d column counters in LDS: tkr_vbpr_colplan_lds_bytes(batch_size, d)
+ *                      <= 160 KB, else TKR_E_UNSUPPORTED (the caller then stays with tkr_vbpr_run).
+ *   tkr_vbpr_run_cols  the batches themselves; arguments as tkr_vbpr_run (tri_u and tpar required; st->feat and the CSC
+ *                      members of st are not read) plus the column plan.  cols_per_block: feature columns per 256-thread
+ *                      workgroup of the dense update, 0 = as many as fit (sparse features); 1-2 when runs are long (a narrow
+ *                      dense feat: every column meets every triplet).
+ * Same arithmetic as tkr_vbpr_run up to the order of fp32 sums; bitwise reproducible run to run. */
+int64_t tkr_vbpr_colplan_lds_bytes(int32_t batch_size, int32_t d);
+int tkr_vbpr_colplan(const int32_t* f_ptr, const int32_t* f_col, const float* f_val, int32_t d, const int32_t* tri_i,
+                     const int32_t* tri_j, int32_t batch_size, int32_t n_batches, int32_t row_cap, int32_t* colh, int32_t* cent,
+                     int32_t* tcnt, int32_t* tent, void* stream);
+int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* tri_j, const int32_t* rec, const int32_t* occ,
+                      const int32_t* hdr, const int32_t* occt, const int32_t* tri_u, const int32_t* tpar, const int32_t* colh,
+                      const int32_t* cent, const int32_t* tcnt, const int32_t* tent, int32_t row_cap, int32_t cols_per_block,
+                      int32_t batch_size, int32_t n_batches, float* workspace, float* loss_out, void* stream);
 
 /* ---- K4: full-catalogue score -> rated mask -> top-K -------------------------------------------
  * Replaces evaluate.py:78-81 (np.dot + bias + np.argsort over every row) and the rated-item filter

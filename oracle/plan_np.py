@@ -343,3 +343,35 @@ def sample_and_plan(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed, fir
     sample_and_plan.last_tpars = tpars            # per-triplet parities of the last call (kept off the return tuple)
     sample_and_plan.last_flow = dict(pocc=poccs, prec=precs, task=raw_tasks, occ=raw_occs)      # dataflow form of the same plan
     return u, i, j, tasks, occs, recs, hdrs, occts
+
+
+def vbpr_colplan(f_ptr, f_col, f_val, d, ti, tj, row_cap):
+    """The column plan of ONE VBPR batch (include/tkr.h tkr_vbpr_colplan; built beside K1 by csrc/vbpr_cols.hip): which (triplet,
+    feature column) pairs the batch touches.  From the CSR of feat (f_ptr / f_col ascending inside a row / f_val) and the batch's
+    positive / negative items ti, tj:
+      tcnt [B], tent [B][2*row_cap][2]   per triplet (column, value) of f_i's nonzeros (+value) followed by f_j's (-value)
+      cent [E][2]                        the same entries as (t, +-value) grouped by column, every run in (t, side) order
+      colh [d][8]                        (entries, first entry in cent, the first three entries (t, value bits) inline, zeros beyond)
+    Values are returned as float32 with their sign applied; the device stores their bit patterns in int32 words.
+    This is what single/vbpr.py:114 feeds per batch -- feat[ib], feat[jb] -- regrouped for the kernels, nothing more."""
+    B, tcap = len(ti), 2 * row_cap
+    tcnt = np.zeros(B, np.int32)
+    tent_c = np.zeros((B, tcap), np.int32)
+    tent_v = np.zeros((B, tcap), np.float32)
+    runs = [[] for _ in range(d)]
+    for t in range(B):
+        n = 0
+        for side, item in ((0, int(ti[t])), (1, int(tj[t]))):
+            a, b = int(f_ptr[item]), int(f_ptr[item + 1])
+            b = min(b, a + row_cap)
+            for e in range(a, b):
+                v = np.float32(-f_val[e]) if side else np.float32(f_val[e])
+                tent_c[t, n], tent_v[t, n] = f_col[e], v
+                runs[int(f_col[e])].append((t, v))
+                n += 1
+        tcnt[t] = n
+    cent_t = np.array([t for r in runs for t, _ in r], np.int32)
+    cent_v = np.array([v for r in runs for _, v in r], np.float32)
+    colh_n = np.array([len(r) for r in runs], np.int32)
+    colh_beg = np.concatenate([[0], np.cumsum(colh_n)[:-1]]).astype(np.int32)
+    return dict(tcnt=tcnt, tent_c=tent_c, tent_v=tent_v, cent_t=cent_t, cent_v=cent_v, colh_n=colh_n, colh_beg=colh_beg)

@@ -71,9 +71,16 @@ class PlanBuffers:
     """Output of K1 for up to ``cap`` batches of ``B`` triplets.  ``flow``: the dataflow form for the persistent step
     kernel K2f (128-byte task records + versioned occurrences) instead of per-launch wave records."""
 
-    def __init__(self, cap: int, B: int, device, flow: bool = False):
-        self.cap, self.B, self.flow = cap, B, flow
+    def __init__(self, cap: int, B: int, device, flow: bool = False, cols=None):
+        """``cols`` = (d, row_cap): also room for the column plan of the VBPR step (tkr_vbpr_colplan)"""
+        self.cap, self.B, self.flow, self.cols = cap, B, flow, cols
         i32 = dict(dtype=torch.int32, device=device)
+        if cols is not None:
+            d, row_cap = cols
+            self.colh = torch.empty(cap * d * 8, **i32)
+            self.cent = torch.empty(cap * B * 2 * row_cap * 2, **i32)
+            self.tcnt = torch.empty(cap * B, **i32)
+            self.tent = torch.empty(cap * B * 2 * row_cap * 2, **i32)
         self.u = torch.empty(cap * B, **i32)
         self.i = torch.empty(cap * B, **i32)
         self.j = torch.empty(cap * B, **i32)
@@ -128,11 +135,11 @@ class PlanPipeline:
             self._side = PlanPipeline._side_streams[key]
         return self._side
 
-    def ensure(self, cap, B, flow=False):
+    def ensure(self, cap, B, flow=False, cols=None):
         for i in range(2):
-            if self.bufs[i] is None or self.bufs[i].B != B or self.bufs[i].cap < cap or self.bufs[i].flow != flow:
+            if self.bufs[i] is None or self.bufs[i].B != B or self.bufs[i].cap < cap or self.bufs[i].flow != flow or self.bufs[i].cols != cols:
                 self.bufs[i] = None                   # release before allocating the replacement
-                self.bufs[i] = PlanBuffers(cap, B, self.device, flow)
+                self.bufs[i] = PlanBuffers(cap, B, self.device, flow, cols)
                 self.planned[i] = None
 
     def plan(self, i, fn, overlap=True):
@@ -212,6 +219,21 @@ class PlanMixin:
         """queue a copy of the device's status word; the NEXT check_async / check / settle raises if it was set (no host wait
         now: the per-epoch exchange of a sharded run calls this instead of check)"""
 
+    def _cap(self, B):
+        """batches planned per K1 call"""
+        return _chunk_cap(B)
+
+    def _plan_overlap(self, B):
+        """plan the chunk after the running one on the side stream?"""
+        return B >= OVERLAP_MIN_BATCH or self._plan_flow()
+
+    def _plan_cols(self, B):
+        """(d, row_cap) when the step of this engine wants the column plan of its batches beside K1's (VBPR), else None"""
+        return None
+
+    def _plan_extra(self, buf, nb, B):
+        """more planner-side work for the nb batches K1 just wrote into buf (same stream, right behind K1)"""
+
     def _init_plans(self):
         self._cnt = UpdateCounters(self.n_users, self.n_items, self.device)
         self._drawn = 0                 # position in the counter-based sample stream = triplets that RAN
@@ -261,9 +283,12 @@ class PlanMixin:
         self._cur = self._ahead = None
 
     def _plan_chunk(self, idx, csr, B, first, overlap, want):
-        nb = max(1, min(_chunk_cap(B), want))
-        self.pipe.plan(idx, lambda buf: tkr_hip.sample_plan(csr, self.n_users, self.n_items, self.seed, first, nb, B,
-                                                            self._cnt, buf), overlap)
+        nb = max(1, min(self._cap(B), want))
+
+        def fn(buf):
+            tkr_hip.sample_plan(csr, self.n_users, self.n_items, self.seed, first, nb, B, self._cnt, buf)
+            self._plan_extra(buf, nb, B)
+        self.pipe.plan(idx, fn, overlap)
         return _Chunk(idx, nb, B, first, csr)
 
     def _next_chunk(self, csr, B, want):
@@ -276,10 +301,10 @@ class PlanMixin:
             return cur
         if self.pipe is None:
             self.pipe = PlanPipeline(self.device)
-        self.pipe.ensure(_chunk_cap(B), B, self._plan_flow())
+        self.pipe.ensure(self._cap(B), B, self._plan_flow(), self._plan_cols(B))
         # K1 of the chunk after this one on the side stream: behind the per-batch launches of a large batch, or behind the ONE
         # persistent launch of a dataflow chunk (100 us of planner per 512 batches that otherwise sit in front of every 1.4 ms launch)
-        overlap = B >= OVERLAP_MIN_BATCH or self._plan_flow()
+        overlap = self._plan_overlap(B)
         if overlap:
             self.pipe.side                            # exists from the first call on (a warm-up then pays for its creation, not a later call)
         if cur is not None and self._ahead is not None:
@@ -664,6 +689,9 @@ class VbprEngine(PlanMixin):
     cem / icb are dense and single-buffered (their update is its own launch, after every read)."""
 
     SPARSE_DENSITY = 0.25      # below this fraction of nonzeros the step uses the CSR/CSC view of feat (csrc/vbpr_step.hip S1/S3)
+    NARROW_D = 512             # ... and below this width whatever the density
+    COLS_MAX_BATCH = 1024      # the column-plan step (three launches per batch): pair sums are O(B^2) work of B waves
+    PLAN_BYTES = 768 << 20     # column plans held per plan buffer (two buffers): bounds the batches planned per K1 call
 
     def __init__(self, n_users, n_items, k, d, feat, hp, device=None, seed=None, sparse=None, user_seed=None):
         self.device = device or default_device()
@@ -687,8 +715,12 @@ class VbprEngine(PlanMixin):
         self.ws = None
         self.sparse = None
         nnz = int(torch.count_nonzero(self.feat))
-        if sparse or (sparse is None and nnz <= self.SPARSE_DENSITY * n_items * d):
+        # the gather view: sparse features (tf-idf-like, ~0.5 % dense at d = 20,000), and narrow dense ones (BASELINE.json's literal
+        # "d = 128"): the fp32-MFMA kernels tile d by 128 / 64 columns and run on 1-2 workgroups there
+        if sparse or (sparse is None and (nnz <= self.SPARSE_DENSITY * n_items * d or d <= self.NARROW_D)):
             self.sparse = self._sparse_view(self.feat)
+            per_row = (self.sparse['f_ptr'][1:] - self.sparse['f_ptr'][:-1])
+            self.max_row_nnz, self.avg_row_nnz = int(per_row.max()), float(per_row.float().mean())
 
     @staticmethod
     def _sparse_view(feat):
@@ -706,6 +738,39 @@ class VbprEngine(PlanMixin):
         return dict(f_ptr=f_ptr.to(i32), f_col=rc[:, 1].to(i32).contiguous(), f_val=feat[rc[:, 0], rc[:, 1]].contiguous(),
                     c_ptr=c_ptr.to(i32), c_item=cr[:, 1].to(i32).contiguous(), c_val=feat[cr[:, 1], cr[:, 0]].contiguous(),
                     item_tag=torch.zeros(n_items + 8, dtype=torch.int64, device=feat.device))     # slots [n] int32 | two byte maps [ceil(n/4)*4] | counter: 8n + 16 bytes suffice, also for n <= 2
+
+    # ---- column-plan step (csrc/vbpr_step.hip, "column-plan path") --------------------------------
+    def wants_cols(self, B):
+        if self.sparse is None or __import__('os').environ.get('TKR_VBPR_COLS', '1') == '0':
+            return False
+        return (self.kh % 4 == 0 and self.kh <= 128 and B <= self.COLS_MAX_BATCH and 0 < self.max_row_nnz <= 1024 and
+                tkr_hip.vbpr_colplan_lds_bytes(B, self.d) <= 160 * 1024)
+
+    def _plan_cols(self, B):
+        return (self.d, self.max_row_nnz) if self.wants_cols(B) else None
+
+    def _cap(self, B):
+        cap = _chunk_cap(B)
+        if self.wants_cols(B):
+            per_batch = 32 * self.d + 4 * B + 2 * 16 * B * self.max_row_nnz        # colh + tcnt + (cent, tent)
+            cap = max(4, min(cap, self.PLAN_BYTES // per_batch))
+        return cap
+
+    def _plan_overlap(self, B):
+        # the column plan costs ~1.5 us per batch: behind the steps of the chunk before, not in front of its own
+        return B >= OVERLAP_MIN_BATCH or (self.wants_cols(B) and __import__('os').environ.get('TKR_VBPR_OVERLAP', '1') != '0')
+
+    def _plan_extra(self, buf, nb, B):
+        if buf.cols is not None:
+            tkr_hip.vbpr_colplan(self.sparse, self.d, buf, B, nb, buf.cols[1])
+
+    def cols_per_block(self, B):
+        """feature columns per workgroup of the dense update: all the groups of a block own one while runs are short (sparse
+        features: 2B * nnz_row / d entries per column), fewer when every column meets most triplets (narrow dense feat)"""
+        lpc = 4 if self.kh <= 16 else 8 if self.kh <= 32 else 16 if self.kh <= 64 else 32
+        groups = 256 // lpc
+        run = 2.0 * B * self.avg_row_nnz / self.d
+        return int(max(1, min(groups, groups * 8 // max(int(run), 1))))
 
     def state(self):
         hp = self.hp
@@ -772,4 +837,7 @@ class VbprEngine(PlanMixin):
         if self.ws is None or self.ws.numel() < need:
             self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
         state = self.state()
+        if self.wants_cols(B):
+            d, row_cap, cpb = self.d, self.max_row_nnz, self.cols_per_block(B)
+            return lambda plan, lo, nb, loss: tkr_hip.vbpr_run_cols(state, plan, B, nb, self.ws, d, row_cap, cpb, loss, first=lo)
         return lambda plan, lo, nb, loss: tkr_hip.vbpr_run(state, plan, B, nb, self.ws, loss, first=lo)

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TKR_HIP_LIB') or os.path.join(_HERE, 'libtkr_hip.so')      # the override is for A/B builds of the kernels (scripts/)
 
 _lib = None
-VERSION = 108          # TKR_VERSION of include/tkr.h this binding was written against
+VERSION = 109          # TKR_VERSION of include/tkr.h this binding was written against
 
 
 class TkrError(RuntimeError):
@@ -47,13 +47,13 @@ class VbprState(C.Structure):
 
 
 EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_plan_rollback', 'tkr_bpr_run', 'tkr_bpr_flow_run', 'tkr_flow_row_granules', 'tkr_flow_ctl_words',
-           'tkr_vbpr_run', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy',
+           'tkr_vbpr_run', 'tkr_vbpr_colplan', 'tkr_vbpr_run_cols', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy',
            'tkr_idmap_create', 'tkr_idmap_destroy', 'tkr_ratings_parse', 'tkr_ratings_sizes', 'tkr_ratings_copy',
            'tkr_ratings_destroy', 'tkr_matrix_read', 'tkr_matrix_sizes', 'tkr_matrix_copy', 'tkr_matrix_destroy',
            'tkr_matrix_write', 'tkr_raw_ranks', 'tkr_count_hits_rr', 'tkr_topk_set_math',
            'tkr_sync_snapshot', 'tkr_sync_pack', 'tkr_sync_unpack', 'tkr_sync_flow_snapshot', 'tkr_sync_flow_pack',
            'tkr_sync_flow_unpack')
-EXPORTS_I64 = ('tkr_vbpr_workspace_floats', 'tkr_topk_workspace_bytes', 'tkr_plan_workspace_bytes')
+EXPORTS_I64 = ('tkr_vbpr_workspace_floats', 'tkr_vbpr_colplan_lds_bytes', 'tkr_topk_workspace_bytes', 'tkr_plan_workspace_bytes')
 
 
 def lib():
@@ -216,6 +216,29 @@ def vbpr_run(state, plan, B, n_batches, workspace, loss_out=None, first=0):
                               _at(plan.occ, first * 6 * B), _at(plan.hdr, first * 4), _at(plan.occt, first * 3 * B),
                               _at(plan.u, first * B), _at(getattr(plan, 'tpar', None), first * B), C.c_int32(B),
                               C.c_int32(n_batches), _p(workspace), _at(loss_out, first))
+
+
+def vbpr_colplan_lds_bytes(B, d):
+    return int(lib().tkr_vbpr_colplan_lds_bytes(C.c_int32(B), C.c_int32(d)))
+
+
+def vbpr_colplan(sparse, d, plan, B, n_batches, row_cap):
+    """K1-side preparation of the column-plan VBPR step: plan.colh / cent / tcnt / tent from plan.i / plan.j and the CSR of feat"""
+    tcap = 2 * row_cap
+    assert plan.colh.numel() >= n_batches * d * 8 and plan.cent.numel() >= n_batches * B * tcap * 2
+    assert plan.tcnt.numel() >= n_batches * B and plan.tent.numel() >= n_batches * B * tcap * 2
+    _call('tkr_vbpr_colplan', plan.i, _p(sparse['f_ptr']), _p(sparse['f_col']), _p(sparse['f_val']), C.c_int32(d), _p(plan.i), _p(plan.j),
+          C.c_int32(B), C.c_int32(n_batches), C.c_int32(row_cap), _p(plan.colh), _p(plan.cent), _p(plan.tcnt), _p(plan.tent))
+
+
+def vbpr_run_cols(state, plan, B, n_batches, workspace, d, row_cap, cols_per_block=0, loss_out=None, first=0):
+    rs = plan_max_blocks(B) * plan_team(B) * 16
+    ent = B * 2 * row_cap * 2
+    _call('tkr_vbpr_run_cols', plan.rec, C.byref(state), _at(plan.i, first * B), _at(plan.j, first * B), _at(plan.rec, first * rs),
+          _at(plan.occ, first * 6 * B), _at(plan.hdr, first * 4), _at(plan.occt, first * 3 * B), _at(plan.u, first * B),
+          _at(plan.tpar, first * B), _at(plan.colh, first * d * 8), _at(plan.cent, first * ent), _at(plan.tcnt, first * B),
+          _at(plan.tent, first * ent), C.c_int32(row_cap), C.c_int32(cols_per_block), C.c_int32(B), C.c_int32(n_batches), _p(workspace),
+          _at(loss_out, first))
 
 
 # ---- K4 / K5 -------------------------------------------------------------------------------------
