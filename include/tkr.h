@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TKR_VERSION 109 /* 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
+#define TKR_VERSION 110 /* 0.1.10: tkr_topk_workspace_bytes_for (K4 stages pre-converted fp16 tiles). 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
 #define TKR_OK 0
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
@@ -263,6 +263,10 @@ int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i, const int3
  * K <= 32 per launch (larger K: rank 32, add the found columns to the mask with tkr_build_rated_mask, rank
  * again -- top-k-rec_amd/tkr_hip.py score_topk does this), k <= 256. */
 int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K);
+/* the same + room for the item factors of mode 2 pre-converted to scaled fp16 (k <= 128), laid out as the LDS image of every
+ * 32-item tile: with a workspace of at least this size a K4 call converts V once (a ~5 us pre-pass) and every workgroup stages
+ * its tiles with one direct-to-LDS load per thread instead of converting them again (results are identical either way) */
+int64_t tkr_topk_workspace_bytes_for(int32_t n_rows, int32_t n_cols, int32_t k, int32_t K);
 int tkr_topk_set_math(int32_t mode);
 int tkr_build_rated_mask(const int64_t* rated_ptr, const int32_t* rated_cols, int32_t n_rows, int32_t n_cols,
                          uint32_t* mask, int32_t mask_pitch, void* stream);

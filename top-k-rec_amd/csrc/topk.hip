@@ -694,20 +694,54 @@ constexpr int topk_waves_bf16() { return sizeof(IdT) == 2 ? kTopkMaxWaves : 6; }
 // everything within 2 * margin of the K-th best approximate score therefore holds the exact best K; they are rescored exactly
 // at the end.  `extra`: bits of [0] max |v_i|, [1] max |bias|, [2] max |V element| (topk_bounds_kernel); [4 + block] = 1
 // when a list of the block overflowed.
-template <int KS, typename IdT, bool REFINE = false>
+// IMG (bound-and-refine only): the scaled fp16 item factors come PRE-CONVERTED, as the LDS image of every 32-item tile
+// (topk_image_kernel below; `vimg`), and a tile is staged by ONE direct-to-LDS load per thread (global_load_lds_dwordx4): no
+// staging registers, no conversion, no ds_write.  Without it every workgroup converts the same V again -- 1,876 times at the
+// Netflix shape, 2.0 of 10.85 ms (scripts/ablate_topk.sh).  The direct load writes LDS linearly (wave base + 16 * lane), so the
+// image carries no row padding; bank conflicts of the fragment reads are avoided by an XOR swizzle of the 16-byte chunks of a
+// row instead (chunk j of item row r sits at j ^ swz(r), identical in the image and in the read: the b128 lane groups of
+// MI355X_MICROARCH.md hold 16 distinct values of r & 15).
+template <int KS>
+__device__ __forceinline__ int tile_swizzle(int r) {             // KS in {1, 2, 4, 8}: CR = 2 * KS chunks per row, 16 / CR rows per 256 B
+    constexpr int CR = 2 * KS;
+    return (r / (16 / CR)) & (CR - 1);
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void topk_image_kernel(const float* __restrict__ Vt, int n_cols, int k, const uint32_t* __restrict__ extra,
+                                                        unsigned char* __restrict__ vimg) {
+    constexpr int CR = 2 * KS;
+    const int n_tiles = (n_cols + 31) >> 5;
+    const float sv = pow2_scale(__uint_as_float(extra[2]));
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < (long long)n_tiles * 32 * CR; c += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(c % CR), r = (int)((c / CR) & 31);
+        const long long t = c / (32 * CR);
+        const long long col = t * 32 + r;
+        f16x8 out;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = 8 * j + i;
+            out[i] = (_Float16)((col < n_cols && e < k) ? Vt[col * k + e] * sv : 0.f);
+        }
+        *reinterpret_cast<f16x8*>(vimg + ((t * 32 + r) * CR + (j ^ tile_swizzle<KS>(r))) * 16) = out;
+    }
+}
+
+template <int KS, typename IdT, bool REFINE = false, bool IMG = false>
 __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score_topk_bf16_kernel(
     const float* __restrict__ U, const int32_t* __restrict__ uidx, int n_rows, const float* __restrict__ Vt,
     const float* __restrict__ bias, int n_cols, int k, const uint32_t* __restrict__ mask, int mask_pitch, int K,
     int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int tiles_per_split, uint64_t* __restrict__ part,
     uint32_t* __restrict__ thr_shared, const int4* __restrict__ items /*(block, t_begin, t_end, slot | stride << 16) or null*/,
-    uint32_t* __restrict__ extra) {
+    uint32_t* __restrict__ extra, const unsigned char* __restrict__ vimg) {
+    static_assert(!IMG || REFINE, "the tile image is the scaled fp16 operand of the bound-and-refine arithmetic");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 #if TKR_ABL & 256
     const unsigned long long k4_start = __builtin_amdgcn_s_memtime();
 #endif
     constexpr int NPART = REFINE ? 1 : 3;
     constexpr int PARTB = KS * 32;                               // bytes of one bf16 part of an item row (KS*16 elements)
-    constexpr int ROWB = NPART * PARTB + 16;                     // padded row: conflict-free ds_read_b128 (ROWB/4 = 4 mod 8)
+    constexpr int ROWB = IMG ? PARTB : NPART * PARTB + 16;       // padded row: conflict-free ds_read_b128 (ROWB/4 = 4 mod 8); IMG: swizzled instead
     constexpr int KPAD = KS * 16;
     const int W = blockDim.x >> 6;
     const int users = W * 32;
@@ -802,7 +836,27 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
 
     // ---- tile staging: float4 of Vt -> registers (early) -> three 4 x bf16 parts -> LDS (after the MFMA chain)
     constexpr int NT_ = topk_waves_bf16<KS, IdT>() * 64;
-    constexpr int NC = (32 * KPAD / 4 + NT_ - 1) / NT_;          // float4 chunks per thread
+    constexpr int TILEB = 32 * ROWB;                             // bytes of one staged tile
+    constexpr int NG = IMG ? (TILEB / 16 + NT_ - 1) / NT_ : 1;   // IMG: 16-byte direct-to-LDS loads per thread and tile
+    auto stage_direct = [&](int t, int buf) {                     // IMG: tile t of the image -> LDS buffer buf, asynchronously (vmcnt)
+        if constexpr (IMG) {
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                const int c0 = q * NT_ + wave * 64;              // first chunk of this wave's 64 (LDS destination = wave base + 16 * lane)
+                if (c0 < TILEB / 16) {
+                    const int c = min(c0 + lane, TILEB / 16 - 1);
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(vimg + (size_t)t * TILEB + (size_t)c * 16),
+                        (__attribute__((address_space(3))) void*)(smem_raw + buf * TILEB + c0 * 16), 16, 0, 0);
+                }
+            }
+            if (tid < 32) {
+                const int col = t * 32 + tid;
+                sm.tbias[buf * 32 + tid] = (bias && col < n_cols) ? bias[col] : 0.f;
+            }
+        }
+    };
+    constexpr int NC = IMG ? 1 : (32 * KPAD / 4 + NT_ - 1) / NT_;          // float4 chunks per thread
     const bool vec = (k & 3) == 0;
     const int nthreads = blockDim.x;
     const int k4 = k >> 2;
@@ -874,14 +928,21 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
         }
         if (tid < 32) sm.tbias[buf * 32 + tid] = stg_bias;
     };
-    if (vec) {                                                    // zero what the vector path never writes (k..KPAD, padding)
-        for (int c = tid; c < 2 * 32 * ROWB / 4; c += nthreads) reinterpret_cast<uint32_t*>(tile)[c] = 0u;
+    if constexpr (IMG) {
+        stage_direct(t_begin, t_begin & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    } else {
+        if (vec) {                                                // zero what the vector path never writes (k..KPAD, padding)
+            for (int c = tid; c < 2 * 32 * ROWB / 4; c += nthreads) reinterpret_cast<uint32_t*>(tile)[c] = 0u;
+            __syncthreads();
+        }
+        stage_load(t_begin);
+        stage_store(t_begin, t_begin & 1);
+        __syncthreads();
+        if (t_begin + 1 < n_tiles) stage_load(t_begin + 1);
     }
-    stage_load(t_begin);
-    stage_store(t_begin, t_begin & 1);
-    __syncthreads();
-    if (t_begin + 1 < n_tiles) stage_load(t_begin + 1);
+
 
     const uint32_t tail_mask = (n_cols & 31) ? (0xffffffffu << (n_cols & 31)) : 0u;
     int next_sched = t_begin + 2;
@@ -896,10 +957,16 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
         // A operand: lane (item ul, k-group h) reads elements 16s + 8h .. +7 of each part; small terms first.
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const unsigned char* arow = tile + buf * 32 * ROWB + ul * ROWB + h * 16;
+        // IMG: tile t+1 streams into the other buffer while this one is multiplied (nobody reads that buffer after the barrier
+        // of tile t-1; the bias of a tile is folded into the accumulator before its barrier, so tbias is free as well)
+        if constexpr (IMG) { if (t + 1 < n_tiles) stage_direct(t + 1, buf ^ 1); }
         if constexpr (REFINE) {                                   // one MFMA per fragment: all the LDS reads go out first
             f16x8 afrag[KS];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) afrag[s] = *reinterpret_cast<const f16x8*>(arow + s * 32);
+            for (int s = 0; s < KS; ++s) {
+                if constexpr (IMG) afrag[s] = *reinterpret_cast<const f16x8*>(tile + buf * TILEB + ul * ROWB + ((2 * s + h) ^ tile_swizzle<KS>(ul)) * 16);
+                else afrag[s] = *reinterpret_cast<const f16x8*>(arow + s * 32);
+            }
 #pragma unroll
             for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[s], hreg[s], acc, 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);   // the scheduler otherwise reloads one fragment register before every MFMA
@@ -938,9 +1005,12 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
         K4_MARK(0)
 #endif
 #if !(TKR_ABL & 2)
-        if (t + 1 < n_tiles) stage_store(t + 1, buf ^ 1);
-        if (t + 2 < n_tiles) stage_load(t + 2);
+        if constexpr (!IMG) {
+            if (t + 1 < n_tiles) stage_store(t + 1, buf ^ 1);
+            if (t + 2 < n_tiles) stage_load(t + 2);
+        }
 #endif
+        if constexpr (IMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile t+1 has landed (issued a whole MFMA chain ago)
         K4_MARK(1)
         if constexpr (kEarlyBarrier) __syncthreads();
         K4_MARK(2)
@@ -1329,17 +1399,36 @@ static int launch_fp32_planned(const TopkPlan& p, const float* U, const int32_t*
     return TKR_EUNSUPPORTED;
 }
 
+static size_t topk_image_bytes(int n_cols, int k) {               // the fp16 tile image of the bound-and-refine arithmetic (k <= 128)
+    const int KS = k <= 16 ? 1 : (k <= 32 ? 2 : (k <= 64 ? 4 : 8));
+    return (size_t)((n_cols + 31) / 32) * 32 * KS * 32;
+}
+
 template <int KS, typename IdT, bool REFINE>
 static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias, int n_cols,
                             int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
                             void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    constexpr int ROWB = (REFINE ? 1 : 3) * KS * 32 + 16;
+    // REFINE: the tile image lives at the END of the workspace when the caller sized it with tkr_topk_workspace_bytes_for
+    unsigned char* vimg = nullptr;
+    if constexpr (REFINE) {
+        static const bool no_img = getenv("TKR_TOPK_IMAGE") && getenv("TKR_TOPK_IMAGE")[0] == '0';
+        const size_t img = (topk_image_bytes(n_cols, k) + 255) & ~(size_t)255;
+        const size_t base = (size_t)tkr_topk_workspace_bytes(n_rows, K);
+        if (!no_img && workspace && workspace_bytes >= base + img + 256) {
+            const size_t off = (workspace_bytes - img) & ~(size_t)255;
+            vimg = static_cast<unsigned char*>(workspace) + off;
+            workspace_bytes = off;
+        }
+    }
+    const bool use_img = vimg != nullptr;
+    const int ROWB = use_img ? KS * 32 : (REFINE ? 1 : 3) * KS * 32 + 16;
     const int W = topk_waves_bf16<KS, IdT>();
     const int users = W * 32;
-    const size_t lds = (size_t)2 * 32 * ROWB + 64 * 4 + (size_t)users * 4 + (size_t)users * kCap * (4 + sizeof(IdT));
+    const size_t lds = (size_t)2 * 32 * ROWB + 64 * 4 + (size_t)users * 8 + (size_t)users * kCap * (4 + sizeof(IdT));
     if (lds > 160 * 1024) return TKR_EUNSUPPORTED;
-    auto kern = score_topk_bf16_kernel<KS, IdT, REFINE>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+    auto kern = score_topk_bf16_kernel<KS, IdT, REFINE, false>;
+    auto kern_img = score_topk_bf16_kernel<KS, IdT, REFINE, REFINE>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(use_img ? kern_img : kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return (int)e;
     const int n_blocks = (n_rows + users - 1) / users;
@@ -1349,9 +1438,12 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
     if constexpr (REFINE) {
         if (!p.extra) return TKR_EAGAIN_EXACT;                    // no room for the block flags: the caller runs the fp32 kernel
         hipLaunchKernelGGL(topk_bounds_kernel, dim3(std::min(256, (n_cols + 3) / 4)), dim3(256), 0, stream, Vt, bias, n_cols, k, p.extra);
+        if (use_img)
+            hipLaunchKernelGGL(topk_image_kernel<KS>, dim3(std::min(2048, ((n_cols + 31) / 32 * 32 * 2 * KS + 255) / 256)), dim3(256), 0, stream, Vt,
+                               n_cols, k, p.extra, vimg);
     }
-    hipLaunchKernelGGL(kern, p.grid, dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids,
-                       out_scores, p.tps, p.part, p.thr_shared, p.items, p.extra);
+    hipLaunchKernelGGL(use_img ? kern_img : kern, p.grid, dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,
+                       out_ids, out_scores, p.tps, p.part, p.thr_shared, p.items, p.extra, (const unsigned char*)vimg);
     rc = (int)hipGetLastError();
     if (rc != TKR_OK) return rc;
     if constexpr (REFINE) {                                       // blocks with an overflowed list: the fp32 kernel, same work items
@@ -1457,6 +1549,13 @@ extern "C" int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K) {
     const int64_t lists = splits > pieces ? splits : pieces;
     const int64_t refine_words = 4 + ((int64_t)n_rows + 191) / 192;      // bounds + one flag per user block (>= 192 users each)
     return lists * n_rows * K * (int64_t)sizeof(uint64_t) + (int64_t)n_rows * (int64_t)sizeof(uint32_t) + refine_words * 4;
+}
+
+extern "C" int64_t tkr_topk_workspace_bytes_for(int32_t n_rows, int32_t n_cols, int32_t k, int32_t K) {
+    // tkr_topk_workspace_bytes + room for the pre-converted item factors of the bound-and-refine arithmetic (k <= 128)
+    int64_t n = tkr_topk_workspace_bytes(n_rows, K);
+    if (k <= 128 && n_cols > 0) n = ((n + 255) & ~(int64_t)255) + (int64_t)((tkr::topk_image_bytes(n_cols, k) + 255) & ~(size_t)255) + 512;
+    return n;
 }
 
 extern "C" int tkr_score_topk(const float* U, const int32_t* user_idx, int32_t n_rows, const float* Vt,

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TKR_HIP_LIB') or os.path.join(_HERE, 'libtkr_hip.so')      # the override is for A/B builds of the kernels (scripts/)
 
 _lib = None
-VERSION = 109          # TKR_VERSION of include/tkr.h this binding was written against
+VERSION = 110          # TKR_VERSION of include/tkr.h this binding was written against
 
 
 class TkrError(RuntimeError):
@@ -53,7 +53,7 @@ EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_pl
            'tkr_matrix_write', 'tkr_raw_ranks', 'tkr_count_hits_rr', 'tkr_topk_set_math',
            'tkr_sync_snapshot', 'tkr_sync_pack', 'tkr_sync_unpack', 'tkr_sync_flow_snapshot', 'tkr_sync_flow_pack',
            'tkr_sync_flow_unpack')
-EXPORTS_I64 = ('tkr_vbpr_workspace_floats', 'tkr_vbpr_colplan_lds_bytes', 'tkr_topk_workspace_bytes', 'tkr_plan_workspace_bytes')
+EXPORTS_I64 = ('tkr_vbpr_workspace_floats', 'tkr_vbpr_colplan_lds_bytes', 'tkr_topk_workspace_bytes_for', 'tkr_topk_workspace_bytes', 'tkr_plan_workspace_bytes')
 
 
 def lib():
@@ -256,9 +256,9 @@ def build_rated_mask(rated_ptr, rated_cols, n_rows, n_cols):
 _topk_ws = {}
 
 
-def _topk_workspace(n_rows, K, device):
-    """cached scratch for the item-range split (grows on demand, per device)"""
-    need = int(lib().tkr_topk_workspace_bytes(C.c_int32(n_rows), C.c_int32(K)))
+def _topk_workspace(n_rows, K, device, n_cols=0, k=0):
+    """cached scratch for the item-range split and the pre-converted item factors (grows on demand, per device)"""
+    need = int(lib().tkr_topk_workspace_bytes_for(C.c_int32(n_rows), C.c_int32(n_cols), C.c_int32(k), C.c_int32(K)))
     ws = _topk_ws.get(device)
     if ws is None or ws.numel() < need:
         ws = _topk_ws[device] = torch.empty(need, dtype=torch.uint8, device=device)
@@ -272,7 +272,7 @@ def _score_topk_once(U, Vt, K, bias, user_idx, mask, mask_pitch, want_scores, sp
     n_rows = int(user_idx.numel()) if user_idx is not None else int(U.shape[0])
     ids = torch.empty((n_rows, K), dtype=torch.int32, device=U.device)
     scores = torch.empty((n_rows, K), dtype=torch.float32, device=U.device) if want_scores else None
-    ws = _topk_workspace(n_rows, K, U.device) if split else None
+    ws = _topk_workspace(n_rows, K, U.device, int(Vt.shape[0]), int(U.shape[1])) if split else None
     _call('tkr_score_topk', U, _p(U), _p(user_idx), C.c_int32(n_rows), _p(Vt), _p(bias), C.c_int32(Vt.shape[0]),
                                 C.c_int32(U.shape[1]), _p(mask), C.c_int32(mask_pitch), C.c_int32(K), _p(ids),
                                 _p(scores), _p(ws), C.c_int64(ws.numel() if ws is not None else 0))
