@@ -510,8 +510,10 @@ __device__ __forceinline__ void write_rows_refine(const TopkSmem<IdT>& sm, const
 template <int KHP, typename IdT>
 constexpr int topk_waves() { return KHP > 64 ? 4 : (sizeof(IdT) == 2 ? kTopkMaxWaves : 6); }
 
-template <int KHP, typename IdT>
-__global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_topk_kernel(
+// WAVES: waves per workgroup; the default of the width, or the bound-and-refine kernel's (its flagged user blocks are redone
+// here on the SAME work items: both kernels must cut the users into the same blocks)
+template <int KHP, typename IdT, int WAVES = topk_waves<KHP, IdT>()>
+__global__ __launch_bounds__((WAVES * TKR_WAVE)) void score_topk_kernel(
     const float* __restrict__ U, const int32_t* __restrict__ uidx, int n_rows, const float* __restrict__ Vt,
     const float* __restrict__ bias, int n_cols, int k, const uint32_t* __restrict__ mask, int mask_pitch, int K,
     int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int tiles_per_split,
@@ -562,7 +564,7 @@ __global__ __launch_bounds__((topk_waves<KHP, IdT>() * TKR_WAVE)) void score_top
 
     // ---- tile staging: global -> registers (issued early) -> LDS (written after the MFMA chain) ------
     // float4 path when every k-half starts 16-B aligned (k % 8 == 0); scalar path otherwise.
-    constexpr int NT_ = topk_waves<KHP, IdT>() * 64;
+    constexpr int NT_ = WAVES * 64;
     constexpr int NC = (32 * 2 * KHP / 4 + NT_ - 1) / NT_;         // float4 chunks per thread
     const bool vec = (k & 7) == 0;                                // then KH % 4 == 0: no chunk straddles the halves
     const int nthreads = blockDim.x;
@@ -679,8 +681,12 @@ __device__ __forceinline__ void split3(float a, __bf16& p1, __bf16& p2, __bf16& 
     p3 = (__bf16)(r1 - (float)p2);
 }
 
-template <int KS, typename IdT>
-constexpr int topk_waves_bf16() { return sizeof(IdT) == 2 ? kTopkMaxWaves : 6; }
+// waves per workgroup.  bf16x3: 8 (one workgroup per CU).  Bound-and-refine: 4 -- TWO workgroups per CU (LDS: 17 KB of tiles +
+// 48 KB of lists each; 256 VGPRs per wave either way).  The one barrier of a tile makes every wave wait for the slowest filter of
+// its workgroup; with four waves per barrier instead of eight, and a second workgroup to run while one waits, the Netflix
+// shape went 10.18 -> 9.59 ms (ML-10M 1.44 -> 1.35).  The three-part tiles of bf16x3 do not fit twice (measured: 14.4 -> 30.8 ms).
+template <int KS, typename IdT, bool REFINE = false>
+constexpr int topk_waves_bf16() { return sizeof(IdT) == 2 ? (REFINE ? 4 : kTopkMaxWaves) : 6; }
 
 // REFINE = bound-and-refine arithmetic (tkr_topk_set_math(2)): ONE fp16 product per element instead of six bf16 ones
 // (v_mfma_f32_32x32x16_f16, the same rate).  fp16 has 11 significant bits but a narrow exponent range, so both sides are
@@ -728,7 +734,7 @@ __global__ __launch_bounds__(256) void topk_image_kernel(const float* __restrict
 }
 
 template <int KS, typename IdT, bool REFINE = false, bool IMG = false>
-__global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score_topk_bf16_kernel(
+__global__ __launch_bounds__((topk_waves_bf16<KS, IdT, REFINE>() * TKR_WAVE), 2) void score_topk_bf16_kernel(
     const float* __restrict__ U, const int32_t* __restrict__ uidx, int n_rows, const float* __restrict__ Vt,
     const float* __restrict__ bias, int n_cols, int k, const uint32_t* __restrict__ mask, int mask_pitch, int K,
     int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int tiles_per_split, uint64_t* __restrict__ part,
@@ -835,7 +841,7 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT>() * TKR_WAVE)) void score
     const int n_tiles = items ? it.z : min(n_tiles_all, t_begin + tiles_per_split);
 
     // ---- tile staging: float4 of Vt -> registers (early) -> three 4 x bf16 parts -> LDS (after the MFMA chain)
-    constexpr int NT_ = topk_waves_bf16<KS, IdT>() * 64;
+    constexpr int NT_ = topk_waves_bf16<KS, IdT, REFINE>() * 64;
     constexpr int TILEB = 32 * ROWB;                             // bytes of one staged tile
     constexpr int NG = IMG ? (TILEB / 16 + NT_ - 1) / NT_ : 1;   // IMG: 16-byte direct-to-LDS loads per thread and tile
     auto stage_direct = [&](int t, int buf) {                     // IMG: tile t of the image -> LDS buffer buf, asynchronously (vmcnt)
@@ -1351,15 +1357,15 @@ static int merge_planned(const TopkPlan& p, int users, int n_rows, int K, int32_
     return (int)hipGetLastError();
 }
 
-template <int KHP, typename IdT>
+template <int KHP, typename IdT, int WAVES = topk_waves<KHP, IdT>()>
 static int launch_topk_planned(const TopkPlan& p, const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias,
                                int n_cols, int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
                                const uint32_t* only_flagged, hipStream_t stream) {
     constexpr int KP = 2 * KHP + 4;
-    const int W = topk_waves<KHP, IdT>(), users = W * 32;
+    const int W = WAVES, users = W * 32;
     const size_t lds = (size_t)(2 * 32 * KP + 64) * 4 + (size_t)users * 4 + (size_t)users * kCap * (4 + sizeof(IdT));
     if (lds > 160 * 1024) return TKR_EUNSUPPORTED;
-    auto kern = score_topk_kernel<KHP, IdT>;
+    auto kern = score_topk_kernel<KHP, IdT, WAVES>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, p.grid, dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids,
@@ -1381,14 +1387,14 @@ static int launch_topk(const float* U, const int32_t* uidx, int n_rows, const fl
 }
 
 // the fp32-MFMA kernel for the factor width k (k <= 128 here: same workgroup shape as the bf16 kernels)
-template <typename IdT>
+template <typename IdT, int WAVES>
 static int launch_fp32_planned(const TopkPlan& p, const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias,
                                int n_cols, int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
                                const uint32_t* only_flagged, hipStream_t stream) {
     const int kh = (k + 1) / 2;
 #define TKR_TOPK_CASE(KHP)                                                                                                    \
     if (kh <= KHP)                                                                                                            \
-        return launch_topk_planned<KHP, IdT>(p, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores,    \
+        return launch_topk_planned<KHP, IdT, WAVES>(p, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores, \
                                              only_flagged, stream);
     TKR_TOPK_CASE(16)
     TKR_TOPK_CASE(28)
@@ -1422,7 +1428,7 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
     }
     const bool use_img = vimg != nullptr;
     const int ROWB = use_img ? KS * 32 : (REFINE ? 1 : 3) * KS * 32 + 16;
-    const int W = topk_waves_bf16<KS, IdT>();
+    const int W = topk_waves_bf16<KS, IdT, REFINE>();
     const int users = W * 32;
     const size_t lds = (size_t)2 * 32 * ROWB + 64 * 4 + (size_t)users * 8 + (size_t)users * kCap * (4 + sizeof(IdT));
     if (lds > 160 * 1024) return TKR_EUNSUPPORTED;
@@ -1447,7 +1453,8 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
     rc = (int)hipGetLastError();
     if (rc != TKR_OK) return rc;
     if constexpr (REFINE) {                                       // blocks with an overflowed list: the fp32 kernel, same work items
-        rc = launch_fp32_planned<IdT>(p, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores, p.extra + 4, stream);
+        rc = launch_fp32_planned<IdT, topk_waves_bf16<KS, IdT, true>()>(p, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores,
+                                                                        p.extra + 4, stream);
         if (rc != TKR_OK) return rc;
     }
     return merge_planned(p, users, n_rows, K, out_ids, out_scores, stream);
@@ -1547,7 +1554,7 @@ extern "C" int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K) {
     if (splits < 2) splits = 2;
     const int64_t pieces = (512 + blocks - 1) / blocks + 1;      // 256 x (spans per CU <= 2)
     const int64_t lists = splits > pieces ? splits : pieces;
-    const int64_t refine_words = 4 + ((int64_t)n_rows + 191) / 192;      // bounds + one flag per user block (>= 192 users each)
+    const int64_t refine_words = 4 + ((int64_t)n_rows + 127) / 128;      // bounds + one flag per user block (>= 128 users each)
     return lists * n_rows * K * (int64_t)sizeof(uint64_t) + (int64_t)n_rows * (int64_t)sizeof(uint32_t) + refine_words * 4;
 }
 
