@@ -112,6 +112,7 @@ typedef struct {
 /* n_batches consecutive batches of a plan (the inner loop of single/bpr.py:139-147), one launch
  * each, in plan order; loss_out (nullable) is float[n_batches], pre-zeroed by the caller: the
  * batch objective (single/bpr.py:93-99) is added to loss_out[b] */
+/* k <= 512; 256 < k <= 512 only for batch_size <= 1024 (TKR_E_UNSUPPORTED otherwise) */
 int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ, const int32_t* hdr,
                 int32_t batch_size, int32_t n_batches, float* loss_out, void* stream);
 
@@ -197,7 +198,7 @@ typedef struct {
 /* floats of scratch tkr_vbpr_run needs (split-K partials, s_t, P_t, W_t) */
 int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d);
 /* n_batches consecutive batches planned by tkr_sample_plan (tri_i / tri_j = its out_i / out_j);
- * kh <= 128, batch_size <= 8192; loss_out as in tkr_bpr_run */
+ * kh <= 128, batch_size <= 65536 (batches above 8192 are planned grid-wide, see tkr_sample_plan); loss_out as in tkr_bpr_run */
 int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* tri_j, const int32_t* rec,
                  const int32_t* occ, const int32_t* hdr, const int32_t* occt, const int32_t* tri_u /*nullable*/,
                  const int32_t* tpar /*nullable*/, int32_t batch_size,

@@ -6,11 +6,14 @@ sequential mini-batches agree with oracle/ref_np.bpr_step on the same init and t
 import ctypes as C
 import os
 
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import plan_np as P
 from oracle import ref_np as R
@@ -126,7 +129,7 @@ def _current(T, name, cnt):
     return T[name][sel, idx].cpu().numpy()
 
 
-@pytest.mark.parametrize('k,B,nb,mode,lr', [(16, 64, 12, 'l2', 0.05), (128, 256, 10, 'l2', 0.05),
+@pytest.mark.parametrize('k,B,nb,mode,lr', [(16, 64, 12, 'l2', 0.05), (128, 256, 10, 'l2', 0.05), (300, 256, 5, 'l2', 0.05), (512, 1024, 3, 'l1', 0.05),
                                            (50, 256, 6, 'l1', 0.05), (200, 128, 4, 'l2', 1e-4),
                                            (128, 2048, 3, 'l2', 0.05), (64, 4096, 9, 'l2', 0.05), (128, 8192, 8, 'l1', 0.05),
                                            (128, 16384, 3, 'l2', 0.05), (64, 65536, 2, 'l1', 0.05), (32, 1048576, 2, 'l2', 0.05)])
@@ -262,3 +265,42 @@ def test_legacy_bpr_api(hip, capfd):
     assert 'switching to a batch size of 40' in capfd.readouterr().err
     m2.W.set_value(np.ones((300, 8), np.float32))
     assert np.all(m2.W.get_value() == 1.0)
+
+
+def test_wide_factors_through_the_class_and_the_stated_limits(tmp_path):
+    """single/bpr.py:20 takes any k: BPR(k=300).train(batch_size=256) runs (plain tables + K2: the granule layout holds k <= 256)
+    and equals the oracle on its stream; what the HIP path does not hold raises a ValueError that names the limit"""
+    sys.path.insert(0, os.path.join(ROOT, 'top-k-rec_amd'))
+    import synth
+    import tkr_hip
+    from single import BPR, _engine
+    r = synth.make_ratings(150, 60, 0, seed=13, mu=2.6, sigma=0.4, min_r=4, max_r=25)
+    data = str(tmp_path / 'data')
+    synth.write_dataset(data, r)
+    k, B, nb = 300, 256, 6
+    m = BPR(k=k, lr=0.02, lambda_b=1e-3)
+    m.load_training_data(data + '/uid', data + '/vid', data + '/f0tr.txt')
+    rng = np.random.Generator(np.random.PCG64(0))
+    init = [(rng.standard_normal((m.n_users, k)) * 0.1).astype(np.float32), (rng.standard_normal((m.n_items, k)) * 0.1).astype(np.float32),
+            np.zeros((m.n_items, 1), np.float32)]
+    m.fue, m.fie, m.fib = (a.copy() for a in init)
+    m.train(epochs=1, batch_size=B, epoch_sample_limit=B * nb, seed=11, verbose=False)
+    assert m._eng.layout == 'bulk'
+    hp = dict(lu=m.lu, li=m.li, lj=m.lj, lb=m.lb, lr=0.02, mode='l2')
+    row_ptr, pos, srt = P.build_csr(m.tr_data, m.n_users)
+    st = dict(U=init[0].copy(), V=init[1].copy(), b=init[2].ravel().copy(), msU=np.ones_like(init[0]), msV=np.ones_like(init[1]),
+              msb=np.ones(m.n_items, np.float32))
+    u, i, j = P.sample_triplets(m.tr_users, row_ptr, pos, srt, m.n_items, 11, 0, nb * B)
+    for s in range(nb):
+        R.bpr_step(st, u[s * B:(s + 1) * B], i[s * B:(s + 1) * B], j[s * B:(s + 1) * B], hp)
+    np.testing.assert_allclose(m.fue, st['U'], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(m.fie, st['V'], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(m.fib.ravel(), st['b'], rtol=2e-4, atol=1e-5)
+    dev = torch.device('cuda')
+    csr = m._csr
+    for kk, BB in ((600, 256), (300, 2048)):
+        eng = _engine.BprEngine(m.n_users, m.n_items, kk, hp, dev, seed=1)
+        with pytest.raises(ValueError, match='k <= 512'):
+            eng.run_batches(csr, 1, BB)
+    with pytest.raises(ValueError, match='up to 256'):
+        tkr_hip.score_topk(torch.zeros((4, 300), device=dev), torch.zeros((8, 300), device=dev), 3)

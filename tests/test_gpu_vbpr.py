@@ -182,14 +182,14 @@ def test_column_plan_bit_exact(d, density, B):
             np.testing.assert_array_equal(colh[b, has, 3 + 2 * q], ref['cent_v'][at].view(np.int32))
 
 
-@pytest.mark.parametrize('k,d,B,nb,cols', [(128, 700, 256, 4, False), (64, 300, 2048, 2, None)])
+@pytest.mark.parametrize('k,d,B,nb,cols', [(128, 700, 256, 4, False), (64, 300, 2048, 2, None), (32, 200, 16384, 1, None)])
 def test_vbpr_four_launch_sparse_view_still_right(k, d, B, nb, cols, monkeypatch):
     """the CSR/CSC walk of round 2 (S1 / pair / rows / S3) stays the path of batches above 1024 and of kh % 4 != 0: exercised with
     the column plan switched off (TKR_VBPR_COLS=0) and at batch 2048"""
     from single import _engine
     if cols is False:
         monkeypatch.setenv('TKR_VBPR_COLS', '0')
-    n_users, n_items, kh = 300, 90, k // 2
+    n_users, n_items, kh = (300, 90, k // 2) if B <= 8192 else (6000, 1500, k // 2)     # batch 16384 (vbpr.py:76 takes any): the grid-wide planner
     tr, tr_users = _toy(n_users, n_items, seed=k + d)
     feat = _sparse_feat(n_items, d, 0.1, seed=3)
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, le=1e-3, lr=0.02, mode='l2')

@@ -357,7 +357,11 @@ static int dispatch_step(const tkr_bpr_state& st, const int32_t* rec, const int3
         case 3: return launch_step<3, false>(st, rec, occ, hdr, B, loss_out, stream);
         case 4: return full ? launch_step<4, true>(st, rec, occ, hdr, B, loss_out, stream)
                             : launch_step<4, false>(st, rec, occ, hdr, B, loss_out, stream);
-        default: return TKR_EUNSUPPORTED;       // k > 256
+        case 5: case 6: case 7: case 8:         // 256 < k <= 512: eight elements per lane, predicated rows; the 4-wave teams of batches
+            // up to 1024 only (a 16-wave workgroup leaves a wave 128 registers: four partner-row pairs of eight do not fit)
+            if (tkr_plan_team(B) != 4) return TKR_EUNSUPPORTED;
+            return launch_step_t<8, false, 4>(st, rec, occ, hdr, B, loss_out, stream);
+        default: return TKR_EUNSUPPORTED;       // k > 512
     }
 }
 
@@ -370,7 +374,7 @@ static int check_state(const tkr_bpr_state* st) {
     if (st->opt != 0 && st->opt != 1) return TKR_EINVAL;
     if (st->opt == 0 && (!st->msU || !st->msV || !st->msb)) return TKR_EINVAL;
     if (st->n_users <= 0 || st->n_items <= 0 || st->k <= 0) return TKR_EINVAL;
-    if (st->k > 256) return TKR_EUNSUPPORTED;
+    if (st->k > 512) return TKR_EUNSUPPORTED;
     return TKR_OK;
 }
 

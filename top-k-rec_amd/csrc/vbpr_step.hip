@@ -697,7 +697,7 @@ extern "C" int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, cons
         return TKR_EINVAL;
     if (st->n_users <= 0 || st->n_items <= 0 || st->kh <= 0 || st->d <= 0) return TKR_EINVAL;
     if (!tri_i || !tri_j || !rec || !occ || !hdr || !occt || !workspace || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
-    if (st->kh > 128 || batch_size > 8192) return TKR_EUNSUPPORTED;
+    if (st->kh > 128 || batch_size > 65536) return TKR_EUNSUPPORTED;     // the launch records carry a triplet's index in 16 bits
     if (st->f_ptr && (!st->f_col || !st->f_val || !st->c_ptr || !st->c_item || !st->c_val || !st->item_tag)) return TKR_EINVAL;
     const size_t stride_r = (size_t)tkr_plan_max_blocks(batch_size) * tkr_plan_team(batch_size) * 16;
     const size_t stride_o = (size_t)3 * batch_size;

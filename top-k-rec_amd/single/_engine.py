@@ -668,6 +668,9 @@ class BprEngine(PlanMixin):
     def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True):
         """sample + plan + step for n_batches consecutive batches; returns the per-batch
         losses of the LAST chunk as a device tensor (or None)."""
+        if self.k > 512 or (self.k > 256 and B > 1024):
+            raise ValueError('BPR on the HIP path: k <= 512, and k <= 256 for batch sizes above 1024 (got k = %d, batch_size = %d): a wave '
+                             'holds a row in k / 64 registers per array (csrc/bpr_step.hip)' % (self.k, B))
         self.prepare(B)
         key = (self.layout_epoch, B, FLOW_WAVES_PER_CU)
         if getattr(self, '_step_key', None) != key:       # the C struct and the closure are built once per layout, not per call
@@ -828,6 +831,8 @@ class VbprEngine(PlanMixin):
     copy_model_from = BprEngine.copy_model_from
 
     def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True):
+        if self.kh > 128 or B > 65536:
+            raise ValueError('VBPR on the HIP path: k // 2 <= 128 and batch_size <= 65536 (got k = %d, batch_size = %d)' % (self.k, B))
         if getattr(self, '_step_key', None) != B:           # the C struct and the closure are built once per batch size, not per call
             self._step_key, self._step = B, self.step_fn(B)
         return self._run(csr, n_batches, B, want_loss, self._step)
