@@ -313,8 +313,9 @@ int tkr_sync_snapshot(const float* P, const int32_t* cnt, float* start, int64_t 
 int tkr_sync_flow_snapshot(const void* V, const void* tailV, const int32_t* icnt, float* start, int32_t n, int32_t k, void* stream);
 int tkr_sync_flow_pack(const void* V, const void* msV, const void* tailV, const int32_t* icnt, const float* start, float* flat_delta,
                        float* flat_ms, int32_t n, int32_t k, float inv_world, void* stream);
-int tkr_sync_flow_unpack(void* V, void* msV, void* tailV, uint32_t* rdV, int32_t* icnt, const float* start, const float* flat_delta,
-                         const float* flat_ms, int32_t n, int32_t k, void* stream);
+int tkr_sync_flow_unpack(void* V, void* msV, void* tailV, uint32_t* rdV, int32_t* icnt, float* start /* in: epoch start; out: the new
+                         values = the next epoch's start (no snapshot needed if nothing else writes the tables in between) */,
+                         const float* flat_delta, const float* flat_ms, int32_t n, int32_t k, void* stream);
 int tkr_sync_pack(const float* P, const float* ms, const int32_t* cnt, const float* start, float* flat_delta, float* flat_ms,
                   int64_t n, int32_t w, float inv_world, void* stream);
 int tkr_sync_unpack(float* P, float* ms, const float* start, const float* flat_delta, const float* flat_ms, int64_t n, int32_t w,

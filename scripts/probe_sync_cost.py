@@ -18,4 +18,10 @@ for B in (256, 8192):
         isync.begin(); torch.cuda.synchronize(); t1 = time.perf_counter()
         eng.run_batches(csr, 16, B, want_loss=False); torch.cuda.synchronize(); t2 = time.perf_counter()
         isync.end(); torch.cuda.synchronize(); t3 = time.perf_counter()
-    print('batch %5d (%s layout): begin %.0f us, end %.0f us (no collective)' % (B, eng.layout, (t1 - t0) * 1e6, (t3 - t2) * 1e6), flush=True)
+    isync.timing = []
+    for rep in range(4):
+        isync.begin(); eng.run_batches(csr, 16, B, want_loss=False); isync.end()
+    torch.cuda.synchronize()
+    ev = [(a.elapsed_time(b) * 1e3, b.elapsed_time(c) * 1e3, c.elapsed_time(d) * 1e3) for a, b, c, d in isync.timing]
+    print('batch %5d (%s layout): begin %.0f us, end %.0f us host wall (no collective); device: pack %.1f us, unpack %.1f us'
+          % (B, eng.layout, (t1 - t0) * 1e6, (t3 - t2) * 1e6, min(e[0] for e in ev), min(e[2] for e in ev)), flush=True)

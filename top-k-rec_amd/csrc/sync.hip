@@ -48,56 +48,82 @@ __global__ void sync_unpack_kernel(float* __restrict__ P, float* __restrict__ ms
 // unpack re-creates what a fresh assignment of the tables looks like: version 0 of every row in buffer 0 (tags 0, padding 0 / slot
 // padding 1), no version in buffer 1 (tags 0xffffffff), expect = 0, rd = 0, update counters 0 -- one launch instead of ~20
 // framework ops (fills, strided copies, tag resets) on 2 x 21 MB: measured 464 -> ~60 us per exchange at the ML-10M shape.
-__global__ void sync_flow_snapshot_kernel(const float2* __restrict__ P, const float2* __restrict__ tail, const int32_t* __restrict__ cnt,
-                                          float* __restrict__ start, int n, int k, int kp) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)n * (k + 1)) return;
-    const int r = (int)(i / (k + 1)), c = (int)(i % (k + 1));
+// One thread per PAIR of granules (16 bytes: the access width of csrc/bpr_flow.hip), 64 threads per 128-granule row, no
+// integer division (round 2: one thread per element with i / (k + 1) and 8-byte accesses: 110 us for the three launches of an
+// exchange at the ML-10M shape).  The row's tail (bias, its slot) rides with thread 0 of the row.
+__global__ __launch_bounds__(256) void sync_flow_snapshot_kernel(const float4* __restrict__ P, const float2* __restrict__ tail,
+                                                                const int32_t* __restrict__ cnt, float* __restrict__ start, int n,
+                                                                int k, int kp) {
+    const int hp = kp >> 1;                                      // pairs per row
+    const int r = blockIdx.x * (256 / 64) + (threadIdx.x >> 6);
+    if (r >= n) return;
     const int64_t par = cnt[r] & 1;
-    if (c < k) start[(int64_t)r * k + c] = P[(par * n + r) * kp + c].x;
-    else start[(int64_t)n * k + r] = tail[(par * n + r) * 4 + 0].x;
+    for (int q = threadIdx.x & 63; q < hp; q += 64) {
+        const float4 g = P[(par * n + r) * hp + q];
+        const int c = 2 * q;
+        if (c < k) start[(int64_t)r * k + c] = g.x;
+        if (c + 1 < k) start[(int64_t)r * k + c + 1] = g.z;
+    }
+    if ((threadIdx.x & 63) == 0) start[(int64_t)n * k + r] = tail[(par * n + r) * 4 + 0].x;
 }
 
-__global__ void sync_flow_pack_kernel(const float2* __restrict__ P, const float2* __restrict__ M, const float2* __restrict__ tail,
-                                      const int32_t* __restrict__ cnt, const float* __restrict__ start, float* __restrict__ flat_delta,
-                                      float* __restrict__ flat_ms, int n, int k, int kp, float inv_world) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)n * (k + 1)) return;
-    const int r = (int)(i / (k + 1)), c = (int)(i % (k + 1));
+__global__ __launch_bounds__(256) void sync_flow_pack_kernel(const float4* __restrict__ P, const float4* __restrict__ M,
+                                                            const float2* __restrict__ tail, const int32_t* __restrict__ cnt,
+                                                            const float* __restrict__ start, float* __restrict__ flat_delta,
+                                                            float* __restrict__ flat_ms, int n, int k, int kp, float inv_world) {
+    const int hp = kp >> 1;
+    const int r = blockIdx.x * (256 / 64) + (threadIdx.x >> 6);
+    if (r >= n) return;
     const int64_t par = cnt[r] & 1;
-    if (c < k) {
-        const int64_t o = (int64_t)r * k + c, g = (par * n + r) * kp + c;
-        flat_delta[o] = P[g].x - start[o];
-        flat_ms[o] = M[g].x * inv_world;
-    } else {
+    for (int q = threadIdx.x & 63; q < hp; q += 64) {
+        const float4 g = P[(par * n + r) * hp + q], m = M[(par * n + r) * hp + q];
+        const int c = 2 * q;
+        const int64_t o = (int64_t)r * k + c;
+        if (c < k) { flat_delta[o] = g.x - start[o]; flat_ms[o] = m.x * inv_world; }
+        if (c + 1 < k) { flat_delta[o + 1] = g.z - start[o + 1]; flat_ms[o + 1] = m.z * inv_world; }
+    }
+    if ((threadIdx.x & 63) == 0) {
         const int64_t o = (int64_t)n * k + r, g = (par * n + r) * 4;
         flat_delta[o] = tail[g + 0].x - start[o];
         flat_ms[o] = tail[g + 1].x * inv_world;
     }
 }
 
-__global__ void sync_flow_unpack_kernel(float2* __restrict__ P, float2* __restrict__ M, float2* __restrict__ tail,
-                                        uint32_t* __restrict__ rd, int32_t* __restrict__ cnt, const float* __restrict__ start,
-                                        const float* __restrict__ flat_delta, const float* __restrict__ flat_ms, int n, int k, int kp) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)n * kp) return;
-    const int r = (int)(i / kp), c = (int)(i % kp);
+// unpack also leaves the NEW values in `start`: they are the next epoch's starting point, so the next exchange needs no
+// snapshot launch (dist.ItemSync keeps track of whether anything else touched the tables in between)
+__global__ __launch_bounds__(256) void sync_flow_unpack_kernel(float4* __restrict__ P, float4* __restrict__ M, float2* __restrict__ tail,
+                                                              uint32_t* __restrict__ rd, int32_t* __restrict__ cnt,
+                                                              float* __restrict__ start, const float* __restrict__ flat_delta,
+                                                              const float* __restrict__ flat_ms, int n, int k, int kp) {
+    const int hp = kp >> 1;
+    const int r = blockIdx.x * (256 / 64) + (threadIdx.x >> 6);
+    if (r >= n) return;
     const float none = __uint_as_float(0xffffffffu), zero_tag = __uint_as_float(0u);
-    const int64_t g0 = (int64_t)r * kp + c, g1 = ((int64_t)n + r) * kp + c;
-    const int64_t o = (int64_t)r * k + c;
-    P[g0] = make_float2(c < k ? start[o] + flat_delta[o] : 0.f, zero_tag);
-    M[g0] = make_float2(c < k ? flat_ms[o] : 1.f, zero_tag);
-    P[g1] = make_float2(0.f, none);
-    M[g1] = make_float2(0.f, none);
-    if (c < 4) {
-        const int64_t ob = (int64_t)n * k + r;
-        float v = 0.f;
-        if (c == 0) v = start[ob] + flat_delta[ob];
-        if (c == 1) v = flat_ms[ob];
-        tail[(int64_t)r * 4 + c] = make_float2(v, zero_tag);
-        tail[((int64_t)n + r) * 4 + c] = make_float2(0.f, none);
+    for (int q = threadIdx.x & 63; q < hp; q += 64) {
+        const int c = 2 * q;
+        const int64_t o = (int64_t)r * k + c;
+        float v0 = 0.f, v1 = 0.f, m0 = 1.f, m1 = 1.f;            // padding: value 0, slot 1
+        if (c < k) { v0 = start[o] + flat_delta[o]; m0 = flat_ms[o]; start[o] = v0; }
+        if (c + 1 < k) { v1 = start[o + 1] + flat_delta[o + 1]; m1 = flat_ms[o + 1]; start[o + 1] = v1; }
+        P[(int64_t)r * hp + q] = make_float4(v0, zero_tag, v1, zero_tag);
+        M[(int64_t)r * hp + q] = make_float4(m0, zero_tag, m1, zero_tag);
+        P[((int64_t)n + r) * hp + q] = make_float4(0.f, none, 0.f, none);
+        M[((int64_t)n + r) * hp + q] = make_float4(0.f, none, 0.f, none);
     }
-    if (c == 0) { rd[2 * (int64_t)r] = 0u; rd[2 * (int64_t)r + 1] = 0u; cnt[r] = 0; }
+    if ((threadIdx.x & 63) == 0) {
+        const int64_t ob = (int64_t)n * k + r;
+        const float b = start[ob] + flat_delta[ob];
+        start[ob] = b;
+        tail[(int64_t)r * 4 + 0] = make_float2(b, zero_tag);
+        tail[(int64_t)r * 4 + 1] = make_float2(flat_ms[ob], zero_tag);
+        tail[(int64_t)r * 4 + 2] = make_float2(0.f, zero_tag);
+        tail[(int64_t)r * 4 + 3] = make_float2(0.f, zero_tag);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tail[((int64_t)n + r) * 4 + c] = make_float2(0.f, none);
+        rd[2 * (int64_t)r] = 0u;
+        rd[2 * (int64_t)r + 1] = 0u;
+        cnt[r] = 0;
+    }
 }
 
 }  // namespace tkr
@@ -106,9 +132,8 @@ extern "C" int tkr_sync_flow_snapshot(const void* P, const void* tail, const int
                                       void* stream) {
     if (!P || !tail || !cnt || !start || n <= 0 || k <= 0) return TKR_EINVAL;
     const int kp = (k + 127) / 128 * 128;
-    const int64_t tot = (int64_t)n * (k + 1);
-    hipLaunchKernelGGL(tkr::sync_flow_snapshot_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       static_cast<const float2*>(P), static_cast<const float2*>(tail), cnt, start, n, k, kp);
+    hipLaunchKernelGGL(tkr::sync_flow_snapshot_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const float4*>(P), static_cast<const float2*>(tail), cnt, start, n, k, kp);
     TKR_LAUNCH_CHECK();
     return TKR_OK;
 }
@@ -117,21 +142,19 @@ extern "C" int tkr_sync_flow_pack(const void* P, const void* M, const void* tail
                                   float* flat_delta, float* flat_ms, int32_t n, int32_t k, float inv_world, void* stream) {
     if (!P || !M || !tail || !cnt || !start || !flat_delta || !flat_ms || n <= 0 || k <= 0) return TKR_EINVAL;
     const int kp = (k + 127) / 128 * 128;
-    const int64_t tot = (int64_t)n * (k + 1);
-    hipLaunchKernelGGL(tkr::sync_flow_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       static_cast<const float2*>(P), static_cast<const float2*>(M), static_cast<const float2*>(tail), cnt, start,
+    hipLaunchKernelGGL(tkr::sync_flow_pack_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const float4*>(P), static_cast<const float4*>(M), static_cast<const float2*>(tail), cnt, start,
                        flat_delta, flat_ms, n, k, kp, inv_world);
     TKR_LAUNCH_CHECK();
     return TKR_OK;
 }
 
-extern "C" int tkr_sync_flow_unpack(void* P, void* M, void* tail, uint32_t* rd, int32_t* cnt, const float* start,
+extern "C" int tkr_sync_flow_unpack(void* P, void* M, void* tail, uint32_t* rd, int32_t* cnt, float* start,
                                     const float* flat_delta, const float* flat_ms, int32_t n, int32_t k, void* stream) {
     if (!P || !M || !tail || !rd || !cnt || !start || !flat_delta || !flat_ms || n <= 0 || k <= 0) return TKR_EINVAL;
     const int kp = (k + 127) / 128 * 128;
-    const int64_t tot = (int64_t)n * kp;
-    hipLaunchKernelGGL(tkr::sync_flow_unpack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       static_cast<float2*>(P), static_cast<float2*>(M), static_cast<float2*>(tail), rd, cnt, start, flat_delta,
+    hipLaunchKernelGGL(tkr::sync_flow_unpack_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<float4*>(P), static_cast<float4*>(M), static_cast<float2*>(tail), rd, cnt, start, flat_delta,
                        flat_ms, n, k, kp);
     TKR_LAUNCH_CHECK();
     return TKR_OK;

@@ -90,6 +90,7 @@ class ItemSync:
         self.start = None
         self.tabs = None
         self._bound = None
+        self._start_valid = None     # (binding, engine.item_mutations) for which start_flat already holds the epoch's start
         self.timing = None           # a list: end() appends (before pack, after pack, after collective, after unpack) timing events
         self._bind()
 
@@ -138,7 +139,11 @@ class ItemSync:
         if self.flow is not None:
             import tkr_hip
             V, msV, tail, rd, icnt, n, k = self.flow
-            tkr_hip.sync_flow_snapshot(V, tail, icnt, self.start_flat, n, k)
+            # the unpack of the exchange before left the new values in start_flat: they ARE this epoch's start, unless somebody wrote
+            # the item tables since (set_items, a layout change: the engine counts those)
+            if self._start_valid != (self._bound, getattr(self.eng, 'item_mutations', 0)):
+                tkr_hip.sync_flow_snapshot(V, tail, icnt, self.start_flat, n, k)
+            self._start_valid = None
             self.start = True
             return
         if self.tabs is None:
@@ -182,6 +187,7 @@ class ItemSync:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self._mark(marks)
             tkr_hip.sync_flow_unpack(V, msV, tail, rd, icnt, self.start_flat, self.flat[:total], self.flat[total:], n, k)
+            self._start_valid = (self._bound, getattr(self.eng, 'item_mutations', 0))
             self._mark(marks)
             return
         if self.tabs is None:

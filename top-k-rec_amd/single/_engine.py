@@ -497,6 +497,7 @@ class BprEngine(PlanMixin):
         self.V = DoubleTable(n_items, k, self.device, 0.01, gen)
         self.b = DoubleTable(n_items, 0, self.device)
         self.tailU = self.tailV = self.ctl = None
+        self.item_mutations = 0         # writes to the item tables from outside the step kernels (dist.ItemSync: is its snapshot still the truth?)
         self._flow_ran = False          # a persistent launch ran since the status word was last looked at
         self._status_host = self._status_event = None
         self._init_plans()
@@ -536,6 +537,7 @@ class BprEngine(PlanMixin):
             self.b = DoubleTable(self.n_items, 0, self.device)
         self.layout = layout
         self.layout_epoch += 1
+        self.item_mutations += 1
         self.U.assign(pu, mu)
         self.V.assign(pv, mv)
         if layout == 'flow':
@@ -623,6 +625,7 @@ class BprEngine(PlanMixin):
         self._cnt.ucnt.zero_()
 
     def set_items(self, V=None, b=None, msV=None, msb=None):
+        self.item_mutations += 1
         cv, mv = self.V.current(self.cnt.icnt)
         cb, mb = self.get('b')
         nb = cb.clone() if b is None else self._dev(b).reshape(-1)
