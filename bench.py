@@ -340,7 +340,9 @@ def topk_bench_netflix(k, device, K=30, reps=3):
     tf = flops / (ms * 1e-3) / 1e12
     return {'value': n_users * reps / wall, 'unit': 'users/s', 'ms_per_pass': wall * 1e3 / reps,
             'config': {'workload': '%d users x %d items, k=%d, top-%d, %d rated items per user masked' % (n_users, n_items, k, K, deg)},
-            'roofline': dict(topk_roofline(tf, k), launch_ms=ms), 'ms_per_pass_other_arithmetics': others}
+            'roofline': dict(topk_roofline(tf, k), launch_ms=ms, traffic=None,
+                             traffic_from_profile=pmc_traffic('score_topk_netflix_k128') if k == 128 else None),
+            'ms_per_pass_other_arithmetics': others}
 
 
 def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
@@ -375,7 +377,9 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
                                'tkr::vbpr_colplan beside K1' if eng.wants_cols(B) else
                                'tkr::vbpr_sproject / pair / rows / sdense (4 launches per batch)', 'bound': 'hbm', 'achieved': gbs,
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch_chain': bytes_,
-                    'step_us': step_s * 1e6, 'traffic': None}
+                    'step_us': step_s * 1e6, 'traffic': None,
+                    'traffic_from_profile': (sum(pmc_traffic('vbpr_%s_B256' % n) or 0 for n in ('tproject', 'pairsum', 'update')) or None)
+                                            if (eng.wants_cols(B) and B == 256 and d == 20000) else None}
         else:
             flops = 4.0 * d * kh * B                                     # project the difference once, fwd + dense gradient
             tf = flops / step_s / 1e12
@@ -554,6 +558,7 @@ def main():
             out['throughput_mode_B%d' % Bb] = {'batch_size': Bb, 'steps': Tb, 'value': Tb * Bb / wb, 'unit': 'triplets/s', 'ms_per_step': wb * 1e3 / Tb,
                                                'roofline': {'bound': 'hbm', 'achieved': ab, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ab / HBM_PEAK_GBS,
                                                             'launch_us': sb * 1e3 / Tb, 'traffic': None,
+                                                            'traffic_from_profile': pmc_traffic('bpr_step_B%d' % Bb) if (k == 128 and args.shape == 'ml10m') else None,
                                                             'note': 'algorithmic bytes give no credit for in-batch duplicates: %d item draws over %d items'
                                                                     % (2 * Bb, eng.n_items)}}
             del engb

@@ -8,7 +8,7 @@
 #   driver           HIP API + kernel trace of the round-end driver's exact command (--steps 20 --warmup 5): what the timed region calls
 # Output: gpurun_out/prof_<tag>/...; summarise afterwards with `python scripts/summarize_profile.py gpurun_out/prof_<tag> <tag>`.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -22,6 +22,15 @@ for C in FETCH_SIZE WRITE_SIZE; do
         python "$REPO/bench.py" --no-cpu-baseline --no-extras --batch-size 8192 --steps 256 --warmup 128 > /dev/null 2> "$OUT/b8192_$C.err" < /dev/null
     timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/calib_$C" -o c -- \
         python "$REPO/scripts/pmc_calibrate.py" > /dev/null 2> "$OUT/calib_$C.err" < /dev/null
+    # round 3: K4's bound-and-refine kernel (ML-10M and Netflix shape), the per-launch kernel at batch 65,536, the VBPR step
+    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/topk_$C" -o b -- \
+        python "$REPO/scripts/probe_topk.py" > /dev/null 2> "$OUT/topk_$C.err" < /dev/null
+    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/topknf_$C" -o b -- \
+        python "$REPO/scripts/probe_topk.py" 480189 17770 128 30 > /dev/null 2> "$OUT/topknf_$C.err" < /dev/null
+    timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/b65536_$C" -o b -- \
+        python "$REPO/bench.py" --no-cpu-baseline --no-extras --batch-size 65536 --steps 32 --warmup 16 > /dev/null 2> "$OUT/b65536_$C.err" < /dev/null
+    NB=256 timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/vbpr_$C" -o b -- \
+        python "$REPO/scripts/probe_vbpr.py" > /dev/null 2> "$OUT/vbpr_$C.err" < /dev/null
 done
 timeout 600 rocprofv3 --hip-trace --kernel-trace --stats --output-format csv -d "$OUT/driver" -o d -- \
     python "$REPO/bench.py" --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > "$OUT/driver_cmd.json" 2> "$OUT/driver.err" < /dev/null

@@ -8,14 +8,15 @@ KERN = ('bpr_flow_kernel', 'bpr_step_kernel', 'sample_plan_kernel', 'resolve_flo
         'DeviceRadixSort', 'radix_sort', 'DeviceScan', 'scan', 'vbpr_pair_kernel', 'score_topk_bf16_kernel', 'score_topk_kernel', 'merge_topk_kernel', 'topk_bounds_kernel',
         'raw_rank_kernel', 'count_hits_rr_kernel',
         'build_mask_kernel', 'vbpr_sproject_kernel', 'vbpr_sdense_kernel', 'vbpr_project_kernel', 'vbpr_reduce_kernel', 'vbpr_occur_kernel', 'vbpr_rows_kernel', 'vbpr_dense_kernel',
-        'calib_rowcopy_kernel')
+        'vbpr_tproject_kernel', 'vbpr_pairsum_kernel', 'vbpr_update_kernel', 'vbpr_colplan_kernel', 'topk_image_kernel',
+        'sync_flow_pack_kernel', 'sync_flow_unpack_kernel', 'sync_flow_snapshot_kernel', 'calib_rowcopy_kernel')
 def short(n):
     for k in KERN:
         if k in n:
             if k == 'bpr_step_kernel' and re.search(r'bpr_step_kernel<\d+, (?:true|false), \d+, true>', n):
                 return 'tkr::bpr_step_kernel<SGD>'
             if k == 'score_topk_bf16_kernel':           # <KS, IdT, REFINE>: the bound-and-refine arithmetic is its own line
-                return 'tkr::score_topk_bf16_kernel<refine>' if re.search(r'score_topk_bf16_kernel<\d+, [a-z ]+, true>', n) else 'tkr::score_topk_bf16_kernel<bf16x3>'
+                return 'tkr::score_topk_bf16_kernel<refine>' if re.search(r'score_topk_bf16_kernel<\d+, [a-z ]+, true', n) else 'tkr::score_topk_bf16_kernel<bf16x3>'
             if k == 'score_topk_kernel':
                 return 'tkr::score_topk_kernel (fp32 MFMA; ~5-8 us calls: the no-op fallback pass behind a refine launch)'
             return 'tkr::' + k
@@ -63,8 +64,23 @@ res['bpr_step_B256'] = res['bpr_flow_B256']          # the key bench.py looks up
 rd, wr, n = total('b8192', 'bpr_step_kernel')
 res['bpr_step_B8192'] = {'launches': n, 'hbm_bytes_per_launch_corrected': (rd + wr) / max(n, 1), 'hbm_read_bytes_per_launch': rd / max(n, 1),
                          'hbm_write_bytes_per_launch': wr / max(n, 1)}
-for key in ('bpr_flow_B256', 'bpr_step_B8192'):
-    print(key, res[key])
+# round 3: more legs (each optional: a pass that did not run is skipped)
+def leg(tagdir, pat, key, per, note):
+    try:
+        rd, wr, n = total(tagdir, pat)
+    except AssertionError:
+        return
+    if n:
+        res[key] = {'launches': n, 'hbm_read_bytes_per_launch': rd / n, 'hbm_write_bytes_per_launch': wr / n,
+                    'hbm_bytes_per_launch_corrected': (rd + wr) / n, 'per': per, 'note': note}
+leg('topk', r'score_topk_bf16_kernel<\d+, [a-z ]+, true', 'score_topk_ml10m_k128', 'pass over 69,878 users x 10,380 items, k = 128, top-30',
+    'bound-and-refine kernel alone (the bounds / image / merge launches are a few hundred KB)')
+leg('topknf', r'score_topk_bf16_kernel<\d+, [a-z ]+, true', 'score_topk_netflix_k128', 'pass over 480,189 users x 17,770 items, k = 128, top-30', '')
+leg('b65536', 'bpr_step_kernel', 'bpr_step_B65536', 'batch of 65,536 triplets', 'algorithmic 406 MB: no credit for the duplicates of 131,072 item draws over 10,380 items')
+for pat, key in (('vbpr_tproject_kernel', 'vbpr_tproject_B256'), ('vbpr_pairsum_kernel', 'vbpr_pairsum_B256'), ('vbpr_update_kernel', 'vbpr_update_B256')):
+    leg('vbpr', pat, key, 'batch of 256 triplets, d = 20,000, ~100 nonzeros per feature row', '')
+for key in ('bpr_flow_B256', 'bpr_step_B8192', 'score_topk_ml10m_k128', 'score_topk_netflix_k128', 'bpr_step_B65536', 'vbpr_tproject_B256', 'vbpr_update_B256'):
+    print(key, res.get(key))
 json.dump(res, open('profiles/%s_pmc_traffic.json' % tag, 'w'), indent=1)
 if os.path.exists(os.path.join(src, 'bench_under_rocprof.json')):
     import shutil
