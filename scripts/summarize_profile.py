@@ -46,7 +46,7 @@ cf = counter('calib', 'FETCH_SIZE', 'calib_rowcopy').Counter_Value.mean()
 cw = counter('calib', 'WRITE_SIZE', 'calib_rowcopy').Counter_Value.mean()
 fr, fw = known_r / (cf * 1024), known_w / (cw * 1024)
 res = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) around `python bench.py --no-cpu-baseline '
-                 '--no-extras --steps 2048 --warmup 256` (headline: the persistent kernel, 2,304 batches of 256) and `... --batch-size 8192 --steps 256 '
+                 '--no-extras --steps 2048 --warmup 256` (headline: the persistent kernel; with the epoch_mode leg of the same process 11,718 batches of 256) and `... --batch-size 8192 --steps 256 '
                  '--warmup 128` (one launch per batch); corrected by the factors measured with scripts/pmc_calibrate.py (known-byte gather copy); '
                  'bytes = KB * 1024 * factor',
        'calibration': {'known_read_bytes': known_r, 'known_write_bytes': known_w, 'FETCH_SIZE_KB': cf, 'WRITE_SIZE_KB': cw,
@@ -56,6 +56,7 @@ def total(tagdir, pat):
     return float(f.Counter_Value.sum()) * 1024 * fr, float(w.Counter_Value.sum()) * 1024 * fw, len(f)
 rd, wr, n = total('headline', 'bpr_flow_kernel')
 batches = 2048 + 256
+batches += (3906 - batches % 3906) % 3906 + 2 * 3906          # bench.py's epoch_mode leg of the same process: to the epoch boundary, then two reference epochs
 res['bpr_flow_B256'] = {'launches': n, 'batches': batches, 'hbm_read_bytes_per_batch': rd / batches, 'hbm_write_bytes_per_batch': wr / batches,
                         'hbm_bytes_per_launch_corrected': (rd + wr) / batches,
                         'note': 'per BATCH (a launch of the persistent kernel covers up to 512 batches); algorithmic 1,587,200 B; the granule '
@@ -96,8 +97,8 @@ try:
     ht = pd.read_csv(find('driver', 'd_hip_api_trace.csv*'))
     kt = pd.read_csv(find('driver', 'd_kernel_trace.csv*'))
     flow = kt[kt.Kernel_Name.str.contains('bpr_flow_kernel')].sort_values('Start_Timestamp')
-    last = flow.iloc[-1]                                            # the timed 20 batches = the last persistent launch
-    prev_end = flow.iloc[-2].End_Timestamp if len(flow) > 1 else 0
+    last = flow.iloc[1]                                             # warm-up (5 batches), then the timed 20 batches; the epoch_mode leg follows
+    prev_end = flow.iloc[0].End_Timestamp
     win = ht[(ht.Start_Timestamp > prev_end) & (ht.Start_Timestamp < last.End_Timestamp)]
     calls = win.Function.value_counts().to_dict()
     json.dump({'window': 'HIP API calls between the end of the warm-up launch and the end of the timed launch of `bench.py --steps 20 --warmup 5`',

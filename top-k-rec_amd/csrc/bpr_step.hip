@@ -23,6 +23,8 @@
 // Roofline: HBM / cache-bandwidth bound gather-scatter.  Algorithmic bytes per triplet
 // (no credit for in-batch duplicates): 3 rows x (param+ms) x (read+write)
 // = 48k B + 32 B biases + 24 B ids  ->  6,200 B at k = 128.
+#include <stdlib.h>
+
 #include "tkr_common.h"
 #include "../../include/tkr.h"
 
@@ -214,7 +216,7 @@ __device__ __forceinline__ void run_group(const tkr_bpr_state& st, int lane, int
 template <int NE, bool VEC, int kTeam, bool SGD>
 __global__ __launch_bounds__((kTeam * TKR_WAVE)) void bpr_step_kernel(
     tkr_bpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
-    const int4* __restrict__ hdr, float* __restrict__ loss_out) {
+    const int4* __restrict__ hdr, float* __restrict__ loss_out, int reverse) {
     __shared__ float red[kTeam][NE * TKR_WAVE + 1];
     const int lane = threadIdx.x & (TKR_WAVE - 1);
     const int wave = threadIdx.x >> 6;
@@ -224,7 +226,11 @@ __global__ __launch_bounds__((kTeam * TKR_WAVE)) void bpr_step_kernel(
     const int k = st.k;
     const size_t ustride = (size_t)st.n_users * k, istride = (size_t)st.n_items * k;
 
-    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    // The heavy teams sit at the END of the record list (oracle/plan_np.py launch_plan); the grid walks it BACKWARDS, so the
+    // longest tasks -- a popular item's hundreds of occurrences summed by one team -- start first and the light workgroups fill in
+    // behind them (longest-processing-time order; forwards, the last workgroups to start were the slowest: TKR_K2_ORDER=0).
+    for (int it = blockIdx.x; it < n_blocks; it += gridDim.x) {
+        const int blk = reverse ? n_blocks - 1 - it : it;
         const bool heavy = blk >= nlb;           // workgroup-uniform
         const int word = (lane < 16) ? rec_all[((size_t)blk * kTeam + wave) * 16 + lane] : 0;
         const int rowk = bcast_i(word, 0);
@@ -329,12 +335,13 @@ static int step_grid(int B, int team) {
 template <int NE, bool VEC, int TEAM>
 static int launch_step_t(const tkr_bpr_state& st, const int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
                        float* loss_out, hipStream_t stream) {
+    static const int reverse = (getenv("TKR_K2_ORDER") && getenv("TKR_K2_ORDER")[0] == '0') ? 0 : 1;
     if (st.opt == 1)
         hipLaunchKernelGGL((bpr_step_kernel<NE, VEC, TEAM, true>), dim3(step_grid(B, TEAM)), dim3(TEAM * TKR_WAVE), 0, stream,
-                           st, rec, reinterpret_cast<const int2*>(occ), reinterpret_cast<const int4*>(hdr), loss_out);
+                           st, rec, reinterpret_cast<const int2*>(occ), reinterpret_cast<const int4*>(hdr), loss_out, reverse);
     else
         hipLaunchKernelGGL((bpr_step_kernel<NE, VEC, TEAM, false>), dim3(step_grid(B, TEAM)), dim3(TEAM * TKR_WAVE), 0, stream,
-                           st, rec, reinterpret_cast<const int2*>(occ), reinterpret_cast<const int4*>(hdr), loss_out);
+                           st, rec, reinterpret_cast<const int2*>(occ), reinterpret_cast<const int4*>(hdr), loss_out, reverse);
     return (int)hipGetLastError();
 }
 
