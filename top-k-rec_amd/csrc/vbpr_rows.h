@@ -99,7 +99,8 @@ __device__ __forceinline__ void vbpr_rows_body(
     const int kh = st.kh, k2 = 2 * kh;
     const size_t ustride = (size_t)st.n_users * k2, istride = (size_t)st.n_items * kh;
     const bool l2 = st.mode == 0;
-    for (int blk = first_blk; blk < n_blocks; blk += blk_stride) {
+    for (int it = first_blk; it < n_blocks; it += blk_stride) {
+        const int blk = n_blocks - 1 - it;           // backwards: the heavy teams at the end of the record list start first (csrc/bpr_step.hip)
         const bool heavy = blk >= nlb;
         const WaveRec r = read_rec(rec_all, kVTeam, blk, wave, lane);
         if (r.rowk == -1) continue;
