@@ -1287,7 +1287,7 @@ static int topk_spans_per_cu() {
     if (m < 0) {
         const char* e = getenv("TKR_TOPK_SPANS");
         m = e ? atoi(e) : 2;                                     // measured: 2 spans per CU at both benchmark shapes
-        if (m < 0 || m > 2) m = 2;
+        if (m < 0 || m > 4) m = 2;
     }
     return m;
 }
@@ -1548,11 +1548,11 @@ extern "C" int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K) {
     // room for the partial lists a launch can use + one shared threshold word per row.  Plain grid of (block, range)
     // workgroups: enough ranges to balance 256 CUs, at most kMaxSplits.  Item table: the pieces one block can be cut
     // into, at most ceil(G / blocks) + 1 with G <= 512 spans.
-    const int64_t blocks = ((int64_t)n_rows + 255) / 256;
+    const int64_t blocks = ((int64_t)n_rows + 255) / 256;        // (a lower bound of the blocks: 128-256 users each)
     int64_t splits = (16 * 256 + blocks - 1) / blocks;
     if (splits > tkr::kMaxSplits) splits = tkr::kMaxSplits;
     if (splits < 2) splits = 2;
-    const int64_t pieces = (512 + blocks - 1) / blocks + 1;      // 256 x (spans per CU <= 2)
+    const int64_t pieces = (1024 + blocks - 1) / blocks + 1;     // 256 x (spans per CU <= 4)
     const int64_t lists = splits > pieces ? splits : pieces;
     const int64_t refine_words = 4 + ((int64_t)n_rows + 127) / 128;      // bounds + one flag per user block (>= 128 users each)
     return lists * n_rows * K * (int64_t)sizeof(uint64_t) + (int64_t)n_rows * (int64_t)sizeof(uint32_t) + refine_words * 4;
