@@ -268,7 +268,7 @@ __global__ __launch_bounds__(W * 64) void vbpr_tproject_kernel(tkr_vbpr_state st
         const int c = lane + e * 64;
         if (c < kh) Wraw[(size_t)t * kh + c] = uce[e];
     }
-    if (lane == 0) { ab_out[t] = alpha; ab_out[B + t] = beta; }
+    if (lane == 0) { ab_out[t] = alpha; ab_out[B + t] = beta; ab_out[2 * B + t] = pair_exp(alpha); ab_out[3 * B + t] = pair_exp(beta); }
     if (loss_out) {
         const bool l2 = st.mode == 0;
         float loss = 0.f, loss_lane = 0.f;
@@ -294,17 +294,18 @@ __global__ __launch_bounds__(256) void vbpr_pairsum_kernel(const float* __restri
                                                           float* __restrict__ sT, float* __restrict__ loss_out) {
     const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= B) return;
-    const float* alpha = ab;
     const float* beta = ab + B;
-    const float a_t = alpha[t], b_t = beta[t];
+    const float* ealpha = ab + 2 * B;                                // e^alpha, e^beta (pair_exp, tkr_common.h)
+    const float* ebeta = ab + 3 * B;
+    const float a_t = ab[t], ea_t = ealpha[t], eb_t = ebeta[t];
     float al[16], be[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         al[r] = 0.f; be[r] = 0.f;
         if (64 * r < B) {                                            // uniform
             const int o = min(lane + 64 * r, B - 1);
-            al[r] = alpha[o];
-            be[r] = beta[o];
+            al[r] = ealpha[o];
+            be[r] = ebeta[o];
         }
     }
     float s_row = 0.f, s_col = 0.f, loss = 0.f;
@@ -312,10 +313,9 @@ __global__ __launch_bounds__(256) void vbpr_pairsum_kernel(const float* __restri
     for (int r = 0; r < 16; ++r) {
         if (64 * r < B) {                                            // uniform
             const bool in = lane + 64 * r < B;
-            const float xr = a_t + be[r];
-            s_row += in ? sigmoid_neg(xr) : 0.f;
-            if (loss_out) loss += in ? softplus_neg(xr) : 0.f;
-            s_col += in ? sigmoid_neg(al[r] + b_t) : 0.f;
+            s_row += in ? pair_sigmoid(ea_t, be[r]) : 0.f;
+            if (loss_out) loss += in ? softplus_neg(a_t + beta[min(lane + 64 * r, B - 1)]) : 0.f;
+            s_col += in ? pair_sigmoid(al[r], eb_t) : 0.f;
         }
     }
     s_row = wave_sum(s_row);
@@ -572,11 +572,11 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
     const int B = batch_size, kh = st->kh, tcap = 2 * row_cap;
     const size_t stride_r = (size_t)tkr_plan_max_blocks(B) * tkr_plan_team(B) * 16;
     const size_t stride_o = (size_t)3 * B;
-    if (tkr_vbpr_workspace_floats(B, kh, st->d) < (int64_t)B * (4 + 2 * kh)) return TKR_EINVAL;
-    float* s_buf = workspace;                                        // S_t [B] | T_t [B] | alpha, beta [2B] | P [B][kh] | uce rows [B][kh]
+    if (tkr_vbpr_workspace_floats(B, kh, st->d) < (int64_t)B * (6 + 2 * kh)) return TKR_EINVAL;
+    float* s_buf = workspace;                                        // S_t [B] | T_t [B] | alpha, beta, e^alpha, e^beta [4B] | P [B][kh] | uce rows [B][kh]
     float* t_buf = s_buf + B;
     float* ab2 = t_buf + B;
-    float* P = ab2 + 2 * (size_t)B;
+    float* P = ab2 + 4 * (size_t)B;
     float* Wm = P + (size_t)B * kh;
     const int NH = (kh + 63) / 64, NE = (2 * kh + 63) / 64;
     hipStream_t s = (hipStream_t)stream;

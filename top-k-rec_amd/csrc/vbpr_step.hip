@@ -160,7 +160,7 @@ template <int NH, int kVTeam>
 __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_occur_kernel(
     tkr_vbpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
     const int32_t* __restrict__ occt, const int4* __restrict__ hdr, int B, const float* __restrict__ Q,
-    float* __restrict__ ab_out /*[2][B]: alpha, beta*/, const float* __restrict__ P, float* __restrict__ Wm,
+    float* __restrict__ ab_out /*[4][B]: alpha, beta, e^alpha, e^beta*/, const float* __restrict__ P, float* __restrict__ Wm,
     float* __restrict__ loss_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_blocks = __builtin_amdgcn_readfirstlane((*hdr).x);
@@ -224,7 +224,7 @@ __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_occur_kernel(
                     const int c = lane + e * 64;
                     if (c < kh) Wm[(size_t)t * kh + c] = uce[e];          // scaled by -T_t once the pair kernel knows it
                 }
-                if (lane == 0) { ab_out[t] = alpha; ab_out[B + t] = beta; }
+                if (lane == 0) { ab_out[t] = alpha; ab_out[B + t] = beta; ab_out[2 * B + t] = pair_exp(alpha); ab_out[3 * B + t] = pair_exp(beta); }
             }
         }
         if (loss_out) {
@@ -243,15 +243,15 @@ __global__ __launch_bounds__(256) void vbpr_pair_kernel(const float* __restrict_
                                                        float* __restrict__ loss_out) {
     const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= B) return;
-    const float* alpha = ab;
     const float* beta = ab + B;
-    const float a_t = alpha[t], b_t = beta[t];
+    const float* ealpha = ab + 2 * B;                 // e^alpha, e^beta (pair_exp, written beside alpha and beta)
+    const float* ebeta = ab + 3 * B;
+    const float a_t = ab[t], ea_t = ealpha[t], eb_t = ebeta[t];
     float s_row = 0.f, s_col = 0.f, loss = 0.f;
     for (int o = lane; o < B; o += 64) {
-        const float xr = a_t + beta[o];
-        s_row += sigmoid_neg(xr);
-        if (loss_out) loss += softplus_neg(xr);
-        s_col += sigmoid_neg(alpha[o] + b_t);
+        s_row += pair_sigmoid(ea_t, ebeta[o]);
+        if (loss_out) loss += softplus_neg(a_t + beta[o]);
+        s_col += pair_sigmoid(ealpha[o], eb_t);
     }
     s_row = wave_sum(s_row);
     s_col = wave_sum(s_col);
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void vbpr_sproject_kernel(tkr_vbpr_state st, c
                 const int c = lane + e * 64;
                 if (c < kh) Wm[(size_t)t * kh + c] = uce[e];              // scaled by -T_t once the pair kernel knows it
             }
-            if (lane == 0) { ab_out[t] = alpha; ab_out[B + t] = beta; }
+            if (lane == 0) { ab_out[t] = alpha; ab_out[B + t] = beta; ab_out[2 * B + t] = pair_exp(alpha); ab_out[3 * B + t] = pair_exp(beta); }
             if (loss_out) {
                 const bool l2 = st.mode == 0;
                 float loss = 0.f, loss_lane = 0.f;
@@ -625,8 +625,8 @@ static int launch_vbpr_t(const tkr_vbpr_state& st, const int32_t* ti, const int3
     float* P = s_buf + B;
     float* Wm = P + (size_t)B * kh;
     float* Q = Wm + (size_t)B * kh;
-    float* ab2 = ws + tkr_vbpr_workspace_floats(B, kh, st.d) - 3 * (size_t)B;      // alpha[B], beta[B] of the batch
-    float* t_buf = ab2 + 2 * (size_t)B;                                            // T_t (s_buf holds S_t)
+    float* ab2 = ws + tkr_vbpr_workspace_floats(B, kh, st.d) - 5 * (size_t)B;      // alpha, beta, e^alpha, e^beta [B] of the batch
+    float* t_buf = ab2 + 4 * (size_t)B;                                            // T_t (s_buf holds S_t)
     const int2* occ2 = reinterpret_cast<const int2*>(occ);
     const int4* hdr4 = reinterpret_cast<const int4*>(hdr);
     const dim3 rgrid(vbpr_grid(B, TEAM)), rblock(TEAM * 64);
@@ -685,7 +685,7 @@ extern "C" int tkr_plan_max_blocks(int32_t batch_size);
 extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d) {
     const int64_t S = tkr::vbpr_slices(d);
     const int64_t slots = (int64_t)tkr_plan_max_blocks(batch_size) * tkr_plan_team(batch_size);     // sparse view: A, a per item task
-    return S * batch_size * (kh + 1) + 2ll * batch_size + 2ll * batch_size * kh + slots * (kh + 1) + 3ll * batch_size;
+    return S * batch_size * (kh + 1) + 2ll * batch_size + 2ll * batch_size * kh + slots * (kh + 1) + 5ll * batch_size;
 }
 
 extern "C" int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* tri_j, const int32_t* rec,
