@@ -13,6 +13,10 @@
 // and every consumer polling the granules it needs itself was worse still (62 us per batch: 120 k scattered 8-byte reads of the
 // same 4 KB).  An all-to-all hand-off inside a launch is dearer than a kernel boundary on this chip (MI355X_MICROARCH.md,
 // rows allgather / boundary); a done-counter bumped by every block of a 1,500-block grid costs 18 us (atomics on one word).
+// Also dropped: no S, T arrays at all -- every task recomputes the pair sums it needs from e^alpha, e^beta held in registers
+// (one fma + one reciprocal per term, 16-lane DPP reduction per column group).  Bit-compatible within tolerance, but a column
+// ENTRY then costs 2 * 256 terms instead of two loads: 26 M reciprocals per batch against the pair launch's 130 k, and the
+// step went from 23.1 to 30.5 us (d = 20,000; 21.1 -> 26.6 us for the dense d = 128 feat).
 //
 // The four-launch sparse view walked the static CSC of feat per batch: 1.04 M entries read for the 5 % whose item is in the
 // batch, through a byte map (is the item in the batch?), a slot table (where is its sum A = sum +-W_t?) and only then the A row
