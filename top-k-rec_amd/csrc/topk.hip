@@ -312,7 +312,30 @@ __device__ __forceinline__ void filter_tile(const TopkSmem<IdT>& sm, const f32x1
     hits &= (nm & 0xfu) | ((nm >> 4) & 0xf0u) | ((nm >> 8) & 0xf00u) | ((nm >> 12) & 0xf000u);
     uint32_t unplaced = 0;
     int pos = 0;
-    if (hits) pos = atomicAdd(&sm.cnt[uw], __popc(hits));        // one LDS atomic per lane reserves all its slots
+    const int n_mine = __popc(hits);
+    if (hits) pos = atomicAdd(&sm.cnt[uw], n_mine);              // one LDS atomic per lane reserves all its slots
+#if !(TKR_ABL & 512)
+    if (__ballot(pos + n_mine > kCap) == 0) {
+        // Every reservation of the wave fits (the rule; an overflow takes the general loop below): a visit is then the bit test, two
+        // stores and two address increments -- no capacity test, no index arithmetic (the general visit is ~25 issued instructions
+        // for the one or two lanes that hold a candidate in a register, and the filter is bound by instruction issue).
+        float* ps = sm.cs + pos * users + uw;
+        IdT* pi = sm.ci + pos * users + uw;
+        const int col0 = t * 32 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (hr[r]) {
+                asm volatile("" ::: "memory");
+                if (hits & (1u << r)) {
+                    *ps = REFINE ? sc[r] : sc[r] + 0.0f;         // refine: approximate scores, rescored exactly at the end
+                    *pi = (IdT)(col0 + (r & 3) + 8 * (r >> 2));
+                    ps += users;
+                    pi += users;
+                }
+            }
+        return;
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r)
         if (hr[r]) {                                             // scalar branch: most registers hold no candidate
