@@ -260,6 +260,48 @@ __device__ __forceinline__ float trim_all_users(const TopkSmem<IdT>& sm, int uw,
     return active ? fmaxf(thr, __uint_as_float(f)) : thr;
 }
 
+// One visit of the filter's fast path (filter_tile): the lanes of mask m append register R of the score block to their lists.
+// as / ai: LDS byte addresses of the lane's next score / id slot, ss / si: their strides.  MASKED: m is taken from the lane's
+// hit bits (a rated item of some lane passed its threshold in this tile), otherwise it is the compare's own SGPR mask.
+template <typename IdT, bool REFINE, bool MASKED, int R>
+struct FastVisit {
+    static __device__ __forceinline__ void run(const uint64_t (&hr)[16], uint32_t hits, const float (&sc)[16], uint32_t& as, uint32_t& ai,
+                                               uint32_t ss, uint32_t si, int col0) {
+        static_assert(sizeof(IdT) == 2 || sizeof(IdT) == 4, "ids are 16 or 32 bits");
+        if (hr[R]) {
+            asm volatile("" ::: "memory");                       // keeps the scalar branch
+            uint64_t m = hr[R];
+            if constexpr (MASKED) m = __ballot((hits & (1u << R)) != 0u);
+            const float val = REFINE ? sc[R] : sc[R] + 0.0f;     // -0.0 -> +0.0: ties with 0.0 like numpy (refine: rescored exactly later)
+            uint64_t saved;
+            uint32_t id;
+            if constexpr (sizeof(IdT) == 2)
+                asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                             "v_add_u32 %[id], %[c], %[col0]\n\t"
+                             "ds_write_b32 %[as], %[val]\n\t"
+                             "ds_write_b16 %[ai], %[id]\n\t"
+                             "v_add_u32 %[as], %[ss], %[as]\n\t"
+                             "v_add_u32 %[ai], %[si], %[ai]\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [sv] "=&s"(saved), [id] "=&v"(id), [as] "+v"(as), [ai] "+v"(ai)
+                             : [m] "s"(m), [c] "n"((R & 3) + 8 * (R >> 2)), [col0] "v"(col0), [val] "v"(val), [ss] "s"(ss), [si] "s"(si)
+                             : "memory", "scc");
+            else
+                asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+                             "v_add_u32 %[id], %[c], %[col0]\n\t"
+                             "ds_write_b32 %[as], %[val]\n\t"
+                             "ds_write_b32 %[ai], %[id]\n\t"
+                             "v_add_u32 %[as], %[ss], %[as]\n\t"
+                             "v_add_u32 %[ai], %[si], %[ai]\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [sv] "=&s"(saved), [id] "=&v"(id), [as] "+v"(as), [ai] "+v"(ai)
+                             : [m] "s"(m), [c] "n"((R & 3) + 8 * (R >> 2)), [col0] "v"(col0), [val] "v"(val), [ss] "s"(ss), [si] "s"(si)
+                             : "memory", "scc");
+        }
+        if constexpr (R + 1 < 16) FastVisit<IdT, REFINE, MASKED, R + 1>::run(hr, hits, sc, as, ai, ss, si, col0);
+    }
+};
+
 // Filter of one 32x32 score block (accumulator layout of the 32x32 MFMAs: register r of lane (ul, h) = item
 // (r&3) + 8*(r>>2) + 4h of the tile, user ul of the wave) into the candidate lists.
 // fp32 MFMA and VALU time add up on a SIMD (measured: nothing hides in the MFMA shadow, from the same wave or the
@@ -308,7 +350,7 @@ __device__ __forceinline__ void filter_tile(const TopkSmem<IdT>& sm, const f32x1
 #pragma unroll
     for (int r = 0; r < 16; ++r) hits |= (sc[r] >= thr) ? (1u << r) : 0u;
     // register r <-> mask bit (r&3) + 8*(r>>2): gather the four nibbles at bits 0, 8, 16, 24 of ~mh
-    const uint32_t nm = ~mh;
+    const uint32_t nm = ~mh, raw_hits = hits;
     hits &= (nm & 0xfu) | ((nm >> 4) & 0xf0u) | ((nm >> 8) & 0xf00u) | ((nm >> 12) & 0xf000u);
     uint32_t unplaced = 0;
     int pos = 0;
@@ -316,23 +358,16 @@ __device__ __forceinline__ void filter_tile(const TopkSmem<IdT>& sm, const f32x1
     if (hits) pos = atomicAdd(&sm.cnt[uw], n_mine);              // one LDS atomic per lane reserves all its slots
 #if !(TKR_ABL & 512)
     if (__ballot(pos + n_mine > kCap) == 0) {
-        // Every reservation of the wave fits (the rule; an overflow takes the general loop below): a visit is then the bit test, two
-        // stores and two address increments -- no capacity test, no index arithmetic (the general visit is ~25 issued instructions
-        // for the one or two lanes that hold a candidate in a register, and the filter is bound by instruction issue).
-        float* ps = sm.cs + pos * users + uw;
-        IdT* pi = sm.ci + pos * users + uw;
-        const int col0 = t * 32 + 4 * h;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (hr[r]) {
-                asm volatile("" ::: "memory");
-                if (hits & (1u << r)) {
-                    *ps = REFINE ? sc[r] : sc[r] + 0.0f;         // refine: approximate scores, rescored exactly at the end
-                    *pi = (IdT)(col0 + (r & 3) + 8 * (r >> 2));
-                    ps += users;
-                    pi += users;
-                }
-            }
+        // Every reservation of the wave fits (the rule; an overflow takes the general loop below).  The filter is bound by
+        // instruction issue, and the general visit is ~25 issued instructions for the one or two lanes that hold a candidate in a
+        // register; here a visit is exec <- the candidate lanes (the SGPR mask of the compare itself unless a lane of the wave had a
+        // rated candidate in this tile), two stores, two address increments (FastVisit).
+        uint32_t as = (uint32_t)(uintptr_t)(sm.cs + pos * users + uw), ai = (uint32_t)(uintptr_t)(sm.ci + pos * users + uw);
+        const uint32_t ss = (uint32_t)users * 4u, si = (uint32_t)users * (uint32_t)sizeof(IdT);
+        int col0 = t * 32 + 4 * h;
+        asm volatile("" : "+v"(col0));
+        if (__ballot(hits != raw_hits) == 0) FastVisit<IdT, REFINE, false, 0>::run(hr, hits, sc, as, ai, ss, si, col0);
+        else FastVisit<IdT, REFINE, true, 0>::run(hr, hits, sc, as, ai, ss, si, col0);
         return;
     }
 #endif
