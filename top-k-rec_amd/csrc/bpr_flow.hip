@@ -821,9 +821,11 @@ extern "C" int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, c
     }
     const uint32_t tune = ((uint32_t)waves_per_cu >> 8) & 0xffu;     // experiment switches ride in bits 8..15
     waves_per_cu &= 0xff;
-    // default: one 4-wave workgroup per CU = 1024 waves, about 1.3 batches of 256 in flight.  Measured at the ML-10M shape:
-    // 3.4-3.8 us per batch with 4 waves per CU, 4.0 with 8 (waves that wait poll, and the polls slow everybody's loads)
-    int want = (waves_per_cu > 0 ? waves_per_cu : 4) / 4;            // 256-thread workgroups
+    // default: one 4-wave workgroup per CU = 1024 waves, about 1.3 batches of 256 in flight; two per CU from batch 320 on.
+    // Measured at the ML-10M shape (round 3, us per batch with 4 / 8 waves per CU): batch 128 1.80 / 1.81, 256 2.44 / 2.45 (bound
+    // by the chains through the popular items: more waves only wait more, 1.0 -> 4.0 poll passes per task), 320 2.81 / 2.78,
+    // 384 3.30 / 3.13, 448 3.85 / 3.50, 512 4.35 / 3.98 (task throughput starts to matter), 12 per CU no better than 8.
+    int want = (waves_per_cu > 0 ? waves_per_cu : (batch_size >= 320 ? 8 : 4)) / 4;            // 256-thread workgroups
     if (want < 1) want = 1;
     if (want > per_cu - (per_cu > 2 ? 1 : 0)) want = per_cu - (per_cu > 2 ? 1 : 0);   // stay inside what is resident at once
     uint32_t grid = (uint32_t)(want * cus);
