@@ -524,14 +524,25 @@ __device__ __forceinline__ float exact_score(const float* __restrict__ up, const
 // lists (a rescoring is four dependent memory round trips of 16 loads -- ~5 us whether 34 lanes work or 64; per list that
 // was 32 passes per wave, flat it is ~17) and writes the exact score over the approximate one; phase 2 is the final
 // stage of the exact kernels (lower-bound trim to K..32 entries, two users per sort).  `offs`: 33 ints of LDS of this wave.
-template <typename IdT>
+constexpr int kStageUsers = 4;       // user rows staged per rescoring pass (write_rows_refine)
+#ifndef TKR_RESCORE_IN_FLIGHT
+#define TKR_RESCORE_IN_FLIGHT 8
+#endif
+constexpr int kRescoreInFlight = TKR_RESCORE_IN_FLIGHT;   // 16-byte loads of each half of an item row in flight per lane
+
+template <typename IdT, int KS>
 __device__ __forceinline__ void write_rows_refine(const TopkSmem<IdT>& sm, const TopkSlot& ws, int n_rows, int K, float thr, float m2,
                                                   const float* __restrict__ U, const int32_t* __restrict__ uidx,
                                                   const float* __restrict__ Vt, const float* __restrict__ bias, int k,
                                                   int32_t* __restrict__ out_ids, float* __restrict__ out_scores,
-                                                  uint64_t* __restrict__ part, int* offs) {
+                                                  uint64_t* __restrict__ part, unsigned char* scratch, int scratch_bytes) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int me = lane & 31, half = lane >> 5;
+    const int n_waves = blockDim.x >> 6;
+    int* offs = reinterpret_cast<int*>(scratch) + wave * 64;     // 33 ints of this wave
+    // rows of the (up to kStageUsers) users of a pass, staged for the fast rescoring below: behind every wave's `offs`
+    float* ust = reinterpret_cast<float*>(scratch + n_waves * 256) + (size_t)wave * kStageUsers * k;
+    const bool staged = k == 16 * KS && KS <= 8 && n_waves * (256 + kStageUsers * k * 4) <= scratch_bytes;      // full-width rows: every trip count below is a constant
     if (__ballot(sm.cnt[wave * 32 + me] > 32) != 0) {
         (void)trim_all_users<IdT, true>(sm, wave * 32 + me, half, K, thr, m2);
         __builtin_amdgcn_wave_barrier();
@@ -553,7 +564,59 @@ __device__ __forceinline__ void write_rows_refine(const TopkSmem<IdT>& sm, const
 #pragma unroll
         for (int step = 16; step > 0; step >>= 1)
             if (offs[u + step] <= f) u += step;
-        if (f < total) {
+        const int u_first = __builtin_amdgcn_readfirstlane(u);
+        const int u_last = __builtin_amdgcn_readlane(u, min(63, total - base - 1));
+        if (staged && u_last - u_first < kStageUsers) {
+            // The fast pass (k = 16, 32, 64 or 128; at most kStageUsers lists under the 64 candidates: the rule from K = 16 on).
+            // exact_score runs four dependent memory round trips per candidate (32 of its 64 row loads fit the registers at a time)
+            // and the final stage is bound by exactly that chain (68 round trips per wave: 16 % of the Netflix pass, 30 % of the
+            // ML-10M pass).  Here ALL the loads of the candidate's item row go out first (128 registers), the few user rows of the
+            // pass follow through LDS (every lane of a user reads the same addresses: broadcasts), and the fma chain -- the same
+            // chain, element for element -- starts after ONE round trip.
+            const bool live = f < total;
+            const int e = f - offs[u], uq = wave * 32 + u;
+            const int col = live ? (int)sm.ci[e * sm.users + uq] : 0;
+            constexpr int q4 = 2 * KS;                           // float4 per k-half
+            constexpr int NF = q4 < kRescoreInFlight ? q4 : kRescoreInFlight;       // float4 of each half in flight at a time
+            const float4* vrow = reinterpret_cast<const float4*>(Vt + (size_t)col * (16 * KS));
+            float4 va[NF], vb[NF];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) { va[j] = vrow[j]; vb[j] = vrow[q4 + j]; }
+            constexpr int per_row = 4 * KS;
+            const int n_stage = (u_last - u_first + 1) * per_row;      // float4 of the staged rows: <= 128
+            // (two named registers, not an array: a conditionally written array stays a stack object -- scratch)
+            auto stage_ptr = [&](int idx) {
+                const int sr = idx / per_row, sc4 = idx - sr * per_row;
+                const int rr = min(ws.block * sm.users + wave * 32 + u_first + sr, n_rows - 1);
+                return reinterpret_cast<const float4*>(U + (size_t)(uidx ? uidx[rr] : rr) * (16 * KS)) + sc4;
+            };
+            float4 su0 = make_float4(0.f, 0.f, 0.f, 0.f), su1 = su0;
+            if (lane < n_stage) su0 = *stage_ptr(lane);
+            if (lane + 64 < n_stage) su1 = *stage_ptr(lane + 64);
+            if (lane < n_stage) reinterpret_cast<float4*>(ust)[lane] = su0;
+            if (lane + 64 < n_stage) reinterpret_cast<float4*>(ust)[lane + 64] = su1;
+            __builtin_amdgcn_wave_barrier();
+            const float4* urow = reinterpret_cast<const float4*>(ust + (size_t)(u - u_first) * k);
+            float acc = 0.f;
+#pragma unroll 1
+            for (int j0 = 0; j0 < q4; j0 += NF) {
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    const float4 b0 = urow[j0 + j], b1 = urow[q4 + j0 + j];
+                    acc = fmaf(va[j].x, b0.x, acc); acc = fmaf(vb[j].x, b1.x, acc);
+                    acc = fmaf(va[j].y, b0.y, acc); acc = fmaf(vb[j].y, b1.y, acc);
+                    acc = fmaf(va[j].z, b0.z, acc); acc = fmaf(vb[j].z, b1.z, acc);
+                    acc = fmaf(va[j].w, b0.w, acc); acc = fmaf(vb[j].w, b1.w, acc);
+                }
+                if (j0 + NF < q4) {
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) { va[j] = vrow[j0 + NF + j]; vb[j] = vrow[q4 + j0 + NF + j]; }
+                }
+            }
+            acc = acc + (bias ? bias[col] : 0.f);
+            if (live) sm.cs[e * sm.users + uq] = acc + 0.0f;
+            __builtin_amdgcn_wave_barrier();                     // the next pass overwrites the staged rows
+        } else if (f < total) {
             const int e = f - offs[u], uq = wave * 32 + u, r = ws.block * sm.users + uq;
             const int col = (int)sm.ci[e * sm.users + uq];
             sm.cs[e * sm.users + uq] = exact_score(U + (size_t)(uidx ? uidx[r] : r) * k, Vt + (size_t)col * k, k, bias, col);
@@ -1110,8 +1173,8 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT, REFINE>() * TKR_WAVE), 2)
     if constexpr (REFINE) {
         if (__ballot(lost) != 0 && lane == 0) extra[4 + ws.block] = 1u;       // the exact kernel redoes this block
 #if !(TKR_ABL & 64)
-        write_rows_refine<IdT>(sm, ws, n_rows, K, thr, m2, U, uidx, Vt, bias, k, out_ids, out_scores, part,
-                               reinterpret_cast<int*>(tile) + wave * 64);      // the tile buffers are free now
+        write_rows_refine<IdT, KS>(sm, ws, n_rows, K, thr, m2, U, uidx, Vt, bias, k, out_ids, out_scores, part,
+                                   tile, 2 * TILEB);                                // the tile buffers are free now
 #endif
     } else {
         write_rows<IdT>(sm, ws, n_rows, K, thr, out_ids, out_scores, part);
