@@ -530,7 +530,7 @@ constexpr int kStageUsers = 4;       // user rows staged per rescoring pass (wri
 #endif
 constexpr int kRescoreInFlight = TKR_RESCORE_IN_FLIGHT;   // 16-byte loads of each half of an item row in flight per lane
 
-template <typename IdT, int KS>
+template <typename IdT, int KS, int IN_FLIGHT = kRescoreInFlight>
 __device__ __forceinline__ void write_rows_refine(const TopkSmem<IdT>& sm, const TopkSlot& ws, int n_rows, int K, float thr, float m2,
                                                   const float* __restrict__ U, const int32_t* __restrict__ uidx,
                                                   const float* __restrict__ Vt, const float* __restrict__ bias, int k,
@@ -577,7 +577,7 @@ __device__ __forceinline__ void write_rows_refine(const TopkSmem<IdT>& sm, const
             const int e = f - offs[u], uq = wave * 32 + u;
             const int col = live ? (int)sm.ci[e * sm.users + uq] : 0;
             constexpr int q4 = 2 * KS;                           // float4 per k-half
-            constexpr int NF = q4 < kRescoreInFlight ? q4 : kRescoreInFlight;       // float4 of each half in flight at a time
+            constexpr int NF = q4 < IN_FLIGHT ? q4 : IN_FLIGHT;       // float4 of each half in flight at a time
             const float4* vrow = reinterpret_cast<const float4*>(Vt + (size_t)col * (16 * KS));
             float4 va[NF], vb[NF];
 #pragma unroll
@@ -1173,8 +1173,9 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT, REFINE>() * TKR_WAVE), 2)
     if constexpr (REFINE) {
         if (__ballot(lost) != 0 && lane == 0) extra[4 + ws.block] = 1u;       // the exact kernel redoes this block
 #if !(TKR_ABL & 64)
-        write_rows_refine<IdT, KS>(sm, ws, n_rows, K, thr, m2, U, uidx, Vt, bias, k, out_ids, out_scores, part,
-                                   tile, 2 * TILEB);                                // the tile buffers are free now
+        // (the kernel that stages its tiles through registers has fewer to spare: 4 instead of 8 loads per half in flight, no scratch)
+        write_rows_refine<IdT, KS, IMG ? kRescoreInFlight : 4>(sm, ws, n_rows, K, thr, m2, U, uidx, Vt, bias, k, out_ids, out_scores, part,
+                                                               tile, 2 * TILEB);                                // the tile buffers are free now
 #endif
     } else {
         write_rows<IdT>(sm, ws, n_rows, K, thr, out_ids, out_scores, part);
