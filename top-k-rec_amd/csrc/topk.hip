@@ -196,43 +196,95 @@ __device__ __forceinline__ float trim_user(const TopkSmem<IdT>& sm, int uw, int 
     return (n >= K) ? __uint_as_float(kf) : -INFINITY;
 }
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// wave-wide OR, returned to every lane (uniform)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_or(uint32_t v) {
+    return v | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+    v = dpp_or<0xb1>(v); v = dpp_or<0x4e>(v); v = dpp_or<0x124>(v); v = dpp_or<0x128>(v);
+    v = dpp_or<0x142, 0xa>(v); v = dpp_or<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// how many of the two 15-bit keys packed in xo (each with bit 15 set on top) reach cand: (key | 0x8000) - cand keeps bit 15
+// exactly when key >= cand and never borrows from the neighbouring field; the answers are added up as two 16-bit counters
+__device__ __forceinline__ u16x2 count_ge2(uint32_t xo, uint32_t cand2, u16x2 acc) {
+    return acc + (__builtin_bit_cast(u16x2, xo - cand2) >> (unsigned short)15);
+}
+
 // Scheduled trim of ALL 32 users of a wave at once, one user per lane pair (half h scans entries
 // [32h, 32h+32)).  The filter only needs a LOWER BOUND of the K-th best score (a superset of the top K may
 // stay; order and exact cut come from the final sort), so the search runs on the upper 16 bits of the ordered
-// score: 16 bitwise steps over 32 keys packed two per register, then in-place compaction of the entries whose
-// 16-bit key reaches the bound.  A list that does not shrink enough is caught by the on-demand exact trim.
+// score, held as 15-bit keys two per register: a list whose keys (and threshold) all carry the same top bit -- every list but
+// one that straddles zero -- drops that bit, the others drop the lowest one.  One subtraction, one packed shift and one packed add
+// then answer "key >= candidate" for a pair of keys (count_ge2; the compare / carry form of the same count took 4 instructions
+// and 2 wait states per pair), and the bitwise search only walks the bits in which the threshold and the largest key of a list
+// differ (the K-th best lies between them, or below the threshold, where the threshold wins anyway): 6-8 steps instead of 16.
+// Then in-place compaction of the entries whose key reaches the bound.  A list that does not shrink enough is caught by the
+// on-demand exact trim.
 // REFINE: approximate scores, see trim_user -- the bound found is lowered by m2 before it becomes the threshold and the cut.
 template <typename IdT, bool REFINE = false>
 __device__ __forceinline__ float trim_all_users(const TopkSmem<IdT>& sm, int uw, int h, int K, float thr, float m2 = 0.f) {
     const int n = sm.cnt[uw];
-    uint32_t kp[16];                                         // entries 2e (low half) and 2e+1 (high half); 0 = absent
+    uint32_t xo[16];                                         // entries 2e (low half) and 2e+1 (high half)
+    const uint32_t tkey = ordered_bits(thr) >> 16;
+    uint32_t unlike = 0;                                     // bits in which some key present differs from the threshold's
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int p0 = 32 * h + 2 * e;
         const float v0 = sm.cs[p0 * sm.users + uw], v1 = sm.cs[(p0 + 1) * sm.users + uw];   // slots exist; masked below
-        const uint32_t k0 = (p0 < n) ? (ordered_bits(v0) >> 16) : 0u;
+        const uint32_t k0 = (p0 < n) ? (ordered_bits(v0) >> 16) : 0u;                    // absent: key 0
         const uint32_t k1 = (p0 + 1 < n) ? (ordered_bits(v1) >> 16) : 0u;
-        kp[e] = k0 | (k1 << 16);
+        unlike |= ((p0 < n) ? (k0 ^ tkey) : 0u) | ((p0 + 1 < n) ? (k1 ^ tkey) : 0u);
+        xo[e] = k0 | (k1 << 16);
     }
-    uint32_t prefix = 0;
-#pragma unroll 1
-    for (int b = 15; b >= 0; --b) {
-        const uint32_t cand = prefix | (1u << b);
-        int c = 0;
+    uint32_t mixed = unlike & 0x8000u;                       // keys on both sides of zero: keep the top bit, drop the lowest
+    mixed |= (uint32_t)__shfl_xor((int)mixed, 32, 64);
+    const int s1 = mixed ? 1 : 0;                            // per user (both halves agree)
+    const uint32_t top_bit = mixed ? 0u : (tkey & 0x8000u);
+    // the bits to search: below the common prefix of the threshold's key and the largest key of the list (over both halves)
+    u16x2 mx = {0, 0};
 #pragma unroll
-        for (int e = 0; e < 16; ++e) c += ((kp[e] & 0xffffu) >= cand) + ((kp[e] >> 16) >= cand);
+    for (int e = 0; e < 16; ++e) {
+        xo[e] = ((xo[e] >> s1) & 0x7fff7fffu) | 0x80008000u;
+        const u16x2 o = __builtin_bit_cast(u16x2, xo[e]);
+        mx = u16x2{(unsigned short)max(mx.x, o.x), (unsigned short)max(mx.y, o.y)};
+    }
+    uint32_t hi = (uint32_t)max(mx.x, mx.y) & 0x7fffu;
+    hi = max(hi, (uint32_t)__shfl_xor((int)hi, 32, 64));
+    const uint32_t lo = (tkey >> s1) & 0x7fffu;
+    const uint32_t differ = (n >= K) ? (lo ^ hi) : 0u;       // lists with fewer than K entries keep everything
+    const uint32_t every = wave_or(differ);
+    const int top = 31 - __clz((int)(every | 1u));            // wave-uniform: the highest bit any list has to decide
+    uint32_t prefix = hi & ~((2u << top) - 1u);               // the bits above it: common to threshold and largest key
+#pragma unroll 1
+    for (int b = top; b >= 0; --b) {
+        const uint32_t cand = prefix | (1u << b);
+        const uint32_t cand2 = cand | (cand << 16);
+        u16x2 acc = {0, 0};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc = count_ge2(xo[e], cand2, acc);
+        int c = (int)acc.x + (int)acc.y;
         c += __shfl_xor(c, 32, 64);
         if (c >= K) prefix = cand;
     }
     const bool active = n >= K && prefix != 0;               // fewer than K candidates: keep all, threshold unchanged
+    // the smallest ordered score with this key
+    uint32_t ob = mixed ? (prefix << 17) : ((top_bit | prefix) << 16);
     float refined = thr;
     if constexpr (REFINE) {
-        refined = fmaxf(thr, unordered_bits(prefix << 16) - m2);
-        prefix = min(prefix, ordered_bits(refined) >> 16);   // every entry >= refined has a 16-bit key >= this one
+        refined = fmaxf(thr, unordered_bits(ob) - m2);
+        // every entry >= refined has a key >= this one (refined lies between the threshold and the largest entry: same top bit)
+        prefix = min(prefix, ((ordered_bits(refined) >> 16) >> s1) & 0x7fffu);
     }
-    int mine = 0;
+    const uint32_t cut2 = prefix | (prefix << 16);
+    u16x2 macc = {0, 0};
 #pragma unroll
-    for (int e = 0; e < 16; ++e) mine += ((kp[e] & 0xffffu) >= prefix) + ((kp[e] >> 16) >= prefix);
+    for (int e = 0; e < 16; ++e) macc = count_ge2(xo[e], cut2, macc);
+    const int mine = (int)macc.x + (int)macc.y;
     const int other = __shfl_xor(mine, 32, 64);
     // in-place compaction, half 0 first (writes at or below what it reads), then half 1 behind it
 #pragma unroll 1
@@ -241,8 +293,8 @@ __device__ __forceinline__ float trim_all_users(const TopkSmem<IdT>& sm, int uw,
             int pos = h ? other : 0;
 #pragma unroll
             for (int e = 0; e < 32; ++e) {
-                const uint32_t k16 = (e & 1) ? (kp[e >> 1] >> 16) : (kp[e >> 1] & 0xffffu);
-                if (k16 >= prefix) {
+                const uint32_t k15 = ((e & 1) ? (xo[e >> 1] >> 16) : xo[e >> 1]) & 0x7fffu;
+                if (k15 >= prefix) {
                     const float v = sm.cs[(32 * h + e) * sm.users + uw];
                     const IdT id = sm.ci[(32 * h + e) * sm.users + uw];
                     sm.cs[pos * sm.users + uw] = v;
@@ -255,7 +307,6 @@ __device__ __forceinline__ float trim_all_users(const TopkSmem<IdT>& sm, int uw,
     }
     if (active && h == 0) sm.cnt[uw] = mine + other;
     if constexpr (REFINE) return active ? refined : thr;
-    const uint32_t ob = prefix << 16;                        // smallest ordered score with this 16-bit key
     const uint32_t f = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
     return active ? fmaxf(thr, __uint_as_float(f)) : thr;
 }
@@ -1147,10 +1198,18 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT, REFINE>() * TKR_WAVE), 2)
             if (__ballot(sm.cnt[uw] > kCap / 2) != 0) {            // lists still short (thresholds shared by earlier ranges): nothing to gain
                 if constexpr (REFINE) {
                     thr = trim_all_users<IdT, true>(sm, uw, h, K, thr, m2);
-                    thr = share_bound(thr_shared, row, user_ok && h == 0, thr, margin, bscale, inv_bscale);
+                    // 1 / scale (a power of two) is rebuilt here from an opaque copy: hoisted out of the tile loop it is one more
+                    // register alive across it, and the allocator, at its 256-register cap, spilled exactly that one
+                    float bs = bscale;
+                    int row_here = row;                          // likewise the address of the row's shared bound
+                    asm volatile("" : "+v"(bs), "+v"(row_here));
+                    thr = share_bound(thr_shared, row_here, user_ok && h == 0, thr, margin, bscale,
+                                      __uint_as_float((254u - ((__float_as_uint(bs) >> 23) & 0xffu)) << 23));
                 } else {
                     thr = trim_all_users<IdT>(sm, uw, h, K, thr);
-                    thr = share_threshold(thr_shared, row, user_ok && h == 0, thr);
+                    int row_here = row;
+                    asm volatile("" : "+v"(row_here));
+                    thr = share_threshold(thr_shared, row_here, user_ok && h == 0, thr);
                 }
             }
             next_sched = t + ((t - t_begin + 1) >> 1);
