@@ -132,7 +132,8 @@ int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ,
  * ticket words at zero again (the last workgroup out does it), so calls on one stream follow each other without a
  * memset between them.  One ctl serves one launch at a time.  ctl[status word] != 0 after a launch means a bounded spin
  * ran out (results invalid; zero ctl again before anything else runs on it).
- * waves_per_cu: 0 = default.  k <= 256, 3 * batch_size * n_batches < 2^29. */
+ * waves_per_cu: 0 = default (one 4-wave workgroup per CU below batch 320, two from there on: csrc/bpr_flow.hip).
+ * k <= 256, 3 * batch_size * n_batches < 2^29. */
 typedef struct {
     void* U;
     void* msU;
