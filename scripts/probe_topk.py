@@ -12,6 +12,8 @@ deg = 100
 ptr = torch.arange(0, (n_users + 1) * deg, deg, dtype=torch.int64, device='cuda')
 cols = torch.randint(0, n_items, (n_users * deg,), device='cuda', generator=g, dtype=torch.int32)
 mask, pitch = tkr_hip.build_rated_mask(ptr, cols, n_users, n_items)
+if os.environ.get('TKR_TOPK_MATH'):          # 'fp32' / 'bf16x3' / 'refine': the other score arithmetics (PMC passes of the fp32-MFMA kernel)
+    tkr_hip.set_topk_math(os.environ['TKR_TOPK_MATH'])
 tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -19,7 +19,7 @@ else:
     feat.scatter_(1, cols, torch.rand((n_items, 100), device=dev, generator=g) + 0.1)
 feat /= feat.norm(dim=1, keepdim=True)
 hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, le=0.0, lr=1e-4, mode='l2')
-eng = _engine.VbprEngine(n_users, n_items, k, d, feat, hp, dev, seed=3)
+eng = _engine.VbprEngine(n_users, n_items, k, d, feat, hp, dev, seed=3, sparse=False if os.environ.get('VIEW') == 'dense' else None)   # VIEW=dense: the fp32-MFMA kernels
 eng.run_batches(csr, nb, B, want_loss=False)
 torch.cuda.synchronize()
 t0 = time.perf_counter()

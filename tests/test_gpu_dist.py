@@ -264,3 +264,13 @@ print('ok')
     assert both.returncode == 0, both.stderr[-2000:]
     pick = lambda out: [l for l in out.strip().split('\n') if l.startswith(('im,', 'om,'))]
     assert pick(both.stdout) == pick(single.stdout) and len(pick(single.stdout)) == 2
+    # and the bench itself, exactly as the round-end driver launches it at N = 2: its first RCCL run should not be the 8-GPU one
+    import json
+    bench = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                            '--master-port', '29673', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5', '--no-extras'],
+                           capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert bench.returncode == 0, bench.stderr[-3000:]
+    line = [l for l in bench.stdout.strip().split('\n') if l.startswith('{')]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['epoch_mode']['exchanges'] == 2 and d['epoch_mode']['exchange_us']['collective'] > 0

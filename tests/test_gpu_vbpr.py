@@ -106,6 +106,58 @@ def test_vbpr_class_end_to_end(tmp_path):
     assert np.isfinite(m.fie).all()
 
 
+def test_vbpr_streams_mode_matches_oracle_simulation(tmp_path):
+    """VBPR.train(streams=2) on the column-plan step (plan_ahead built its buffers without the column plan and the step
+    raised AttributeError; only BPR had a streams test): two user shards on two HIP streams == the oracle simulation of two shards
+    with the per-epoch exchange of ire / irb / cem / icb (sum of deltas, slots averaged)"""
+    import synth
+    import dist as tdist
+    from single import VBPR, _engine
+    r = synth.make_ratings(160, 70, 10, seed=19, mu=2.8, sigma=0.4, min_r=4, max_r=30, om_per_user=2)
+    data = str(tmp_path / 'data')
+    synth.write_dataset(data, r)
+    d, k, B, epochs, S, nbt = 48, 16, 32, 2, 2, 12
+    kh = k // 2
+    feats = synth.make_content(80, d, nnz_per_row=10, seed=3)
+    pickle.dump(feats, open(tmp_path / 'meta.pkl', 'wb'))
+    m = VBPR(k=k, d=d, lambda_e=1e-3, lambda_b=1e-3, lr=0.02)
+    m.load_training_data(os.path.join(data, 'uid'), os.path.join(data, 'vid'), os.path.join(data, 'f0tr.txt'))
+    m.load_content_data(str(tmp_path / 'meta.pkl'), os.path.join(data, 'vid'))
+    m.train(epochs=epochs, batch_size=B, epoch_sample_limit=B * nbt, seed=5, verbose=False, streams=S)
+    assert m._eng.wants_cols(B)                                      # the path that used to crash
+    eng0 = _engine.VbprEngine(m.n_users, m.n_items, k, d, m.feat, m._hyper(), torch.device('cuda'), seed=5)
+    U0 = eng0.get('U')[0].cpu().numpy()
+    base = dict(ure=U0[:, :kh].copy(), uce=U0[:, kh:].copy(), ire=eng0.get('I')[0].cpu().numpy(), irb=np.zeros(m.n_items, np.float32),
+                cem=eng0.cem.cpu().numpy(), icb=np.zeros(d, np.float32))
+    for n in list(base):
+        base['ms_' + n] = np.ones_like(base[n])
+    st = [{n: v.copy() for n, v in base.items()} for _ in range(S)]
+    nb = nbt // S
+    row_ptr, pos, srt = P.build_csr(m.tr_data, m.n_users)
+    drawn = [q * epochs * nb * B for q in range(S)]
+    shared = ('ire', 'irb', 'cem', 'icb')
+    for e in range(epochs):
+        start = {n: st[0][n].copy() for n in shared}
+        for q in range(S):
+            users = tdist.shard_users(m.tr_users, q, S)
+            u, i, j = P.sample_triplets(users, row_ptr, pos, srt, m.n_items, 5, drawn[q], nb * B)
+            drawn[q] += nb * B
+            for t in range(nb):
+                R.vbpr_step(st[q], m.feat, u[t * B:(t + 1) * B], i[t * B:(t + 1) * B], j[t * B:(t + 1) * B], m._hyper())
+        for n in shared:
+            p = start[n] + sum(x[n] - start[n] for x in st)
+            ms = sum(x['ms_' + n] for x in st) / S
+            for x in st:
+                x[n], x['ms_' + n] = p.copy(), ms.copy()
+    ref = dict(st[0])
+    ref['ure'] = base['ure'] + sum(x['ure'] - base['ure'] for x in st)      # every user row was changed by at most one shard
+    ref['uce'] = base['uce'] + sum(x['uce'] - base['uce'] for x in st)
+    fue, fie, fib = R.vbpr_fold(ref, m.feat)
+    np.testing.assert_allclose(m.fue, fue, rtol=3e-4, atol=2e-5)
+    np.testing.assert_allclose(m.fie, fie, rtol=3e-4, atol=2e-5)
+    np.testing.assert_allclose(m.fib, fib, rtol=3e-4, atol=2e-5)
+
+
 def test_vbpr_sparse_view_is_deterministic_and_auto_selected():
     """tf-idf-like features pick the sparse view on their own; two runs from the same state are bitwise identical
     (the column walk adds the batch's items in ascending item order, no float atomics on parameters)"""

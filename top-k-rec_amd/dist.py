@@ -126,15 +126,24 @@ class ItemSync:
         n = P.shape[1] if cnt is not None else P.shape[0]
         return int(n), int(P.numel() // (2 if cnt is not None else 1) // n)
 
-    def _settle(self):
-        """the counters this object holds must describe the tables: drop planned-but-not-run batches (PlanMixin.settle)"""
+    def _settle(self, keep_epoch_ahead=False):
+        """the counters this object holds must describe the tables: drop planned-but-not-run batches (PlanMixin.settle).
+        ``keep_epoch_ahead``: not the chunk an engine planned AHEAD of this exchange for the epoch after it (its item counts live
+        on a shadow until after_exchange(); afterwards they describe exactly the freshly re-assigned tables)."""
         settle = getattr(self.eng, 'settle', None)
         if settle is not None:
-            settle(check=False)
+            if keep_epoch_ahead:
+                settle(check=False, keep_epoch_ahead=True)
+            else:
+                settle(check=False)
             self.eng.check_async()       # a failed persistent step surfaces at the next exchange (or at the final get): no host wait here
 
     def begin(self):
-        self._settle()
+        # no snapshot launch is needed when the unpack of the exchange before left this epoch's start in start_flat: then nothing here
+        # reads the item counters, and a chunk planned ahead of that exchange may stay
+        fresh = (self.flow is not None and self._bound == getattr(self.eng, 'layout_epoch', 0) and
+                 self._start_valid == (self._bound, getattr(self.eng, 'item_mutations', 0)))
+        self._settle(keep_epoch_ahead=fresh)
         self._bind()
         if self.flow is not None:
             import tkr_hip
@@ -169,7 +178,7 @@ class ItemSync:
         _, w = world()
         if w == 1:
             return
-        self._settle()
+        self._settle(keep_epoch_ahead=True)
         if getattr(self.eng, 'layout_epoch', 0) != self._bound:
             # the engine re-allocated its tables after begin() (a different batch size -> a different layout): the snapshot and the
             # counters this object holds belong to tables that no longer exist.  Round 2's bench.py did exactly that in its warm-up
@@ -189,6 +198,9 @@ class ItemSync:
             tkr_hip.sync_flow_unpack(V, msV, tail, rd, icnt, self.start_flat, self.flat[:total], self.flat[total:], n, k)
             self._start_valid = (self._bound, getattr(self.eng, 'item_mutations', 0))
             self._mark(marks)
+            after = getattr(self.eng, 'after_exchange', None)
+            if after is not None:
+                after()                  # a chunk planned ahead of this exchange becomes runnable
             return
         if self.tabs is None:
             cur = {n: self.eng.get(n) for n in self.names}

@@ -181,11 +181,21 @@ def _chunk_cap(B):
 
 
 class _Chunk:
-    """a planned chunk: batches [used, nb) of plan buffer `idx` have not run yet; batch 0 starts at triplet `first`"""
-    __slots__ = ('idx', 'nb', 'used', 'B', 'first', 'csr')
+    """a planned chunk: batches [used, nb) of plan buffer `idx` have not run yet; batch 0 starts at triplet `first`.
+    ``shadow``: the chunk was planned AHEAD OF AN EXCHANGE against a zeroed copy of the item counters (this tensor); it only
+    becomes runnable once the exchange has zeroed the real ones (PlanMixin.after_exchange)."""
+    __slots__ = ('idx', 'nb', 'used', 'B', 'first', 'csr', 'shadow', 'epoch_ahead')
 
-    def __init__(self, idx, nb, B, first, csr):
+    def __init__(self, idx, nb, B, first, csr, shadow=None):
         self.idx, self.nb, self.used, self.B, self.first, self.csr = idx, nb, 0, B, first, csr
+        self.shadow, self.epoch_ahead = shadow, shadow is not None
+
+
+class _ShadowCounters:
+    """the engine's update counters with the item counts replaced (K1 of the epoch after an exchange: users go on, items restart at 0)"""
+
+    def __init__(self, cnt, icnt):
+        self.ucnt, self.icnt, self.touch_u, self.touch_i = cnt.ucnt, icnt, cnt.touch_u, cnt.touch_i
 
 
 def _event_pair():
@@ -267,38 +277,69 @@ class PlanMixin:
                 e.record()
             self._event_pool.append(pair)
 
-    def settle(self, check=True):
+    def settle(self, check=True, keep_epoch_ahead=False):
         """drop what is planned but has not run; afterwards the counters describe the tables.  Everything that takes results
         out of an engine (get / set, the exchange, the counters) comes through here, so this is also where a failed
-        persistent step is reported (only BPR._run_epoch looked at the status word)."""
+        persistent step is reported (only BPR._run_epoch looked at the status word).
+        ``keep_epoch_ahead`` (the exchange itself): a chunk planned ahead of the exchange stays -- the item counters it was
+        planned against are its own (shadow) or, once adopted, describe tables that are exactly as the plan assumes."""
         if check:
             self.check()
         if self._cur is None and self._ahead is None:
+            return
+        ah, cur = self._ahead, self._cur
+        if keep_epoch_ahead and ah is not None and ah.epoch_ahead and ah.used == 0 and (cur is None or cur.used == cur.nb):
             return
         self.pipe.drain()
         for ch in (self._ahead, self._cur):          # newest first, like unwinding
             if ch is not None and ch.used < ch.nb:
                 buf = self.pipe.bufs[ch.idx]
-                tkr_hip.plan_rollback(buf, ch.B, ch.used, ch.nb - ch.used, self._cnt)
+                cnt = self._cnt if ch.shadow is None else _ShadowCounters(self._cnt, ch.shadow)
+                tkr_hip.plan_rollback(buf, ch.B, ch.used, ch.nb - ch.used, cnt)
         self._cur = self._ahead = None
 
-    def _plan_chunk(self, idx, csr, B, first, overlap, want):
+    def after_exchange(self):
+        """dist.ItemSync calls this right after it re-assigned the item tables (every row at version 0, item counters zero):
+        what a chunk planned ahead of the exchange counted on its shadow becomes the real counters."""
+        ah = self._ahead
+        if ah is None or ah.shadow is None:
+            return
+        ev = self.pipe.planned[ah.idx]
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        self._cnt.icnt.copy_(ah.shadow)
+        ah.shadow = None
+
+    def _plan_chunk(self, idx, csr, B, first, overlap, want, shadow=None):
         nb = max(1, min(self._cap(B), want))
+        cnt = self._cnt if shadow is None else _ShadowCounters(self._cnt, shadow)
 
         def fn(buf):
-            tkr_hip.sample_plan(csr, self.n_users, self.n_items, self.seed, first, nb, B, self._cnt, buf)
+            if shadow is not None:
+                shadow.zero_()
+            tkr_hip.sample_plan(csr, self.n_users, self.n_items, self.seed, first, nb, B, cnt, buf)
             self._plan_extra(buf, nb, B)
         self.pipe.plan(idx, fn, overlap)
-        return _Chunk(idx, nb, B, first, csr)
+        return _Chunk(idx, nb, B, first, csr, shadow)
 
-    def _next_chunk(self, csr, B, want):
-        """the chunk that holds the batch at the current stream position; `want` = batches the running call still has to run"""
+    def _epoch_ahead_ok(self, B):
+        """may the first chunk of the epoch AFTER an exchange be planned before it?  Only where the exchange leaves the tables in
+        a state K1 can name in advance without touching them (the granule layout: every item at version 0, dist.ItemSync's
+        fused unpack) and takes no snapshot at the next begin()."""
+        return self._plan_flow() and __import__('os').environ.get('TKR_EPOCH_AHEAD', '1') != '0'
+
+    def _next_chunk(self, csr, B, want, then_exchange=0):
+        """the chunk that holds the batch at the current stream position; `want` = batches the running call still has to run;
+        `then_exchange` = batches of the NEXT epoch when an exchange of the item tables follows this call (0: none)"""
         cur = self._cur
         if cur is not None and (cur.B != B or cur.csr is not csr):
             self.settle(check=False)
             cur = None
         if cur is not None and cur.used < cur.nb:
             return cur
+        if self._ahead is not None and self._ahead.shadow is not None:      # planned ahead of an exchange that never came
+            self.settle(check=False)
+            cur = None
         if self.pipe is None:
             self.pipe = PlanPipeline(self.device)
         self.pipe.ensure(self._cap(B), B, self._plan_flow(), self._plan_cols(B))
@@ -313,14 +354,22 @@ class PlanMixin:
             nxt = self._plan_chunk(0 if cur is None else cur.idx ^ 1, csr, B, self._drawn, False, want)
         if overlap and want > nxt.nb:                 # the chunk after it, behind the steps of this one
             self._ahead = self._plan_chunk(nxt.idx ^ 1, csr, B, nxt.first + nxt.nb * B, True, want - nxt.nb)
+        elif then_exchange > 0 and want <= nxt.nb and self._epoch_ahead_ok(B):
+            # the LAST chunk of an epoch: after the exchange every item row is at version 0 again and the users go on where this
+            # chunk leaves them -- everything K1 needs to plan the first chunk of the next epoch, so it runs now, on the side stream
+            # behind this chunk's steps and the exchange, instead of ~120 us in front of the next epoch's first step
+            if getattr(self, '_shadow_icnt', None) is None:
+                self._shadow_icnt = torch.zeros_like(self._cnt.icnt)
+            self.pipe.side
+            self._ahead = self._plan_chunk(nxt.idx ^ 1, csr, B, nxt.first + nxt.nb * B, True, then_exchange, shadow=self._shadow_icnt)
         self._cur = nxt
         return nxt
 
-    def _run(self, csr, n_batches, B, want_loss, step_fn):
+    def _run(self, csr, n_batches, B, want_loss, step_fn, then_exchange=0):
         """n_batches consecutive batches from the current stream position; step_fn(plan, first_batch, nb, loss)"""
         loss, left = None, n_batches
         while left > 0:
-            ch = self._next_chunk(csr, B, left)
+            ch = self._next_chunk(csr, B, left, then_exchange)
             plan = self.pipe.acquire(ch.idx)
             m = min(left, ch.nb - ch.used)
             lo = ch.used
@@ -345,20 +394,22 @@ def plan_ahead(eng, csr, n_batches, B):
     """K1 for n_batches batches into freshly held buffers (no stepping): -> [(PlanBuffers, nb), ...].
     Used by the multi-stream mode, where planner launches would disturb the other streams' step chains."""
     eng.settle()
-    cap = _chunk_cap(B)
+    cap = eng._cap(B)                 # an engine may plan fewer batches per call than the bitmap allows (VBPR: its column plans)
+    cols = eng._plan_cols(B)          # ... and want the column plan of its batches beside K1's (ADVICE r3: VBPR train(streams > 1) crashed without)
     planned, left = [], n_batches
     pool = getattr(eng, '_plan_pool', [])
     idx = 0
     while left:
         nb = min(cap, left)
-        if idx >= len(pool) or pool[idx].B != B or pool[idx].cap < nb:
-            buf = PlanBuffers(cap, B, eng.device)
+        if idx >= len(pool) or pool[idx].B != B or pool[idx].cap < nb or pool[idx].cols != cols or pool[idx].flow:
+            buf = PlanBuffers(cap, B, eng.device, cols=cols)
             if idx < len(pool):
                 pool[idx] = buf
             else:
                 pool.append(buf)
         buf = pool[idx]
         tkr_hip.sample_plan(csr, eng.n_users, eng.n_items, eng.seed, eng._drawn, nb, B, eng._cnt, buf)
+        eng._plan_extra(buf, nb, B)
         eng._drawn += nb * B
         planned.append((buf, nb))
         left -= nb
@@ -668,9 +719,10 @@ class BprEngine(PlanMixin):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
 
     # ---- the loop ------------------------------------------------------------------------------
-    def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True):
+    def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True, then_exchange=0):
         """sample + plan + step for n_batches consecutive batches; returns the per-batch
-        losses of the LAST chunk as a device tensor (or None)."""
+        losses of the LAST chunk as a device tensor (or None).  ``then_exchange`` = m > 0: the caller runs dist.ItemSync.end()
+        right after this call and then goes on with an epoch of m batches -- its first chunk is planned ahead (PlanMixin)."""
         if self.k > 512 or (self.k > 256 and B > 1024):
             raise ValueError('BPR on the HIP path: k <= 512, and k <= 256 for batch sizes above 1024 (got k = %d, batch_size = %d): a wave '
                              'holds a row in k / 64 registers per array (csrc/bpr_step.hip)' % (self.k, B))
@@ -679,7 +731,7 @@ class BprEngine(PlanMixin):
         if getattr(self, '_step_key', None) != key:       # the C struct and the closure are built once per layout, not per call
             self._step_key, self._step = key, self.step_fn(B)
         self._flow_ran = self._flow_ran or self.layout == 'flow'
-        return self._run(csr, n_batches, B, want_loss, self._step)
+        return self._run(csr, n_batches, B, want_loss, self._step, then_exchange)
 
     def step_fn(self, B):
         state = self.state()
@@ -833,7 +885,7 @@ class VbprEngine(PlanMixin):
                 ('cem', self.cem, self.mscem, None), ('icb', self.icb, self.msicb, None)]
     copy_model_from = BprEngine.copy_model_from
 
-    def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True):
+    def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True, then_exchange=0):
         if self.kh > 128 or B > 65536:
             raise ValueError('VBPR on the HIP path: k // 2 <= 128 and batch_size <= 65536 (got k = %d, batch_size = %d)' % (self.k, B))
         if getattr(self, '_step_key', None) != B:           # the C struct and the closure are built once per batch size, not per call

@@ -247,9 +247,12 @@ class BPR(REC):
             t0 = time.time()
             if world > 1:
                 sync.begin()
-            loss = self._run_epoch(n_batches, batch_size)
+            # sharded: the exchange follows this call, then an epoch of n_batches more -- its first chunk is planned behind this
+            # epoch's last steps (PlanMixin), and the host looks at the loss only after the exchange is queued
+            loss = self._run_epoch(n_batches, batch_size, n_batches if (world > 1 and eid + 1 < epochs) else 0, defer=world > 1)
             if world > 1:
                 sync.end()
+                loss = self._epoch_loss(loss)
             torch.cuda.synchronize(self._eng.device)
             spent = time.time() - t0
             self.last_epoch_loss = loss
@@ -306,9 +309,14 @@ class BPR(REC):
         lead.set_users(U=users_start + sum(p - users_start for p, _ in parts),
                        msU=users_ms_start + sum(ms - users_ms_start for _, ms in parts))     # slots may come from a checkpoint, not 1
 
-    def _run_epoch(self, n_batches, batch_size):
-        losses = self._eng.run_batches(self._csr, n_batches, batch_size, want_loss=True)
-        last = float(losses[-1])
+    def _run_epoch(self, n_batches, batch_size, then_exchange=0, defer=False):
+        losses = self._eng.run_batches(self._csr, n_batches, batch_size, want_loss=True, then_exchange=then_exchange)
+        if defer:
+            return losses[-1:].clone()         # read by _epoch_loss once the exchange is queued behind the steps
+        return self._epoch_loss(losses[-1:])
+
+    def _epoch_loss(self, last):
+        last = float(last[0])
         self._eng.check()
         return last
 
