@@ -188,8 +188,8 @@ def test_abi_rejects_bad_arguments(hip):
     st = hip.BprState()
     assert hip.lib().tkr_bpr_run(C.byref(st), None, None, None, 256, 1, None, None) == -1
     args = [None] * 24
-    assert hip.lib().tkr_sample_plan(None, 0, None, None, None, 5, 10, 0, 0, None, 1, 256, *([None] * 14), None, C.c_int64(0), None) == -1
-    assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 513, 256, *([None] * 14), None, C.c_int64(0), None) == -2
+    assert hip.lib().tkr_sample_plan(None, 0, None, None, None, 5, 10, 0, 0, None, 1, 256, *([None] * 15), None, C.c_int64(0), None) == -1
+    assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 513, 256, *([None] * 15), None, C.c_int64(0), None) == -2
     assert hip.lib().tkr_plan_workspace_bytes(2048, 128) == 0 and hip.plan_workspace_bytes(16384, 4) > 16384 * 4 * 8 * 6
 
 

@@ -322,3 +322,20 @@ def test_fused_exchange_of_the_granule_tables(monkeypatch):
     for x, y in ((a.V.p, b.V.p), (a.V.ms, b.V.ms), (a.tailV.t, b.tailV.t), (a.U.p, b.U.p)):       # granules incl. tags, both buffers
         assert torch.equal(x.view(torch.int32), y.view(torch.int32))
     assert torch.equal(a.tailV.rd, b.tailV.rd) and torch.equal(a.cnt.icnt, b.cnt.icnt)
+    # the unpack leaves the next epoch's start in the snapshot buffer and begin() then launches nothing -- unless somebody wrote the
+    # item tables in between: through the engine (set_items) or behind its back (a direct assign on the table objects)
+    for how in ('set_items', 'assign'):
+        eng = _engine.BprEngine(n_users, n_items, k, hp, dev, seed=9)
+        eng.run_batches(csr, 3, 256, want_loss=False)
+        sync = tdist.ItemSync(eng)
+        sync.begin()
+        eng.run_batches(csr, 4, 256, want_loss=False)
+        sync.end()
+        newV = torch.randn(n_items, k, device=dev) * 0.03
+        if how == 'set_items':
+            eng.set_items(V=newV)
+        else:
+            eng.settle()
+            eng.V.assign(newV, torch.ones(n_items, k, device=dev))
+        sync.begin()
+        assert torch.equal(sync.start_flat[:n_items * k].view(n_items, k), newV), how

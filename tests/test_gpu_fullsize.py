@@ -127,6 +127,45 @@ def test_vbpr_full_size_sparse_view(ml10m):
     np.testing.assert_allclose(loss, np.array(ref_loss), rtol=2e-4)
 
 
+def test_vbpr_full_size_dense_dc128(ml10m):
+    """the LITERAL reading of BASELINE.json configs[2] ("d=128"): DENSE content features of width 128 at the ML-10M shape, k = 128,
+    batch 256 -- eight batches of the column-plan step (every feature column meets every triplet: 512-entry runs split over the
+    groups of a workgroup; the pair sums by the last workgroup of the projection) against the oracle (this view was
+    benchmarked but parity-tested at toy shape only)"""
+    from single import _engine
+    d_, k, B, nb, dfeat = ml10m, 128, 256, 8, 128
+    kh = k // 2
+    rng = np.random.Generator(np.random.PCG64(5))
+    n_items = d_['n_items']
+    feat = (rng.random((n_items, dfeat)) + 0.1).astype(np.float32)
+    feat /= np.linalg.norm(feat, axis=1, keepdims=True)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, le=1e-3, lr=0.01, mode='l2')
+    dev = torch.device('cuda')
+    eng = _engine.VbprEngine(d_['n_users'], n_items, k, dfeat, feat, hp, dev, seed=13)
+    assert eng.sparse is not None and eng.wants_cols(B)             # a narrow feat takes the gather view + column plan whatever its density
+    eng.set_dense(cem=(rng.standard_normal((dfeat, kh)) * 0.05).astype(np.float32), icb=(rng.standard_normal(dfeat) * 0.05).astype(np.float32))
+    U0 = eng.get('U')[0].cpu().numpy()
+    ref = dict(ure=U0[:, :kh].copy(), uce=U0[:, kh:].copy(), ire=eng.get('I')[0].cpu().numpy(), irb=eng.get('irb')[0].cpu().numpy(),
+               cem=eng.cem.cpu().numpy(), icb=eng.icb.cpu().numpy())
+    for n in list(ref):
+        ref['ms_' + n] = np.ones_like(ref[n])
+    csr = _engine.TrainingCSR.from_arrays(d_['row_ptr'], d_['pos'], d_['tr_users'], dev)
+    loss = eng.run_batches(csr, nb, B).cpu().numpy()
+    torch.cuda.synchronize()
+    u, i, j = P.sample_triplets(d_['tr_users'], d_['row_ptr'], d_['pos'], d_['srt'], n_items, 13, 0, nb * B)
+    ref_loss = [R.vbpr_step(ref, feat, u[b * B:(b + 1) * B], i[b * B:(b + 1) * B], j[b * B:(b + 1) * B], hp) for b in range(nb)]
+    tol = dict(rtol=3e-4, atol=2e-5)
+    Uc = eng.get('U')[0].cpu().numpy()
+    np.testing.assert_allclose(Uc[:, :kh], ref['ure'], err_msg='ure', **tol)
+    np.testing.assert_allclose(Uc[:, kh:], ref['uce'], err_msg='uce', **tol)
+    np.testing.assert_allclose(eng.get('I')[0].cpu().numpy(), ref['ire'], err_msg='ire', **tol)
+    np.testing.assert_allclose(eng.get('irb')[0].cpu().numpy(), ref['irb'], err_msg='irb', **tol)
+    np.testing.assert_allclose(eng.cem.cpu().numpy(), ref['cem'], err_msg='cem', **tol)
+    np.testing.assert_allclose(eng.icb.cpu().numpy(), ref['icb'], err_msg='icb', **tol)
+    np.testing.assert_allclose(eng.mscem.cpu().numpy(), ref['ms_cem'], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(loss, np.array(ref_loss), rtol=2e-4)
+
+
 def test_netflix_shape_chunk_matches_oracle():
     """BASELINE.json configs[3] shape (480,189 users x 17,770 items, k = 128, batch 256) on one GPU: one full plan chunk (512 batches)
     against the oracle replaying the same 131,072 triplets, sampler invariants on every triplet, counters = batches touching a row"""

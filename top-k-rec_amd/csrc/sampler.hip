@@ -69,14 +69,25 @@ __device__ __forceinline__ int emit_tasks(const uint64_t* keys, int n, int4* tas
     int cnt = 0;
     for (int p = beg; p < end; ++p)
         cnt += (p == 0) || ((uint32_t)(keys[p] >> 32) != (uint32_t)(keys[p - 1] >> 32));
-    scan[threadIdx.x + 1] = cnt;
-    if (threadIdx.x == 0) scan[0] = 0;
+    // exclusive scan of the per-thread head counts: inside a wave by DPP-free shuffles, the <= 16 wave totals by every thread
+    // (thread 0 used to walk all T entries of the LDS array: 256 dependent read-modify-writes, ~7 us of a 35 us kernel, twice)
+    const int lane = threadIdx.x & (TKR_WAVE - 1), wave = threadIdx.x / TKR_WAVE;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < TKR_WAVE; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    __syncthreads();                                  // `scan` may still be read from the call before
+    if (lane == TKR_WAVE - 1) scan[wave] = incl;
     __syncthreads();
-    if (threadIdx.x == 0)
-        for (int t = 1; t <= T; ++t) scan[t] += scan[t - 1];
-    __syncthreads();
-    int s = scan[threadIdx.x];
-    const int total = scan[T];
+    int s = incl - cnt, total = 0;
+#pragma unroll
+    for (int w = 0; w < T / TKR_WAVE; ++w) {
+        const int t = scan[w];
+        if (w < wave) s += t;
+        total += t;
+    }
     for (int p = beg; p < end; ++p) {
         const uint32_t row = (uint32_t)(keys[p] >> 32);
         if ((p == 0) || (row != (uint32_t)(keys[p - 1] >> 32))) {
@@ -176,19 +187,29 @@ __device__ __forceinline__ int parity_of(const int32_t* __restrict__ cnt, const 
 
 __device__ __forceinline__ int block_exclusive_scan2(int a, int b, int* scan /*LDS [2*(T+1)]*/, int& tot_a,
                                                       int& tot_b, int& ex_b) {
-    int* sa = scan;
-    int* sb = scan + kPlanThreads + 1;
-    sa[threadIdx.x + 1] = a;
-    sb[threadIdx.x + 1] = b;
-    if (threadIdx.x == 0) { sa[0] = 0; sb[0] = 0; }
+    // wave scans + the four wave totals (thread 0 used to walk all 256 entries)
+    const int lane = threadIdx.x & (TKR_WAVE - 1), wave = threadIdx.x / TKR_WAVE;
+    int ia = a, ib = b;
+#pragma unroll
+    for (int d = 1; d < TKR_WAVE; d <<= 1) {
+        const int ua = __shfl_up(ia, d), ub = __shfl_up(ib, d);
+        if (lane >= d) { ia += ua; ib += ub; }
+    }
     __syncthreads();
-    if (threadIdx.x == 0)
-        for (int t = 1; t <= kPlanThreads; ++t) { sa[t] += sa[t - 1]; sb[t] += sb[t - 1]; }
+    if (lane == TKR_WAVE - 1) { scan[wave] = ia; scan[kPlanThreads / TKR_WAVE + wave] = ib; }
     __syncthreads();
-    tot_a = sa[kPlanThreads];
-    tot_b = sb[kPlanThreads];
-    ex_b = sb[threadIdx.x];
-    return sa[threadIdx.x];
+    int ea = ia - a;
+    ex_b = ib - b;
+    tot_a = 0;
+    tot_b = 0;
+#pragma unroll
+    for (int w = 0; w < kPlanThreads / TKR_WAVE; ++w) {
+        const int ta = scan[w], tb = scan[kPlanThreads / TKR_WAVE + w];
+        if (w < wave) { ea += ta; ex_b += tb; }
+        tot_a += ta;
+        tot_b += tb;
+    }
+    return ea;
 }
 
 __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(

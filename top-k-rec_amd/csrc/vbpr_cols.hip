@@ -13,6 +13,12 @@
 // and every consumer polling the granules it needs itself was worse still (62 us per batch: 120 k scattered 8-byte reads of the
 // same 4 KB).  An all-to-all hand-off inside a launch is dearer than a kernel boundary on this chip (MI355X_MICROARCH.md,
 // rows allgather / boundary); a done-counter bumped by every block of a 1,500-block grid costs 18 us (atomics on one word).
+// Round 4, also dropped: the pair sums by the LAST workgroup of the projection to finish (a one-to-all hand-off: every workgroup
+// stores its four values write-through, drains them and bumps one counter; whoever counts B - 1 computes S_t, T_t for the batch
+// from LDS) -- two launches per batch instead of three.  Correct on every parity test, but the projection went 6.9 -> 14.2 us
+// (one thread per (triplet, side), 256 reciprocals each; 25 us with one wave per triplet and its two reductions) where the
+// pair launch costs 4.0 us + a 2.7 us boundary: one workgroup does in 7 us what 64 do in 1.3, and every workgroup first waits
+// for its write-through stores (scratch/k3_lastwg.patch in the builder's tree; 28.7 vs 28.3 us per batch under rocprofv3).
 // Also dropped: no S, T arrays at all -- every task recomputes the pair sums it needs from e^alpha, e^beta held in registers
 // (one fma + one reciprocal per term, 16-lane DPP reduction per column group).  Bit-compatible within tolerance, but a column
 // ENTRY then costs 2 * 256 terms instead of two loads: 26 M reciprocals per batch against the pair launch's 130 k, and the
@@ -587,7 +593,10 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
     static const int tune = getenv("TKR_VBPR_TUNE") ? atoi(getenv("TKR_VBPR_TUNE")) : 0;      // timing experiments only (results invalid)
     static const int pw_env = getenv("TKR_VBPR_PWAVES") ? atoi(getenv("TKR_VBPR_PWAVES")) : 0;
     // waves per triplet of the projection: enough that a triplet's gather list (2 rows of feat) is one round of <= 32 gathers per wave
-    const int pw = pw_env ? pw_env : (row_cap <= 64 ? 4 : (row_cap <= 128 || B > 256 ? 8 : 16));
+    if (pw_env && pw_env != 4 && pw_env != 8 && pw_env != 16) return TKR_EINVAL;       // the instantiated team sizes
+    int pw = pw_env ? pw_env : (row_cap <= 64 ? 4 : (row_cap <= 128 || B > 256 ? 8 : 16));
+    if (NH == 2 && pw > 8) pw = 8;          // kh > 64: two registers per gathered row and wave -- the 16-wave team is not instantiated there:
+                                            // two rounds of gathers per wave instead of one (was a silent fall-through)
     for (int b = 0; b < n_batches; ++b) {
         const int32_t* ti = tri_i + (size_t)b * B;
         const int32_t* tj = tri_j + (size_t)b * B;

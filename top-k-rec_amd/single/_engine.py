@@ -156,6 +156,7 @@ class PlanPipeline:
             ev = torch.cuda.Event()
             ev.record(self.side)
             self.planned[i] = ev
+        self._side_dirty = True                       # something runs on the side stream that the main stream has not waited for
 
     def acquire(self, i):
         if self.planned[i] is not None:
@@ -164,8 +165,11 @@ class PlanPipeline:
         return self.bufs[i]
 
     def drain(self):
-        if self._side is not None:
+        # only when a side-stream plan was queued since the last drain: an event create + record + wait + destroy is ~15 us of host
+        # time in front of the first launch of a short call (the driver's 20-step run)
+        if self._side is not None and getattr(self, '_side_dirty', False):
             torch.cuda.current_stream(self.device).wait_stream(self._side)
+            self._side_dirty = False
 
 
 OVERLAP_MIN_BATCH = int(__import__('os').environ.get('TKR_OVERLAP_MIN_BATCH', 2048))     # below this the planner is < 5 % of the time and a second active queue slows
@@ -317,7 +321,14 @@ class PlanMixin:
         def fn(buf):
             if shadow is not None:
                 shadow.zero_()
-            tkr_hip.sample_plan(csr, self.n_users, self.n_items, self.seed, first, nb, B, cnt, buf)
+            key = (id(csr), id(cnt.ucnt), id(cnt.icnt), self.seed)          # the closure holds csr and cnt: their ids stay theirs
+            callers = buf.__dict__.setdefault('_callers', {})
+            call = callers.get(key)
+            if call is None:
+                if len(callers) > 4:
+                    callers.clear()
+                call = callers[key] = tkr_hip.plan_caller(csr, self.n_users, self.n_items, self.seed, B, cnt, buf)
+            call(first, nb)
             self._plan_extra(buf, nb, B)
         self.pipe.plan(idx, fn, overlap)
         return _Chunk(idx, nb, B, first, csr, shadow)
@@ -449,6 +460,7 @@ class DoubleTable:
 
     def assign(self, values, ms=None):
         """write values into buffer 0 (the caller zeroes the update counters so that buffer 0 is current)"""
+        self.mutations = getattr(self, 'mutations', 0) + 1
         self.p[0].copy_(values)
         if ms is not None:
             self.ms[0].copy_(ms)
@@ -494,6 +506,7 @@ class FlowTable:
 
     def assign(self, values, ms):
         """version 0 of every row in buffer 0 (the caller zeroes the update counters); buffer 1 holds no version"""
+        self.mutations = getattr(self, 'mutations', 0) + 1
         for t, v, pad in ((self.p, values, 0.0), (self.ms, ms, 1.0)):
             t.zero_()
             t[0, :, :, 0] = pad
@@ -516,6 +529,7 @@ class FlowTail:
         return self.t[sel, idx, 0, 0], self.t[sel, idx, 1, 0]
 
     def assign(self, b=None, msb=None):
+        self.mutations = getattr(self, 'mutations', 0) + 1
         self.t.zero_()
         if b is not None:
             self.t[0, :, 0, 0] = b
@@ -548,10 +562,20 @@ class BprEngine(PlanMixin):
         self.V = DoubleTable(n_items, k, self.device, 0.01, gen)
         self.b = DoubleTable(n_items, 0, self.device)
         self.tailU = self.tailV = self.ctl = None
-        self.item_mutations = 0         # writes to the item tables from outside the step kernels (dist.ItemSync: is its snapshot still the truth?)
+        self._item_mutations = 0        # writes to the item tables from outside the step kernels (dist.ItemSync: is its snapshot still the truth?)
         self._flow_ran = False          # a persistent launch ran since the status word was last looked at
         self._status_host = self._status_event = None
         self._init_plans()
+
+    @property
+    def item_mutations(self):
+        """every write to the item tables from outside the step kernels: the engine's own (set_items, prepare) AND direct
+        assign() calls on the table objects (those left dist.ItemSync's cached epoch start stale, silently)"""
+        return self._item_mutations + sum(getattr(t, 'mutations', 0) for t in (self.V, self.b, self.tailV) if t is not None)
+
+    @item_mutations.setter
+    def item_mutations(self, value):
+        self._item_mutations = value - sum(getattr(t, 'mutations', 0) for t in (self.V, self.b, self.tailV) if t is not None)
 
     # ---- layout ----------------------------------------------------------------------------------
     def _plan_flow(self):
@@ -563,12 +587,19 @@ class BprEngine(PlanMixin):
         the plain layout), and prepare() holds a copy of the old tables while it builds the new ones."""
         if B > FLOW_MAX_BATCH or __import__('os').environ.get('TKR_FLOW', '1') == '0' or self.k > tkr_hip.FLOW_MAX_K:
             return False
+        if getattr(self, '_flow_disabled', False):     # a bounded spin of the persistent kernel ran out in this process: K2 from here on
+            return False
         if self.layout == 'flow':
             return True
-        rows = self.n_users + self.n_items
-        need = rows * (tkr_hip.flow_row_granules(self.k) * 32 + 96 + 8 * self.k)
-        free = torch.cuda.mem_get_info(self.device)[0] if self.device.type == 'cuda' else need
-        return need <= 0.7 * free
+        # decided ONCE per engine (ADVICE r3: asked on every call, the answer -- and with it the summation order of the step --
+        # followed whatever memory happened to be free, could differ between ranks and flip in mid-training)
+        fits = getattr(self, '_flow_fits', None)
+        if fits is None:
+            rows = self.n_users + self.n_items
+            need = rows * (tkr_hip.flow_row_granules(self.k) * 32 + 96 + 8 * self.k)
+            free = torch.cuda.mem_get_info(self.device)[0] if self.device.type == 'cuda' else need
+            fits = self._flow_fits = need <= 0.7 * free
+        return fits
 
     def prepare(self, B, layout=None):
         """put the tables into the layout that batch size B runs on (or the one named)"""
@@ -603,8 +634,13 @@ class BprEngine(PlanMixin):
         post = self.ctl[tkr_hip.FLOW_CTL_DEBUG:tkr_hip.FLOW_CTL_DEBUG + 16].cpu().tolist()      # what the first wave that gave up waited for
         self.ctl.zero_()
         self._flow_ran = False
-        raise tkr_hip.TkrError('persistent BPR step gave up waiting for a row version (status %d): tables are invalid; '
-                               'post-mortem words (csrc/bpr_flow.hip kCtlDebug) %r' % (code, post))
+        # The persistent kernel needs one resident wave per ticket queue; where that cannot be had (a GPU shared with a kernel that
+        # never ends) every later launch would time out the same way.  The tables of THIS run are lost -- a launch is not
+        # transactional -- but the engine stays usable: from here on it steps with K2 (one launch per batch, no co-residency
+        # assumption), e.g. after the caller re-imports a checkpoint.
+        self._flow_disabled = True
+        raise tkr_hip.TkrError('persistent BPR step gave up waiting for a row version (status %d): tables are invalid; this engine uses the '
+                               'per-batch step (K2) from now on; post-mortem words (csrc/bpr_flow.hip kCtlDebug) %r' % (code, post))
 
     def _raise_pending(self):
         ev, self._status_event = self._status_event, None

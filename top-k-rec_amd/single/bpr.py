@@ -178,9 +178,9 @@ class BPR(REC):
             base = (np.random.Generator(np.random.PCG64(self._eng.seed)).standard_normal((self.n_users, width)) * 0.01).astype(np.float32)
         base_ms = np.ones_like(base)
         old = getattr(self, '_global_users', None)
-        if old is not None:                                # slots of users nobody trains: what the checkpoint / previous train() left
-            assert old[1].shape == base_ms.shape, 'model shape changed between train() calls: %r vs %r' % (old[1].shape, base_ms.shape)
-            base_ms = old[1].numpy().copy()
+        if old is not None and old[1].shape == base_ms.shape:      # slots of users nobody trains: what the checkpoint / previous train() left
+            base_ms = old[1].numpy().copy()                # (a table of another shape -- k or the user list changed between train() calls -- is
+                                                           # dropped: ADVICE r3, an assert here lost a whole sharded run at its very end)
         for ids, rows, slots in tdist.gather_owned_rows(self._owned, p, ms):
             base[ids], base_ms[ids] = rows, slots
         self._global_users = (torch.from_numpy(base.copy()), torch.from_numpy(base_ms))       # what export_model writes

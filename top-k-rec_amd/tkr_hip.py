@@ -145,6 +145,52 @@ def sample_plan(csr, n_users, n_items, seed, first_triplet, n_batches, B, cnt, p
                                  _p(ws), C.c_int64(ws.numel() if ws is not None else 0))
 
 
+_PLAN_ARGTYPES = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p,
+                  C.c_int32, C.c_int32] + [C.c_void_p] * 15 + [C.c_void_p, C.c_int64, C.c_void_p]
+
+
+def plan_caller(csr, n_users, n_items, seed, B, cnt, plan):
+    """-> call(first_triplet, n_batches): sample_plan with everything that does not change between calls checked and marshalled
+    ONCE (a short run_batches call is ~150 us of device time; building ~30 ctypes arguments and their assertions per call sat in
+    front of its first launch with the GPU idle)."""
+    sample_plan.__doc__                                  # same contract
+    prec, pocc = getattr(plan, 'prec', None), getattr(plan, 'pocc', None)
+    ws = getattr(plan, 'ws', None)
+    assert B <= 8192 or ws is not None
+    assert cnt.ucnt.numel() == n_users and cnt.touch_u.numel() == n_users * 16
+    assert cnt.icnt.numel() == n_items and cnt.touch_i.numel() == n_items * 16
+    cap = plan.u.numel() // B
+    fn = lib().tkr_sample_plan
+    fn.argtypes = _PLAN_ARGTYPES
+    ptr = lambda t: None if t is None else t.data_ptr()
+    for t in (csr.tr_users, csr.row_ptr, csr.pos_cols, csr.cols_sorted, cnt.ucnt, cnt.icnt, cnt.touch_u, cnt.touch_i, plan.u, plan.task):
+        assert t.is_cuda and t.is_contiguous()
+    fixed_a = (ptr(csr.tr_users), int(csr.tr_users.numel()), ptr(csr.row_ptr), ptr(csr.pos_cols), ptr(csr.cols_sorted), n_users, n_items, seed)
+    fixed_b = (ptr(cnt.ucnt), ptr(cnt.icnt), ptr(cnt.touch_u), ptr(cnt.touch_i), ptr(plan.u), ptr(plan.i), ptr(plan.j), ptr(plan.task), ptr(plan.occ),
+               ptr(getattr(plan, 'rec', None)), ptr(getattr(plan, 'hdr', None)), ptr(plan.occt), ptr(getattr(plan, 'tpar', None)), ptr(prec), ptr(pocc),
+               ptr(ws), int(ws.numel()) if ws is not None else 0)
+    device = plan.u.device
+    keep = (csr, cnt)                                    # these live as long as the closure; the closure itself is kept ON the plan buffer
+                                                         # (no reference back to it: a cycle would delay the release of a replaced buffer)
+
+    def call(first_triplet, n_batches):
+        assert 0 < n_batches <= min(cap, PLAN_MAX_BATCHES) and keep
+        if torch.cuda.current_device() != device.index:
+            prev = torch.cuda.current_device()
+            torch.cuda.set_device(device.index)
+            try:
+                rc = fn(*fixed_a, first_triplet, None, n_batches, B, *fixed_b, torch.cuda.current_stream(device).cuda_stream)
+            finally:
+                torch.cuda.set_device(prev)
+            if rc:
+                _check(rc, 'tkr_sample_plan')
+            return
+        rc = fn(*fixed_a, first_triplet, None, n_batches, B, *fixed_b, torch.cuda.current_stream(device).cuda_stream)
+        if rc:
+            _check(rc, 'tkr_sample_plan')
+    return call
+
+
 def plan_rollback(plan, B, first_batch, n_batches, cnt):
     """take batches [first_batch, first_batch + n_batches) of a plan out of the update counters again"""
     _call('tkr_plan_rollback', plan.task, _p(plan.task), C.c_int32(B), C.c_int32(first_batch), C.c_int32(n_batches),
