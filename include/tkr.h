@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TKR_VERSION 110 /* 0.1.10: tkr_topk_workspace_bytes_for (K4 stages pre-converted fp16 tiles). 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
+#define TKR_VERSION 111 /* 0.1.11: K2o (tkr_sample_plan_owned, tkr_bpr_own_run: item rows owned by one workgroup each, resident in its LDS); prec[5] = last batch of the call that updated the row. 0.1.10: tkr_topk_workspace_bytes_for (K4 stages pre-converted fp16 tiles). 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
 #define TKR_OK 0
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
@@ -62,7 +62,8 @@ int tkr_version(void);
  *                            be NULL)  pocc [n_batches][3B][4]: per sorted occurrence (a, version of a, b | role<<31,
  *                            version of b); prec [n_batches][3B][32]: one 128-byte record per task slot:
  *                            [0] row | kind<<31 (-1 = unused slot) [1] version of the row [2] occurrences [3] index of its
- *                            first occurrence in pocc counted from batch 0 [4] batch [8+4q..] pocc of occurrence q < 4
+ *                            first occurrence in pocc counted from batch 0 [4] batch [5] last batch < [4] of this call
+ *                            that updated the row (-1: none) [8+4q..] pocc of occurrence q < 4
  *   workspace                (batch_size > 8192 only, else NULL) tkr_plan_workspace_bytes(batch_size, n_batches) bytes of device
  *                            scratch: such batches are planned grid-wide (device radix sort of batch|row|occurrence keys, scans)
  *                            instead of one workgroup per batch -- single/bpr.py:103-113 accepts any batch_size
@@ -155,6 +156,34 @@ int32_t tkr_flow_ctl_words(void);
 #define TKR_FLOW_CTL_SPINS 1027  /* diagnostics: spin passes taken since the caller last zeroed it */
 int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, int32_t batch_size,
                      int32_t n_batches, uint32_t* ctl, float* loss_out, int32_t waves_per_cu, void* stream);
+
+/* ---- K2o: the persistent step with OWNED item rows (csrc/bpr_own.hip) ---------------------------------------------
+ * Replaces the same call site as K2 / K2f (single/bpr.py:139-147) on the same granule tables (tkr_flow_state), and leaves them
+ * in the same state as K2f does: the two kernels, the exchange and get / set may be mixed freely between launches.  Item row r is
+ * served by workgroup r % n_owner, which keeps the row, its slot, bias and acknowledge totals in LDS from the row's first update
+ * in a launch on: the task of batch t+1 finds the row of batch t there instead of polling memory for it (what bounded K2f at
+ * batch 256).  User tasks are handed out by tickets as in K2f.
+ *   tkr_bpr_own_owners(n_items, k)   n_owner for the current device (its CU count), or 0 when ceil(n_items / CUs) rows of
+ *                                    8*kp + 16 bytes do not fit one CU's 160 KB of LDS (use K2f then)
+ *   tkr_sample_plan_owned            tkr_sample_plan's dataflow form (prec, pocc; batch_size <= 1024) with the records of every
+ *                                    batch's ITEM tasks in (row % n_owner, row) order -- same slots -- and
+ *                                    ohdr[owner * ohdr_stride + batch] = first slot | tasks << 16 (ohdr_stride >= n_batches).
+ *                                    K2f runs such a plan unchanged (the order of tasks inside a batch means nothing to it).
+ *   tkr_bpr_own_run                  batches [first_batch, first_batch + n_batches) of such a plan in ONE launch of n_owner
+ *                                    workgroups (all resident: n_owner <= CUs).  prec / pocc / ohdr / loss_out point at batch 0 of
+ *                                    the plan call; owner_waves: waves per workgroup that serve the owner queue, 0 = default
+ *                                    (5 of 8 at k <= 128, 3 of 4 above); ctl as for tkr_bpr_flow_run (same words, same status).
+ * k <= 256, n_batches <= 512. */
+int32_t tkr_bpr_own_owners(int32_t n_items, int32_t k);
+int tkr_sample_plan_owned(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,
+                          const int32_t* cols_sorted, int32_t n_users, int32_t n_items, uint64_t seed, uint64_t first_triplet,
+                          int32_t n_batches, int32_t batch_size, int32_t* ucnt, int32_t* icnt, uint32_t* touch_u,
+                          uint32_t* touch_i, int32_t* out_u, int32_t* out_i, int32_t* out_j, int32_t* task, int32_t* occ,
+                          int32_t* occt, int32_t* prec, int32_t* pocc, int32_t n_owner, int32_t* ohdr, int32_t ohdr_stride,
+                          void* stream);
+int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, const int32_t* ohdr, int32_t ohdr_stride,
+                    int32_t n_owner, int32_t batch_size, int32_t first_batch, int32_t n_batches, uint32_t* ctl, float* loss_out,
+                    int32_t owner_waves, void* stream);
 
 /* ---- K3: VBPR mini-batch step -------------------------------------------------------------
  * Replaces sess.run([solver, obj]) of single/vbpr.py:114 on the graph of single/vbpr.py:50-73 and the

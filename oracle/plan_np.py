@@ -235,13 +235,17 @@ def resolve_parity(task, occ, B, ucnt, icnt):
     icnt[rows[is_item]] += 1
 
 
-def flow_records(task, occ, B, ucnt, icnt, batch):
-    """Dataflow form of one batch's plan (tkr_sample_plan with prec / pocc; consumed by the persistent step kernel,
-    csrc/bpr_flow.hip).  `task`, `occ` are plan_batch's output BEFORE resolve_parity; ucnt / icnt the update counters
-    before this batch = the VERSION of every row this batch reads.
+def flow_records(task, occ, B, ucnt, icnt, batch, last_u=None, last_i=None, n_owner=0):
+    """Dataflow form of one batch's plan (tkr_sample_plan with prec / pocc; consumed by the persistent step kernels,
+    csrc/bpr_flow.hip and csrc/bpr_own.hip).  `task`, `occ` are plan_batch's output BEFORE resolve_parity; ucnt / icnt the
+    update counters before this batch = the VERSION of every row this batch reads; last_u / last_i (optional, updated in
+    place) the last batch of this call that updated each row, -1 = none.
       pocc[3B,4]   per sorted occurrence (a, version of a, b | role<<31, version of b)
       prec[3B,32]  per task slot: [0] row|kind<<31 (-1 unused) [1] version [2] occurrences [3] batch*3B + first occurrence
-                   [4] batch [8+4q..11+4q] pocc of occurrence q < min(4, occurrences); everything else 0"""
+                   [4] batch [5] last batch < [4] of this call that updated the row (-1: none)
+                   [8+4q..11+4q] pocc of occurrence q < min(4, occurrences); everything else 0
+    n_owner > 0 (tkr_sample_plan_owned, K2o): the records of the batch's ITEM tasks sit in (row % n_owner, row) order instead of
+    row order (same slots), and ohdr[n_owner] = first slot | tasks << 16 of every owner's run is returned as a third value."""
     pocc = np.zeros((3 * B, 4), dtype=np.int32)
     pocc[:B, 0] = occ[:B, 0]
     pocc[:B, 1] = icnt[occ[:B, 0]]
@@ -253,17 +257,35 @@ def flow_records(task, occ, B, ucnt, icnt, batch):
     pocc[B:, 3] = icnt[occ[B:, 1] & 0x3FFFFFFF]
     prec = np.zeros((3 * B, 32), dtype=np.int32)
     prec[:, 0] = -1
-    for s in np.flatnonzero(task[:, 0] != -1):
-        rowk, start, cnt, _ = task[s]
+    live = np.flatnonzero(task[:, 0] != -1)
+    dst = {int(s): int(s) for s in live}
+    ohdr = None
+    if n_owner > 0:
+        items = [int(s) for s in live if task[s, 0] < 0]                 # row order
+        first = items[0]
+        owner = [(int(task[s, 0]) & 0x7FFFFFFF) % n_owner for s in items]
+        order = sorted(range(len(items)), key=lambda q: (owner[q], q))     # stable: row order inside an owner
+        for rank, q in enumerate(order):
+            dst[items[q]] = first + rank
+        cnt = np.bincount(owner, minlength=n_owner)
+        start = first + np.concatenate([[0], np.cumsum(cnt)[:-1]])
+        ohdr = (start | (cnt << 16)).astype(np.int32)
+    for s in live:
+        rowk, start_, cnt_, _ = task[s]
         row = int(rowk) & 0x7FFFFFFF
-        prec[s, 0] = rowk
-        prec[s, 1] = icnt[row] if rowk < 0 else ucnt[row]
-        prec[s, 2] = cnt
-        prec[s, 3] = batch * 3 * B + start
-        prec[s, 4] = batch
-        inl = min(int(cnt), 4)
-        prec[s, 8:8 + 4 * inl] = pocc[start:start + inl].reshape(-1)
-    return pocc, prec
+        r = prec[dst[int(s)]]
+        r[0] = rowk
+        r[1] = icnt[row] if rowk < 0 else ucnt[row]
+        r[2] = cnt_
+        r[3] = batch * 3 * B + start_
+        r[4] = batch
+        last = last_i if rowk < 0 else last_u
+        r[5] = -1 if last is None else last[row]
+        if last is not None:
+            last[row] = batch
+        inl = min(int(cnt_), 4)
+        r[8:8 + 4 * inl] = pocc[start_:start_ + inl].reshape(-1)
+    return (pocc, prec) if n_owner <= 0 else (pocc, prec, ohdr)
 
 
 def triplet_parity(u, i, j, ucnt, icnt):
@@ -313,7 +335,7 @@ def launch_plan(task, occ, B, occt=None):
 
 
 def sample_and_plan(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed, first_triplet,
-                    n_batches, B, ucnt=None, icnt=None, n_users=None):
+                    n_batches, B, ucnt=None, icnt=None, n_users=None, n_owner=0):
     """What ``tkr_sample_plan`` produces for n_batches batches: (u,i,j)[n_batches*B],
     task[n_batches,3B,4], occ[n_batches,3B,2], rec[n_batches, max_blocks*TEAM, 16],
     hdr[n_batches,4], occt[n_batches,3B]; ucnt/icnt (int32 update counters) are advanced in place."""
@@ -332,16 +354,21 @@ def sample_and_plan(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed, fir
     precs = np.zeros((n_batches, 3 * B, 32), dtype=np.int32)
     raw_tasks = np.zeros((n_batches, 3 * B, 4), dtype=np.int32)
     raw_occs = np.zeros((n_batches, 3 * B, 2), dtype=np.int32)
+    last_u, last_i = np.full(n_users, -1, dtype=np.int32), np.full(n_items, -1, dtype=np.int32)
+    ohdrs = np.zeros((max(n_owner, 0), n_batches), dtype=np.int32)
     for b in range(n_batches):
         sl = slice(b * B, (b + 1) * B)
         tasks[b], occs[b], occts[b] = plan_batch(u[sl], i[sl], j[sl], return_t=True)
         tpars[b] = triplet_parity(u[sl], i[sl], j[sl], ucnt, icnt)
         raw_tasks[b], raw_occs[b] = tasks[b], occs[b]
-        poccs[b], precs[b] = flow_records(tasks[b], occs[b], B, ucnt, icnt, b)
+        if n_owner > 0:
+            poccs[b], precs[b], ohdrs[:, b] = flow_records(tasks[b], occs[b], B, ucnt, icnt, b, last_u, last_i, n_owner)
+        else:
+            poccs[b], precs[b] = flow_records(tasks[b], occs[b], B, ucnt, icnt, b, last_u, last_i)
         resolve_parity(tasks[b], occs[b], B, ucnt, icnt)
         recs[b], hdrs[b] = launch_plan(tasks[b], occs[b], B, occts[b])
     sample_and_plan.last_tpars = tpars            # per-triplet parities of the last call (kept off the return tuple)
-    sample_and_plan.last_flow = dict(pocc=poccs, prec=precs, task=raw_tasks, occ=raw_occs)      # dataflow form of the same plan
+    sample_and_plan.last_flow = dict(pocc=poccs, prec=precs, task=raw_tasks, occ=raw_occs, ohdr=ohdrs)      # dataflow form of the same plan
     return u, i, j, tasks, occs, recs, hdrs, occts
 
 

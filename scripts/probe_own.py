@@ -1,0 +1,34 @@
+"""timing probe of K2o (owned item rows) against K2f at the headline shape:
+python scripts/probe_own.py [steps] [variant,variant,...] [B] [shape]; variant = f (K2f) | o<owner waves> (K2o, 0 = default)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'top-k-rec_amd')]
+import numpy as np, torch
+import bench, tkr_hip
+from single import _engine
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+variants = sys.argv[2].split(',') if len(sys.argv) > 2 else ['f', 'o0']
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+shape = sys.argv[4] if len(sys.argv) > 4 else 'ml10m'
+dev = torch.device('cuda', 0)
+r, csr, eng, nnz = bench.build_problem(shape, 128, 0, 1, dev)
+for v in variants:
+    os.environ['TKR_OWN'] = '0' if v == 'f' else '1'
+    _engine.OWN_WAVES = int(v[1:], 0) if v != 'f' else 0
+    eng.run_batches(csr, 512, B, want_loss=False)
+    torch.cuda.synchronize()
+    eng.check()
+    eng.ctl[tkr_hip.FLOW_CTL_SPINS] = 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    eng.run_batches(csr, steps, B, want_loss=False)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    eng.check()
+    spins = int(eng.ctl[tkr_hip.FLOW_CTL_SPINS])
+    print('%s B %d %-3s owners %d: %.3f us/batch (events %.3f), %.1f M triplets/s, %.2f spin passes per task' %
+          (shape, B, v, eng._plan_owners(B), wall / steps * 1e6, e0.elapsed_time(e1) * 1e3 / steps, steps * B / wall / 1e6,
+           spins / (steps * 3.0 * B)), flush=True)

@@ -1,4 +1,5 @@
-"""-m gpu: the persistent dataflow form of the BPR step (K2f, csrc/bpr_flow.hip) and the dataflow form of K1's plan.
+"""-m gpu: the persistent dataflow forms of the BPR step (K2f, csrc/bpr_flow.hip; K2o with owned item rows, csrc/bpr_own.hip)
+and the dataflow form of K1's plan.
 
 K1's extra outputs are integer work: bit-exact against oracle/plan_np.flow_records.  K2f is held to the SAME bars as K2
 (tests/test_gpu_bpr.py): tables after N sequential mini-batches within 1e-5 + 2e-4*|x| of oracle/ref_np.bpr_step on the
@@ -33,31 +34,45 @@ def _toy(n_users, n_items, seed, max_deg=12):
     return tr, list(tr.keys())
 
 
-def _plan(hip, tr, tr_users, n_users, n_items, seed, first, nb, B, chunks=1):
+def _owners(hip, which, n_items, k):
+    """'f': K2f (no owners); 'o': K2o with the device's owner count; 'o8' / 'o3': K2o on 8 / 3 workgroups (several rows per owner)"""
+    if which == 'f':
+        return 0
+    n = hip.bpr_own_owners(n_items, k)
+    assert n > 0
+    return n if which == 'o' else int(which[1:])
+
+
+def _plan(hip, tr, tr_users, n_users, n_items, seed, first, nb, B, chunks=1, owners=0):
     from single import _engine
     dev = torch.device('cuda')
     row_ptr, pos, srt = P.build_csr(tr, n_users)
     csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
     cnt = _engine.UpdateCounters(n_users, n_items, dev)
-    plan = _engine.PlanBuffers(nb, B, dev, flow=True)
+    plan = _engine.PlanBuffers(nb, B, dev, flow=True, owners=owners)
     ucnt, icnt = np.zeros(n_users, np.int32), np.zeros(n_items, np.int32)
     for c in range(chunks):
         hip.sample_plan(csr, n_users, n_items, seed, first + c * nb * B, nb, B, cnt, plan)
-        exp = P.sample_and_plan(tr_users, row_ptr, pos, srt, n_items, seed, first + c * nb * B, nb, B, ucnt, icnt)
+        exp = P.sample_and_plan(tr_users, row_ptr, pos, srt, n_items, seed, first + c * nb * B, nb, B, ucnt, icnt, n_owner=owners)
     torch.cuda.synchronize()
     return plan, exp, cnt, (ucnt, icnt)
 
 
+@pytest.mark.parametrize('owners', [0, 1, 7, 256])
 @pytest.mark.parametrize('n_users,n_items,B,nb,chunks', [(60, 40, 32, 5, 1), (300, 150, 256, 7, 3), (300, 150, 100, 3, 2),
                                                          (5000, 900, 1024, 3, 1), (40, 30, 1, 4, 1), (300, 150, 64, 512, 2)])
-def test_flow_plan_bit_exact(hip, n_users, n_items, B, nb, chunks):
+def test_flow_plan_bit_exact(hip, n_users, n_items, B, nb, chunks, owners):
     tr, tr_users = _toy(n_users, n_items, seed=n_users + B)
-    plan, exp, cnt, (ucnt, icnt) = _plan(hip, tr, tr_users, n_users, n_items, 0x1234567890ABCDEF, (1 << 33) + 17, nb, B, chunks)
+    plan, exp, cnt, (ucnt, icnt) = _plan(hip, tr, tr_users, n_users, n_items, 0x1234567890ABCDEF, (1 << 33) + 17, nb, B, chunks, owners)
     flow = P.sample_and_plan.last_flow
     np.testing.assert_array_equal(plan.u.cpu().numpy(), exp[0])
     np.testing.assert_array_equal(plan.j.cpu().numpy(), exp[2])
     np.testing.assert_array_equal(plan.pocc.cpu().numpy().reshape(nb, 3 * B, 4), flow['pocc'], err_msg='pocc')
     np.testing.assert_array_equal(plan.prec.cpu().numpy().reshape(nb, 3 * B, 32), flow['prec'], err_msg='prec')
+    if owners:
+        np.testing.assert_array_equal(plan.ohdr.cpu().numpy().reshape(owners, plan.cap)[:, :nb], flow['ohdr'], err_msg='ohdr')
+        live = flow['prec'][:, :, 0] != -1
+        assert ((flow['prec'][:, :, 5] >= -1) & (flow['prec'][:, :, 5] < np.arange(nb)[:, None]))[live].all()
     np.testing.assert_array_equal(plan.task.cpu().numpy().reshape(nb, 3 * B, 4)[:, :, :3], flow['task'][:, :, :3], err_msg='task')
     np.testing.assert_array_equal(cnt.ucnt.cpu().numpy(), ucnt)
     np.testing.assert_array_equal(cnt.icnt.cpu().numpy(), icnt)
@@ -89,7 +104,10 @@ class _Flow:
         self.st = st
 
     def run(self, plan, B, nb, loss=None, first=0, waves_per_cu=0):
-        self.hip.bpr_flow_run(self.st, plan, B, nb, self.ctl, loss, first=first, waves_per_cu=waves_per_cu)
+        if plan.owners:                  # K2o; waves_per_cu = owner waves per workgroup here
+            self.hip.bpr_own_run(self.st, plan, B, nb, self.ctl, loss, first=first, owner_waves=waves_per_cu)
+        else:
+            self.hip.bpr_flow_run(self.st, plan, B, nb, self.ctl, loss, first=first, waves_per_cu=waves_per_cu)
 
     def status(self):
         torch.cuda.synchronize()
@@ -151,7 +169,8 @@ def _check(F, ref, ucnt, icnt, uocc, iocc, tol=dict(rtol=2e-4, atol=1e-5), slots
 @pytest.mark.parametrize('k,B,nb,mode,lr', [(16, 64, 12, 'l2', 0.05), (128, 256, 10, 'l2', 0.05), (50, 256, 6, 'l1', 0.05),
                                            (200, 128, 4, 'l2', 1e-4), (64, 1024, 5, 'l2', 0.05), (128, 256, 40, 'l1', 0.02),
                                            (256, 64, 6, 'l2', 0.05)])
-def test_bpr_flow_parity(hip, k, B, nb, mode, lr):
+@pytest.mark.parametrize('kernel', ['f', 'o', 'o8'])
+def test_bpr_flow_parity(hip, k, B, nb, mode, lr, kernel):
     n_users, n_items = 400, 120               # small tables: every item is updated in (almost) every batch, many rows have > 4 occurrences
     tr, tr_users = _toy(n_users, n_items, seed=k + B)
     rng = np.random.Generator(np.random.PCG64(k))
@@ -159,7 +178,7 @@ def test_bpr_flow_parity(hip, k, B, nb, mode, lr):
     ref['b'][:] = (rng.standard_normal(n_items) * 0.01).astype(np.float32)
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=lr, mode=mode)
     F = _Flow(hip, ref, n_users, n_items, k, hp)
-    plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 42, 0, nb, B)
+    plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 42, 0, nb, B, owners=_owners(hip, kernel, n_items, k))
     loss = torch.zeros(nb, device='cuda')
     F.run(plan, B, nb, loss)
     ucnt, icnt, uocc, iocc, ref_loss = _oracle(ref, exp, n_users, n_items, nb, B, hp)
@@ -169,28 +188,39 @@ def test_bpr_flow_parity(hip, k, B, nb, mode, lr):
     assert B < 256 or heavy > 0               # the walk over more than 4 occurrences is exercised
 
 
-def test_flow_is_deterministic_and_launch_split_invariant(hip):
-    """bitwise: two runs of one launch, and the same chunk cut into launches of 1 + 3 + the rest"""
+@pytest.mark.parametrize('kernel', ['f', 'o', 'o3'])
+def test_flow_is_deterministic_and_launch_split_invariant(hip, kernel):
+    """bitwise: two runs of one launch, and the same chunk cut into launches of 1 + 3 + the rest (K2o: the rows an owner holds in
+    LDS do not outlive a launch; the first task of a row in the next launch takes it from the tables again); and K2f on the
+    owner-ordered plan, K2o and K2f cut into alternating launches: one state, whoever wrote it"""
     n_users, n_items, k, B, nb = 300, 80, 128, 256, 12
     tr, tr_users = _toy(n_users, n_items, seed=9)
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=0.01, mode='l2')
-    plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 3, 0, nb, B)
+    plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 3, 0, nb, B, owners=_owners(hip, kernel, n_items, k))
     outs = []
-    for cuts in ((nb,), (nb,), (1, 3, nb - 4)):
+    for cuts in ((nb,), (nb,), (1, 3, nb - 4), (2, 1, 4, nb - 7)):
         ref = R.init_bpr_state(n_users, n_items, k, np.random.Generator(np.random.PCG64(0)))
         F = _Flow(hip, ref, n_users, n_items, k, hp)
         at = 0
-        for m in cuts:
-            F.run(plan, B, m, None, first=at)
+        for n, m in enumerate(cuts):
+            if len(cuts) == 4 and n % 2 == 1:         # K2f on the same plan and the same tables
+                hip.bpr_flow_run(F.st, plan, B, m, F.ctl, None, first=at)
+            else:
+                F.run(plan, B, m, None, first=at)
             at += m
         assert F.status()[0] == 0
         outs.append(F.raw())
-    for a, b, c in zip(*outs):
+    for a, b, c, d in zip(*outs):
         assert torch.equal(a, b) and torch.equal(a, c)
+        if kernel == 'f':
+            assert torch.equal(a, d)
+    if kernel != 'f':                                 # the two kernels sum in the same order per row: mixing them changes nothing
+        for a, d in zip(outs[0], outs[3]):
+            assert torch.equal(a, d)
 
 
-@pytest.mark.parametrize('waves_per_cu', [4, 8, 12])
-def test_flow_few_waves_and_hot_rows(hip, waves_per_cu):
+@pytest.mark.parametrize('kernel,waves_per_cu', [('f', 4), ('f', 8), ('f', 12), ('o', 0), ('o', 1), ('o', 7), ('o3', 2)])
+def test_flow_few_waves_and_hot_rows(hip, kernel, waves_per_cu):
     """12 items: every item row is rewritten in every batch (a hand-off chain through all 64 batches), all of them with dozens of
     occurrences; and the result must not depend on how many waves run"""
     n_users, n_items, k, B, nb = 500, 12, 64, 128, 64
@@ -200,14 +230,15 @@ def test_flow_few_waves_and_hot_rows(hip, waves_per_cu):
     ref = R.init_bpr_state(n_users, n_items, k, rng)
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.02, mode='l2')
     F = _Flow(hip, ref, n_users, n_items, k, hp)
-    plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 77, 0, nb, B)
+    plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 77, 0, nb, B, owners=_owners(hip, kernel, n_items, k))
     F.run(plan, B, nb, None, waves_per_cu=waves_per_cu)
     ucnt, icnt, uocc, iocc, _ = _oracle(ref, exp, n_users, n_items, nb, B, hp)
     assert icnt.min() >= nb - 2
     _check(F, ref, ucnt, icnt, uocc, iocc, tol=dict(rtol=5e-4, atol=2e-5))
 
 
-def test_flow_sgd(hip):
+@pytest.mark.parametrize('kernel', ['f', 'o'])
+def test_flow_sgd(hip, kernel):
     n_users, n_items, k, B, nb = 400, 120, 128, 256, 8
     tr, tr_users = _toy(n_users, n_items, seed=5)
     rng = np.random.Generator(np.random.PCG64(2))
@@ -215,7 +246,7 @@ def test_flow_sgd(hip):
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.05, mode='l2', opt='sgd')
     F = _Flow(hip, ref, n_users, n_items, k, hp)
     F.st.msU = F.st.msV = None                # the slots are neither read nor written
-    plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 43, 0, nb, B)
+    plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 43, 0, nb, B, owners=_owners(hip, kernel, n_items, k))
     loss = torch.zeros(nb, device='cuda')
     F.run(plan, B, nb, loss)
     ucnt, icnt, uocc, iocc, ref_loss = _oracle(ref, exp, n_users, n_items, nb, B, hp)

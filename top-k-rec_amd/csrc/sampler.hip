@@ -310,18 +310,33 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
 }
 
 // ---- K1b', dataflow form: full versions + one 128-byte record per task -----------------------------------
-// The persistent step kernel (csrc/bpr_flow.hip) runs the batches of a chunk inside ONE launch; what orders them is
-// data: every row carries the number of updates it has seen (its version) in-band, and a task names the exact version
-// of its own row and of every partner row.  Output per batch (oracle/plan_np.py flow_plan):
+// The persistent step kernels (csrc/bpr_flow.hip, csrc/bpr_own.hip) run the batches of a chunk inside ONE launch; what orders
+// them is data: every row carries the number of updates it has seen (its version) in-band, and a task names the exact version
+// of its own row and of every partner row.  Output per batch (oracle/plan_np.py flow_records):
 //   pocc[3B] int4   per sorted occurrence: (a, version of a, b | role<<31, version of b); user occurrence: a = i, b = j;
 //                   item occurrence: a = u, b = the other item
 //   prec[3B][32]    per task slot: [0] row | kind<<31 (-1 = unused slot)  [1] version of the row  [2] occurrences
-//                   [3] index of its first occurrence in pocc, counted from batch 0 of this call  [4] batch  [5..7] 0
+//                   [3] index of its first occurrence in pocc, counted from batch 0 of this call  [4] batch
+//                   [5] the last batch < [4] of this call that updated the row, -1 = none  [6..7] 0
 //                   [8+4q .. 11+4q] = pocc of occurrence q < min(4, occurrences)  [24..31] 0
+// With n_owner > 0 (K2o: item row r is served by workgroup r % n_owner, which keeps the row in its LDS) the records of a batch's
+// ITEM tasks are laid out in (owner, row) order instead of row order -- still the slots [users, users + items) of the batch, the
+// order of tasks inside a batch means nothing to the step -- and ohdr[owner * ohdr_stride + batch] = first slot | tasks << 16
+// names every owner's run.
+__device__ __forceinline__ int prev_batch_of(const uint32_t* __restrict__ touch, int row, int batch) {
+    const uint32_t* w = touch + (size_t)row * kTouchWords;
+    int q = batch >> 5;
+    uint32_t bits = w[q] & ((1u << (batch & 31)) - 1u);
+    while (bits == 0u && q > 0) bits = w[--q];
+    return bits ? q * 32 + 31 - __clz(bits) : -1;
+}
+
 __global__ __launch_bounds__(kPlanThreads) void resolve_flow_kernel(
     int B, const int4* __restrict__ task_all, const int2* __restrict__ occ_all, const int32_t* __restrict__ ucnt,
     const int32_t* __restrict__ icnt, const uint32_t* __restrict__ touch_u, const uint32_t* __restrict__ touch_i,
-    int4* __restrict__ pocc_all, int4* __restrict__ prec_all) {
+    int4* __restrict__ pocc_all, int4* __restrict__ prec_all, int n_owner, int32_t* __restrict__ ohdr, int ohdr_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_first_item, s_end, s_wave[kPlanThreads / TKR_WAVE];
     const int b = blockIdx.x;
     const int4* task = task_all + (size_t)b * 3 * B;
     const int2* occ = occ_all + (size_t)b * 3 * B;
@@ -337,11 +352,66 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_flow_kernel(
         pocc[B + p] = make_int4(o.x, version_of(ucnt, touch_u, o.x, b), o.y,
                                 version_of(icnt, touch_i, o.y & 0x3fffffff, b));
     }
+    // ---- owner order of the item tasks: slot of item task q (q-th in row order) = first item slot + its rank by (owner, row)
+    uint16_t* own_of = reinterpret_cast<uint16_t*>(smem);                              // [2B]
+    uint32_t* own_cnt = reinterpret_cast<uint32_t*>(smem + (((size_t)4 * B + 15) & ~(size_t)15));   // [n_owner] tasks, then first rank
+    int first_item = 0, n_item = 0;
+    if (n_owner > 0) {
+        if (threadIdx.x == 0) { s_first_item = 3 * B; s_end = 0; }
+        for (int w = threadIdx.x; w < n_owner; w += kPlanThreads) own_cnt[w] = 0u;
+        __syncthreads();
+        for (int s = threadIdx.x; s < 3 * B; s += kPlanThreads) {   // tasks are [users][items][-1 ...]
+            const int x = task[s].x;
+            if (x < 0 && x != -1) {
+                if (s == 0 || task[s - 1].x >= 0) s_first_item = s;
+                if (s == 3 * B - 1 || task[s + 1].x == -1) s_end = s + 1;
+            }
+        }
+        __syncthreads();
+        first_item = s_first_item;
+        n_item = s_end - first_item;
+        for (int q = threadIdx.x; q < n_item; q += kPlanThreads) {
+            const int w = (task[first_item + q].x & 0x7fffffff) % n_owner;
+            own_of[q] = (uint16_t)w;
+            atomicAdd(&own_cnt[w], 1u);                             // a count: the same whatever the order of arrival
+        }
+        __syncthreads();
+        // exclusive scan of the counts over the owners (each thread a run of consecutive owners), header words on the way
+        const int per = (n_owner + kPlanThreads - 1) / kPlanThreads;
+        const int w0 = min((int)threadIdx.x * per, n_owner), w1 = min(w0 + per, n_owner);
+        int mine = 0;
+        for (int w = w0; w < w1; ++w) mine += (int)own_cnt[w];
+        const int lane = threadIdx.x & (TKR_WAVE - 1), wave = threadIdx.x / TKR_WAVE;
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < TKR_WAVE; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == TKR_WAVE - 1) s_wave[wave] = incl;
+        __syncthreads();
+        int run = incl - mine;
+        for (int w = 0; w < wave; ++w) run += s_wave[w];
+        for (int w = w0; w < w1; ++w) {
+            const int c = (int)own_cnt[w];
+            ohdr[(size_t)w * ohdr_stride + b] = (first_item + run) | (c << 16);
+            own_cnt[w] = (uint32_t)run;
+            run += c;
+        }
+    }
     __threadfence_block();
     __syncthreads();
     for (int s = threadIdx.x; s < 3 * B; s += kPlanThreads) {
         const int4 t = task[s];
-        int4* r = prec + (size_t)s * 8;
+        int dst = s;
+        if (n_owner > 0 && t.x < 0 && t.x != -1) {                   // rank among the tasks of the same owner: those before it in row order
+            const int q = s - first_item;
+            const uint16_t w = own_of[q];
+            int before = 0;
+            for (int e = 0; e < q; ++e) before += own_of[e] == w;
+            dst = first_item + (int)own_cnt[w] + before;
+        }
+        int4* r = prec + (size_t)dst * 8;
         if (t.x == -1) {
             r[0] = make_int4(-1, 0, 0, 0);
 #pragma unroll
@@ -350,8 +420,9 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_flow_kernel(
         }
         const int row = t.x & 0x7fffffff;
         const int ver = (t.x < 0) ? version_of(icnt, touch_i, row, b) : version_of(ucnt, touch_u, row, b);
+        const int prev = (t.x < 0) ? prev_batch_of(touch_i, row, b) : prev_batch_of(touch_u, row, b);
         r[0] = make_int4(t.x, ver, t.z, b * 3 * B + t.y);
-        r[1] = make_int4(b, 0, 0, 0);
+        r[1] = make_int4(b, prev, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) r[2 + q] = (q < t.z) ? pocc[t.y + q] : make_int4(0, 0, 0, 0);
         r[6] = make_int4(0, 0, 0, 0);
@@ -410,14 +481,16 @@ extern "C" int tkr_sample_plan_big(const int32_t* tr_users, int32_t n_tr, const 
                                    int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr, int32_t* occt,
                                    int32_t* tpar, void* workspace, int64_t workspace_bytes, void* stream);      // csrc/planner_big.hip
 
-extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr,
+static int sample_plan_impl(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr,
                                const int32_t* pos_cols, const int32_t* cols_sorted, int32_t n_users,
                                int32_t n_items, uint64_t seed, uint64_t first_triplet, const int64_t* ctl,
                                int32_t n_batches, int32_t batch_size, int32_t* ucnt, int32_t* icnt,
                                uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u, int32_t* out_i,
                                int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr,
                                int32_t* occt, int32_t* tpar, int32_t* prec, int32_t* pocc, void* workspace,
-                               int64_t workspace_bytes, void* stream) {
+                               int64_t workspace_bytes, int32_t n_owner, int32_t* ohdr, int32_t ohdr_stride, void* stream) {
+    if (n_owner < 0 || n_owner > 65535 || (n_owner > 0 && (!prec || !ohdr || ohdr_stride < n_batches))) return TKR_EINVAL;
+    if (n_owner > 0 && batch_size > 1024) return TKR_EUNSUPPORTED;      // the owner order is ranked by a walk over a batch's item tasks
     if (n_tr <= 0 || n_items <= 0 || n_users <= 0 || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
     if (n_users >= (1 << 30) || n_items >= (1 << 30)) return TKR_EUNSUPPORTED;   // id bits 30/31 carry flags
     if (n_batches > 32 * tkr::kTouchWords) return TKR_EUNSUPPORTED;
@@ -467,9 +540,10 @@ extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int3
     }
     TKR_LAUNCH_CHECK();
     if (flow)
-        hipLaunchKernelGGL(tkr::resolve_flow_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), 0, s, batch_size,
+        hipLaunchKernelGGL(tkr::resolve_flow_kernel, dim3(n_batches), dim3(tkr::kPlanThreads),
+                           n_owner > 0 ? (((size_t)4 * batch_size + 15) & ~(size_t)15) + (size_t)4 * n_owner : 0, s, batch_size,
                            reinterpret_cast<const int4*>(task), reinterpret_cast<const int2*>(occ), ucnt, icnt, touch_u,
-                           touch_i, reinterpret_cast<int4*>(pocc), reinterpret_cast<int4*>(prec));
+                           touch_i, reinterpret_cast<int4*>(pocc), reinterpret_cast<int4*>(prec), n_owner, ohdr, ohdr_stride);
     else
         hipLaunchKernelGGL(tkr::resolve_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), 0, s, batch_size,
                            tkr_plan_max_blocks(batch_size) * tkr::team_for(batch_size), reinterpret_cast<int4*>(task),
@@ -481,6 +555,31 @@ extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int3
                        touch_u, touch_i);
     TKR_LAUNCH_CHECK();
     return TKR_OK;
+}
+
+extern "C" int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr,
+                               const int32_t* pos_cols, const int32_t* cols_sorted, int32_t n_users,
+                               int32_t n_items, uint64_t seed, uint64_t first_triplet, const int64_t* ctl,
+                               int32_t n_batches, int32_t batch_size, int32_t* ucnt, int32_t* icnt,
+                               uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u, int32_t* out_i,
+                               int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec, int32_t* hdr,
+                               int32_t* occt, int32_t* tpar, int32_t* prec, int32_t* pocc, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+    return sample_plan_impl(tr_users, n_tr, row_ptr, pos_cols, cols_sorted, n_users, n_items, seed, first_triplet, ctl, n_batches,
+                            batch_size, ucnt, icnt, touch_u, touch_i, out_u, out_i, out_j, task, occ, rec, hdr, occt, tpar, prec, pocc,
+                            workspace, workspace_bytes, 0, nullptr, 0, stream);
+}
+
+extern "C" int tkr_sample_plan_owned(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr,
+                                     const int32_t* pos_cols, const int32_t* cols_sorted, int32_t n_users,
+                                     int32_t n_items, uint64_t seed, uint64_t first_triplet, int32_t n_batches,
+                                     int32_t batch_size, int32_t* ucnt, int32_t* icnt, uint32_t* touch_u, uint32_t* touch_i,
+                                     int32_t* out_u, int32_t* out_i, int32_t* out_j, int32_t* task, int32_t* occ, int32_t* occt,
+                                     int32_t* prec, int32_t* pocc, int32_t n_owner, int32_t* ohdr, int32_t ohdr_stride, void* stream) {
+    if (n_owner <= 0) return TKR_EINVAL;
+    return sample_plan_impl(tr_users, n_tr, row_ptr, pos_cols, cols_sorted, n_users, n_items, seed, first_triplet, nullptr, n_batches,
+                            batch_size, ucnt, icnt, touch_u, touch_i, out_u, out_i, out_j, task, occ, nullptr, nullptr, occt, nullptr, prec,
+                            pocc, nullptr, 0, n_owner, ohdr, ohdr_stride, stream);
 }
 
 extern "C" int tkr_plan_rollback(const int32_t* task, int32_t batch_size, int32_t first_batch, int32_t n_batches,

@@ -71,9 +71,10 @@ class PlanBuffers:
     """Output of K1 for up to ``cap`` batches of ``B`` triplets.  ``flow``: the dataflow form for the persistent step
     kernel K2f (128-byte task records + versioned occurrences) instead of per-launch wave records."""
 
-    def __init__(self, cap: int, B: int, device, flow: bool = False, cols=None):
-        """``cols`` = (d, row_cap): also room for the column plan of the VBPR step (tkr_vbpr_colplan)"""
-        self.cap, self.B, self.flow, self.cols = cap, B, flow, cols
+    def __init__(self, cap: int, B: int, device, flow: bool = False, cols=None, owners: int = 0):
+        """``cols`` = (d, row_cap): also room for the column plan of the VBPR step (tkr_vbpr_colplan); ``owners`` > 0 (with flow):
+        the owner-ordered form for K2o (csrc/bpr_own.hip) -- item records of a batch in (row % owners, row) order + ``ohdr``"""
+        self.cap, self.B, self.flow, self.cols, self.owners = cap, B, flow, cols, (owners if flow else 0)
         i32 = dict(dtype=torch.int32, device=device)
         if cols is not None:
             d, row_cap = cols
@@ -90,6 +91,8 @@ class PlanBuffers:
         if flow:
             self.prec = torch.empty(cap * 3 * B * 32, **i32)
             self.pocc = torch.empty(cap * 3 * B * 4, **i32)
+            if self.owners:
+                self.ohdr = torch.zeros(self.owners * cap, **i32)
         else:
             self.rec_stride = tkr_hip.plan_max_blocks(B) * tkr_hip.plan_team(B) * 16
             self.rec = torch.empty(cap * self.rec_stride, **i32)
@@ -135,11 +138,12 @@ class PlanPipeline:
             self._side = PlanPipeline._side_streams[key]
         return self._side
 
-    def ensure(self, cap, B, flow=False, cols=None):
+    def ensure(self, cap, B, flow=False, cols=None, owners=0):
         for i in range(2):
-            if self.bufs[i] is None or self.bufs[i].B != B or self.bufs[i].cap < cap or self.bufs[i].flow != flow or self.bufs[i].cols != cols:
-                self.bufs[i] = None                   # release before allocating the replacement
-                self.bufs[i] = PlanBuffers(cap, B, self.device, flow, cols)
+            b = self.bufs[i]
+            if b is None or b.B != B or b.cap < cap or b.flow != flow or b.cols != cols or b.owners != (owners if flow else 0):
+                self.bufs[i] = b = None               # release before allocating the replacement
+                self.bufs[i] = PlanBuffers(cap, B, self.device, flow, cols, owners)
                 self.planned[i] = None
 
     def plan(self, i, fn, overlap=True):
@@ -222,6 +226,10 @@ class PlanMixin:
     def _plan_flow(self):
         """does the step of this engine read the dataflow form of the plan?"""
         return False
+
+    def _plan_owners(self, B):
+        """owners of item rows when the step is K2o (the owner-ordered dataflow form), else 0"""
+        return 0
 
     def prepare(self, B, layout=None):
         """engines with more than one table layout pick the one batch size B runs on"""
@@ -353,7 +361,7 @@ class PlanMixin:
             cur = None
         if self.pipe is None:
             self.pipe = PlanPipeline(self.device)
-        self.pipe.ensure(self._cap(B), B, self._plan_flow(), self._plan_cols(B))
+        self.pipe.ensure(self._cap(B), B, self._plan_flow(), self._plan_cols(B), self._plan_owners(B))
         # K1 of the chunk after this one on the side stream: behind the per-batch launches of a large batch, or behind the ONE
         # persistent launch of a dataflow chunk (100 us of planner per 512 batches that otherwise sit in front of every 1.4 ms launch)
         overlap = self._plan_overlap(B)
@@ -482,6 +490,9 @@ def _generators(device, seed, user_seed):
 FLOW_MAX_BATCH = int(__import__('os').environ.get('TKR_FLOW_MAX_BATCH', 512))     # batch sizes up to this take the persistent dataflow step (K2f);
                                    # measured per batch, K2f vs K2: 64: 1.3 vs 3.9 us, 128: 1.8 vs 4.1, 256: 2.6 vs 4.5, 512: 5.1 vs 5.2, 1024: 8.8 vs 6.8
 FLOW_WAVES_PER_CU = int(__import__('os').environ.get('TKR_FLOW_WAVES_PER_CU', 0))    # 0 = the library default
+OWN_MAX_BATCH = int(__import__('os').environ.get('TKR_OWN_MAX_BATCH', 512))    # batch sizes up to this take K2o (item rows owned by one workgroup each, resident
+                                   # in its LDS) where the item table fits the CUs' LDS; TKR_OWN=0: always K2f
+OWN_WAVES = int(__import__('os').environ.get('TKR_OWN_WAVES', 0))               # owner waves per workgroup, 0 = the library default
 
 
 def _tags(t):
@@ -580,6 +591,14 @@ class BprEngine(PlanMixin):
     # ---- layout ----------------------------------------------------------------------------------
     def _plan_flow(self):
         return self.layout == 'flow'
+
+    def _plan_owners(self, B):
+        if self.layout != 'flow' or B > min(OWN_MAX_BATCH, 1024) or __import__('os').environ.get('TKR_OWN', '1') == '0':
+            return 0
+        n = getattr(self, '_owners', None)
+        if n is None:                                  # once per engine: a property of the device and the table shape
+            n = self._owners = tkr_hip.bpr_own_owners(self.n_items, self.k, self.device)
+        return n
 
     def wants_flow(self, B):
         """the granule layout + persistent step for this batch size?  Not when the granule tables would not fit: a granule row
@@ -763,7 +782,7 @@ class BprEngine(PlanMixin):
             raise ValueError('BPR on the HIP path: k <= 512, and k <= 256 for batch sizes above 1024 (got k = %d, batch_size = %d): a wave '
                              'holds a row in k / 64 registers per array (csrc/bpr_step.hip)' % (self.k, B))
         self.prepare(B)
-        key = (self.layout_epoch, B, FLOW_WAVES_PER_CU)
+        key = (self.layout_epoch, B, FLOW_WAVES_PER_CU, self._plan_owners(B), OWN_WAVES)
         if getattr(self, '_step_key', None) != key:       # the C struct and the closure are built once per layout, not per call
             self._step_key, self._step = key, self.step_fn(B)
         self._flow_ran = self._flow_ran or self.layout == 'flow'
@@ -772,6 +791,8 @@ class BprEngine(PlanMixin):
     def step_fn(self, B):
         state = self.state()
         if self.layout == 'flow':
+            if self._plan_owners(B):
+                return tkr_hip.own_stepper(state, B, self.ctl, OWN_WAVES)
             return tkr_hip.flow_stepper(state, B, self.ctl, FLOW_WAVES_PER_CU)
         return lambda plan, lo, nb, loss: tkr_hip.bpr_run(state, plan, B, nb, loss, first=lo)
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TKR_HIP_LIB') or os.path.join(_HERE, 'libtkr_hip.so')      # the override is for A/B builds of the kernels (scripts/)
 
 _lib = None
-VERSION = 110          # TKR_VERSION of include/tkr.h this binding was written against
+VERSION = 111          # TKR_VERSION of include/tkr.h this binding was written against
 
 
 class TkrError(RuntimeError):
@@ -46,7 +46,7 @@ class VbprState(C.Structure):
                [(n, C.c_void_p) for n in ('f_ptr', 'f_col', 'f_val', 'c_ptr', 'c_item', 'c_val', 'item_tag')]
 
 
-EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_plan_rollback', 'tkr_bpr_run', 'tkr_bpr_flow_run', 'tkr_flow_row_granules', 'tkr_flow_ctl_words',
+EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_sample_plan_owned', 'tkr_plan_rollback', 'tkr_bpr_run', 'tkr_bpr_flow_run', 'tkr_bpr_own_run', 'tkr_bpr_own_owners', 'tkr_flow_row_granules', 'tkr_flow_ctl_words',
            'tkr_vbpr_run', 'tkr_vbpr_colplan', 'tkr_vbpr_run_cols', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy',
            'tkr_idmap_create', 'tkr_idmap_destroy', 'tkr_ratings_parse', 'tkr_ratings_sizes', 'tkr_ratings_copy',
            'tkr_ratings_destroy', 'tkr_matrix_read', 'tkr_matrix_sizes', 'tkr_matrix_copy', 'tkr_matrix_destroy',
@@ -122,11 +122,20 @@ def plan_max_blocks(B):
 
 def sample_plan(csr, n_users, n_items, seed, first_triplet, n_batches, B, cnt, plan, ctl=None):
     """csr: tensors tr_users,row_ptr,pos_cols,cols_sorted; cnt: ucnt,icnt,touch_u,touch_i;
-    plan: u,i,j,task,occ,occt + either rec,hdr,tpar (one launch per batch, K2/K3) or prec,pocc (dataflow form, K2f);
-    all int32 device tensors."""
+    plan: u,i,j,task,occ,occt + either rec,hdr,tpar (one launch per batch, K2/K3) or prec,pocc (dataflow form, K2f; with
+    plan.owners > 0 and plan.ohdr the owner-ordered form of K2o); all int32 device tensors."""
     assert n_batches <= PLAN_MAX_BATCHES
     assert plan.u.numel() >= n_batches * B and plan.task.numel() >= n_batches * 3 * B * 4
     prec, pocc = getattr(plan, 'prec', None), getattr(plan, 'pocc', None)
+    if getattr(plan, 'owners', 0) > 0:
+        assert ctl is None and prec.numel() >= n_batches * 3 * B * 32 and pocc.numel() >= n_batches * 3 * B * 4
+        assert plan.ohdr.numel() >= plan.owners * plan.cap and plan.cap >= n_batches
+        _call('tkr_sample_plan_owned', plan.u, _p(csr.tr_users), C.c_int32(csr.tr_users.numel()), _p(csr.row_ptr), _p(csr.pos_cols),
+              _p(csr.cols_sorted), C.c_int32(n_users), C.c_int32(n_items), C.c_uint64(seed), C.c_uint64(first_triplet),
+              C.c_int32(n_batches), C.c_int32(B), _p(cnt.ucnt), _p(cnt.icnt), _p(cnt.touch_u), _p(cnt.touch_i), _p(plan.u), _p(plan.i),
+              _p(plan.j), _p(plan.task), _p(plan.occ), _p(plan.occt), _p(prec), _p(pocc), C.c_int32(plan.owners), _p(plan.ohdr),
+              C.c_int32(plan.cap))
+        return
     ws = getattr(plan, 'ws', None)                      # device scratch of the grid-wide planner (B > 8192)
     assert ws is None or ws.numel() >= plan_workspace_bytes(B, n_batches)
     assert B <= 8192 or ws is not None
@@ -172,6 +181,27 @@ def plan_caller(csr, n_users, n_items, seed, B, cnt, plan):
     device = plan.u.device
     keep = (csr, cnt)                                    # these live as long as the closure; the closure itself is kept ON the plan buffer
                                                          # (no reference back to it: a cycle would delay the release of a replaced buffer)
+    owners = getattr(plan, 'owners', 0)
+    if owners > 0:                                       # the owner-ordered dataflow form (K2o)
+        fo = lib().tkr_sample_plan_owned
+        fo.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32,
+                       C.c_int32] + [C.c_void_p] * 12 + [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        tail = (ptr(cnt.ucnt), ptr(cnt.icnt), ptr(cnt.touch_u), ptr(cnt.touch_i), ptr(plan.u), ptr(plan.i), ptr(plan.j), ptr(plan.task),
+                ptr(plan.occ), ptr(plan.occt), ptr(prec), ptr(pocc), owners, ptr(plan.ohdr), plan.cap)
+
+        def call_owned(first_triplet, n_batches):
+            assert 0 < n_batches <= min(cap, PLAN_MAX_BATCHES) and keep
+            prev = torch.cuda.current_device()
+            if prev != device.index:
+                torch.cuda.set_device(device.index)
+            try:
+                rc = fo(*fixed_a, first_triplet, n_batches, B, *tail, torch.cuda.current_stream(device).cuda_stream)
+            finally:
+                if prev != device.index:
+                    torch.cuda.set_device(prev)
+            if rc:
+                _check(rc, 'tkr_sample_plan_owned')
+        return call_owned
 
     def call(first_triplet, n_batches):
         assert 0 < n_batches <= min(cap, PLAN_MAX_BATCHES) and keep
@@ -249,6 +279,38 @@ def flow_stepper(state, B, ctl, waves_per_cu=0):
         if rc:
             _check(rc, 'tkr_bpr_flow_run')
     step.state = state                                              # the struct lives as long as the closure
+    return step
+
+
+def bpr_own_owners(n_items, k, device=None):
+    """workgroups (= owners of item rows) of the persistent step K2o on the current device, 0 = the rows do not fit its LDS"""
+    if device is not None and torch.cuda.current_device() != device.index:
+        with torch.cuda.device(device):
+            return int(lib().tkr_bpr_own_owners(C.c_int32(n_items), C.c_int32(k)))
+    return int(lib().tkr_bpr_own_owners(C.c_int32(n_items), C.c_int32(k)))
+
+
+def bpr_own_run(state, plan, B, n_batches, ctl, loss_out=None, first=0, owner_waves=0):
+    """batches [first, first + n_batches) of an owner-ordered dataflow plan in ONE persistent launch of K2o"""
+    _call('tkr_bpr_own_run', plan.prec, C.byref(state), _p(plan.prec), _p(plan.pocc), _p(plan.ohdr), C.c_int32(plan.cap), C.c_int32(plan.owners),
+          C.c_int32(B), C.c_int32(first), C.c_int32(n_batches), _p(ctl), _p(loss_out), C.c_int32(owner_waves))
+
+
+def own_stepper(state, B, ctl, owner_waves=0):
+    """-> step(plan, first, n_batches, loss_out): bpr_own_run with the fixed arguments bound once (as flow_stepper)"""
+    fn = lib().tkr_bpr_own_run
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                   C.c_void_p, C.c_int32, C.c_void_p]
+    device, st, ctl_ptr = ctl.device, C.addressof(state), ctl.data_ptr()
+
+    def step(plan, first, n_batches, loss_out):
+        if torch.cuda.current_device() != device.index:
+            return bpr_own_run(state, plan, B, n_batches, ctl, loss_out, first, owner_waves)
+        rc = fn(st, plan.prec.data_ptr(), plan.pocc.data_ptr(), plan.ohdr.data_ptr(), plan.cap, plan.owners, B, first, n_batches, ctl_ptr,
+                None if loss_out is None else loss_out.data_ptr(), owner_waves, torch.cuda.current_stream(device).cuda_stream)
+        if rc:
+            _check(rc, 'tkr_bpr_own_run')
+    step.state = state
     return step
 
 
