@@ -127,6 +127,10 @@ int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ,
  *            zeros for the first two
  *   rdU/V    [n][2] uint32: acknowledged partner reads of the row, by parity of the version read
  * A freshly assigned table holds version 0 in buffer 0 (all tags 0, expects 0, rd 0) and tags 0xffffffff in buffer 1.
+ * item_bufs = 4 (round 4): the ITEM tables have FOUR buffers -- V, msV [4][n_items][kp], tailV [4][n_items][8] granules per row
+ * {bias, its slot, expect[0..3], 0, 0}, rdV [n_items][4], version v in buffer v & 3 -- so the task that writes version v+1 waits
+ * for the readers of v-3 instead of v-1: with the rows of a chain handed over in LDS (K2o) the acknowledge round trip of TWO
+ * buffers (publish -> partner reads -> acknowledge -> next publish, once per two batches) is what paces batch 256.
  * The plan is tkr_sample_plan's dataflow form (prec / pocc non-NULL there): `prec` points at the record of the first
  * task of the first batch to run, `pocc` and `loss_out` (nullable, pre-zeroed) at batch 0 of that plan call.
  * ctl: tkr_flow_ctl_words() uint32 of caller-owned device memory, zeroed once by the caller; every launch leaves its
@@ -149,6 +153,7 @@ typedef struct {
     float lu, li, lj, lb;
     float lr, rho, eps;
     int32_t opt;             /* 0 = sparse RMSProp, 1 = plain SGD (ms tables unused, may be NULL) */
+    int32_t item_bufs;       /* buffers per ITEM row: 0 or 2 = two (as the user rows), 4 = four (see below) */
 } tkr_flow_state;
 int32_t tkr_flow_row_granules(int32_t k);
 int32_t tkr_flow_ctl_words(void);
@@ -339,13 +344,15 @@ int tkr_count_hits_rr(const int32_t* ids, const int32_t* raw_rank, int32_t n_row
 int tkr_sync_snapshot(const float* P, const int32_t* cnt, float* start, int64_t n, int32_t w, void* stream);
 /* the same exchange for the granule tables of tkr_flow_state (item side: V, msV, tailV, rdV; n = n_items): start / flat_delta /
  * flat_ms hold the n*k elements of V followed by the n item biases.  tkr_sync_flow_unpack leaves the tables as a fresh assignment
- * does (version 0 in buffer 0, none in buffer 1, expect = rd = 0) and zeroes the update counters itself. */
-int tkr_sync_flow_snapshot(const void* V, const void* tailV, const int32_t* icnt, float* start, int32_t n, int32_t k, void* stream);
+ * does (version 0 in buffer 0, none in the others, expect = rd = 0) and zeroes the update counters itself.  item_bufs = 2 or 4:
+ * the buffers per item row of the tables (tkr_flow_state.item_bufs). */
+int tkr_sync_flow_snapshot(const void* V, const void* tailV, const int32_t* icnt, float* start, int32_t n, int32_t k, int32_t item_bufs,
+                           void* stream);
 int tkr_sync_flow_pack(const void* V, const void* msV, const void* tailV, const int32_t* icnt, const float* start, float* flat_delta,
-                       float* flat_ms, int32_t n, int32_t k, float inv_world, void* stream);
+                       float* flat_ms, int32_t n, int32_t k, float inv_world, int32_t item_bufs, void* stream);
 int tkr_sync_flow_unpack(void* V, void* msV, void* tailV, uint32_t* rdV, int32_t* icnt, float* start /* in: epoch start; out: the new
                          values = the next epoch's start (no snapshot needed if nothing else writes the tables in between) */,
-                         const float* flat_delta, const float* flat_ms, int32_t n, int32_t k, void* stream);
+                         const float* flat_delta, const float* flat_ms, int32_t n, int32_t k, int32_t item_bufs, void* stream);
 int tkr_sync_pack(const float* P, const float* ms, const int32_t* cnt, const float* start, float* flat_delta, float* flat_ms,
                   int64_t n, int32_t w, float inv_world, void* stream);
 int tkr_sync_unpack(float* P, float* ms, const float* start, const float* flat_delta, const float* flat_ms, int64_t n, int32_t w,

@@ -20,6 +20,7 @@ for v in variants:
     torch.cuda.synchronize()
     eng.check()
     eng.ctl[tkr_hip.FLOW_CTL_SPINS] = 0
+    eng.ctl[tkr_hip.FLOW_CTL_PROF:tkr_hip.FLOW_CTL_PROF + 32] = 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
@@ -32,3 +33,10 @@ for v in variants:
     print('%s B %d %-3s owners %d: %.3f us/batch (events %.3f), %.1f M triplets/s, %.2f spin passes per task' %
           (shape, B, v, eng._plan_owners(B), wall / steps * 1e6, e0.elapsed_time(e1) * 1e3 / steps, steps * B / wall / 1e6,
            spins / (steps * 3.0 * B)), flush=True)
+    if os.environ.get('TKR_OWN_PROF') == '1' and v != 'f':          # a library built with -DTKR_OWN_PROF (TKR_HIP_LIB)
+        pr = eng.ctl[tkr_hip.FLOW_CTL_PROF:tkr_hip.FLOW_CTL_PROF + 32].cpu().numpy().view(np.uint64).astype(np.float64)
+        n, m = max(pr[6], 1), max(pr[13], 1)
+        print('   item task (cycles; 2400 = 1 us): partners %.0f  own row %.0f  math %.0f  lds+acks %.0f  stores %.0f  next %.0f   (%d tasks, %.0f %% from LDS)'
+              % (pr[0] / n, pr[1] / n, pr[2] / n, pr[3] / n, pr[4] / n, pr[5] / n, n, 100 * pr[7] / n), flush=True)
+        print('   user task: between %.0f  rows %.0f  own %.0f  acks %.0f  stores %.0f   (%d tasks)'
+              % (pr[8] / m, pr[9] / m, pr[10] / m, pr[11] / m, pr[12] / m, m), flush=True)

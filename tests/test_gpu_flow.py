@@ -82,12 +82,14 @@ def test_flow_plan_bit_exact(hip, n_users, n_items, B, nb, chunks, owners):
 class _Flow:
     """granule tables of one model, initialised from an oracle state dict"""
 
-    def __init__(self, hip, ref, n_users, n_items, k, hp):
+    def __init__(self, hip, ref, n_users, n_items, k, hp, bufs=None):
+        """bufs: buffers per item row (2 or 4; default: alternating between the tests' parameter sets by the parity of k // 16 + n_items)"""
         from single import _engine
         dev = torch.device('cuda')
-        self.hip, self.n_users, self.n_items, self.k = hip, n_users, n_items, k
-        self.U, self.V = _engine.FlowTable(n_users, k, dev), _engine.FlowTable(n_items, k, dev)
-        self.tU, self.tV = _engine.FlowTail(n_users, dev), _engine.FlowTail(n_items, dev)
+        bufs = bufs or (4 if (k // 16 + n_items) % 2 == 0 else 2)
+        self.hip, self.n_users, self.n_items, self.k, self.bufs = hip, n_users, n_items, k, bufs
+        self.U, self.V = _engine.FlowTable(n_users, k, dev), _engine.FlowTable(n_items, k, dev, bufs)
+        self.tU, self.tV = _engine.FlowTail(n_users, dev), _engine.FlowTail(n_items, dev, bufs)
         self.U.assign(torch.from_numpy(ref['U']).cuda(), torch.from_numpy(ref['msU']).cuda())
         self.V.assign(torch.from_numpy(ref['V']).cuda(), torch.from_numpy(ref['msV']).cuda())
         self.tU.assign()
@@ -101,6 +103,7 @@ class _Flow:
         st.lu, st.li, st.lj, st.lb, st.lr = hp['lu'], hp['li'], hp['lj'], hp['lb'], hp['lr']
         st.rho, st.eps = 0.9, 1e-10
         st.opt = 1 if hp.get('opt') == 'sgd' else 0
+        st.item_bufs = bufs
         self.st = st
 
     def run(self, plan, B, nb, loss=None, first=0, waves_per_cu=0):
@@ -154,16 +157,16 @@ def _check(F, ref, ucnt, icnt, uocc, iocc, tol=dict(rtol=2e-4, atol=1e-5), slots
             np.testing.assert_allclose(got['ms' + name], ref['ms' + name], rtol=2e-4, atol=1e-7, err_msg='ms' + name)
     # bookkeeping the kernel leaves behind: every partner read acknowledged (2 per occurrence), current tags = update counts
     np.testing.assert_array_equal(F.tU.rd.cpu().numpy().reshape(-1, 2).sum(1), 2 * uocc)
-    np.testing.assert_array_equal(F.tV.rd.cpu().numpy().reshape(-1, 2).sum(1), 2 * iocc)
+    np.testing.assert_array_equal(F.tV.rd.cpu().numpy().reshape(-1, F.bufs).sum(1), 2 * iocc)
     from single._engine import _tags
     for tab, cnt in ((F.U.p, ucnt), (F.V.p, icnt), (F.tV.t, icnt), (F.tU.t, ucnt)):
-        sel = torch.from_numpy(cnt & 1).cuda().long()
+        sel = torch.from_numpy(cnt & (tab.shape[0] - 1)).cuda().long()
         idx = torch.arange(len(cnt), device='cuda')
         tags = _tags(tab)[sel, idx].cpu().numpy()
         assert (tags == cnt.reshape(-1, 1)).all()
-    for tail, rd, cnt in ((F.tU, F.tU.rd, ucnt), (F.tV, F.tV.rd, icnt)):              # expect[parity] of the current version = rd[parity]
-        cur = tail.t.view(torch.int32)[torch.from_numpy(cnt & 1).cuda().long(), torch.arange(len(cnt), device='cuda')]
-        np.testing.assert_array_equal(cur[:, 2:4, 0].cpu().numpy(), rd.cpu().numpy().reshape(-1, 2))
+    for tail, rd, cnt in ((F.tU, F.tU.rd, ucnt), (F.tV, F.tV.rd, icnt)):              # expect[buffer] of the current version = rd[buffer]
+        cur = tail.t.view(torch.int32)[torch.from_numpy(cnt & (tail.bufs - 1)).cuda().long(), torch.arange(len(cnt), device='cuda')]
+        np.testing.assert_array_equal(cur[:, 2:2 + tail.bufs, 0].cpu().numpy(), rd.cpu().numpy().reshape(-1, tail.bufs))
 
 
 @pytest.mark.parametrize('k,B,nb,mode,lr', [(16, 64, 12, 'l2', 0.05), (128, 256, 10, 'l2', 0.05), (50, 256, 6, 'l1', 0.05),
@@ -188,8 +191,9 @@ def test_bpr_flow_parity(hip, k, B, nb, mode, lr, kernel):
     assert B < 256 or heavy > 0               # the walk over more than 4 occurrences is exercised
 
 
+@pytest.mark.parametrize('bufs', [2, 4])
 @pytest.mark.parametrize('kernel', ['f', 'o', 'o3'])
-def test_flow_is_deterministic_and_launch_split_invariant(hip, kernel):
+def test_flow_is_deterministic_and_launch_split_invariant(hip, kernel, bufs):
     """bitwise: two runs of one launch, and the same chunk cut into launches of 1 + 3 + the rest (K2o: the rows an owner holds in
     LDS do not outlive a launch; the first task of a row in the next launch takes it from the tables again); and K2f on the
     owner-ordered plan, K2o and K2f cut into alternating launches: one state, whoever wrote it"""
@@ -200,7 +204,7 @@ def test_flow_is_deterministic_and_launch_split_invariant(hip, kernel):
     outs = []
     for cuts in ((nb,), (nb,), (1, 3, nb - 4), (2, 1, 4, nb - 7)):
         ref = R.init_bpr_state(n_users, n_items, k, np.random.Generator(np.random.PCG64(0)))
-        F = _Flow(hip, ref, n_users, n_items, k, hp)
+        F = _Flow(hip, ref, n_users, n_items, k, hp, bufs)
         at = 0
         for n, m in enumerate(cuts):
             if len(cuts) == 4 and n % 2 == 1:         # K2f on the same plan and the same tables
@@ -219,8 +223,9 @@ def test_flow_is_deterministic_and_launch_split_invariant(hip, kernel):
             assert torch.equal(a, d)
 
 
+@pytest.mark.parametrize('bufs', [2, 4])
 @pytest.mark.parametrize('kernel,waves_per_cu', [('f', 4), ('f', 8), ('f', 12), ('o', 0), ('o', 1), ('o', 7), ('o3', 2)])
-def test_flow_few_waves_and_hot_rows(hip, kernel, waves_per_cu):
+def test_flow_few_waves_and_hot_rows(hip, kernel, waves_per_cu, bufs):
     """12 items: every item row is rewritten in every batch (a hand-off chain through all 64 batches), all of them with dozens of
     occurrences; and the result must not depend on how many waves run"""
     n_users, n_items, k, B, nb = 500, 12, 64, 128, 64
@@ -229,7 +234,7 @@ def test_flow_few_waves_and_hot_rows(hip, kernel, waves_per_cu):
     tr_users = list(tr.keys())
     ref = R.init_bpr_state(n_users, n_items, k, rng)
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.02, mode='l2')
-    F = _Flow(hip, ref, n_users, n_items, k, hp)
+    F = _Flow(hip, ref, n_users, n_items, k, hp, bufs)
     plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 77, 0, nb, B, owners=_owners(hip, kernel, n_items, k))
     F.run(plan, B, nb, None, waves_per_cu=waves_per_cu)
     ucnt, icnt, uocc, iocc, _ = _oracle(ref, exp, n_users, n_items, nb, B, hp)
@@ -311,7 +316,8 @@ def test_engine_layouts_and_piecewise_plans():
         np.testing.assert_allclose(a.get(n)[0].cpu().numpy(), ref[n], rtol=3e-4, atol=2e-5, err_msg=n)
 
 
-def test_fused_exchange_of_the_granule_tables(monkeypatch):
+@pytest.mark.parametrize('bufs', [2, 4])
+def test_fused_exchange_of_the_granule_tables(monkeypatch, bufs):
     """dist.ItemSync on the dataflow layout (tkr_sync_flow_snapshot / pack / unpack) against the same exchange through get /
     set_replicated: two 'ranks' that did the same work (the all-reduce doubles the packed vector) must leave V = start + 2 * delta,
     b alike, the slots unchanged, and the tables in the freshly assigned state -- bit for bit, and training goes on from there
@@ -324,6 +330,7 @@ def test_fused_exchange_of_the_granule_tables(monkeypatch):
     dev = torch.device('cuda')
     csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.02, mode='l2')
+    monkeypatch.setattr(_engine, 'FLOW_ITEM_BUFS', bufs)
     monkeypatch.setattr(tdist, 'world', lambda: (0, 2))
     monkeypatch.setattr(tdist.dist, 'all_reduce', lambda t, op=None, group=None: t.mul_(2.0))     # two ranks with identical deltas
 

@@ -97,7 +97,7 @@ def test_integration_md_sequence():
 class tkr_flow_state(C.Structure):                # include/tkr.h
     _fields_ = [(n, C.c_void_p) for n in ('U', 'msU', 'tailU', 'rdU', 'V', 'msV', 'tailV', 'rdV')] + \
                [(n, C.c_int32) for n in ('n_users', 'n_items', 'k', 'mode')] + \
-               [(n, C.c_float) for n in ('lu', 'li', 'lj', 'lb', 'lr', 'rho', 'eps')] + [('opt', C.c_int32)]
+               [(n, C.c_float) for n in ('lu', 'li', 'lj', 'lb', 'lr', 'rho', 'eps')] + [('opt', C.c_int32), ('item_bufs', C.c_int32)]
 
 
 def test_integration_md_persistent_sequence():
@@ -141,7 +141,7 @@ def test_integration_md_persistent_sequence():
     loss = torch.zeros(nb, device=dev)
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.05, mode='l2')
     st = tkr_flow_state(ptr(U), ptr(msU), ptr(tailU), ptr(rdU), ptr(V), ptr(msV), ptr(tailV), ptr(rdV), n_users, n_items, k, 0,
-                        hp['lu'], hp['li'], hp['lj'], hp['lb'], hp['lr'], 0.9, 1e-10, 0)
+                        hp['lu'], hp['li'], hp['lj'], hp['lb'], hp['lr'], 0.9, 1e-10, 0, 2)      # opt = RMSProp, two buffers per item row
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     assert lib.tkr_sample_plan(ptr(tr_users), len(tr_users_l), ptr(row_ptr), ptr(pos_cols), ptr(cols_sorted), n_users, n_items,
                                C.c_uint64(seed), C.c_uint64(0), None, nb, B, ptr(ucnt), ptr(icnt), ptr(touch_u), ptr(touch_i),

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
     T.kp = NP * 128;
     T.ustride = (size_t)st.n_users * T.kp;
     T.istride = (size_t)st.n_items * T.kp;
+    T.imask = st.item_bufs == 4 ? 3u : 1u;
     T.U = reinterpret_cast<u64*>(st.U); T.msU = reinterpret_cast<u64*>(st.msU); T.tailU = reinterpret_cast<u64*>(st.tailU);
     T.V = reinterpret_cast<u64*>(st.V); T.msV = reinterpret_cast<u64*>(st.msV); T.tailV = reinterpret_cast<u64*>(st.tailV);
     T.rdU = st.rdU; T.rdV = st.rdV;
@@ -127,12 +128,14 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
 
         TKR_TRACE(0)
         const size_t n_rows = is_item ? st.n_items : st.n_users;
-        const size_t roff = (size_t)(ver & 1u) * (is_item ? T.istride : T.ustride) + (size_t)row * T.kp;
-        const size_t woff = (size_t)((ver + 1u) & 1u) * (is_item ? T.istride : T.ustride) + (size_t)row * T.kp;
+        const uint32_t bmask = is_item ? T.imask : 1u;                         // buffers of the own row's table - 1
+        const int own_halves = tail_halves(bmask);
+        const size_t roff = (size_t)(ver & bmask) * (is_item ? T.istride : T.ustride) + (size_t)row * T.kp;
+        const size_t woff = (size_t)((ver + 1u) & bmask) * (is_item ? T.istride : T.ustride) + (size_t)row * T.kp;
         u64* tabP = is_item ? T.V : T.U;
         u64* tabM = is_item ? T.msV : T.msU;
         u64* tabT = is_item ? T.tailV : T.tailU;
-        const uint32_t* own_rd = (is_item ? T.rdV : T.rdU) + 2 * (size_t)row + ((ver + 1u) & 1u);
+        const uint32_t* own_rd = (is_item ? T.rdV : T.rdU) + (bmask + 1u) * (size_t)row + ((ver + 1u) & bmask);
 
         float own[NE], ms[NE], g[NE];
 #pragma unroll
@@ -140,9 +143,9 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
         Own o = {};
         float gb = 0.f, loss_lane = 0.f, loss_x = 0.f;
 
-        const u64* own_tail = tabT + ((size_t)(ver & 1u) * n_rows + row) * 4;
+        const u64* own_tail = tabT + ((size_t)(ver & bmask) * n_rows + row) * (2 * own_halves);
         TicketSrc src{ticket, home, total, prec};
-        GlobalOwn<NP> own_step{T, lane, tabP + roff, tabM + roff, own_tail, own_rd, ver, sgd, ctl, spins};
+        GlobalOwn<NP> own_step{T, lane, tabP + roff, tabM + roff, own_tail, own_rd, ver, sgd, ctl, spins, own_halves};
         alive = is_item ? run_task<NP, true>(st, T, lane, n_occ, first, w, pocc, tabP + roff, tabM + roff, own_tail, ver, own, ms, o,
                                              g, gb, loss_lane, false, sgd, ctl, spins, nx, src, own_step)
                         : run_task<NP, false>(st, T, lane, n_occ, first, w, pocc, tabP + roff, tabM + roff, own_tail, ver, own, ms,
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
         }
 
         // version ver+1 lands on the buffer that held ver-1: wait until every reader of ver-1 has acknowledged
-        const uint32_t expect = (ver & 1u) ? o.exp_even : o.exp_odd;        // readers of version ver-1
+        const uint32_t expect = pick_exp(o, (ver + 1u) & bmask);            // readers of the version that buffer holds now (ver-1, or ver-3 with four buffers)
         uint32_t waited = 0;
 #ifdef TKR_FLOW_TRACE
         if (T.tune & 8u) o.rd = expect;             // experiment: no acknowledge wait
@@ -213,18 +216,7 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
         asm volatile("" : "+v"(nx.w.x), "+v"(nx.w.y), "+v"(nx.w.z), "+v"(nx.w.w));
         store_row<NP>(tabP + woff, lane, pn, nv);
         if (!sgd) store_row<NP>(tabM + woff, lane, mn, nv);
-        if (lane < 2) {                             // tail = {bias, its slot | expect[0], expect[1]}
-            v4u tv;
-            tv.y = nv; tv.w = nv;
-            if (lane == 0) {
-                tv.x = is_item ? __float_as_uint(bn) : 0u;
-                tv.z = is_item ? __float_as_uint(mbn) : 0u;
-            } else {                                // this batch read version ver: its parity's total grows by 2 per occurrence
-                tv.x = o.exp_even + ((ver & 1u) ? 0u : 2u * (uint32_t)n_occ);
-                tv.z = o.exp_odd + ((ver & 1u) ? 2u * (uint32_t)n_occ : 0u);
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(tv, row_rsrc(tabT + ((size_t)(nv & 1u) * n_rows + row) * 4, 32), lane * 16, 0, kAuxStore);
-        }
+        store_tail(tabT, n_rows, row, bmask, lane, is_item, bn, mbn, o, ver, n_occ);
         TKR_TRACE(3)
         if constexpr (PROF) prof[5] += 1;
         TKR_PROF_MARK(4)
@@ -268,6 +260,7 @@ extern "C" int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, c
     if (st->opt == 0 && (!st->msU || !st->msV)) return TKR_EINVAL;
     if (st->n_users <= 0 || st->n_items <= 0 || st->k <= 0) return TKR_EINVAL;
     if (st->k > 256) return TKR_EUNSUPPORTED;
+    if (st->item_bufs != 0 && st->item_bufs != 2 && st->item_bufs != 4) return TKR_EINVAL;
     if (!prec || !pocc || !ctl || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
     if (n_batches == 0) return TKR_OK;
     const uint64_t total64 = (uint64_t)n_batches * 3u * (uint64_t)batch_size;

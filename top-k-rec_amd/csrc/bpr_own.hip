@@ -98,8 +98,12 @@ struct LdsOwn {
     uint32_t& spins;
     bool from_lds;
     const volatile uint32_t* tag;        // the row's version word in LDS
-    const float* row;                    // [kp] values, [kp] slots, {bias, its slot, expect[0], expect[1]}
+    const float* row;                    // [kp] values, [kp] slots, {bias, its slot, expect[0..3], -, -}
+    int own_halves;
     __device__ __forceinline__ bool operator()(float (&own)[2 * NP], float (&ms)[2 * NP], Own& o) {
+#ifdef TKR_OWN_PROF
+        o.t_own0 = __builtin_amdgcn_s_memtime();
+#endif
         if (from_lds) {
             uint32_t waited = 0;
             while (*tag != ver) {
@@ -123,10 +127,16 @@ struct LdsOwn {
                 }
             }
             const float4 t = *reinterpret_cast<const float4*>(row + 2 * KP);
+            const float2 t2 = *reinterpret_cast<const float2*>(row + 2 * KP + 4);
             o.b = t.x; o.msb = t.y;
-            o.exp_even = __float_as_uint(t.z); o.exp_odd = __float_as_uint(t.w);
+            o.exp[0] = __float_as_uint(t.z); o.exp[1] = __float_as_uint(t.w);
+            o.exp[2] = __float_as_uint(t2.x); o.exp[3] = __float_as_uint(t2.y);
         }
-        return flow_own<NP>(T, lane, own_p, own_ms, own_tail, own_rd, ver, own, ms, o, sgd, ctl, spins);     // o.ok: only the acknowledge word is loaded
+        const bool ok = flow_own<NP>(T, lane, own_p, own_ms, own_tail, own_rd, ver, own, ms, o, sgd, ctl, spins, own_halves);     // o.ok: only the acknowledge word is loaded
+#ifdef TKR_OWN_PROF
+        o.t_own1 = __builtin_amdgcn_s_memtime();
+#endif
+        return ok;
     }
 };
 
@@ -154,11 +164,16 @@ __device__ __forceinline__ void own_update(const tkr_flow_state& st, bool sgd, c
 
 // version ver+1 lands on the buffer that held ver-1: wait until every reader of ver-1 has acknowledged, then write through
 template <int NP>
-__device__ __forceinline__ bool own_publish(int lane, bool is_item, bool sgd, u64* tabP, u64* tabM, u64* tabT, size_t woff, size_t n_rows, int row,
-                                            int rowk, uint32_t ver, int n_occ, Own& o, const uint32_t* own_rd, const float (&pn)[2 * NP],
-                                            const float (&mn)[2 * NP], float bn, float mbn, uint32_t* ctl, uint32_t& spins, NextTask& nx) {
+__device__ __forceinline__ bool own_publish(int lane, bool is_item, uint32_t bmask, bool sgd, u64* tabP, u64* tabM, u64* tabT, size_t woff,
+                                            size_t n_rows, int row, int rowk, uint32_t ver, int n_occ, Own& o, const uint32_t* own_rd,
+                                            const float (&pn)[2 * NP],
+                                            const float (&mn)[2 * NP], float bn, float mbn, uint32_t* ctl, uint32_t& spins, NextTask& nx,
+                                            bool skip_ack = false) {
     const uint32_t nv = ver + 1u;
-    const uint32_t expect = (ver & 1u) ? o.exp_even : o.exp_odd;        // readers of version ver-1
+    const uint32_t expect = pick_exp(o, (ver + 1u) & bmask);            // readers of the version that buffer holds now
+#ifdef TKR_OWN_PROF
+    if (skip_ack) o.rd = expect;                // timing experiment only (unsafe): no acknowledge wait
+#endif
     uint32_t waited = 0;
     while ((int32_t)(o.rd - expect) < 0) {
         if (spin_fail(waited, ctl)) {
@@ -170,21 +185,13 @@ __device__ __forceinline__ bool own_publish(int lane, bool is_item, bool sgd, u6
         o.rd = ld_u32(own_rd);
     }
     spins += waited;
+#ifdef TKR_OWN_PROF
+    o.t_ack = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("" : "+v"(nx.w.x), "+v"(nx.w.y), "+v"(nx.w.z), "+v"(nx.w.w));      // the next record is consumed before the stores go out
     store_row<NP>(tabP + woff, lane, pn, nv);
     if (!sgd) store_row<NP>(tabM + woff, lane, mn, nv);
-    if (lane < 2) {                             // tail = {bias, its slot | expect[0], expect[1]}
-        v4u tv;
-        tv.y = nv; tv.w = nv;
-        if (lane == 0) {
-            tv.x = is_item ? __float_as_uint(bn) : 0u;
-            tv.z = is_item ? __float_as_uint(mbn) : 0u;
-        } else {                                // this batch read version ver: its parity's total grows by 2 per occurrence
-            tv.x = o.exp_even + ((ver & 1u) ? 0u : 2u * (uint32_t)n_occ);
-            tv.z = o.exp_odd + ((ver & 1u) ? 2u * (uint32_t)n_occ : 0u);
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(tv, row_rsrc(tabT + ((size_t)(nv & 1u) * n_rows + row) * 4, 32), lane * 16, 0, kAuxStore);
-    }
+    store_tail(tabT, n_rows, row, bmask, lane, is_item, bn, mbn, o, ver, n_occ);
     return true;
 }
 
@@ -197,13 +204,15 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     int B, int n_owner, int owner_waves, uint32_t tune, uint32_t* __restrict__ ctl, float* __restrict__ loss_out) {
     constexpr int NE = 2 * NP;
     constexpr int KP = NP * 128;
-    constexpr int ROWF = 2 * KP + 4;                                  // floats per resident row
+    constexpr int ROWF = 2 * KP + 8;                                  // floats per resident row
     const int lane = threadIdx.x & (TKR_WAVE - 1), wave = threadIdx.x / TKR_WAVE;
     FlowTables T;
     T.tune = 0u;
     T.kp = KP;
     T.ustride = (size_t)st.n_users * T.kp;
     T.istride = (size_t)st.n_items * T.kp;
+    T.imask = st.item_bufs == 4 ? 3u : 1u;
+    const int item_halves = tail_halves(T.imask);
     T.U = reinterpret_cast<u64*>(st.U); T.msU = reinterpret_cast<u64*>(st.msU); T.tailU = reinterpret_cast<u64*>(st.tailU);
     T.V = reinterpret_cast<u64*>(st.V); T.msV = reinterpret_cast<u64*>(st.msV); T.tailV = reinterpret_cast<u64*>(st.tailV);
     T.rdU = st.rdU; T.rdV = st.rdV;
@@ -250,6 +259,10 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
 
     uint32_t spins = 0;
     bool alive = true;
+#ifdef TKR_OWN_PROF
+    u64 prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    u64 tprev = __builtin_amdgcn_s_memtime();
+#endif
     NextTask nx;
     nx.idx = 0u; nx.w = make_int4(0, 0, 0, 0); nx.have = false;
 
@@ -263,6 +276,9 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             if (idx == 0xffffffffu) break;
             nx.have = false;
             const int rowk = bcast_i(w.x, 0);
+#ifdef TKR_OWN_PROF
+            const u64 t0 = __builtin_amdgcn_s_memtime();
+#endif
             const uint32_t ver = (uint32_t)bcast_i(w.y, 0);
             const int n_occ = bcast_i(w.z, 0);
             const int first = bcast_i(w.w, 0);
@@ -271,10 +287,10 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             const int slot = row / n_owner;
             const bool from_lds = prev >= first_batch;                 // an earlier task of THIS launch updated the row: it is (or will be) in LDS
 
-            const size_t roff = (size_t)(ver & 1u) * T.istride + (size_t)row * T.kp;
-            const size_t woff = (size_t)((ver + 1u) & 1u) * T.istride + (size_t)row * T.kp;
-            const uint32_t* own_rd = T.rdV + 2 * (size_t)row + ((ver + 1u) & 1u);
-            const u64* own_tail = T.tailV + ((size_t)(ver & 1u) * st.n_items + row) * 4;
+            const size_t roff = (size_t)(ver & T.imask) * T.istride + (size_t)row * T.kp;
+            const size_t woff = (size_t)((ver + 1u) & T.imask) * T.istride + (size_t)row * T.kp;
+            const uint32_t* own_rd = T.rdV + (T.imask + 1u) * (size_t)row + ((ver + 1u) & T.imask);
+            const u64* own_tail = T.tailV + ((size_t)(ver & T.imask) * st.n_items + row) * (2 * item_halves);
             float* lrow = rows + (size_t)slot * ROWF;
 
             float own[NE], ms[NE], g[NE];
@@ -285,10 +301,13 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             const bool lazy = (tune & 1u) != 0u;                        // experiment: the next task is only taken once this one is done
             if (lazy) nx.have = true;
             float gb = 0.f, loss_lane = 0.f;
-            LdsOwn<NP> own_step{T, lane, T.V + roff, T.msV + roff, own_tail, own_rd, ver, sgd, ctl, spins, from_lds, tags + slot, lrow};
+            LdsOwn<NP> own_step{T, lane, T.V + roff, T.msV + roff, own_tail, own_rd, ver, sgd, ctl, spins, from_lds, tags + slot, lrow, item_halves};
             alive = run_task<NP, true>(st, T, lane, n_occ, first, w, pocc, T.V + roff, T.msV + roff, own_tail, ver, own, ms, o, g, gb,
                                        loss_lane, false, sgd, ctl, spins, nx, feed, own_step);
             if (!alive) break;
+#ifdef TKR_OWN_PROF
+            const u64 t1 = __builtin_amdgcn_s_memtime();
+#endif
             float pn[NE], mn[NE], bn, mbn;
             own_update<NP>(st, sgd, own, ms, o, g, gb, pn, mn, bn, mbn);
 
@@ -298,16 +317,30 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
                 *reinterpret_cast<float2*>(lrow + qq * 128 + 2 * lane) = make_float2(pn[2 * qq], pn[2 * qq + 1]);
                 if (!sgd) *reinterpret_cast<float2*>(lrow + KP + qq * 128 + 2 * lane) = make_float2(mn[2 * qq], mn[2 * qq + 1]);
             }
-            if (lane == 0)
-                *reinterpret_cast<float4*>(lrow + 2 * KP) =
-                    make_float4(bn, mbn, __uint_as_float(o.exp_even + ((ver & 1u) ? 0u : 2u * (uint32_t)n_occ)),
-                                __uint_as_float(o.exp_odd + ((ver & 1u) ? 2u * (uint32_t)n_occ : 0u)));
+            if (lane == 0) {
+                const uint32_t rb = ver & T.imask, add = 2u * (uint32_t)n_occ;
+                *reinterpret_cast<float4*>(lrow + 2 * KP) = make_float4(bn, mbn, __uint_as_float(o.exp[0] + (rb == 0u ? add : 0u)),
+                                                                        __uint_as_float(o.exp[1] + (rb == 1u ? add : 0u)));
+                *reinterpret_cast<float2*>(lrow + 2 * KP + 4) =
+                    make_float2(__uint_as_float(o.exp[2] + (rb == 2u ? add : 0u)), __uint_as_float(o.exp[3] + (rb == 3u ? add : 0u)));
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the row is in LDS before its tag says so
             if (lane == 0) *reinterpret_cast<volatile uint32_t*>(tags + slot) = ver + 1u;
 
-            alive = own_publish<NP>(lane, true, sgd, T.V, T.msV, T.tailV, woff, (size_t)st.n_items, row, rowk, ver, n_occ, o, own_rd, pn, mn,
-                                    bn, mbn, ctl, spins, nx);
+            alive = own_publish<NP>(lane, true, T.imask, sgd, T.V, T.msV, T.tailV, woff, (size_t)st.n_items, row, rowk, ver, n_occ, o, own_rd, pn, mn,
+                                    bn, mbn, ctl, spins, nx, (tune & 2u) != 0u);
+#ifdef TKR_OWN_PROF
+            const u64 t4 = __builtin_amdgcn_s_memtime();
+#endif
             if (lazy && alive) feed.prefetch(nx, lane);
+#ifdef TKR_OWN_PROF
+            {
+                asm volatile("" : "+v"(nx.w.x) :: "memory");
+                const u64 t5 = __builtin_amdgcn_s_memtime();
+                prof[0] += o.t_own0 - t0; prof[1] += o.t_own1 - o.t_own0; prof[2] += t1 - o.t_own1; prof[3] += o.t_ack - t1;
+                prof[4] += t4 - o.t_ack; prof[5] += t5 - t4; prof[6] += 1; prof[7] += from_lds ? 1 : 0;
+            }
+#endif
         }
     } else {
         // ================= user tasks, by ticket =================
@@ -328,7 +361,16 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             nx.have = false;
             ticket = grab_issue(ctl, lane, home);                      // the ticket of the task after this one
             const int rowk = bcast_i(w.x, 0);
-            if (rowk < 0) continue;                                     // an item task (its owner runs it) or an unused slot
+#ifdef TKR_OWN_PROF
+            const u64 t0 = __builtin_amdgcn_s_memtime();
+            prof[8] += t0 - tprev;
+#endif
+            if (rowk < 0) {                                             // an item task (its owner runs it) or an unused slot
+#ifdef TKR_OWN_PROF
+                tprev = t0;
+#endif
+                continue;
+            }
             const uint32_t ver = (uint32_t)bcast_i(w.y, 0);
             const int n_occ = bcast_i(w.z, 0);
             const int first = bcast_i(w.w, 0);
@@ -346,22 +388,33 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             Own o = {};
             float gb = 0.f, loss_lane = 0.f;
             UserTicketSrc feed{ticket, home, queues, total, (uint32_t)B, prec};
-            GlobalOwn<NP> own_step{T, lane, T.U + roff, T.msU + roff, own_tail, own_rd, ver, sgd, ctl, spins};
+            GlobalOwn<NP> own_step{T, lane, T.U + roff, T.msU + roff, own_tail, own_rd, ver, sgd, ctl, spins, 2};
             alive = run_task<NP, false>(st, T, lane, n_occ, first, w, pocc, T.U + roff, T.msU + roff, own_tail, ver, own, ms, o, g, gb,
                                         loss_lane, want_loss, sgd, ctl, spins, nx, feed, own_step);
             if (!alive) break;
+#ifdef TKR_OWN_PROF
+            const u64 t1 = __builtin_amdgcn_s_memtime();
+#endif
             if (want_loss) {
                 const float tot = wave_sum(loss_lane);
                 if (lane == 0) atomicAdd(loss_out + batch, tot);
             }
             float pn[NE], mn[NE], bn, mbn;
             own_update<NP>(st, sgd, own, ms, o, g, gb, pn, mn, bn, mbn);
-            alive = own_publish<NP>(lane, false, sgd, T.U, T.msU, T.tailU, woff, (size_t)st.n_users, row, rowk, ver, n_occ, o, own_rd, pn, mn,
+            alive = own_publish<NP>(lane, false, 1u, sgd, T.U, T.msU, T.tailU, woff, (size_t)st.n_users, row, rowk, ver, n_occ, o, own_rd, pn, mn,
                                     bn, mbn, ctl, spins, nx);
+#ifdef TKR_OWN_PROF
+            tprev = __builtin_amdgcn_s_memtime();
+            prof[9] += t1 - t0; prof[11] += o.t_ack - t1; prof[12] += tprev - o.t_ack; prof[13] += 1;
+#endif
         }
     }
 
     if (lane == 0 && spins) atomicAdd(ctl + kCtlSpins, spins);
+#ifdef TKR_OWN_PROF
+    if (lane == 0)
+        for (int qq = 0; qq < 16; ++qq) atomicAdd(reinterpret_cast<u64*>(ctl + kCtlProf) + qq, prof[qq]);
+#endif
     // the last workgroup out puts the ticket words back to zero (as K2f: the next launch needs no memset)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -376,7 +429,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
 static size_t own_lds_bytes(int np, int nb, int n_items, int n_owner) {
     const int rows_here = (n_items + n_owner - 1) / n_owner;
     const size_t head = (sizeof(OwnQueue) + (size_t)4 * (2 * nb + 1 + TKR_WAVE + rows_here) + 15) & ~(size_t)15;
-    return head + (size_t)rows_here * (2 * np * 128 + 4) * 4;
+    return head + (size_t)rows_here * (2 * np * 128 + 8) * 4;
 }
 
 }  // namespace tkr
@@ -400,6 +453,7 @@ extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, co
     if (st->opt == 0 && (!st->msU || !st->msV)) return TKR_EINVAL;
     if (st->n_users <= 0 || st->n_items <= 0 || st->k <= 0) return TKR_EINVAL;
     if (st->k > 256) return TKR_EUNSUPPORTED;
+    if (st->item_bufs != 0 && st->item_bufs != 2 && st->item_bufs != 4) return TKR_EINVAL;
     if (!prec || !pocc || !ohdr || !ctl || batch_size <= 0 || n_batches < 0 || first_batch < 0 || n_owner <= 0) return TKR_EINVAL;
     if (ohdr_stride < first_batch + n_batches || n_batches > 512) return TKR_EINVAL;
     if (n_batches == 0) return TKR_OK;

@@ -74,9 +74,10 @@ __device__ __forceinline__ void store_row(u64* __restrict__ row, int lane, const
 __device__ __forceinline__ v2u issue_bias(const u64* __restrict__ tail) {
     return __builtin_amdgcn_raw_buffer_load_b64(row_rsrc(tail, 32), 0, 0, kAuxLoad);
 }
-// a row's tail (4 granules = 32 bytes): `half` 0 = {bias, its slot}, 1 = {expect[0], expect[1]}
-__device__ __forceinline__ v4u issue_tail(const u64* __restrict__ tail, int half) {
-    return __builtin_amdgcn_raw_buffer_load_b128(row_rsrc(tail, 32), half * 16, 0, kAuxLoad);
+// a row's tail (4 granules = 32 bytes with two buffers per row, 8 = 64 bytes with four): `half` 0 = {bias, its slot},
+// 1 = {expect[0], expect[1]}, 2 = {expect[2], expect[3]}, 3 = padding (tagged like the rest)
+__device__ __forceinline__ v4u issue_tail(const u64* __restrict__ tail, int half, int halves) {
+    return __builtin_amdgcn_raw_buffer_load_b128(row_rsrc(tail, halves * 16), half * 16, 0, kAuxLoad);
 }
 
 template <int NE>
@@ -140,9 +141,13 @@ struct FlowTables {                       // device view of tkr_flow_state
     u64 *U, *msU, *tailU, *V, *msV, *tailV;
     uint32_t *rdU, *rdV;
     size_t ustride, istride;              // granules per buffer
+    uint32_t imask;                       // buffers per ITEM row - 1 (1 or 3; user rows: always two buffers): version v lives in buffer v & imask
     int kp;
     uint32_t tune;                        // experiment switches (scripts/probe_flow_bench.py): bit 0 late acks, bit 1 nap while only the own row is missing
 };
+
+// buffers of a row's table: items T.imask + 1, users 2; a tail is 2 halves (two buffers) or 4 (four) of 16 bytes
+__device__ __forceinline__ int tail_halves(uint32_t mask) { return mask == 1u ? 2 : 4; }
 
 struct NextTask {                         // the task after the current one, fetched while the current one waits for its rows
     uint32_t idx;                         // its index (0xffffffff: the queue is exhausted)
@@ -152,12 +157,27 @@ struct NextTask {                         // the task after the current one, fet
 
 struct Own {                              // a task's own row while it is processed
     float b, msb;
-    uint32_t exp_even, exp_odd, rd;       // expect[0], expect[1] as carried by the version read; rd[(version + 1) & 1]
+    uint32_t exp[4], rd;                  // expect[buffer] as carried by the version read; rd[buffer of version + 1]
     bool ok;
 #ifdef TKR_FLOW_TRACE
     unsigned long long t_valid, t_part;   // when the own row / the partner rows validated
 #endif
+#ifdef TKR_OWN_PROF
+    unsigned long long t_own0, t_own1, t_ack;      // entering / leaving the own-row step, readers acknowledged (csrc/bpr_own.hip)
+#endif
 };
+
+__device__ __forceinline__ void own_tail_values(const v4u xt, Own& o, int halves) {
+    o.b = bcast_f(__uint_as_float(xt.x), 0);
+    o.msb = bcast_f(__uint_as_float(xt.z), 0);
+    o.exp[0] = (uint32_t)bcast_i((int)xt.x, 1);
+    o.exp[1] = (uint32_t)bcast_i((int)xt.z, 1);
+    o.exp[2] = halves > 2 ? (uint32_t)bcast_i((int)xt.x, 2) : 0u;
+    o.exp[3] = halves > 2 ? (uint32_t)bcast_i((int)xt.z, 2) : 0u;
+}
+__device__ __forceinline__ uint32_t pick_exp(const Own& o, uint32_t buf) {
+    return buf == 0u ? o.exp[0] : buf == 1u ? o.exp[1] : buf == 2u ? o.exp[2] : o.exp[3];
+}
 
 __device__ __forceinline__ bool spin_fail(uint32_t& spins, uint32_t* ctl, int nap = 4) {
     asm volatile("" ::: "memory");                 // the next pass re-loads
@@ -241,12 +261,14 @@ __device__ __forceinline__ bool flow_fetch(const tkr_flow_state& st, const FlowT
     v4u xa[G][NP], xb[G][NP];
     v2u xta[G], xtb[G];
     uint32_t waited = 0;
+    const int own_halves = tail_halves(ITEM ? T.imask : 1u);
+    const size_t itg = 2 * (size_t)tail_halves(T.imask);           // granules of an item row's tail
     for (;;) {
         // a pass first ISSUES every load it still needs and only then looks at tags: one round trip per pass, not per row
         if (!o.ok) {
             issue_row<NP>(own_p, lane, xo);
             if (!sgd) issue_row<NP>(own_ms, lane, xm);
-            xt = issue_tail(own_tail, lane & 1);
+            xt = issue_tail(own_tail, lane & (own_halves - 1), own_halves);
         }
 #pragma unroll
         for (int q = 0; q < G; ++q) {
@@ -257,11 +279,11 @@ __device__ __forceinline__ bool flow_fetch(const tkr_flow_state& st, const FlowT
                 issue_row<NP>(T.U + (va & 1u) * T.ustride + (size_t)a * T.kp, lane, xa[q]);
                 xta[q] = v2u{0u, va};
             } else {
-                issue_row<NP>(T.V + (va & 1u) * T.istride + (size_t)a * T.kp, lane, xa[q]);
-                xta[q] = issue_bias(T.tailV + ((size_t)(va & 1u) * st.n_items + a) * 4);
+                issue_row<NP>(T.V + (va & T.imask) * T.istride + (size_t)a * T.kp, lane, xa[q]);
+                xta[q] = issue_bias(T.tailV + ((size_t)(va & T.imask) * st.n_items + a) * itg);
             }
-            issue_row<NP>(T.V + (vb & 1u) * T.istride + (size_t)b * T.kp, lane, xb[q]);
-            xtb[q] = issue_bias(T.tailV + ((size_t)(vb & 1u) * st.n_items + b) * 4);
+            issue_row<NP>(T.V + (vb & T.imask) * T.istride + (size_t)b * T.kp, lane, xb[q]);
+            xtb[q] = issue_bias(T.tailV + ((size_t)(vb & T.imask) * st.n_items + b) * itg);
         }
         if (!o.ok) {
             bool lane_own = row_tagged<NP>(xo, own_ver) && xt.y == own_ver && xt.w == own_ver;
@@ -273,10 +295,7 @@ __device__ __forceinline__ bool flow_fetch(const tkr_flow_state& st, const FlowT
 #endif
                 row_values<NP>(xo, own);
                 if (!sgd) row_values<NP>(xm, ms);
-                o.b = bcast_f(__uint_as_float(xt.x), 0);
-                o.msb = bcast_f(__uint_as_float(xt.z), 0);
-                o.exp_even = (uint32_t)bcast_i((int)xt.x, 1);
-                o.exp_odd = (uint32_t)bcast_i((int)xt.z, 1);
+                own_tail_values(xt, o, own_halves);
             }
         }
         bool lane_part = true;
@@ -293,16 +312,18 @@ __device__ __forceinline__ bool flow_fetch(const tkr_flow_state& st, const FlowT
         // a quarter of a wave's time per task.
         if (!nx.have) feed.prefetch(nx, lane);
         if (part_ok) break;
-        // How far away is what we wait for?  The buffer of version v holds v, v-2, v-4, ...: a tag of v-2 means the producer is
-        // one or two updates away (poll), v-4 or older at least three -- two whole hand-offs: sleep through that (a waiting
-        // wave that polls costs everybody's loads latency, a sleeping one nothing)
+        // How far away is what we wait for?  The buffer of version v holds v, v-2, v-4, ... (two buffers per row; v-4, v-8 with
+        // four): the tag of the version before means the producer is one or two updates away (poll), an older one at least three
+        // -- two whole hand-offs: sleep through that (a waiting wave that polls costs everybody's loads latency, a sleeping one
+        // nothing)
         bool far = false;
+        const int far_items = 2 * (int)(T.imask + 1u);
         if (!(T.tune & 2u)) {
 #pragma unroll
             for (int q = 0; q < G; ++q) {
                 const int src = (q < n) ? q : 0;
-                far = far || (int)((uint32_t)bcast_i(d.y, src) - (uint32_t)bcast_i((int)xa[q][0].y, 0)) >= 4 ||
-                      (int)((uint32_t)bcast_i(d.w, src) - (uint32_t)bcast_i((int)xb[q][0].y, 0)) >= 4;
+                far = far || (int)((uint32_t)bcast_i(d.y, src) - (uint32_t)bcast_i((int)xa[q][0].y, 0)) >= (ITEM ? 4 : far_items) ||
+                      (int)((uint32_t)bcast_i(d.w, src) - (uint32_t)bcast_i((int)xb[q][0].y, 0)) >= far_items;
             }
         }
         if (far) __builtin_amdgcn_s_sleep(127);      // 127 x 64 clocks = 3.4 us
@@ -335,8 +356,8 @@ __device__ __forceinline__ bool flow_fetch(const tkr_flow_state& st, const FlowT
     // The partner rows are in registers: acknowledge the reads NOW (lane q: one add on rd[version & 1] of both partner rows of
     // occurrence q), not after this task's own row has arrived too -- the next writers of those rows are waiting for exactly this.
     if (lane < n) {
-        uint32_t* pa_rd = (ITEM ? T.rdU : T.rdV) + 2 * (size_t)d.x + (d.y & 1);
-        uint32_t* pb_rd = T.rdV + 2 * (size_t)(d.z & 0x3fffffff) + (d.w & 1);
+        uint32_t* pa_rd = ITEM ? T.rdU + 2 * (size_t)d.x + (d.y & 1) : T.rdV + (T.imask + 1u) * (size_t)d.x + ((uint32_t)d.y & T.imask);
+        uint32_t* pb_rd = T.rdV + (T.imask + 1u) * (size_t)(d.z & 0x3fffffff) + ((uint32_t)d.w & T.imask);
         __hip_atomic_fetch_add(pa_rd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(pb_rd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -385,19 +406,19 @@ __device__ __forceinline__ bool flow_fetch(const tkr_flow_state& st, const FlowT
 template <int NP>
 __device__ __forceinline__ bool flow_own(const FlowTables& T, int lane, const u64* own_p, const u64* own_ms, const u64* own_tail,
                                          const uint32_t* own_rd, uint32_t own_ver, float (&own)[2 * NP], float (&ms)[2 * NP], Own& o,
-                                         bool sgd, uint32_t* ctl, uint32_t& spins) {
+                                         bool sgd, uint32_t* ctl, uint32_t& spins, int own_halves) {
     if (!o.ok) {
         v4u xo[NP], xm[NP], xt = {0u, 0u, 0u, 0u};
         uint32_t waited = 0;
         for (;;) {
             issue_row<NP>(own_p, lane, xo);
             if (!sgd) issue_row<NP>(own_ms, lane, xm);
-            xt = issue_tail(own_tail, lane & 1);
+            xt = issue_tail(own_tail, lane & (own_halves - 1), own_halves);
             bool lane_own = row_tagged<NP>(xo, own_ver) && xt.y == own_ver && xt.w == own_ver;
             if (!sgd) lane_own = lane_own && row_tagged<NP>(xm, own_ver);
             if (__all(lane_own)) break;
             // a tag two versions of this buffer back: the producer is at least three updates away -- sleep through two hand-offs
-            if (!(T.tune & 2u) && (int)(own_ver - (uint32_t)bcast_i((int)xt.y, 0)) >= 4) __builtin_amdgcn_s_sleep(127);
+            if (!(T.tune & 2u) && (int)(own_ver - (uint32_t)bcast_i((int)xt.y, 0)) >= 2 * own_halves) __builtin_amdgcn_s_sleep(127);
             if (spin_fail(waited, ctl, 0)) {
                 if (waited >= kSpinLimit && lane == 0 && atomicCAS(ctl + kCtlDebug, 0u, 3u) == 0u) {
                     ctl[kCtlDebug + 1] = 0u;
@@ -416,15 +437,38 @@ __device__ __forceinline__ bool flow_own(const FlowTables& T, int lane, const u6
 #endif
         row_values<NP>(xo, own);
         if (!sgd) row_values<NP>(xm, ms);
-        o.b = bcast_f(__uint_as_float(xt.x), 0);
-        o.msb = bcast_f(__uint_as_float(xt.z), 0);
-        o.exp_even = (uint32_t)bcast_i((int)xt.x, 1);
-        o.exp_odd = (uint32_t)bcast_i((int)xt.z, 1);
+        own_tail_values(xt, o, own_halves);
     }
     // the acknowledge count is loaded NOW, once, and returns while the gradients are computed (not in every pass: the word is
     // under atomic update by the readers, and the copy of an earlier pass predates the last acknowledgements anyway)
     o.rd = ld_u32(own_rd);
     return true;
+}
+
+// the tail of version ver + 1 of a row (bias, its slot, the acknowledge totals: this batch read version ver, so the total of ITS
+// buffer grows by 2 per occurrence), written by lanes 0 .. halves-1
+__device__ __forceinline__ void store_tail(u64* tabT, size_t n_rows, int row, uint32_t mask, int lane, bool is_item, float bn, float mbn,
+                                           const Own& o, uint32_t ver, int n_occ) {
+    const int halves = tail_halves(mask);
+    const uint32_t nv = ver + 1u, rb = ver & mask, add = 2u * (uint32_t)n_occ;
+    if (lane < halves) {
+        v4u tv;
+        tv.y = nv; tv.w = nv;
+        if (lane == 0) {
+            tv.x = is_item ? __float_as_uint(bn) : 0u;
+            tv.z = is_item ? __float_as_uint(mbn) : 0u;
+        } else if (lane == 1) {
+            tv.x = o.exp[0] + (rb == 0u ? add : 0u);
+            tv.z = o.exp[1] + (rb == 1u ? add : 0u);
+        } else if (lane == 2) {
+            tv.x = o.exp[2] + (rb == 2u ? add : 0u);
+            tv.z = o.exp[3] + (rb == 3u ? add : 0u);
+        } else {
+            tv.x = 0u; tv.z = 0u;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(tv, row_rsrc(tabT + ((size_t)(nv & mask) * n_rows + row) * (2 * halves), halves * 16), lane * 16, 0,
+                                               kAuxStore);
+    }
 }
 
 // x_t of every occurrence: one dot product each (user row: <u, v_i - v_j>; item row: <u, v_row - v_other>, single/bpr.py:87-89),
@@ -504,8 +548,9 @@ struct GlobalOwn {
     bool sgd;
     uint32_t* ctl;
     uint32_t& spins;
+    int own_halves;
     __device__ __forceinline__ bool operator()(float (&own)[2 * NP], float (&ms)[2 * NP], Own& o) {
-        return flow_own<NP>(T, lane, own_p, own_ms, own_tail, own_rd, ver, own, ms, o, sgd, ctl, spins);
+        return flow_own<NP>(T, lane, own_p, own_ms, own_tail, own_rd, ver, own, ms, o, sgd, ctl, spins, own_halves);
     }
 };
 

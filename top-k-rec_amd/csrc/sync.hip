@@ -43,8 +43,8 @@ __global__ void sync_unpack_kernel(float* __restrict__ P, float* __restrict__ ms
 }
 
 // ---- the same three steps for the GRANULE tables of the dataflow step (csrc/bpr_flow.hip) -----------------------------
-// V / msV: [2][n][kp] granules {fp32 value, uint32 version tag}; the item bias and its slot are granules 0 and 1 of the row's
-// tail [2][n][4].  "Current" is buffer (cnt[r] & 1).  The flat vectors hold the n*k elements of V followed by the n biases.
+// V / msV: [nbuf][n][kp] granules {fp32 value, uint32 version tag}, nbuf = 2 or 4 (tkr_flow_state.item_bufs); the item bias and its
+// slot are granules 0 and 1 of the row's tail [nbuf][n][tg], tg = 4 (two buffers) or 8 (four).  "Current" is buffer cnt[r] & (nbuf - 1).  The flat vectors hold the n*k elements of V followed by the n biases.
 // unpack re-creates what a fresh assignment of the tables looks like: version 0 of every row in buffer 0 (tags 0, padding 0 / slot
 // padding 1), no version in buffer 1 (tags 0xffffffff), expect = 0, rd = 0, update counters 0 -- one launch instead of ~20
 // framework ops (fills, strided copies, tag resets) on 2 x 21 MB: measured 464 -> ~60 us per exchange at the ML-10M shape.
@@ -53,28 +53,30 @@ __global__ void sync_unpack_kernel(float* __restrict__ P, float* __restrict__ ms
 // exchange at the ML-10M shape).  The row's tail (bias, its slot) rides with thread 0 of the row.
 __global__ __launch_bounds__(256) void sync_flow_snapshot_kernel(const float4* __restrict__ P, const float2* __restrict__ tail,
                                                                 const int32_t* __restrict__ cnt, float* __restrict__ start, int n,
-                                                                int k, int kp) {
+                                                                int k, int kp, int nbuf) {
     const int hp = kp >> 1;                                      // pairs per row
+    const int tg = nbuf == 4 ? 8 : 4;
     const int r = blockIdx.x * (256 / 64) + (threadIdx.x >> 6);
     if (r >= n) return;
-    const int64_t par = cnt[r] & 1;
+    const int64_t par = cnt[r] & (nbuf - 1);
     for (int q = threadIdx.x & 63; q < hp; q += 64) {
         const float4 g = P[(par * n + r) * hp + q];
         const int c = 2 * q;
         if (c < k) start[(int64_t)r * k + c] = g.x;
         if (c + 1 < k) start[(int64_t)r * k + c + 1] = g.z;
     }
-    if ((threadIdx.x & 63) == 0) start[(int64_t)n * k + r] = tail[(par * n + r) * 4 + 0].x;
+    if ((threadIdx.x & 63) == 0) start[(int64_t)n * k + r] = tail[(par * n + r) * tg + 0].x;
 }
 
 __global__ __launch_bounds__(256) void sync_flow_pack_kernel(const float4* __restrict__ P, const float4* __restrict__ M,
                                                             const float2* __restrict__ tail, const int32_t* __restrict__ cnt,
                                                             const float* __restrict__ start, float* __restrict__ flat_delta,
-                                                            float* __restrict__ flat_ms, int n, int k, int kp, float inv_world) {
+                                                            float* __restrict__ flat_ms, int n, int k, int kp, float inv_world, int nbuf) {
     const int hp = kp >> 1;
+    const int tg = nbuf == 4 ? 8 : 4;
     const int r = blockIdx.x * (256 / 64) + (threadIdx.x >> 6);
     if (r >= n) return;
-    const int64_t par = cnt[r] & 1;
+    const int64_t par = cnt[r] & (nbuf - 1);
     for (int q = threadIdx.x & 63; q < hp; q += 64) {
         const float4 g = P[(par * n + r) * hp + q], m = M[(par * n + r) * hp + q];
         const int c = 2 * q;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void sync_flow_pack_kernel(const float4* __res
         if (c + 1 < k) { flat_delta[o + 1] = g.z - start[o + 1]; flat_ms[o + 1] = m.z * inv_world; }
     }
     if ((threadIdx.x & 63) == 0) {
-        const int64_t o = (int64_t)n * k + r, g = (par * n + r) * 4;
+        const int64_t o = (int64_t)n * k + r, g = (par * n + r) * tg;
         flat_delta[o] = tail[g + 0].x - start[o];
         flat_ms[o] = tail[g + 1].x * inv_world;
     }
@@ -94,8 +96,9 @@ __global__ __launch_bounds__(256) void sync_flow_pack_kernel(const float4* __res
 __global__ __launch_bounds__(256) void sync_flow_unpack_kernel(float4* __restrict__ P, float4* __restrict__ M, float2* __restrict__ tail,
                                                               uint32_t* __restrict__ rd, int32_t* __restrict__ cnt,
                                                               float* __restrict__ start, const float* __restrict__ flat_delta,
-                                                              const float* __restrict__ flat_ms, int n, int k, int kp) {
+                                                              const float* __restrict__ flat_ms, int n, int k, int kp, int nbuf) {
     const int hp = kp >> 1;
+    const int tg = nbuf == 4 ? 8 : 4;
     const int r = blockIdx.x * (256 / 64) + (threadIdx.x >> 6);
     if (r >= n) return;
     const float none = __uint_as_float(0xffffffffu), zero_tag = __uint_as_float(0u);
@@ -107,21 +110,21 @@ __global__ __launch_bounds__(256) void sync_flow_unpack_kernel(float4* __restric
         if (c + 1 < k) { v1 = start[o + 1] + flat_delta[o + 1]; m1 = flat_ms[o + 1]; start[o + 1] = v1; }
         P[(int64_t)r * hp + q] = make_float4(v0, zero_tag, v1, zero_tag);
         M[(int64_t)r * hp + q] = make_float4(m0, zero_tag, m1, zero_tag);
-        P[((int64_t)n + r) * hp + q] = make_float4(0.f, none, 0.f, none);
-        M[((int64_t)n + r) * hp + q] = make_float4(0.f, none, 0.f, none);
+        for (int64_t bf = 1; bf < nbuf; ++bf) {
+            P[(bf * n + r) * hp + q] = make_float4(0.f, none, 0.f, none);
+            M[(bf * n + r) * hp + q] = make_float4(0.f, none, 0.f, none);
+        }
     }
     if ((threadIdx.x & 63) == 0) {
         const int64_t ob = (int64_t)n * k + r;
         const float b = start[ob] + flat_delta[ob];
         start[ob] = b;
-        tail[(int64_t)r * 4 + 0] = make_float2(b, zero_tag);
-        tail[(int64_t)r * 4 + 1] = make_float2(flat_ms[ob], zero_tag);
-        tail[(int64_t)r * 4 + 2] = make_float2(0.f, zero_tag);
-        tail[(int64_t)r * 4 + 3] = make_float2(0.f, zero_tag);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) tail[((int64_t)n + r) * 4 + c] = make_float2(0.f, none);
-        rd[2 * (int64_t)r] = 0u;
-        rd[2 * (int64_t)r + 1] = 0u;
+        tail[(int64_t)r * tg + 0] = make_float2(b, zero_tag);
+        tail[(int64_t)r * tg + 1] = make_float2(flat_ms[ob], zero_tag);
+        for (int c = 2; c < tg; ++c) tail[(int64_t)r * tg + c] = make_float2(0.f, zero_tag);
+        for (int64_t bf = 1; bf < nbuf; ++bf)
+            for (int c = 0; c < tg; ++c) tail[(bf * n + r) * tg + c] = make_float2(0.f, none);
+        for (int c = 0; c < nbuf; ++c) rd[(int64_t)nbuf * r + c] = 0u;
         cnt[r] = 0;
     }
 }
@@ -129,33 +132,33 @@ __global__ __launch_bounds__(256) void sync_flow_unpack_kernel(float4* __restric
 }  // namespace tkr
 
 extern "C" int tkr_sync_flow_snapshot(const void* P, const void* tail, const int32_t* cnt, float* start, int32_t n, int32_t k,
-                                      void* stream) {
-    if (!P || !tail || !cnt || !start || n <= 0 || k <= 0) return TKR_EINVAL;
+                                      int32_t item_bufs, void* stream) {
+    if (!P || !tail || !cnt || !start || n <= 0 || k <= 0 || (item_bufs != 2 && item_bufs != 4)) return TKR_EINVAL;
     const int kp = (k + 127) / 128 * 128;
     hipLaunchKernelGGL(tkr::sync_flow_snapshot_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       static_cast<const float4*>(P), static_cast<const float2*>(tail), cnt, start, n, k, kp);
+                       static_cast<const float4*>(P), static_cast<const float2*>(tail), cnt, start, n, k, kp, item_bufs);
     TKR_LAUNCH_CHECK();
     return TKR_OK;
 }
 
 extern "C" int tkr_sync_flow_pack(const void* P, const void* M, const void* tail, const int32_t* cnt, const float* start,
-                                  float* flat_delta, float* flat_ms, int32_t n, int32_t k, float inv_world, void* stream) {
-    if (!P || !M || !tail || !cnt || !start || !flat_delta || !flat_ms || n <= 0 || k <= 0) return TKR_EINVAL;
+                                  float* flat_delta, float* flat_ms, int32_t n, int32_t k, float inv_world, int32_t item_bufs, void* stream) {
+    if (!P || !M || !tail || !cnt || !start || !flat_delta || !flat_ms || n <= 0 || k <= 0 || (item_bufs != 2 && item_bufs != 4)) return TKR_EINVAL;
     const int kp = (k + 127) / 128 * 128;
     hipLaunchKernelGGL(tkr::sync_flow_pack_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        static_cast<const float4*>(P), static_cast<const float4*>(M), static_cast<const float2*>(tail), cnt, start,
-                       flat_delta, flat_ms, n, k, kp, inv_world);
+                       flat_delta, flat_ms, n, k, kp, inv_world, item_bufs);
     TKR_LAUNCH_CHECK();
     return TKR_OK;
 }
 
 extern "C" int tkr_sync_flow_unpack(void* P, void* M, void* tail, uint32_t* rd, int32_t* cnt, float* start,
-                                    const float* flat_delta, const float* flat_ms, int32_t n, int32_t k, void* stream) {
-    if (!P || !M || !tail || !rd || !cnt || !start || !flat_delta || !flat_ms || n <= 0 || k <= 0) return TKR_EINVAL;
+                                    const float* flat_delta, const float* flat_ms, int32_t n, int32_t k, int32_t item_bufs, void* stream) {
+    if (!P || !M || !tail || !rd || !cnt || !start || !flat_delta || !flat_ms || n <= 0 || k <= 0 || (item_bufs != 2 && item_bufs != 4)) return TKR_EINVAL;
     const int kp = (k + 127) / 128 * 128;
     hipLaunchKernelGGL(tkr::sync_flow_unpack_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        static_cast<float4*>(P), static_cast<float4*>(M), static_cast<float2*>(tail), rd, cnt, start, flat_delta,
-                       flat_ms, n, k, kp);
+                       flat_ms, n, k, kp, item_bufs);
     TKR_LAUNCH_CHECK();
     return TKR_OK;
 }

@@ -147,11 +147,11 @@ class ItemSync:
         self._bind()
         if self.flow is not None:
             import tkr_hip
-            V, msV, tail, rd, icnt, n, k = self.flow
+            V, msV, tail, rd, icnt, n, k, bufs = self.flow
             # the unpack of the exchange before left the new values in start_flat: they ARE this epoch's start, unless somebody wrote
             # the item tables since (set_items, a layout change: the engine counts those)
             if self._start_valid != (self._bound, getattr(self.eng, 'item_mutations', 0)):
-                tkr_hip.sync_flow_snapshot(V, tail, icnt, self.start_flat, n, k)
+                tkr_hip.sync_flow_snapshot(V, tail, icnt, self.start_flat, n, k, bufs)
             self._start_valid = None
             self.start = True
             return
@@ -188,14 +188,14 @@ class ItemSync:
         marks = []
         if self.flow is not None:
             import tkr_hip
-            V, msV, tail, rd, icnt, n, k = self.flow
+            V, msV, tail, rd, icnt, n, k, bufs = self.flow
             total = n * (k + 1)
             self._mark(marks)
-            tkr_hip.sync_flow_pack(V, msV, tail, icnt, self.start_flat, self.flat[:total], self.flat[total:], n, k, 1.0 / w)
+            tkr_hip.sync_flow_pack(V, msV, tail, icnt, self.start_flat, self.flat[:total], self.flat[total:], n, k, 1.0 / w, bufs)
             self._mark(marks)
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self._mark(marks)
-            tkr_hip.sync_flow_unpack(V, msV, tail, rd, icnt, self.start_flat, self.flat[:total], self.flat[total:], n, k)
+            tkr_hip.sync_flow_unpack(V, msV, tail, rd, icnt, self.start_flat, self.flat[:total], self.flat[total:], n, k, bufs)
             self._start_valid = (self._bound, getattr(self.eng, 'item_mutations', 0))
             self._mark(marks)
             after = getattr(self.eng, 'after_exchange', None)

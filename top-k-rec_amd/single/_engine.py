@@ -493,6 +493,7 @@ FLOW_WAVES_PER_CU = int(__import__('os').environ.get('TKR_FLOW_WAVES_PER_CU', 0)
 OWN_MAX_BATCH = int(__import__('os').environ.get('TKR_OWN_MAX_BATCH', 512))    # batch sizes up to this take K2o (item rows owned by one workgroup each, resident
                                    # in its LDS) where the item table fits the CUs' LDS; TKR_OWN=0: always K2f
 OWN_WAVES = int(__import__('os').environ.get('TKR_OWN_WAVES', 0))               # owner waves per workgroup, 0 = the library default
+FLOW_ITEM_BUFS = int(__import__('os').environ.get('TKR_FLOW_ITEM_BUFS', 4))     # buffers per item row of the granule tables (2 or 4; include/tkr.h)
 
 
 def _tags(t):
@@ -501,41 +502,44 @@ def _tags(t):
 
 
 class FlowTable:
-    """A parameter table + its RMSProp slot in the layout of the dataflow step (csrc/bpr_flow.hip): [2][n][kp] granules
+    """A parameter table + its RMSProp slot in the layout of the dataflow step (csrc/bpr_flow.hip): [bufs][n][kp] granules
     {fp32 value, uint32 version tag}, kp = k rounded up to 128 (tkr_flow_row_granules); version v of a row lives in
-    buffer v & 1.  Same interface as DoubleTable."""
+    buffer v & (bufs - 1); bufs = 2, or 4 for the item tables (tkr_flow_state.item_bufs).  Same interface as DoubleTable."""
 
-    def __init__(self, n, k, device):
-        self.n, self.k, self.kp = n, k, tkr_hip.flow_row_granules(k)
-        self.p = torch.zeros((2, n, self.kp, 2), dtype=torch.float32, device=device)
-        self.ms = torch.zeros((2, n, self.kp, 2), dtype=torch.float32, device=device)
+    def __init__(self, n, k, device, bufs=2):
+        assert bufs in (2, 4)
+        self.n, self.k, self.kp, self.bufs = n, k, tkr_hip.flow_row_granules(k), bufs
+        self.p = torch.zeros((bufs, n, self.kp, 2), dtype=torch.float32, device=device)
+        self.ms = torch.zeros((bufs, n, self.kp, 2), dtype=torch.float32, device=device)
 
     def current(self, cnt):
-        sel = (cnt & 1).long()
+        sel = (cnt & (self.bufs - 1)).long()
         idx = torch.arange(self.n, device=self.p.device)
         return self.p[sel, idx, :self.k, 0], self.ms[sel, idx, :self.k, 0]
 
     def assign(self, values, ms):
-        """version 0 of every row in buffer 0 (the caller zeroes the update counters); buffer 1 holds no version"""
+        """version 0 of every row in buffer 0 (the caller zeroes the update counters); the other buffers hold no version"""
         self.mutations = getattr(self, 'mutations', 0) + 1
         for t, v, pad in ((self.p, values, 0.0), (self.ms, ms, 1.0)):
             t.zero_()
             t[0, :, :, 0] = pad
             t[0, :, :self.k, 0] = v
-            _tags(t)[1] = -1
+            _tags(t)[1:] = -1
 
 
 class FlowTail:
-    """[2][n][4] granules per row: {item bias, its RMSProp slot, expect[0], expect[1]} + the two rd words of every row"""
+    """[bufs][n][2 * bufs] granules per row: {item bias, its RMSProp slot, expect[0 .. bufs-1] (+ two of padding with four
+    buffers)} + the bufs rd words of every row"""
 
-    def __init__(self, n, device):
-        self.n = n
-        self.t = torch.zeros((2, n, 4, 2), dtype=torch.float32, device=device)
-        self.rd = torch.zeros(2 * n, dtype=torch.int32, device=device)
-        _tags(self.t)[1] = -1
+    def __init__(self, n, device, bufs=2):
+        assert bufs in (2, 4)
+        self.n, self.bufs = n, bufs
+        self.t = torch.zeros((bufs, n, 2 * bufs, 2), dtype=torch.float32, device=device)
+        self.rd = torch.zeros(bufs * n, dtype=torch.int32, device=device)
+        _tags(self.t)[1:] = -1
 
     def current(self, cnt):
-        sel = (cnt & 1).long()
+        sel = (cnt & (self.bufs - 1)).long()
         idx = torch.arange(self.n, device=self.t.device)
         return self.t[sel, idx, 0, 0], self.t[sel, idx, 1, 0]
 
@@ -545,7 +549,7 @@ class FlowTail:
         if b is not None:
             self.t[0, :, 0, 0] = b
             self.t[0, :, 1, 0] = msb
-        _tags(self.t)[1] = -1
+        _tags(self.t)[1:] = -1
         self.rd.zero_()
 
 
@@ -615,7 +619,7 @@ class BprEngine(PlanMixin):
         fits = getattr(self, '_flow_fits', None)
         if fits is None:
             rows = self.n_users + self.n_items
-            need = rows * (tkr_hip.flow_row_granules(self.k) * 32 + 96 + 8 * self.k)
+            need = (rows + (FLOW_ITEM_BUFS // 2 - 1) * self.n_items) * (tkr_hip.flow_row_granules(self.k) * 32 + 96 + 8 * self.k)
             free = torch.cuda.mem_get_info(self.device)[0] if self.device.type == 'cuda' else need
             fits = self._flow_fits = need <= 0.7 * free
         return fits
@@ -629,8 +633,8 @@ class BprEngine(PlanMixin):
         (pu, mu), (pv, mv), (pb, mb) = (tuple(t.clone() for t in self.get(n)) for n in ('U', 'V', 'b'))
         self.U = self.V = self.b = self.tailU = self.tailV = None
         if layout == 'flow':
-            self.U, self.V = FlowTable(self.n_users, self.k, self.device), FlowTable(self.n_items, self.k, self.device)
-            self.tailU, self.tailV = FlowTail(self.n_users, self.device), FlowTail(self.n_items, self.device)
+            self.U, self.V = FlowTable(self.n_users, self.k, self.device), FlowTable(self.n_items, self.k, self.device, FLOW_ITEM_BUFS)
+            self.tailU, self.tailV = FlowTail(self.n_users, self.device), FlowTail(self.n_items, self.device, FLOW_ITEM_BUFS)
             if self.ctl is None:
                 self.ctl = torch.zeros(tkr_hip.flow_ctl_words(), dtype=torch.int32, device=self.device)
         else:
@@ -708,6 +712,7 @@ class BprEngine(PlanMixin):
             st = tkr_hip.FlowState()
             st.U, st.msU, st.tailU, st.rdU = self.U.p.data_ptr(), self.U.ms.data_ptr(), self.tailU.t.data_ptr(), self.tailU.rd.data_ptr()
             st.V, st.msV, st.tailV, st.rdV = self.V.p.data_ptr(), self.V.ms.data_ptr(), self.tailV.t.data_ptr(), self.tailV.rd.data_ptr()
+            st.item_bufs = self.V.bufs
             return self._hyper_into(st)
         st = tkr_hip.BprState()
         st.U, st.msU = self.U.p.data_ptr(), self.U.ms.data_ptr()
@@ -756,7 +761,7 @@ class BprEngine(PlanMixin):
         """the item-side granule tables for dist.ItemSync's fused exchange (csrc/sync.hip tkr_sync_flow_*), or None in the plain layout"""
         if self.layout != 'flow':
             return None
-        return self.V.p, self.V.ms, self.tailV.t, self.tailV.rd, self._cnt.icnt, self.n_items, self.k
+        return self.V.p, self.V.ms, self.tailV.t, self.tailV.rd, self._cnt.icnt, self.n_items, self.k, self.V.bufs
 
     def copy_model_from(self, other):
         """start from another engine's current parameters and slots (shards of one model)"""

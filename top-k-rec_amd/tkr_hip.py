@@ -35,7 +35,7 @@ class FlowState(C.Structure):
     """mirror of tkr_flow_state (include/tkr.h): granule tables of the persistent dataflow step"""
     _fields_ = [(n, C.c_void_p) for n in ('U', 'msU', 'tailU', 'rdU', 'V', 'msV', 'tailV', 'rdV')] + \
                [(n, C.c_int32) for n in ('n_users', 'n_items', 'k', 'mode')] + \
-               [(n, C.c_float) for n in ('lu', 'li', 'lj', 'lb', 'lr', 'rho', 'eps')] + [('opt', C.c_int32)]
+               [(n, C.c_float) for n in ('lu', 'li', 'lj', 'lb', 'lr', 'rho', 'eps')] + [('opt', C.c_int32), ('item_bufs', C.c_int32)]
 
 
 class VbprState(C.Structure):
@@ -473,18 +473,18 @@ def sync_pack(P, ms, cnt, start, flat_delta, flat_ms, n, w, inv_world):
                                C.c_float(inv_world))
 
 
-def sync_flow_snapshot(V, tailV, icnt, start, n, k):
-    _call('tkr_sync_flow_snapshot', V, _p(V), _p(tailV), _p(icnt), _p(start), C.c_int32(n), C.c_int32(k))
+def sync_flow_snapshot(V, tailV, icnt, start, n, k, item_bufs=2):
+    _call('tkr_sync_flow_snapshot', V, _p(V), _p(tailV), _p(icnt), _p(start), C.c_int32(n), C.c_int32(k), C.c_int32(item_bufs))
 
 
-def sync_flow_pack(V, msV, tailV, icnt, start, flat_delta, flat_ms, n, k, inv_world):
+def sync_flow_pack(V, msV, tailV, icnt, start, flat_delta, flat_ms, n, k, inv_world, item_bufs=2):
     _call('tkr_sync_flow_pack', V, _p(V), _p(msV), _p(tailV), _p(icnt), _p(start), _p(flat_delta), _p(flat_ms), C.c_int32(n),
-          C.c_int32(k), C.c_float(inv_world))
+          C.c_int32(k), C.c_float(inv_world), C.c_int32(item_bufs))
 
 
-def sync_flow_unpack(V, msV, tailV, rdV, icnt, start, flat_delta, flat_ms, n, k):
+def sync_flow_unpack(V, msV, tailV, rdV, icnt, start, flat_delta, flat_ms, n, k, item_bufs=2):
     _call('tkr_sync_flow_unpack', V, _p(V), _p(msV), _p(tailV), _p(rdV), _p(icnt), _p(start), _p(flat_delta), _p(flat_ms),
-          C.c_int32(n), C.c_int32(k))
+          C.c_int32(n), C.c_int32(k), C.c_int32(item_bufs))
 
 
 def sync_unpack(P, ms, start, flat_delta, flat_ms, n, w):
