@@ -63,7 +63,8 @@ int tkr_version(void);
  *                            version of b); prec [n_batches][3B][32]: one 128-byte record per task slot:
  *                            [0] row | kind<<31 (-1 = unused slot) [1] version of the row [2] occurrences [3] index of its
  *                            first occurrence in pocc counted from batch 0 [4] batch [5] last batch < [4] of this call
- *                            that updated the row (-1: none) [8+4q..] pocc of occurrence q < 4
+ *                            that updated the row (-1: none) [8+4q..] pocc of occurrence q < 4 [24+q] the index of that
+ *                            occurrence's triplet in its batch (= occt)
  *   workspace                (batch_size > 8192 only, else NULL) tkr_plan_workspace_bytes(batch_size, n_batches) bytes of device
  *                            scratch: such batches are planned grid-wide (device radix sort of batch|row|occurrence keys, scans)
  *                            instead of one workgroup per batch -- single/bpr.py:103-113 accepts any batch_size
@@ -167,17 +168,22 @@ int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, const int32_
  * in the same state as K2f does: the two kernels, the exchange and get / set may be mixed freely between launches.  Item row r is
  * served by workgroup r % n_owner, which keeps the row, its slot, bias and acknowledge totals in LDS from the row's first update
  * in a launch on: the task of batch t+1 finds the row of batch t there instead of polling memory for it (what bounded K2f at
- * batch 256).  User tasks are handed out by tickets as in K2f.
+ * batch 256), and the two item tasks of a triplet exchange the scalars <u, v> + b through an 8-byte slot instead of reading each
+ * other's rows (csrc/bpr_own.hip has the protocol).  User tasks are handed out by tickets as in K2f.
  *   tkr_bpr_own_owners(n_items, k)   n_owner for the current device (its CU count), or 0 when ceil(n_items / CUs) rows of
  *                                    8*kp + 16 bytes do not fit one CU's 160 KB of LDS (use K2f then)
  *   tkr_sample_plan_owned            tkr_sample_plan's dataflow form (prec, pocc; batch_size <= 1024) with the records of every
  *                                    batch's ITEM tasks in (row % n_owner, row) order -- same slots -- and
  *                                    ohdr[owner * ohdr_stride + batch] = first slot | tasks << 16 (ohdr_stride >= n_batches).
- *                                    K2f runs such a plan unchanged (the order of tasks inside a batch means nothing to it).
+ *                                    (K2f runs such a plan too: the order of tasks inside a batch means nothing to it.)
  *   tkr_bpr_own_run                  batches [first_batch, first_batch + n_batches) of such a plan in ONE launch of n_owner
- *                                    workgroups (all resident: n_owner <= CUs).  prec / pocc / ohdr / loss_out point at batch 0 of
- *                                    the plan call; owner_waves: waves per workgroup that serve the owner queue, 0 = default
- *                                    (5 of 8 at k <= 128, 3 of 4 above); ctl as for tkr_bpr_flow_run (same words, same status).
+ *                                    workgroups (all resident: n_owner <= CUs).  prec / pocc / occt / ohdr / loss_out point at
+ *                                    batch 0 of the plan call; owner_waves: waves per workgroup that serve the owner queue, 0 =
+ *                                    default (9 of 16 at k <= 128, 4 of 8 above; one more wave is the scout, the rest run user
+ *                                    tasks); ctl as for tkr_bpr_flow_run (same words, same status).
+ *                                    xch: 16 * batch_size bytes per batch of the plan (the scalar slots {value, epoch} of every
+ *                                    (triplet, role)), caller-owned, zeroed once; epoch: a number > 0 that no earlier launch on
+ *                                    this xch used (a counter per plan buffer does).
  * k <= 256, n_batches <= 512. */
 int32_t tkr_bpr_own_owners(int32_t n_items, int32_t k);
 int tkr_sample_plan_owned(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,
@@ -186,9 +192,9 @@ int tkr_sample_plan_owned(const int32_t* tr_users, int32_t n_tr, const int32_t* 
                           uint32_t* touch_i, int32_t* out_u, int32_t* out_i, int32_t* out_j, int32_t* task, int32_t* occ,
                           int32_t* occt, int32_t* prec, int32_t* pocc, int32_t n_owner, int32_t* ohdr, int32_t ohdr_stride,
                           void* stream);
-int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, const int32_t* ohdr, int32_t ohdr_stride,
-                    int32_t n_owner, int32_t batch_size, int32_t first_batch, int32_t n_batches, uint32_t* ctl, float* loss_out,
-                    int32_t owner_waves, void* stream);
+int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, const int32_t* occt, const int32_t* ohdr,
+                    int32_t ohdr_stride, int32_t n_owner, int32_t batch_size, int32_t first_batch, int32_t n_batches, uint32_t* ctl, float* loss_out,
+                    int32_t owner_waves, void* xch, uint32_t epoch, void* stream);
 
 /* ---- K3: VBPR mini-batch step -------------------------------------------------------------
  * Replaces sess.run([solver, obj]) of single/vbpr.py:114 on the graph of single/vbpr.py:50-73 and the

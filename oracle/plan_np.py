@@ -235,7 +235,7 @@ def resolve_parity(task, occ, B, ucnt, icnt):
     icnt[rows[is_item]] += 1
 
 
-def flow_records(task, occ, B, ucnt, icnt, batch, last_u=None, last_i=None, n_owner=0):
+def flow_records(task, occ, B, ucnt, icnt, batch, last_u=None, last_i=None, n_owner=0, occt=None):
     """Dataflow form of one batch's plan (tkr_sample_plan with prec / pocc; consumed by the persistent step kernels,
     csrc/bpr_flow.hip and csrc/bpr_own.hip).  `task`, `occ` are plan_batch's output BEFORE resolve_parity; ucnt / icnt the
     update counters before this batch = the VERSION of every row this batch reads; last_u / last_i (optional, updated in
@@ -245,7 +245,9 @@ def flow_records(task, occ, B, ucnt, icnt, batch, last_u=None, last_i=None, n_ow
                    [4] batch [5] last batch < [4] of this call that updated the row (-1: none)
                    [8+4q..11+4q] pocc of occurrence q < min(4, occurrences); everything else 0
     n_owner > 0 (tkr_sample_plan_owned, K2o): the records of the batch's ITEM tasks sit in (row % n_owner, row) order instead of
-    row order (same slots), and ohdr[n_owner] = first slot | tasks << 16 of every owner's run is returned as a third value."""
+    row order (same slots) and ohdr[n_owner] = first slot | tasks << 16 of every owner's run is returned as a third value.
+    occt (the triplet index of every sorted occurrence): prec[24+q] = triplet of occurrence q < min(4, occurrences) -- K2o's item
+    tasks exchange the scalars <u, v> + b of a triplet through a slot named by it."""
     pocc = np.zeros((3 * B, 4), dtype=np.int32)
     pocc[:B, 0] = occ[:B, 0]
     pocc[:B, 1] = icnt[occ[:B, 0]]
@@ -285,6 +287,8 @@ def flow_records(task, occ, B, ucnt, icnt, batch, last_u=None, last_i=None, n_ow
             last[row] = batch
         inl = min(int(cnt_), 4)
         r[8:8 + 4 * inl] = pocc[start_:start_ + inl].reshape(-1)
+        if occt is not None:
+            r[24:24 + inl] = occt[start_:start_ + inl]
     return (pocc, prec) if n_owner <= 0 else (pocc, prec, ohdr)
 
 
@@ -362,9 +366,9 @@ def sample_and_plan(tr_users, row_ptr, pos_cols, cols_sorted, n_items, seed, fir
         tpars[b] = triplet_parity(u[sl], i[sl], j[sl], ucnt, icnt)
         raw_tasks[b], raw_occs[b] = tasks[b], occs[b]
         if n_owner > 0:
-            poccs[b], precs[b], ohdrs[:, b] = flow_records(tasks[b], occs[b], B, ucnt, icnt, b, last_u, last_i, n_owner)
+            poccs[b], precs[b], ohdrs[:, b] = flow_records(tasks[b], occs[b], B, ucnt, icnt, b, last_u, last_i, n_owner, occts[b])
         else:
-            poccs[b], precs[b] = flow_records(tasks[b], occs[b], B, ucnt, icnt, b, last_u, last_i)
+            poccs[b], precs[b] = flow_records(tasks[b], occs[b], B, ucnt, icnt, b, last_u, last_i, occt=occts[b])
         resolve_parity(tasks[b], occs[b], B, ucnt, icnt)
         recs[b], hdrs[b] = launch_plan(tasks[b], occs[b], B, occts[b])
     sample_and_plan.last_tpars = tpars            # per-triplet parities of the last call (kept off the return tuple)

@@ -1,55 +1,61 @@
-// K2o -- the persistent BPR step with OWNED item rows (round 4): the same arithmetic, tables, versions and acknowledge protocol as
-// K2f (csrc/bpr_flow.hip; sess.run([solver, obj]) of single/bpr.py:141 inside the loop of single/bpr.py:139-147, batch t+1 reads
-// what batch t wrote), but the chain that set K2f's pace is taken out of memory.
+// K2o -- the persistent BPR step with OWNED item rows (round 4): the tables, versions and acknowledge protocol of K2f
+// (csrc/bpr_flow.hip; sess.run([solver, obj]) of single/bpr.py:141 inside the loop of single/bpr.py:139-147, batch t+1 reads what
+// batch t wrote), with the two dependencies that set K2f's pace taken out of memory.
 //
-// What bounded K2f at batch 256: a popular item is updated in (nearly) every batch, and the task of batch t+1 can only start its
-// arithmetic once the row written by the task of batch t has made the trip write-through store -> memory -> polling load of another
-// CU: 1.65-1.9 us per link against 1.5 us per batch of task throughput.  Here every item row r has an OWNER: the
-// workgroup with arrival number r % n_owner (one workgroup per CU, all resident).  K1 lays the item tasks of a batch out in
-// (owner, row) order and names every owner's run (tkr_sample_plan_owned: `ohdr`), so
-//   * the owner's waves take the item tasks of their rows in plan order from a queue in LDS (one LDS atomic per task instead of a
-//     device-wide ticket),
-//   * the row, its RMSProp slot, bias and acknowledge totals live in the owner's LDS from their first update of a launch on:
-//     the task of batch t+1 finds what the task of batch t left there ~0.1 us after it was computed -- BEFORE the acknowledge wait and
-//     the write-through stores of batch t, which now only serve the row's PARTNERS (user tasks and the other item of a triplet read
-//     the granule tables exactly as in K2f),
-//   * user tasks are handed out by tickets as before, to the remaining waves of every workgroup.
-// The granule tables are written through at every update exactly as by K2f, so a launch leaves them complete: both kernels, the
-// exchange (csrc/sync.hip) and get / set work on the same state, and a chunk may be cut into launches anywhere (a task whose row
-// was not yet updated in THIS launch -- prec[5] < first batch of the launch -- loads it from the tables like K2f does).
+// (1) The own-row chain.  A popular item is updated in (nearly) every batch; under K2f the task of batch t+1 starts its arithmetic
+//     once the row written by the task of batch t has made the trip write-through store -> memory -> polling load of another CU.  Here
+//     every item row r has an OWNER: the workgroup with arrival number r % n_owner (one workgroup per CU, all resident).  K1 lays
+//     the item tasks of a batch out in (owner, row) order and names every owner's run (tkr_sample_plan_owned: `ohdr`); the owner's
+//     waves take them in plan order from a queue in LDS, and the row, its RMSProp slot, bias and acknowledge totals stay in the
+//     owner's LDS from the row's first update of a launch on: the task of batch t+1 finds what the task of batch t left there --
+//     before that task's acknowledge wait and write-through stores, which now only serve the USER tasks.
+// (2) The item -> item edges.  x_uij = (<u, v_i> + b_i) - (<u, v_j> + b_j) (single/bpr.py:87-89): the task of item i needs the
+//     other item of a triplet only through the scalar <u, v_j> + b_j, which the task of item j computes anyway.  Under K2f (and
+//     the first form of this kernel) it read the whole row v_j at its exact version, through memory -- with the own-row chain in
+//     LDS those edges were the critical path of a batch (measured: 4.6 us of an item task's 8 us waiting for partner rows).  Here
+//     the two item tasks of a triplet never read each other's rows: each publishes d = <u, v_own> + b_own as ONE 8-byte granule
+//     {d, epoch} in the slot of (batch, triplet, role) and polls the partner's slot.  A scalar depends only on its own row's
+//     previous update and the user row, so it can be published EARLY: one wave of every workgroup (the "scout") runs ahead of
+//     the queue's head and publishes the scalars of every task whose rows are final, without waiting for anything.  The chain
+//     through a popular item is then: row from LDS -> dots -> partner scalars (already there) -> update -> row to LDS.  Half the
+//     partner traffic as well: only the user rows are read (one acknowledged reader per occurrence of an item row: the user task).
 //
-// Progress: every producer of a task sits in an earlier batch.  An owner queue is taken in plan order by its own waves only (at
-// least one per workgroup serves nothing else), tickets in plan order by the ticket waves; a wave holds at most its current and its
-// next task.  The lowest unfinished task is therefore always held by a wave, or next in line for one that holds only lower tasks,
-// and waits on nothing unfinished.  Needs every workgroup resident (grid = n_owner <= CUs x workgroups per CU); every spin is bounded.
+// User tasks are handed out by tickets as in K2f, to the remaining waves of every workgroup.  The granule tables are written
+// through at every update exactly as by K2f, so a launch leaves them complete (get / set, the exchange of csrc/sync.hip, a K2f
+// launch on a plan of its own all work on the same state), and a chunk may be cut into launches anywhere: a task whose row was
+// not yet updated in THIS launch (prec[5] < first batch of the launch) loads it from the tables like K2f does.
+//
+// Progress.  Producers of a task sit in earlier batches, except the partner scalars of the SAME batch.  Owner queues are taken
+// in plan order by their own waves, tickets in plan order by the ticket waves, one task per wave at a time; the scout never
+// waits.  Take the oldest batch with an unfinished task: all rows its tasks read are final (their writers sit in earlier
+// batches, which are done), so the scouts -- which scan from their queue's head on and skip only what is not final yet -- publish
+// every scalar of that batch that a taken task has not published itself; the tasks of that batch that hold a wave then finish,
+// the heads move.  Needs every workgroup resident (grid = n_owner <= CUs); every spin is bounded (status word).
+//
+// Results are bitwise reproducible run to run and whatever publishes a scalar first (scout and task run the same code on the same
+// versions); against K2f the sums differ in the last bits (x is the difference of two rounded dots): same tolerance to the oracle.
 #include "flow_task.h"
 
 namespace tkr {
 
 constexpr uint32_t kOwnInvalid = 0xffffffffu;
+constexpr int kDotWin = 1024;            // ring of "scalars of queue position p are out" marks (power of two)
+constexpr int kScoutAhead = 48;          // queue positions beyond the head the scout looks at
 
 struct OwnQueue {                        // head of the workgroup's LDS block
     uint32_t head;                       // next position of the owner queue
     uint32_t total;                      // item tasks of this owner in the launch
     uint32_t arrival;
-    uint32_t pad;
+    uint32_t head_batch;                 // a batch <= the batch of position `head` (where a scan may start)
 };
 
 // the owner queue: position -> (batch, slot) through the prefix sums of the per-batch run lengths
-struct OwnerSrc {
-    OwnQueue* q;
+struct QueueMap {
     const uint32_t* pre;                 // [nb + 1 + 64]: pre[0] = 0, pre[b + 1] = tasks up to and including batch b; padding 0xffffffff
     const uint32_t* start;               // [nb]: first slot of the owner's run in batch b
-    const int4* __restrict__ prec;       // record 0 of the launch's first batch
     uint32_t slots_per_batch;            // 3B
-    uint32_t cur;                        // batch of the last task taken (positions only grow)
-    __device__ __forceinline__ void prefetch(NextTask& nx, int lane) {
-        uint32_t pos = 0;
-        if (lane == 0) pos = atomicAdd(&q->head, 1u);
-        pos = (uint32_t)bcast_i((int)pos, 0);
-        nx.have = true;
-        nx.w = make_int4(0, 0, 0, 0);
-        if (pos >= q->total) { nx.idx = 0xffffffffu; return; }
+    // record index of position pos (counted from the launch's first batch); cur: a batch <= the position's, moved to it
+    __device__ __forceinline__ uint32_t locate(uint32_t pos, uint32_t& cur, int lane) const {
         uint32_t before;
         for (;;) {
             const uint32_t v = pre[cur + 1 + lane];
@@ -62,8 +68,7 @@ struct OwnerSrc {
             }
             cur += TKR_WAVE;
         }
-        nx.idx = cur * slots_per_batch + start[cur] + (pos - before);
-        if (lane < 8) nx.w = prec[(size_t)nx.idx * 8 + lane];
+        return cur * slots_per_batch + start[cur] + (pos - before);
     }
 };
 
@@ -85,60 +90,246 @@ struct UserTicketSrc {
     }
 };
 
-// the own row of an item task: from the owner's LDS when an earlier task of this launch left it there, else from the tables
+// ---- the own row of an item task ------------------------------------------------------------------------------------------------
+// LDS layout of a resident row: [kp] values, [kp] slots, {bias, its slot, expect[0..3], -, -}
 template <int NP>
-struct LdsOwn {
-    const FlowTables& T;
-    int lane;
-    const u64 *own_p, *own_ms, *own_tail;
+__device__ __forceinline__ void lds_row_read(const float* row, int lane, bool sgd, float (&own)[2 * NP], float (&ms)[2 * NP], Own& o) {
+    constexpr int KP = NP * 128;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const float2 a = *reinterpret_cast<const float2*>(row + q * 128 + 2 * lane);
+        own[2 * q] = a.x; own[2 * q + 1] = a.y;
+        if (!sgd) {
+            const float2 m = *reinterpret_cast<const float2*>(row + KP + q * 128 + 2 * lane);
+            ms[2 * q] = m.x; ms[2 * q + 1] = m.y;
+        }
+    }
+    const float4 t = *reinterpret_cast<const float4*>(row + 2 * KP);
+    const float2 t2 = *reinterpret_cast<const float2*>(row + 2 * KP + 4);
+    o.b = t.x; o.msb = t.y;
+    o.exp[0] = __float_as_uint(t.z); o.exp[1] = __float_as_uint(t.w);
+    o.exp[2] = __float_as_uint(t2.x); o.exp[3] = __float_as_uint(t2.y);
+}
+
+struct ItemRow {                         // where the own row of an item task is
+    const u64 *own_p, *own_ms, *own_tail;     // the tables, at the version read
     const uint32_t* own_rd;
     uint32_t ver;
-    bool sgd;
-    uint32_t* ctl;
-    uint32_t& spins;
-    bool from_lds;
+    bool from_lds;                       // an earlier task of this launch updated the row: it is (or will be) in LDS
     const volatile uint32_t* tag;        // the row's version word in LDS
-    const float* row;                    // [kp] values, [kp] slots, {bias, its slot, expect[0..3], -, -}
-    int own_halves;
-    __device__ __forceinline__ bool operator()(float (&own)[2 * NP], float (&ms)[2 * NP], Own& o) {
-#ifdef TKR_OWN_PROF
-        o.t_own0 = __builtin_amdgcn_s_memtime();
-#endif
-        if (from_lds) {
-            uint32_t waited = 0;
-            while (*tag != ver) {
-                if (spin_fail(waited, ctl, 0)) {
-                    if (waited >= kSpinLimit && lane == 0 && atomicCAS(ctl + kCtlDebug, 0u, 4u) == 0u) {
-                        ctl[kCtlDebug + 1] = *tag; ctl[kCtlDebug + 3] = ver;
-                    }
-                    return false;
-                }
-            }
-            spins += waited;
-            asm volatile("" ::: "memory");                  // the row is read AFTER its tag
-            constexpr int KP = NP * 128;
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                const float2 a = *reinterpret_cast<const float2*>(row + q * 128 + 2 * lane);
-                own[2 * q] = a.x; own[2 * q + 1] = a.y;
-                if (!sgd) {
-                    const float2 m = *reinterpret_cast<const float2*>(row + KP + q * 128 + 2 * lane);
-                    ms[2 * q] = m.x; ms[2 * q + 1] = m.y;
-                }
-            }
-            const float4 t = *reinterpret_cast<const float4*>(row + 2 * KP);
-            const float2 t2 = *reinterpret_cast<const float2*>(row + 2 * KP + 4);
-            o.b = t.x; o.msb = t.y;
-            o.exp[0] = __float_as_uint(t.z); o.exp[1] = __float_as_uint(t.w);
-            o.exp[2] = __float_as_uint(t2.x); o.exp[3] = __float_as_uint(t2.y);
-        }
-        const bool ok = flow_own<NP>(T, lane, own_p, own_ms, own_tail, own_rd, ver, own, ms, o, sgd, ctl, spins, own_halves);     // o.ok: only the acknowledge word is loaded
-#ifdef TKR_OWN_PROF
-        o.t_own1 = __builtin_amdgcn_s_memtime();
-#endif
-        return ok;
-    }
+    const float* row;                    // the row's slot in LDS
+    int halves;                          // 16-byte halves of a tail in the tables
 };
+
+// the task's way: wait for the row (LDS: the task before it in the chain; tables: only at a launch's first touch), then the acknowledge word
+template <int NP>
+__device__ __forceinline__ bool item_own_wait(const FlowTables& T, int lane, const ItemRow& r, bool sgd, float (&own)[2 * NP], float (&ms)[2 * NP],
+                                              Own& o, uint32_t* ctl, uint32_t& spins) {
+    if (r.from_lds) {
+        uint32_t waited = 0;
+        while (*r.tag != r.ver) {
+            if (spin_fail(waited, ctl, 0)) {
+                if (waited >= kSpinLimit && lane == 0 && atomicCAS(ctl + kCtlDebug, 0u, 4u) == 0u) {
+                    ctl[kCtlDebug + 1] = *r.tag; ctl[kCtlDebug + 3] = r.ver;
+                }
+                return false;
+            }
+        }
+        spins += waited;
+        asm volatile("" ::: "memory");                  // the row is read AFTER its tag
+        lds_row_read<NP>(r.row, lane, sgd, own, ms, o);
+        o.ok = true;
+    }
+    return flow_own<NP>(T, lane, r.own_p, r.own_ms, r.own_tail, r.own_rd, r.ver, own, ms, o, sgd, ctl, spins, r.halves);   // o.ok: only rd is loaded
+}
+
+// the scout's way: the row if it is final NOW (values and bias only), else false
+template <int NP>
+__device__ __forceinline__ bool item_own_peek(int lane, const ItemRow& r, float (&own)[2 * NP], Own& o) {
+    if (r.from_lds) {
+        if (*r.tag != r.ver) return false;
+        asm volatile("" ::: "memory");
+        float ms[2 * NP];
+        lds_row_read<NP>(r.row, lane, true, own, ms, o);
+        return true;
+    }
+    v4u xo[NP];
+    issue_row<NP>(r.own_p, lane, xo);
+    const v2u xb = issue_bias(r.own_tail);
+    if (!__all(row_tagged<NP>(xo, r.ver) && xb.y == r.ver)) return false;
+    row_values<NP>(xo, own);
+    o.b = bcast_f(__uint_as_float(xb.x), 0);
+    return true;
+}
+
+// ---- a round of up to G occurrences of an item task -----------------------------------------------------------------------------
+// Lane q < n of `d` holds occurrence q = (user, version of the user row, other | role<<31, version of the other item [unused]);
+// `tq` its triplet's index in the batch.  MODE kFull: the task's round.  kScout: one pass, nothing acknowledged, nothing waited
+// for, scalars only; false = not final yet.  kAnnounce: the user rows are waited for, the scalars published, nothing else (a task
+// of several rounds announces ALL its scalars before it waits for any partner's: two such tasks would otherwise wait for each
+// other's later rounds).
+constexpr int kFull = 0, kScout = 1, kAnnounce = 2;
+template <int G>
+constexpr int own_shift() { return G <= 4 ? 4 : 3; }      // lane L speaks for occurrence L >> shift
+
+template <int NP, int G, int MODE>
+__device__ __forceinline__ bool item_round(const tkr_flow_state& st, const FlowTables& T, int lane, int n, const int4 d, int tq, bool first_round,
+                                           const ItemRow& r, bool sgd, u64* xch_batch, int xch_bytes, uint32_t epoch, float (&own)[2 * NP],
+                                           float (&ms)[2 * NP], Own& o, float (&g)[2 * NP], float& gb, float& lam_sum, uint32_t* ctl,
+                                           uint32_t& spins, uint32_t tune) {
+    constexpr int SH = own_shift<G>();
+    static_assert(G == 4 || G == 8, "occurrences per round");
+    v4u xa[G][NP];
+    uint32_t waited = 0;
+    for (;;) {                                    // one pass ISSUES every user row of the round and only then looks at tags
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const int src = (q < n) ? q : 0;      // straight-line loads: idle slots repeat occurrence 0 (flow_fetch has the reason)
+            const int a = bcast_i(d.x, src);
+            const uint32_t va = (uint32_t)bcast_i(d.y, src);
+            issue_row<NP>(T.U + (va & 1u) * T.ustride + (size_t)a * T.kp, lane, xa[q]);
+        }
+        bool lane_ok = true, far = false;
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const int src = (q < n) ? q : 0;
+            const uint32_t va = (uint32_t)bcast_i(d.y, src);
+            lane_ok = lane_ok && row_tagged<NP>(xa[q], va);
+            far = far || (int)(va - (uint32_t)bcast_i((int)xa[q][0].y, 0)) >= 4;
+        }
+        if (__all(lane_ok)) break;
+        if constexpr (MODE == kScout) return false;
+        if (far) __builtin_amdgcn_s_sleep(127);
+        if (spin_fail(waited, ctl, 4)) {
+            if (waited >= kSpinLimit && lane == 0 && atomicCAS(ctl + kCtlDebug, 0u, 5u) == 0u) {
+                ctl[kCtlDebug + 1] = (uint32_t)d.x; ctl[kCtlDebug + 2] = (uint32_t)d.y; ctl[kCtlDebug + 3] = xa[0][0].y; ctl[kCtlDebug + 4] = (uint32_t)n;
+            }
+            return false;
+        }
+    }
+    spins += waited;
+    if constexpr (MODE == kScout) {
+        if (first_round && !item_own_peek<NP>(lane, r, own, o)) return false;
+    } else if constexpr (MODE == kFull) {
+        if (lane < n) __hip_atomic_fetch_add(T.rdU + 2 * (size_t)d.x + (d.y & 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (first_round && !item_own_wait<NP>(T, lane, r, sgd, own, ms, o, ctl, spins)) return false;
+    }
+
+    // d_q = <u_q, v_own> + b_own, all reduced together; lane L holds occurrence L >> SH
+    float part[G];
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            acc = fmaf(__uint_as_float(xa[q][c].x), own[2 * c], acc);
+            acc = fmaf(__uint_as_float(xa[q][c].z), own[2 * c + 1], acc);
+        }
+        part[q] = q < n ? acc : 0.f;
+    }
+    const float dme = reduce_multi<G>(part, lane) + o.b;
+    // publish mine, poll the partner's: the first lane of every group, for the occurrence it speaks for
+    const int myq = lane >> SH;
+    const bool live = (lane & ((1 << SH) - 1)) == 0 && myq < n;
+    const bool role = __shfl(d.z, myq) < 0;                        // this row is the NEGATIVE item of the triplet
+    const int slot = (2 * __shfl(tq, myq) + (role ? 1 : 0)) * 8;   // bytes: granule (triplet, role)
+    const __amdgpu_buffer_rsrc_t xr = row_rsrc(xch_batch, xch_bytes);
+    if (live) {
+        v2u pv;
+        pv.x = __float_as_uint(dme); pv.y = epoch;
+        __builtin_amdgcn_raw_buffer_store_b64(pv, xr, slot, 0, kAuxStore);
+    }
+    if constexpr (MODE != kFull) return true;
+    float dother = 0.f;
+    waited = 0;
+    for (;;) {
+        v2u pv;
+        pv.x = 0u; pv.y = epoch;
+        if (live) pv = __builtin_amdgcn_raw_buffer_load_b64(xr, slot ^ 8, 0, kAuxLoad);
+#ifdef TKR_OWN_PROF
+        if (tune & 4u) pv.y = epoch;              // timing experiment only (wrong results): the partner's scalar is never waited for
+#endif
+        dother = __uint_as_float(pv.x);
+        if (__all(pv.y == epoch)) break;
+        if (spin_fail(waited, ctl, 1)) {
+            if (waited >= kSpinLimit && lane == 0 && atomicCAS(ctl + kCtlDebug, 0u, 6u) == 0u) {
+                ctl[kCtlDebug + 1] = (uint32_t)d.x; ctl[kCtlDebug + 2] = (uint32_t)d.z; ctl[kCtlDebug + 3] = (uint32_t)tq; ctl[kCtlDebug + 4] = epoch;
+            }
+            return false;
+        }
+    }
+    spins += waited;
+    const float x = role ? dother - dme : dme - dother;            // x_uij = x_ui - x_uj
+    const float sme = fast_sigmoid_neg(x);
+    const u64 roles = __ballot(lane < n && d.z < 0);
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        if (q < n) {
+            const float sq = bcast_f(sme, q << SH);
+            const bool rj = (roles >> q) & 1ull;
+            const float sg = rj ? sq : -sq;
+            gb += sg;
+            lam_sum += rj ? st.lj : st.li;
+#pragma unroll
+            for (int c = 0; c < NP; ++c) {
+                g[2 * c] = fmaf(sg, __uint_as_float(xa[q][c].x), g[2 * c]);
+                g[2 * c + 1] = fmaf(sg, __uint_as_float(xa[q][c].z), g[2 * c + 1]);
+            }
+        }
+    }
+    return true;
+}
+
+// all the occurrences of an item task: up to four sit in the record (their triplet indices in its words 24..27), more come from
+// pocc / occt in rounds of eight.  SCOUT: scalars only; false = some row is not final yet (nothing is lost: the task publishes them too)
+template <int NP, bool SCOUT>
+__device__ __forceinline__ bool item_task(const tkr_flow_state& st, const FlowTables& T, int lane, int n_occ, int first, const int4 w,
+                                          const int4* __restrict__ pocc, const int32_t* __restrict__ occt, const ItemRow& r, bool sgd,
+                                          u64* xch_batch, int xch_bytes, uint32_t epoch, float (&own)[2 * NP], float (&ms)[2 * NP], Own& o,
+                                          float (&g)[2 * NP], float& gb, uint32_t* ctl, uint32_t& spins, uint32_t tune) {
+    constexpr int NE = 2 * NP;
+    constexpr int M = SCOUT ? kScout : kFull;
+    float lam_sum = 0.f;
+    if (n_occ <= 4) {                             // the common case: its occurrences sit in the record (lanes 2..5), their triplets in lane 6
+        const int src = (lane + 2) & 7;
+        const int4 d = make_int4(__shfl(w.x, src), __shfl(w.y, src), __shfl(w.z, src), __shfl(w.w, src));
+        const int t0 = bcast_i(w.x, 6), t1 = bcast_i(w.y, 6), t2 = bcast_i(w.z, 6), t3 = bcast_i(w.w, 6);
+        const int tq = lane == 0 ? t0 : lane == 1 ? t1 : lane == 2 ? t2 : t3;
+        if (!item_round<NP, 4, M>(st, T, lane, n_occ, d, tq, true, r, sgd, xch_batch, xch_bytes, epoch, own, ms, o, g, gb, lam_sum, ctl, spins, tune))
+            return false;
+    } else {
+        if constexpr (!SCOUT) {
+            if (n_occ > 8) {                      // several rounds: the own row first, then every round's scalars, and only then the waiting
+                if (!item_own_wait<NP>(T, lane, r, sgd, own, ms, o, ctl, spins)) return false;
+                for (int done = 0; done < n_occ; done += 8) {
+                    const int n = min(8, n_occ - done);
+                    int4 d = make_int4(0, 0, 0, 0);
+                    int tq = 0;
+                    if (lane < n) { d = pocc[first + done + lane]; tq = occt[first + done + lane]; }
+                    if (!item_round<NP, 8, kAnnounce>(st, T, lane, n, d, tq, false, r, sgd, xch_batch, xch_bytes, epoch, own, ms, o, g, gb, lam_sum, ctl,
+                                                      spins, tune))
+                        return false;
+                }
+            }
+        }
+        for (int done = 0; done < n_occ; done += 8) {
+            const int n = min(8, n_occ - done);
+            int4 d = make_int4(0, 0, 0, 0);
+            int tq = 0;
+            if (lane < n) { d = pocc[first + done + lane]; tq = occt[first + done + lane]; }
+            if (!item_round<NP, 8, M>(st, T, lane, n, d, tq, done == 0 && (SCOUT || n_occ <= 8), r, sgd, xch_batch, xch_bytes, epoch, own, ms, o, g, gb,
+                                      lam_sum, ctl, spins, tune))
+                return false;
+        }
+    }
+    if constexpr (!SCOUT) {
+        const bool l2 = (st.mode == 0);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) g[e] = fmaf(lam_sum, l2 ? own[e] : sgn(own[e]), g[e]);
+        gb = fmaf((float)n_occ * st.lb, l2 ? o.b : sgn(o.b), gb);
+    }
+    return true;
+}
 
 // the new row from the old one and the gradient (TF SparseApplyRMSProp, momentum 0: single/bpr.py:100; or old/methods/bpr.py:57-61)
 template <int NP>
@@ -162,18 +353,15 @@ __device__ __forceinline__ void own_update(const tkr_flow_state& st, bool sgd, c
     }
 }
 
-// version ver+1 lands on the buffer that held ver-1: wait until every reader of ver-1 has acknowledged, then write through
+// version ver+1 lands on the buffer that held ver-1 (ver-3 with four buffers): wait until every reader of that version has
+// acknowledged, then write through
 template <int NP>
 __device__ __forceinline__ bool own_publish(int lane, bool is_item, uint32_t bmask, bool sgd, u64* tabP, u64* tabM, u64* tabT, size_t woff,
                                             size_t n_rows, int row, int rowk, uint32_t ver, int n_occ, Own& o, const uint32_t* own_rd,
-                                            const float (&pn)[2 * NP],
-                                            const float (&mn)[2 * NP], float bn, float mbn, uint32_t* ctl, uint32_t& spins, NextTask& nx,
-                                            bool skip_ack = false) {
+                                            const float (&pn)[2 * NP], const float (&mn)[2 * NP], float bn, float mbn, uint32_t* ctl,
+                                            uint32_t& spins) {
     const uint32_t nv = ver + 1u;
     const uint32_t expect = pick_exp(o, (ver + 1u) & bmask);            // readers of the version that buffer holds now
-#ifdef TKR_OWN_PROF
-    if (skip_ack) o.rd = expect;                // timing experiment only (unsafe): no acknowledge wait
-#endif
     uint32_t waited = 0;
     while ((int32_t)(o.rd - expect) < 0) {
         if (spin_fail(waited, ctl)) {
@@ -188,20 +376,20 @@ __device__ __forceinline__ bool own_publish(int lane, bool is_item, uint32_t bma
 #ifdef TKR_OWN_PROF
     o.t_ack = __builtin_amdgcn_s_memtime();
 #endif
-    asm volatile("" : "+v"(nx.w.x), "+v"(nx.w.y), "+v"(nx.w.z), "+v"(nx.w.w));      // the next record is consumed before the stores go out
     store_row<NP>(tabP + woff, lane, pn, nv);
     if (!sgd) store_row<NP>(tabM + woff, lane, mn, nv);
-    store_tail(tabT, n_rows, row, bmask, lane, is_item, bn, mbn, o, ver, n_occ);
+    store_tail(tabT, n_rows, row, bmask, lane, is_item, bn, mbn, o, ver, n_occ, is_item ? 1u : 2u);      // an item row's readers: the user tasks only
     return true;
 }
 
-constexpr int own_min_waves(int np, int tpb) { return tpb >= 512 ? 2 : (np == 1 ? 2 : 1); }      // per SIMD: <= 256 registers at 8 waves per CU
+constexpr int own_min_waves(int np, int tpb) { return tpb / 256; }      // per SIMD: 16 waves per CU at <= 128 registers (k <= 128), 8 at <= 256
 
 template <int NP, int TPB>
 __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     tkr_flow_state st, const int4* __restrict__ prec /*record 0 of the first batch to run*/, const int4* __restrict__ pocc,
-    const int32_t* __restrict__ ohdr /*[n_owner][ohdr_stride], at the first batch to run*/, int ohdr_stride, int first_batch, int nb,
-    int B, int n_owner, int owner_waves, uint32_t tune, uint32_t* __restrict__ ctl, float* __restrict__ loss_out) {
+    const int32_t* __restrict__ occt, const int32_t* __restrict__ ohdr /*[n_owner][ohdr_stride], at the first batch to run*/, int ohdr_stride,
+    int first_batch, int nb, int B, int n_owner, int owner_waves, uint32_t tune, uint32_t* __restrict__ ctl, float* __restrict__ loss_out,
+    u64* __restrict__ xch /*scalar slots [batches of the plan][B][2], at batch 0 of the plan*/, uint32_t epoch) {
     constexpr int NE = 2 * NP;
     constexpr int KP = NP * 128;
     constexpr int ROWF = 2 * KP + 8;                                  // floats per resident row
@@ -219,14 +407,15 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     const bool sgd = st.opt == 1;
     const bool want_loss = loss_out != nullptr;
 
-    // ---- the workgroup's LDS: queue head | prefix sums | run starts | row tags | rows
+    // ---- the workgroup's LDS: queue head | prefix sums | run starts | row tags | scout marks | rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     OwnQueue* q = reinterpret_cast<OwnQueue*>(smem);
     uint32_t* pre = reinterpret_cast<uint32_t*>(smem + sizeof(OwnQueue));           // [nb + 1 + 64]
     uint32_t* start = pre + nb + 1 + TKR_WAVE;                                         // [nb]
     const int rows_here = (st.n_items + n_owner - 1) / n_owner;
     uint32_t* tags = start + nb;                                                       // [rows_here]
-    float* rows = reinterpret_cast<float*>(smem + ((sizeof(OwnQueue) + (size_t)4 * (2 * nb + 1 + TKR_WAVE + rows_here) + 15) & ~(size_t)15));
+    uint32_t* dotmark = tags + rows_here;                                              // [kDotWin]: position + 1 of the task whose scalars are out
+    float* rows = reinterpret_cast<float*>(smem + ((sizeof(OwnQueue) + (size_t)4 * (2 * nb + 1 + TKR_WAVE + rows_here + kDotWin) + 15) & ~(size_t)15));
 
     if (threadIdx.x == 0) q->arrival = __hip_atomic_fetch_add(ctl + kCtlArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -238,6 +427,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     }
     for (int b = threadIdx.x; b < TKR_WAVE; b += TPB) pre[nb + 1 + b] = 0xffffffffu;
     for (int s = threadIdx.x; s < rows_here; s += TPB) tags[s] = kOwnInvalid;
+    for (int s = threadIdx.x; s < kDotWin; s += TPB) dotmark[s] = 0u;
     __syncthreads();
     if (wave == 0) {                                                                   // inclusive scan of the run lengths (nb <= 512)
         const int per = (nb + TKR_WAVE - 1) / TKR_WAVE;
@@ -252,7 +442,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
         }
         uint32_t run = incl - mine;
         for (int b = b0; b < b1; ++b) { run += pre[b + 1]; pre[b + 1] = run; }
-        if (lane == TKR_WAVE - 1) { q->total = incl; q->head = 0u; }
+        if (lane == TKR_WAVE - 1) { q->total = incl; q->head = 0u; q->head_batch = 0u; }
         if (lane == 0) pre[0] = 0u;
     }
     __syncthreads();
@@ -263,48 +453,101 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     u64 prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     u64 tprev = __builtin_amdgcn_s_memtime();
 #endif
-    NextTask nx;
-    nx.idx = 0u; nx.w = make_int4(0, 0, 0, 0); nx.have = false;
+    const QueueMap qm{pre, start, 3u * (uint32_t)B};
+    const int xch_bytes = B * 16;
+    const uint32_t q_total = q->total;
 
-    if (wave < owner_waves) {
+    // the own row of the item task whose record is w
+    auto item_row = [&](const int4 w, ItemRow& r, int& row, int& slot) {
+        const int rowk = bcast_i(w.x, 0);
+        const uint32_t ver = (uint32_t)bcast_i(w.y, 0);
+        const int prev = bcast_i(w.y, 1);
+        row = rowk & 0x7fffffff;
+        slot = row / n_owner;
+        const size_t roff = (size_t)(ver & T.imask) * T.istride + (size_t)row * T.kp;
+        r.own_p = T.V + roff; r.own_ms = T.msV + roff;
+        r.own_tail = T.tailV + ((size_t)(ver & T.imask) * st.n_items + row) * (2 * item_halves);
+        r.own_rd = T.rdV + (T.imask + 1u) * (size_t)row + ((ver + 1u) & T.imask);
+        r.ver = ver;
+        r.from_lds = prev >= first_batch;
+        r.tag = tags + slot;
+        r.row = rows + (size_t)slot * ROWF;
+        r.halves = item_halves;
+    };
+
+    if (wave == 0) {
+        // ================= the scout: scalars of the tasks ahead of the queue's head, as soon as their rows are final =================
+        uint32_t hpos = 0, hcur = 0;
+        int idle = 0;
+        const uint32_t ahead = (tune & 16u) ? 12u : (uint32_t)kScoutAhead;
+        for (;;) {
+            if (tune & 8u) break;                                                      // experiment (unsafe): no scout
+            const uint32_t head = *reinterpret_cast<volatile uint32_t*>(&q->head);
+            if (head >= q_total) break;
+            if ((idle & 63) == 63 && ld_u32(ctl + kCtlStatus) != 0u) break;          // somebody gave up
+            if (hpos < head || hpos >= q_total || hpos >= head + ahead) {              // (re)start at the head: what was skipped may be final now
+                if (hpos >= head && idle) {                                           // a whole window without work
+                    if (tune & 32u) __builtin_amdgcn_s_sleep(127);
+                    else __builtin_amdgcn_s_sleep(16);
+                }
+                hpos = head;
+                hcur = *reinterpret_cast<volatile uint32_t*>(&q->head_batch);
+                idle = idle < (1 << 20) ? idle + 1 : idle;
+                if (hpos >= q_total) continue;
+            }
+            const uint32_t pos = hpos++;
+            if (*reinterpret_cast<volatile uint32_t*>(&dotmark[pos & (kDotWin - 1)]) == pos + 1u) continue;
+            const uint32_t idx = qm.locate(pos, hcur, lane);
+            int4 w = make_int4(0, 0, 0, 0);
+            if (lane < 8) w = prec[(size_t)idx * 8 + lane];
+            ItemRow r;
+            int row, slot;
+            item_row(w, r, row, slot);
+            const int n_occ = bcast_i(w.z, 0), first = bcast_i(w.w, 0), batch = bcast_i(w.x, 1);
+            float own[NE], ms[NE], g[NE];
+            Own o = {};
+            float gb = 0.f;
+            if (item_task<NP, true>(st, T, lane, n_occ, first, w, pocc, occt, r, sgd, xch + (size_t)batch * B * 2, xch_bytes, epoch, own, ms, o, g, gb,
+                                    ctl, spins, tune)) {
+                if (lane == 0) dotmark[pos & (kDotWin - 1)] = pos + 1u;
+                idle = 0;
+            }
+        }
+    } else if (wave <= owner_waves) {
         // ================= item tasks of the rows this workgroup owns =================
-        OwnerSrc feed{q, pre, start, prec, 3u * (uint32_t)B, 0u};
-        feed.prefetch(nx, lane);
+        uint32_t cur = 0;
         while (alive) {
-            const uint32_t idx = nx.idx;
-            const int4 w = nx.w;
-            if (idx == 0xffffffffu) break;
-            nx.have = false;
-            const int rowk = bcast_i(w.x, 0);
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&q->head, 1u);
+            pos = (uint32_t)bcast_i((int)pos, 0);
+            if (pos >= q_total) break;
+            const uint32_t idx = qm.locate(pos, cur, lane);
+            if (lane == 0) atomicMax(&q->head_batch, cur);
+            int4 w = make_int4(0, 0, 0, 0);
+            if (lane < 8) w = prec[(size_t)idx * 8 + lane];
 #ifdef TKR_OWN_PROF
+            asm volatile("" : "+v"(w.x) :: "memory");
             const u64 t0 = __builtin_amdgcn_s_memtime();
+            prof[5] += t0 - tprev;
 #endif
-            const uint32_t ver = (uint32_t)bcast_i(w.y, 0);
-            const int n_occ = bcast_i(w.z, 0);
-            const int first = bcast_i(w.w, 0);
-            const int prev = bcast_i(w.y, 1);
-            const int row = rowk & 0x7fffffff;
-            const int slot = row / n_owner;
-            const bool from_lds = prev >= first_batch;                 // an earlier task of THIS launch updated the row: it is (or will be) in LDS
-
-            const size_t roff = (size_t)(ver & T.imask) * T.istride + (size_t)row * T.kp;
+            ItemRow r;
+            int row, slot;
+            item_row(w, r, row, slot);
+            const int rowk = bcast_i(w.x, 0);
+            const uint32_t ver = r.ver;
+            const int n_occ = bcast_i(w.z, 0), first = bcast_i(w.w, 0), batch = bcast_i(w.x, 1);
             const size_t woff = (size_t)((ver + 1u) & T.imask) * T.istride + (size_t)row * T.kp;
-            const uint32_t* own_rd = T.rdV + (T.imask + 1u) * (size_t)row + ((ver + 1u) & T.imask);
-            const u64* own_tail = T.tailV + ((size_t)(ver & T.imask) * st.n_items + row) * (2 * item_halves);
             float* lrow = rows + (size_t)slot * ROWF;
 
             float own[NE], ms[NE], g[NE];
 #pragma unroll
             for (int e = 0; e < NE; ++e) { g[e] = 0.f; ms[e] = 0.f; }
             Own o = {};
-            o.ok = from_lds;                                            // flow_fetch then leaves the own row alone
-            const bool lazy = (tune & 1u) != 0u;                        // experiment: the next task is only taken once this one is done
-            if (lazy) nx.have = true;
-            float gb = 0.f, loss_lane = 0.f;
-            LdsOwn<NP> own_step{T, lane, T.V + roff, T.msV + roff, own_tail, own_rd, ver, sgd, ctl, spins, from_lds, tags + slot, lrow, item_halves};
-            alive = run_task<NP, true>(st, T, lane, n_occ, first, w, pocc, T.V + roff, T.msV + roff, own_tail, ver, own, ms, o, g, gb,
-                                       loss_lane, false, sgd, ctl, spins, nx, feed, own_step);
+            float gb = 0.f;
+            alive = item_task<NP, false>(st, T, lane, n_occ, first, w, pocc, occt, r, sgd, xch + (size_t)batch * B * 2, xch_bytes, epoch, own, ms, o, g,
+                                         gb, ctl, spins, tune);
             if (!alive) break;
+            if (lane == 0) dotmark[pos & (kDotWin - 1)] = pos + 1u;
 #ifdef TKR_OWN_PROF
             const u64 t1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -318,7 +561,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
                 if (!sgd) *reinterpret_cast<float2*>(lrow + KP + qq * 128 + 2 * lane) = make_float2(mn[2 * qq], mn[2 * qq + 1]);
             }
             if (lane == 0) {
-                const uint32_t rb = ver & T.imask, add = 2u * (uint32_t)n_occ;
+                const uint32_t rb = ver & T.imask, add = (uint32_t)n_occ;          // one reader per occurrence: the user task
                 *reinterpret_cast<float4*>(lrow + 2 * KP) = make_float4(bn, mbn, __uint_as_float(o.exp[0] + (rb == 0u ? add : 0u)),
                                                                         __uint_as_float(o.exp[1] + (rb == 1u ? add : 0u)));
                 *reinterpret_cast<float2*>(lrow + 2 * KP + 4) =
@@ -327,28 +570,22 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the row is in LDS before its tag says so
             if (lane == 0) *reinterpret_cast<volatile uint32_t*>(tags + slot) = ver + 1u;
 
-            alive = own_publish<NP>(lane, true, T.imask, sgd, T.V, T.msV, T.tailV, woff, (size_t)st.n_items, row, rowk, ver, n_occ, o, own_rd, pn, mn,
-                                    bn, mbn, ctl, spins, nx, (tune & 2u) != 0u);
+            alive = own_publish<NP>(lane, true, T.imask, sgd, T.V, T.msV, T.tailV, woff, (size_t)st.n_items, row, rowk, ver, n_occ, o, r.own_rd, pn,
+                                    mn, bn, mbn, ctl, spins);
 #ifdef TKR_OWN_PROF
-            const u64 t4 = __builtin_amdgcn_s_memtime();
-#endif
-            if (lazy && alive) feed.prefetch(nx, lane);
-#ifdef TKR_OWN_PROF
-            {
-                asm volatile("" : "+v"(nx.w.x) :: "memory");
-                const u64 t5 = __builtin_amdgcn_s_memtime();
-                prof[0] += o.t_own0 - t0; prof[1] += o.t_own1 - o.t_own0; prof[2] += t1 - o.t_own1; prof[3] += o.t_ack - t1;
-                prof[4] += t4 - o.t_ack; prof[5] += t5 - t4; prof[6] += 1; prof[7] += from_lds ? 1 : 0;
-            }
+            tprev = __builtin_amdgcn_s_memtime();
+            prof[0] += t1 - t0; prof[3] += o.t_ack - t1; prof[4] += tprev - o.t_ack; prof[6] += 1; prof[7] += r.from_lds ? 1 : 0;
 #endif
         }
     } else {
         // ================= user tasks, by ticket =================
-        const int tw = wave - owner_waves, n_tw = TPB / TKR_WAVE - owner_waves;
+        const int tw = wave - owner_waves - 1, n_tw = TPB / TKR_WAVE - owner_waves - 1;
         const int queues = min(kQueues, n_tw * (int)gridDim.x);
         const int home = (int)((me * (uint32_t)n_tw + (uint32_t)tw) % (uint32_t)queues);
         const uint32_t total = (uint32_t)nb * (uint32_t)B;
         uint32_t ticket = grab_issue(ctl, lane, home);
+        NextTask nx;
+        nx.idx = 0u; nx.w = make_int4(0, 0, 0, 0); nx.have = false;
         while (alive) {
             if (!nx.have) {
                 UserTicketSrc first_feed{ticket, home, queues, total, (uint32_t)B, prec};
@@ -389,8 +626,8 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             float gb = 0.f, loss_lane = 0.f;
             UserTicketSrc feed{ticket, home, queues, total, (uint32_t)B, prec};
             GlobalOwn<NP> own_step{T, lane, T.U + roff, T.msU + roff, own_tail, own_rd, ver, sgd, ctl, spins, 2};
-            alive = run_task<NP, false>(st, T, lane, n_occ, first, w, pocc, T.U + roff, T.msU + roff, own_tail, ver, own, ms, o, g, gb,
-                                        loss_lane, want_loss, sgd, ctl, spins, nx, feed, own_step);
+            alive = run_task<NP, false, UserTicketSrc, GlobalOwn<NP>, 4>(st, T, lane, n_occ, first, w, pocc, T.U + roff, T.msU + roff, own_tail, ver,
+                                                                         own, ms, o, g, gb, loss_lane, want_loss, sgd, ctl, spins, nx, feed, own_step);
             if (!alive) break;
 #ifdef TKR_OWN_PROF
             const u64 t1 = __builtin_amdgcn_s_memtime();
@@ -401,8 +638,9 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             }
             float pn[NE], mn[NE], bn, mbn;
             own_update<NP>(st, sgd, own, ms, o, g, gb, pn, mn, bn, mbn);
+            asm volatile("" : "+v"(nx.w.x), "+v"(nx.w.y), "+v"(nx.w.z), "+v"(nx.w.w));      // the next record is consumed before the stores go out
             alive = own_publish<NP>(lane, false, 1u, sgd, T.U, T.msU, T.tailU, woff, (size_t)st.n_users, row, rowk, ver, n_occ, o, own_rd, pn, mn,
-                                    bn, mbn, ctl, spins, nx);
+                                    bn, mbn, ctl, spins);
 #ifdef TKR_OWN_PROF
             tprev = __builtin_amdgcn_s_memtime();
             prof[9] += t1 - t0; prof[11] += o.t_ack - t1; prof[12] += tprev - o.t_ack; prof[13] += 1;
@@ -428,7 +666,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
 
 static size_t own_lds_bytes(int np, int nb, int n_items, int n_owner) {
     const int rows_here = (n_items + n_owner - 1) / n_owner;
-    const size_t head = (sizeof(OwnQueue) + (size_t)4 * (2 * nb + 1 + TKR_WAVE + rows_here) + 15) & ~(size_t)15;
+    const size_t head = (sizeof(OwnQueue) + (size_t)4 * (2 * nb + 1 + TKR_WAVE + rows_here + kDotWin) + 15) & ~(size_t)15;
     return head + (size_t)rows_here * (2 * np * 128 + 8) * 4;
 }
 
@@ -445,16 +683,17 @@ extern "C" int32_t tkr_bpr_own_owners(int32_t n_items, int32_t k) {
     return cus;
 }
 
-extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, const int32_t* ohdr,
+extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, const int32_t* occt, const int32_t* ohdr,
                                int32_t ohdr_stride, int32_t n_owner, int32_t batch_size, int32_t first_batch, int32_t n_batches,
-                               uint32_t* ctl, float* loss_out, int32_t owner_waves, void* stream) {
+                               uint32_t* ctl, float* loss_out, int32_t owner_waves, void* xch, uint32_t epoch, void* stream) {
     if (!st || !st->U || !st->V || !st->tailU || !st->tailV || !st->rdU || !st->rdV) return TKR_EINVAL;
     if (st->opt != 0 && st->opt != 1) return TKR_EINVAL;
     if (st->opt == 0 && (!st->msU || !st->msV)) return TKR_EINVAL;
     if (st->n_users <= 0 || st->n_items <= 0 || st->k <= 0) return TKR_EINVAL;
     if (st->k > 256) return TKR_EUNSUPPORTED;
     if (st->item_bufs != 0 && st->item_bufs != 2 && st->item_bufs != 4) return TKR_EINVAL;
-    if (!prec || !pocc || !ohdr || !ctl || batch_size <= 0 || n_batches < 0 || first_batch < 0 || n_owner <= 0) return TKR_EINVAL;
+    if (!xch || epoch == 0u) return TKR_EINVAL;
+    if (!prec || !pocc || !occt || !ohdr || !ctl || batch_size <= 0 || n_batches < 0 || first_batch < 0 || n_owner <= 0) return TKR_EINVAL;
     if (ohdr_stride < first_batch + n_batches || n_batches > 512) return TKR_EINVAL;
     if (n_batches == 0) return TKR_OK;
     if ((uint64_t)(first_batch + n_batches) * 3u * (uint64_t)batch_size >= 0xffffffffull / 8) return TKR_EUNSUPPORTED;
@@ -472,15 +711,15 @@ extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, co
     if (n_owner > cus) return TKR_EUNSUPPORTED;                    // every owner must be resident: one workgroup per CU
     const size_t lds = tkr::own_lds_bytes(np, n_batches, st->n_items, n_owner);
     if (lds > 160 * 1024) return TKR_EUNSUPPORTED;
-    const int tpb = np == 1 ? 512 : 256;
+    const int tpb = np == 1 ? 1024 : 512;
     const int waves = tpb / TKR_WAVE;
-    // default split: item tasks are ~64 % of a batch's tasks at the ML-10M shape and cheaper than user tasks (no own-row trip)
     const uint32_t tune = ((uint32_t)owner_waves >> 8) & 0xffu;     // experiment switches ride in bits 8..15
     owner_waves &= 0xff;
-    int ow = owner_waves > 0 ? owner_waves : (waves == 8 ? 5 : 3);
+    // one scout, `ow` waves on the owner queue, the rest on user tickets
+    int ow = owner_waves > 0 ? owner_waves : (waves == 16 ? 9 : 4);
     if (ow < 1) ow = 1;
-    if (ow > waves - 1) ow = waves - 1;
-    const void* fn = np == 1 ? (const void*)tkr::bpr_own_kernel<1, 512> : (const void*)tkr::bpr_own_kernel<2, 256>;
+    if (ow > waves - 2) ow = waves - 2;
+    const void* fn = np == 1 ? (const void*)tkr::bpr_own_kernel<1, 1024> : (const void*)tkr::bpr_own_kernel<2, 512>;
     if (lds > 64 * 1024 && !(dev >= 0 && dev < 64 && attr_set[dev][np - 1])) {
         TKR_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (dev >= 0 && dev < 64) attr_set[dev][np - 1] = true;
@@ -490,11 +729,11 @@ extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, co
     const int4* o4 = reinterpret_cast<const int4*>(pocc);
     ohdr += first_batch;
     if (np == 1)
-        hipLaunchKernelGGL((tkr::bpr_own_kernel<1, 512>), dim3(n_owner), dim3(512), lds, s, *st, r4, o4, ohdr, ohdr_stride, first_batch, n_batches,
-                           batch_size, n_owner, ow, tune, ctl, loss_out);
+        hipLaunchKernelGGL((tkr::bpr_own_kernel<1, 1024>), dim3(n_owner), dim3(1024), lds, s, *st, r4, o4, occt, ohdr, ohdr_stride, first_batch,
+                           n_batches, batch_size, n_owner, ow, tune, ctl, loss_out, static_cast<tkr::u64*>(xch), epoch);
     else
-        hipLaunchKernelGGL((tkr::bpr_own_kernel<2, 256>), dim3(n_owner), dim3(256), lds, s, *st, r4, o4, ohdr, ohdr_stride, first_batch, n_batches,
-                           batch_size, n_owner, ow, tune, ctl, loss_out);
+        hipLaunchKernelGGL((tkr::bpr_own_kernel<2, 512>), dim3(n_owner), dim3(512), lds, s, *st, r4, o4, occt, ohdr, ohdr_stride, first_batch,
+                           n_batches, batch_size, n_owner, ow, tune, ctl, loss_out, static_cast<tkr::u64*>(xch), epoch);
     TKR_LAUNCH_CHECK();
     return TKR_OK;
 }

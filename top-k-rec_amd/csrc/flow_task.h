@@ -446,11 +446,12 @@ __device__ __forceinline__ bool flow_own(const FlowTables& T, int lane, const u6
 }
 
 // the tail of version ver + 1 of a row (bias, its slot, the acknowledge totals: this batch read version ver, so the total of ITS
-// buffer grows by 2 per occurrence), written by lanes 0 .. halves-1
+// buffer grows by the readers of an occurrence: both other tasks of the triplet, or only the user task for an item row under K2o),
+// written by lanes 0 .. halves-1
 __device__ __forceinline__ void store_tail(u64* tabT, size_t n_rows, int row, uint32_t mask, int lane, bool is_item, float bn, float mbn,
-                                           const Own& o, uint32_t ver, int n_occ) {
+                                           const Own& o, uint32_t ver, int n_occ, uint32_t readers_per_occ = 2u) {
     const int halves = tail_halves(mask);
-    const uint32_t nv = ver + 1u, rb = ver & mask, add = 2u * (uint32_t)n_occ;
+    const uint32_t nv = ver + 1u, rb = ver & mask, add = readers_per_occ * (uint32_t)n_occ;
     if (lane < halves) {
         v4u tv;
         tv.y = nv; tv.w = nv;
@@ -554,7 +555,7 @@ struct GlobalOwn {
     }
 };
 
-template <int NP, bool ITEM, class Src, class OwnStep>
+template <int NP, bool ITEM, class Src, class OwnStep, int KBIG = 8>
 __device__ __forceinline__ bool run_task(const tkr_flow_state& st, const FlowTables& T, int lane, int n_occ, int first, const int4 w,
                                          const int4* __restrict__ pocc, const u64* own_p, const u64* own_ms, const u64* own_tail,
                                          uint32_t ver, float (&own)[2 * NP], float (&ms)[2 * NP], Own& o,
@@ -580,7 +581,8 @@ __device__ __forceinline__ bool run_task(const tkr_flow_state& st, const FlowTab
             default: TKR_ONE(4, 4, d)
         }
     }
-    constexpr int kBig = 8;
+    constexpr int kBig = KBIG;                    // occurrences per round beyond the record's four (8; K2o's user tasks: 4, fewer registers)
+    static_assert(kBig == 4 || kBig == 8, "round width");
     if (n_occ <= 2 * kBig) {
         const int n0 = min(kBig, n_occ), n1 = n_occ - n0;
         int4 d0 = make_int4(0, 0, 0, 0), d1 = make_int4(0, 0, 0, 0);

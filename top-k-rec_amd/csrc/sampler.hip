@@ -318,7 +318,8 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
 //   prec[3B][32]    per task slot: [0] row | kind<<31 (-1 = unused slot)  [1] version of the row  [2] occurrences
 //                   [3] index of its first occurrence in pocc, counted from batch 0 of this call  [4] batch
 //                   [5] the last batch < [4] of this call that updated the row, -1 = none  [6..7] 0
-//                   [8+4q .. 11+4q] = pocc of occurrence q < min(4, occurrences)  [24..31] 0
+//                   [8+4q .. 11+4q] = pocc of occurrence q < min(4, occurrences)  [24+q] = index of that occurrence's triplet in the
+//                   batch (occt)  [28..31] 0
 // With n_owner > 0 (K2o: item row r is served by workgroup r % n_owner, which keeps the row in its LDS) the records of a batch's
 // ITEM tasks are laid out in (owner, row) order instead of row order -- still the slots [users, users + items) of the batch, the
 // order of tasks inside a batch means nothing to the step -- and ohdr[owner * ohdr_stride + batch] = first slot | tasks << 16
@@ -334,7 +335,8 @@ __device__ __forceinline__ int prev_batch_of(const uint32_t* __restrict__ touch,
 __global__ __launch_bounds__(kPlanThreads) void resolve_flow_kernel(
     int B, const int4* __restrict__ task_all, const int2* __restrict__ occ_all, const int32_t* __restrict__ ucnt,
     const int32_t* __restrict__ icnt, const uint32_t* __restrict__ touch_u, const uint32_t* __restrict__ touch_i,
-    int4* __restrict__ pocc_all, int4* __restrict__ prec_all, int n_owner, int32_t* __restrict__ ohdr, int ohdr_stride) {
+    int4* __restrict__ pocc_all, int4* __restrict__ prec_all, int n_owner, int32_t* __restrict__ ohdr, int ohdr_stride,
+    const int32_t* __restrict__ occt_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_first_item, s_end, s_wave[kPlanThreads / TKR_WAVE];
     const int b = blockIdx.x;
@@ -425,7 +427,8 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_flow_kernel(
         r[1] = make_int4(b, prev, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) r[2 + q] = (q < t.z) ? pocc[t.y + q] : make_int4(0, 0, 0, 0);
-        r[6] = make_int4(0, 0, 0, 0);
+        const int32_t* tt = occt_all + (size_t)b * 3 * B + t.y;          // the triplets of those occurrences (K2o: the slots of their scalars)
+        r[6] = make_int4(tt[0], t.z > 1 ? tt[1] : 0, t.z > 2 ? tt[2] : 0, t.z > 3 ? tt[3] : 0);
         r[7] = make_int4(0, 0, 0, 0);
     }
 }
@@ -543,7 +546,7 @@ static int sample_plan_impl(const int32_t* tr_users, int32_t n_tr, const int32_t
         hipLaunchKernelGGL(tkr::resolve_flow_kernel, dim3(n_batches), dim3(tkr::kPlanThreads),
                            n_owner > 0 ? (((size_t)4 * batch_size + 15) & ~(size_t)15) + (size_t)4 * n_owner : 0, s, batch_size,
                            reinterpret_cast<const int4*>(task), reinterpret_cast<const int2*>(occ), ucnt, icnt, touch_u,
-                           touch_i, reinterpret_cast<int4*>(pocc), reinterpret_cast<int4*>(prec), n_owner, ohdr, ohdr_stride);
+                           touch_i, reinterpret_cast<int4*>(pocc), reinterpret_cast<int4*>(prec), n_owner, ohdr, ohdr_stride, occt);
     else
         hipLaunchKernelGGL(tkr::resolve_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), 0, s, batch_size,
                            tkr_plan_max_blocks(batch_size) * tkr::team_for(batch_size), reinterpret_cast<int4*>(task),

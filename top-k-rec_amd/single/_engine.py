@@ -93,6 +93,8 @@ class PlanBuffers:
             self.pocc = torch.empty(cap * 3 * B * 4, **i32)
             if self.owners:
                 self.ohdr = torch.zeros(self.owners * cap, **i32)
+                self.xch = torch.zeros(cap * B * 2 * 2, **i32)       # K2o's scalar slots: a granule {value, epoch} per (triplet, role)
+                self.epoch = 0                                       # launches on these slots so far
         else:
             self.rec_stride = tkr_hip.plan_max_blocks(B) * tkr_hip.plan_team(B) * 16
             self.rec = torch.empty(cap * self.rec_stride, **i32)

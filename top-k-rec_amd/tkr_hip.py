@@ -292,22 +292,26 @@ def bpr_own_owners(n_items, k, device=None):
 
 def bpr_own_run(state, plan, B, n_batches, ctl, loss_out=None, first=0, owner_waves=0):
     """batches [first, first + n_batches) of an owner-ordered dataflow plan in ONE persistent launch of K2o"""
-    _call('tkr_bpr_own_run', plan.prec, C.byref(state), _p(plan.prec), _p(plan.pocc), _p(plan.ohdr), C.c_int32(plan.cap), C.c_int32(plan.owners),
-          C.c_int32(B), C.c_int32(first), C.c_int32(n_batches), _p(ctl), _p(loss_out), C.c_int32(owner_waves))
+    plan.epoch += 1                       # no two launches on one plan buffer's scalar slots share an epoch
+    _call('tkr_bpr_own_run', plan.prec, C.byref(state), _p(plan.prec), _p(plan.pocc), _p(plan.occt), _p(plan.ohdr), C.c_int32(plan.cap), C.c_int32(plan.owners),
+          C.c_int32(B), C.c_int32(first), C.c_int32(n_batches), _p(ctl), _p(loss_out), C.c_int32(owner_waves), _p(plan.xch),
+          C.c_uint32(plan.epoch & 0xffffffff or 1))
 
 
 def own_stepper(state, B, ctl, owner_waves=0):
     """-> step(plan, first, n_batches, loss_out): bpr_own_run with the fixed arguments bound once (as flow_stepper)"""
     fn = lib().tkr_bpr_own_run
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
-                   C.c_void_p, C.c_int32, C.c_void_p]
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                   C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p]
     device, st, ctl_ptr = ctl.device, C.addressof(state), ctl.data_ptr()
 
     def step(plan, first, n_batches, loss_out):
         if torch.cuda.current_device() != device.index:
             return bpr_own_run(state, plan, B, n_batches, ctl, loss_out, first, owner_waves)
-        rc = fn(st, plan.prec.data_ptr(), plan.pocc.data_ptr(), plan.ohdr.data_ptr(), plan.cap, plan.owners, B, first, n_batches, ctl_ptr,
-                None if loss_out is None else loss_out.data_ptr(), owner_waves, torch.cuda.current_stream(device).cuda_stream)
+        plan.epoch += 1
+        rc = fn(st, plan.prec.data_ptr(), plan.pocc.data_ptr(), plan.occt.data_ptr(), plan.ohdr.data_ptr(), plan.cap, plan.owners, B, first, n_batches, ctl_ptr,
+                None if loss_out is None else loss_out.data_ptr(), owner_waves, plan.xch.data_ptr(), plan.epoch & 0xffffffff or 1,
+                torch.cuda.current_stream(device).cuda_stream)
         if rc:
             _check(rc, 'tkr_bpr_own_run')
     step.state = state
