@@ -34,13 +34,17 @@ def _toy(n_users, n_items, seed, max_deg=12):
     return tr, list(tr.keys())
 
 
+KERNEL_TUNE = {'f': 0, 'o': 0, 's': 0x8000, 'w': 0xc000}      # K2f | K2o, item tasks read rows (default) | ... exchange scalars | ... on 16 waves
+
+
 def _owners(hip, which, n_items, k):
-    """'f': K2f (no owners); 'o': K2o with the device's owner count; 'o8' / 'o3': K2o on 8 / 3 workgroups (several rows per owner)"""
+    """'f': K2f (no owners); 'o' / 's' / 'w': K2o (see KERNEL_TUNE) with the device's owner count; 'o8', 's3', ...: on 8 / 3 workgroups
+    (several rows per owner)"""
     if which == 'f':
         return 0
     n = hip.bpr_own_owners(n_items, k)
     assert n > 0
-    return n if which == 'o' else int(which[1:])
+    return n if len(which) == 1 else int(which[1:])
 
 
 def _plan(hip, tr, tr_users, n_users, n_items, seed, first, nb, B, chunks=1, owners=0):
@@ -106,10 +110,10 @@ class _Flow:
         st.item_bufs = bufs
         self.st = st
 
-    def run(self, plan, B, nb, loss=None, first=0, waves_per_cu=0):
-        self.item_readers = 1 if plan.owners else 2      # K2o: an item row is read by the user tasks only
+    def run(self, plan, B, nb, loss=None, first=0, waves_per_cu=0, kernel='o'):
+        self.item_readers = 1 if plan.owners and kernel[0] in 'sw' else 2      # scalar exchange: an item row is read by the user tasks only
         if plan.owners:                  # K2o; waves_per_cu = owner waves per workgroup here
-            self.hip.bpr_own_run(self.st, plan, B, nb, self.ctl, loss, first=first, owner_waves=waves_per_cu)
+            self.hip.bpr_own_run(self.st, plan, B, nb, self.ctl, loss, first=first, owner_waves=waves_per_cu | KERNEL_TUNE[kernel[0]])
         else:
             self.hip.bpr_flow_run(self.st, plan, B, nb, self.ctl, loss, first=first, waves_per_cu=waves_per_cu)
 
@@ -173,7 +177,7 @@ def _check(F, ref, ucnt, icnt, uocc, iocc, tol=dict(rtol=2e-4, atol=1e-5), slots
 @pytest.mark.parametrize('k,B,nb,mode,lr', [(16, 64, 12, 'l2', 0.05), (128, 256, 10, 'l2', 0.05), (50, 256, 6, 'l1', 0.05),
                                            (200, 128, 4, 'l2', 1e-4), (64, 1024, 5, 'l2', 0.05), (128, 256, 40, 'l1', 0.02),
                                            (256, 64, 6, 'l2', 0.05)])
-@pytest.mark.parametrize('kernel', ['f', 'o', 'o8'])
+@pytest.mark.parametrize('kernel', ['f', 'o', 'o8', 's', 's8', 'w'])
 def test_bpr_flow_parity(hip, k, B, nb, mode, lr, kernel):
     n_users, n_items = 400, 120               # small tables: every item is updated in (almost) every batch, many rows have > 4 occurrences
     tr, tr_users = _toy(n_users, n_items, seed=k + B)
@@ -184,7 +188,7 @@ def test_bpr_flow_parity(hip, k, B, nb, mode, lr, kernel):
     F = _Flow(hip, ref, n_users, n_items, k, hp)
     plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 42, 0, nb, B, owners=_owners(hip, kernel, n_items, k))
     loss = torch.zeros(nb, device='cuda')
-    F.run(plan, B, nb, loss)
+    F.run(plan, B, nb, loss, kernel=kernel)
     ucnt, icnt, uocc, iocc, ref_loss = _oracle(ref, exp, n_users, n_items, nb, B, hp)
     _check(F, ref, ucnt, icnt, uocc, iocc)
     np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, rtol=1e-4)
@@ -193,7 +197,7 @@ def test_bpr_flow_parity(hip, k, B, nb, mode, lr, kernel):
 
 
 @pytest.mark.parametrize('bufs', [2, 4])
-@pytest.mark.parametrize('kernel', ['f', 'o', 'o3'])
+@pytest.mark.parametrize('kernel', ['f', 'o', 'o3', 's', 's3', 'w'])
 def test_flow_is_deterministic_and_launch_split_invariant(hip, kernel, bufs):
     """bitwise: two runs of one launch, and the same chunk cut into launches of 1 + 3 + the rest and 2 + 1 + 4 + the rest (K2o: the
     rows an owner holds in LDS do not outlive a launch; the first task of a row in the next launch takes it from the tables again)"""
@@ -207,7 +211,7 @@ def test_flow_is_deterministic_and_launch_split_invariant(hip, kernel, bufs):
         F = _Flow(hip, ref, n_users, n_items, k, hp, bufs)
         at = 0
         for m in cuts:
-            F.run(plan, B, m, None, first=at)
+            F.run(plan, B, m, None, first=at, kernel=kernel)
             at += m
         assert F.status()[0] == 0
         outs.append(F.raw())
@@ -216,7 +220,8 @@ def test_flow_is_deterministic_and_launch_split_invariant(hip, kernel, bufs):
 
 
 @pytest.mark.parametrize('bufs', [2, 4])
-@pytest.mark.parametrize('kernel,waves_per_cu', [('f', 4), ('f', 8), ('f', 12), ('o', 0), ('o', 1), ('o', 7), ('o3', 2)])
+@pytest.mark.parametrize('kernel,waves_per_cu', [('f', 4), ('f', 8), ('f', 12), ('o', 0), ('o', 1), ('o', 6), ('o3', 2), ('s', 0), ('s', 1), ('s3', 2),
+                                                 ('w', 0), ('w', 13)])
 def test_flow_few_waves_and_hot_rows(hip, kernel, waves_per_cu, bufs):
     """12 items: every item row is rewritten in every batch (a hand-off chain through all 64 batches), all of them with dozens of
     occurrences; and the result must not depend on how many waves run"""
@@ -228,13 +233,13 @@ def test_flow_few_waves_and_hot_rows(hip, kernel, waves_per_cu, bufs):
     hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.02, mode='l2')
     F = _Flow(hip, ref, n_users, n_items, k, hp, bufs)
     plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 77, 0, nb, B, owners=_owners(hip, kernel, n_items, k))
-    F.run(plan, B, nb, None, waves_per_cu=waves_per_cu)
+    F.run(plan, B, nb, None, waves_per_cu=waves_per_cu, kernel=kernel)
     ucnt, icnt, uocc, iocc, _ = _oracle(ref, exp, n_users, n_items, nb, B, hp)
     assert icnt.min() >= nb - 2
     _check(F, ref, ucnt, icnt, uocc, iocc, tol=dict(rtol=5e-4, atol=2e-5))
 
 
-@pytest.mark.parametrize('kernel', ['f', 'o'])
+@pytest.mark.parametrize('kernel', ['f', 'o', 's'])
 def test_flow_sgd(hip, kernel):
     n_users, n_items, k, B, nb = 400, 120, 128, 256, 8
     tr, tr_users = _toy(n_users, n_items, seed=5)
@@ -245,7 +250,7 @@ def test_flow_sgd(hip, kernel):
     F.st.msU = F.st.msV = None                # the slots are neither read nor written
     plan, exp, _, _ = _plan(hip, tr, tr_users, n_users, n_items, 43, 0, nb, B, owners=_owners(hip, kernel, n_items, k))
     loss = torch.zeros(nb, device='cuda')
-    F.run(plan, B, nb, loss)
+    F.run(plan, B, nb, loss, kernel=kernel)
     ucnt, icnt, uocc, iocc, ref_loss = _oracle(ref, exp, n_users, n_items, nb, B, hp)
     _check(F, ref, ucnt, icnt, uocc, iocc, slots=False)
     np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, rtol=1e-4)

@@ -162,6 +162,24 @@ __device__ __forceinline__ bool item_own_peek(int lane, const ItemRow& r, float 
     return true;
 }
 
+// the row-read form of an item task (SCALAR = false: csrc/flow_task.h run_task, both partner rows of an occurrence read from the
+// tables like K2f does) takes its own row the same way and never prefetches a record
+template <int NP>
+struct LdsOwnStep {
+    const FlowTables& T;
+    int lane;
+    const ItemRow& r;
+    bool sgd;
+    uint32_t* ctl;
+    uint32_t& spins;
+    __device__ __forceinline__ bool operator()(float (&own)[2 * NP], float (&ms)[2 * NP], Own& o) {
+        return item_own_wait<NP>(T, lane, r, sgd, own, ms, o, ctl, spins);
+    }
+};
+struct NoFeed {
+    __device__ __forceinline__ void prefetch(NextTask& nx, int) { nx.have = true; }
+};
+
 // ---- a round of up to G occurrences of an item task -----------------------------------------------------------------------------
 // Lane q < n of `d` holds occurrence q = (user, version of the user row, other | role<<31, version of the other item [unused]);
 // `tq` its triplet's index in the batch.  MODE kFull: the task's round.  kScout: one pass, nothing acknowledged, nothing waited
@@ -359,7 +377,7 @@ template <int NP>
 __device__ __forceinline__ bool own_publish(int lane, bool is_item, uint32_t bmask, bool sgd, u64* tabP, u64* tabM, u64* tabT, size_t woff,
                                             size_t n_rows, int row, int rowk, uint32_t ver, int n_occ, Own& o, const uint32_t* own_rd,
                                             const float (&pn)[2 * NP], const float (&mn)[2 * NP], float bn, float mbn, uint32_t* ctl,
-                                            uint32_t& spins) {
+                                            uint32_t& spins, uint32_t readers_per_occ) {
     const uint32_t nv = ver + 1u;
     const uint32_t expect = pick_exp(o, (ver + 1u) & bmask);            // readers of the version that buffer holds now
     uint32_t waited = 0;
@@ -378,13 +396,15 @@ __device__ __forceinline__ bool own_publish(int lane, bool is_item, uint32_t bma
 #endif
     store_row<NP>(tabP + woff, lane, pn, nv);
     if (!sgd) store_row<NP>(tabM + woff, lane, mn, nv);
-    store_tail(tabT, n_rows, row, bmask, lane, is_item, bn, mbn, o, ver, n_occ, is_item ? 1u : 2u);      // an item row's readers: the user tasks only
+    store_tail(tabT, n_rows, row, bmask, lane, is_item, bn, mbn, o, ver, n_occ, readers_per_occ);
     return true;
 }
 
 constexpr int own_min_waves(int np, int tpb) { return tpb / 256; }      // per SIMD: 16 waves per CU at <= 128 registers (k <= 128), 8 at <= 256
 
-template <int NP, int TPB>
+// SCALAR: the item tasks of a triplet exchange scalars (one reader per occurrence of an item row: the user task; wave 0 of a
+// workgroup is the scout); else they read each other's rows like K2f (two readers; wave 0 is one more owner wave)
+template <int NP, int TPB, bool SCALAR>
 __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     tkr_flow_state st, const int4* __restrict__ prec /*record 0 of the first batch to run*/, const int4* __restrict__ pocc,
     const int32_t* __restrict__ occt, const int32_t* __restrict__ ohdr /*[n_owner][ohdr_stride], at the first batch to run*/, int ohdr_stride,
@@ -475,21 +495,18 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
         r.halves = item_halves;
     };
 
-    if (wave == 0) {
+    constexpr uint32_t kItemReaders = SCALAR ? 1u : 2u;
+    if (SCALAR && wave == 0) {
         // ================= the scout: scalars of the tasks ahead of the queue's head, as soon as their rows are final =================
         uint32_t hpos = 0, hcur = 0;
         int idle = 0;
-        const uint32_t ahead = (tune & 16u) ? 12u : (uint32_t)kScoutAhead;
+        const uint32_t ahead = (uint32_t)kScoutAhead;
         for (;;) {
-            if (tune & 8u) break;                                                      // experiment (unsafe): no scout
             const uint32_t head = *reinterpret_cast<volatile uint32_t*>(&q->head);
             if (head >= q_total) break;
             if ((idle & 63) == 63 && ld_u32(ctl + kCtlStatus) != 0u) break;          // somebody gave up
             if (hpos < head || hpos >= q_total || hpos >= head + ahead) {              // (re)start at the head: what was skipped may be final now
-                if (hpos >= head && idle) {                                           // a whole window without work
-                    if (tune & 32u) __builtin_amdgcn_s_sleep(127);
-                    else __builtin_amdgcn_s_sleep(16);
-                }
+                if (hpos >= head && idle) __builtin_amdgcn_s_sleep(16);               // a whole window without work
                 hpos = head;
                 hcur = *reinterpret_cast<volatile uint32_t*>(&q->head_batch);
                 idle = idle < (1 << 20) ? idle + 1 : idle;
@@ -513,7 +530,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
                 idle = 0;
             }
         }
-    } else if (wave <= owner_waves) {
+    } else if (wave <= owner_waves) {                                                  // (SCALAR: waves 1 .. owner_waves; else 0 .. owner_waves)
         // ================= item tasks of the rows this workgroup owns =================
         uint32_t cur = 0;
         while (alive) {
@@ -544,8 +561,19 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             for (int e = 0; e < NE; ++e) { g[e] = 0.f; ms[e] = 0.f; }
             Own o = {};
             float gb = 0.f;
-            alive = item_task<NP, false>(st, T, lane, n_occ, first, w, pocc, occt, r, sgd, xch + (size_t)batch * B * 2, xch_bytes, epoch, own, ms, o, g,
-                                         gb, ctl, spins, tune);
+            if constexpr (SCALAR) {
+                alive = item_task<NP, false>(st, T, lane, n_occ, first, w, pocc, occt, r, sgd, xch + (size_t)batch * B * 2, xch_bytes, epoch, own, ms, o,
+                                             g, gb, ctl, spins, tune);
+            } else {
+                o.ok = r.from_lds;                                       // flow_fetch then leaves the own row alone
+                NextTask nx;
+                nx.idx = 0u; nx.w = make_int4(0, 0, 0, 0); nx.have = true;
+                NoFeed feed;
+                LdsOwnStep<NP> own_step{T, lane, r, sgd, ctl, spins};
+                float loss_lane = 0.f;
+                alive = run_task<NP, true, NoFeed, LdsOwnStep<NP>, 4>(st, T, lane, n_occ, first, w, pocc, r.own_p, r.own_ms, r.own_tail, ver, own, ms, o,
+                                                                      g, gb, loss_lane, false, sgd, ctl, spins, nx, feed, own_step);
+            }
             if (!alive) break;
             if (lane == 0) dotmark[pos & (kDotWin - 1)] = pos + 1u;
 #ifdef TKR_OWN_PROF
@@ -561,7 +589,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
                 if (!sgd) *reinterpret_cast<float2*>(lrow + KP + qq * 128 + 2 * lane) = make_float2(mn[2 * qq], mn[2 * qq + 1]);
             }
             if (lane == 0) {
-                const uint32_t rb = ver & T.imask, add = (uint32_t)n_occ;          // one reader per occurrence: the user task
+                const uint32_t rb = ver & T.imask, add = kItemReaders * (uint32_t)n_occ;
                 *reinterpret_cast<float4*>(lrow + 2 * KP) = make_float4(bn, mbn, __uint_as_float(o.exp[0] + (rb == 0u ? add : 0u)),
                                                                         __uint_as_float(o.exp[1] + (rb == 1u ? add : 0u)));
                 *reinterpret_cast<float2*>(lrow + 2 * KP + 4) =
@@ -571,7 +599,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             if (lane == 0) *reinterpret_cast<volatile uint32_t*>(tags + slot) = ver + 1u;
 
             alive = own_publish<NP>(lane, true, T.imask, sgd, T.V, T.msV, T.tailV, woff, (size_t)st.n_items, row, rowk, ver, n_occ, o, r.own_rd, pn,
-                                    mn, bn, mbn, ctl, spins);
+                                    mn, bn, mbn, ctl, spins, kItemReaders);
 #ifdef TKR_OWN_PROF
             tprev = __builtin_amdgcn_s_memtime();
             prof[0] += t1 - t0; prof[3] += o.t_ack - t1; prof[4] += tprev - o.t_ack; prof[6] += 1; prof[7] += r.from_lds ? 1 : 0;
@@ -640,7 +668,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             own_update<NP>(st, sgd, own, ms, o, g, gb, pn, mn, bn, mbn);
             asm volatile("" : "+v"(nx.w.x), "+v"(nx.w.y), "+v"(nx.w.z), "+v"(nx.w.w));      // the next record is consumed before the stores go out
             alive = own_publish<NP>(lane, false, 1u, sgd, T.U, T.msU, T.tailU, woff, (size_t)st.n_users, row, rowk, ver, n_occ, o, own_rd, pn, mn,
-                                    bn, mbn, ctl, spins);
+                                    bn, mbn, ctl, spins, 2u);
 #ifdef TKR_OWN_PROF
             tprev = __builtin_amdgcn_s_memtime();
             prof[9] += t1 - t0; prof[11] += o.t_ack - t1; prof[12] += tprev - o.t_ack; prof[13] += 1;
@@ -701,7 +729,7 @@ extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, co
     int dev = 0;
     TKR_CHECK(hipGetDevice(&dev));
     static int cached_cus[64];
-    static bool attr_set[64][2];
+    static bool attr_set[64][4][2];
     int cus;
     if (dev >= 0 && dev < 64 && cached_cus[dev] > 0) cus = cached_cus[dev];
     else {
@@ -711,29 +739,38 @@ extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, co
     if (n_owner > cus) return TKR_EUNSUPPORTED;                    // every owner must be resident: one workgroup per CU
     const size_t lds = tkr::own_lds_bytes(np, n_batches, st->n_items, n_owner);
     if (lds > 160 * 1024) return TKR_EUNSUPPORTED;
-    const int tpb = np == 1 ? 1024 : 512;
-    const int waves = tpb / TKR_WAVE;
     const uint32_t tune = ((uint32_t)owner_waves >> 8) & 0xffu;     // experiment switches ride in bits 8..15
     owner_waves &= 0xff;
+    const bool wide = np == 1 && (tune & 64u) != 0u;                 // tune bit 6: 16 waves per workgroup (k <= 128: <= 128 registers) instead of 8
+    const bool mid = np == 1 && !wide && (tune & 32u) == 0u;          // k <= 128: 12 waves (<= 168 registers) unless tune bit 5 asks for 8
+    const int tpb = wide ? 1024 : mid ? 768 : 512;
+    const int waves = tpb / TKR_WAVE;
     // one scout, `ow` waves on the owner queue, the rest on user tickets
-    int ow = owner_waves > 0 ? owner_waves : (waves == 16 ? 9 : 4);
+    int ow = owner_waves > 0 ? owner_waves : (waves == 16 ? 9 : waves == 12 ? 9 : 6);
     if (ow < 1) ow = 1;
     if (ow > waves - 2) ow = waves - 2;
-    const void* fn = np == 1 ? (const void*)tkr::bpr_own_kernel<1, 1024> : (const void*)tkr::bpr_own_kernel<2, 512>;
-    if (lds > 64 * 1024 && !(dev >= 0 && dev < 64 && attr_set[dev][np - 1])) {
+    const bool scalar = (tune & 128u) != 0u;                         // tune bit 7: the scalar-exchange form of the item tasks (default: they read rows)
+    const void* fn = np == 1 ? (wide ? (scalar ? (const void*)tkr::bpr_own_kernel<1, 1024, true> : (const void*)tkr::bpr_own_kernel<1, 1024, false>)
+                                : mid ? (scalar ? (const void*)tkr::bpr_own_kernel<1, 768, true> : (const void*)tkr::bpr_own_kernel<1, 768, false>)
+                                     : (scalar ? (const void*)tkr::bpr_own_kernel<1, 512, true> : (const void*)tkr::bpr_own_kernel<1, 512, false>))
+                             : (scalar ? (const void*)tkr::bpr_own_kernel<2, 512, true> : (const void*)tkr::bpr_own_kernel<2, 512, false>);
+    const int variant = np == 2 ? 3 : wide ? 2 : mid ? 1 : 0;
+    if (lds > 64 * 1024 && !(dev >= 0 && dev < 64 && attr_set[dev][variant][scalar])) {
         TKR_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        if (dev >= 0 && dev < 64) attr_set[dev][np - 1] = true;
+        if (dev >= 0 && dev < 64) attr_set[dev][variant][scalar] = true;
     }
     hipStream_t s = (hipStream_t)stream;
     const int4* r4 = reinterpret_cast<const int4*>(prec) + (size_t)first_batch * 3 * batch_size * 8;      // record 0 of the first batch to run
     const int4* o4 = reinterpret_cast<const int4*>(pocc);
     ohdr += first_batch;
-    if (np == 1)
-        hipLaunchKernelGGL((tkr::bpr_own_kernel<1, 1024>), dim3(n_owner), dim3(1024), lds, s, *st, r4, o4, occt, ohdr, ohdr_stride, first_batch,
-                           n_batches, batch_size, n_owner, ow, tune, ctl, loss_out, static_cast<tkr::u64*>(xch), epoch);
-    else
-        hipLaunchKernelGGL((tkr::bpr_own_kernel<2, 512>), dim3(n_owner), dim3(512), lds, s, *st, r4, o4, occt, ohdr, ohdr_stride, first_batch,
-                           n_batches, batch_size, n_owner, ow, tune, ctl, loss_out, static_cast<tkr::u64*>(xch), epoch);
+#define TKR_OWN_LAUNCH(NPV, TPBV, SC)                                                                                                     \
+    hipLaunchKernelGGL((tkr::bpr_own_kernel<NPV, TPBV, SC>), dim3(n_owner), dim3(TPBV), lds, s, *st, r4, o4, occt, ohdr, ohdr_stride, first_batch, \
+                       n_batches, batch_size, n_owner, ow, tune, ctl, loss_out, static_cast<tkr::u64*>(xch), epoch)
+    if (np == 1 && wide) { if (scalar) TKR_OWN_LAUNCH(1, 1024, true); else TKR_OWN_LAUNCH(1, 1024, false); }
+    else if (np == 1 && mid) { if (scalar) TKR_OWN_LAUNCH(1, 768, true); else TKR_OWN_LAUNCH(1, 768, false); }
+    else if (np == 1) { if (scalar) TKR_OWN_LAUNCH(1, 512, true); else TKR_OWN_LAUNCH(1, 512, false); }
+    else { if (scalar) TKR_OWN_LAUNCH(2, 512, true); else TKR_OWN_LAUNCH(2, 512, false); }
+#undef TKR_OWN_LAUNCH
     TKR_LAUNCH_CHECK();
     return TKR_OK;
 }

@@ -204,6 +204,20 @@ __device__ __forceinline__ uint32_t grab_index(uint32_t ticket, int home, uint32
     return idx < total ? (uint32_t)idx : 0xffffffffu;
 }
 
+// Wait until the first granule pair of a row carries `tag`: ONE 16-byte request per poll (every lane the same address) instead of
+// the whole pass a waiting task used to re-issue -- 4 to 16 KB per poll, and a waiting wave that streams costs every other wave's
+// loads their latency (MI355X_MICROARCH.md: a hand-off is 0.8-1.0 us on an idle chip, 2.3-5 us beside 8-15 streaming waves).  `far`:
+// tags that many versions back mean the producer is at least three updates away: sleep through two hand-offs.
+__device__ __forceinline__ bool wait_pair(const u64* row, uint32_t tag, int far, uint32_t* ctl, uint32_t& waited) {
+    const __amdgpu_buffer_rsrc_t r = row_rsrc(row, 16);
+    for (;;) {
+        const v4u p = __builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, kAuxLoad);
+        if (p.y == tag) return true;
+        if ((int)(tag - p.y) >= far) __builtin_amdgcn_s_sleep(127);
+        if (spin_fail(waited, ctl, 4)) return false;
+    }
+}
+
 // Where a wave's next task comes from.  TicketSrc: the ticket taken before the current task's loads is back by the time their
 // first pass has been waited for; its record is asked for now and lands while the current task validates, waits and computes.
 struct TicketSrc {
@@ -316,8 +330,29 @@ __device__ __forceinline__ bool flow_fetch(const tkr_flow_state& st, const FlowT
         // four): the tag of the version before means the producer is one or two updates away (poll), an older one at least three
         // -- two whole hand-offs: sleep through that (a waiting wave that polls costs everybody's loads latency, a sleeping one
         // nothing)
-        bool far = false;
         const int far_items = 2 * (int)(T.imask + 1u);
+        if (!(T.tune & 64u)) {                       // (tune bit 6: the old way, every pass re-issues everything)
+            // which partner row is not there yet?  Poll ITS first pair until it is, then take the pass again
+            int mq = -1;
+            bool mb = false;
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                const int src = (q < n) ? q : 0;
+                const uint32_t va = (uint32_t)bcast_i(d.y, src), vb = (uint32_t)bcast_i(d.w, src);
+                const bool ra = __all(row_tagged<NP>(xa[q], va) && xta[q].y == va), rb = __all(row_tagged<NP>(xb[q], vb) && xtb[q].y == vb);
+                if (mq < 0 && !ra) { mq = q; mb = false; }
+                if (mq < 0 && !rb) { mq = q; mb = true; }
+            }
+            if (mq >= 0) {
+                const uint32_t id = (uint32_t)(mb ? bcast_i(d.z, mq) & 0x3fffffff : bcast_i(d.x, mq));
+                const uint32_t ver = (uint32_t)(mb ? bcast_i(d.w, mq) : bcast_i(d.y, mq));
+                const bool is_user = ITEM && !mb;
+                const u64* row = is_user ? T.U + (ver & 1u) * T.ustride + (size_t)id * T.kp : T.V + (ver & T.imask) * T.istride + (size_t)id * T.kp;
+                if (!wait_pair(row, ver, is_user ? 4 : far_items, ctl, waited)) return false;
+                continue;
+            }
+        }
+        bool far = false;
         if (!(T.tune & 2u)) {
 #pragma unroll
             for (int q = 0; q < G; ++q) {
