@@ -212,6 +212,15 @@ def timed_run(eng, csr, B, steps, warmup, sync_every, world, names=None, loop=No
     return wall, step_ms, loop
 
 
+def step_kernel(eng, B):
+    """(kernel symbol, C-ABI entry, profile key) of the step that runs batch size B on this engine"""
+    if eng.layout != 'flow':
+        return 'tkr::bpr_step_kernel', 'K2 tkr_bpr_run', 'bpr_step_B%d' % B
+    if eng._plan_owners(B):
+        return 'tkr::bpr_own_kernel', 'K2o tkr_bpr_own_run', 'bpr_own_B%d' % B
+    return 'tkr::bpr_flow_kernel', 'K2f tkr_bpr_flow_run', 'bpr_flow_B%d' % B
+
+
 def max_over_ranks(x, device, world):
     if world == 1:
         return x
@@ -236,10 +245,10 @@ def epoch_mode(eng, csr, B, k, world, device, loop, epochs=2):
            'unit': 'triplets/s', 'ms_per_step': wall * 1e3 / (epochs * per), 'ms_per_epoch': wall * 1e3 / epochs,
            'timed_region': 'per batch: K1 (draw + plan) and the step; per epoch: the exchange of the item tables' if world > 1
                            else 'per batch: K1 (draw + plan, side stream behind the previous chunk) and the step',
-           'roofline': {'kernel': 'tkr::bpr_flow_kernel' if eng.layout == 'flow' else 'tkr::bpr_step_kernel', 'bound': 'hbm', 'achieved': gbs,
+           'roofline': {'kernel': step_kernel(eng, B)[0], 'bound': 'hbm', 'achieved': gbs,
                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'launch_us': us,
                         'algorithmic_bytes_per_launch': B * algorithmic_bytes_per_triplet(k), 'traffic': None,
-                        'traffic_from_profile': pmc_traffic('bpr_flow_B%d' % B) if (k == 128 and eng.layout == 'flow') else None}}
+                        'traffic_from_profile': pmc_traffic(step_kernel(eng, B)[2]) if (k == 128 and eng.layout == 'flow') else None}}
     if loop.isync is not None:
         t = loop.isync.timing
         loop.isync.timing = None
@@ -576,7 +585,7 @@ def main():
                    'batch_size': B, 'k': k, 'sharding': 'users sharded over %d GPU(s), item tables replicated, '
                                                         'all-reduce every %d steps' % (world, sync_every) if world > 1 else 'single GPU'},
         'timed_region': {'per_batch': ['K1 tkr_sample_plan: (u,i,j) draw + plan of the timed batches (planned inside the region: nothing is left over '
-                                       'from the warm-up)', 'K2f tkr_bpr_flow_run' if eng.layout == 'flow' else 'K2 tkr_bpr_run'],
+                                       'from the warm-up)', step_kernel(eng, B)[1]],
                          'exchanges_inside': loop_timed_exchanges,
                          'exchange_share_charged': share, 'exchange_ms_charged_each': exch_ms,
                          'raw': {'wall_ms': raw_wall * 1e3, 'value': world * args.steps * B / raw_wall,
@@ -584,10 +593,10 @@ def main():
                          'note': 'exactly --steps batches; at N > 1 the exchange keeps its per-epoch cadence (every %d batches, counted from the first '
                                  'warm-up batch); value = triplets / (timed wall + (steps / %d - exchanges inside) x the exchange wall measured over '
                                  'whole epochs in epoch_mode): the all-reduce is inside the metric as SURVEY 8d defines it' % (sync_every, sync_every)},
-        'roofline': {'kernel': 'tkr::bpr_flow_kernel (one persistent launch per chunk of batches)' if eng.layout == 'flow' else 'tkr::bpr_step_kernel',
+        'roofline': {'kernel': step_kernel(eng, B)[0] + (' (one persistent launch per chunk of batches)' if eng.layout == 'flow' else ''),
                      'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                     'traffic_from_profile': pmc_traffic('bpr_step_B%d' % B) if (k == 128 and args.shape == 'ml10m') else None,
+                     'traffic_from_profile': pmc_traffic(step_kernel(eng, B)[2]) if (k == 128 and args.shape == 'ml10m') else None,
                      'launch_us': launch_us,          # per BATCH: the persistent kernel's launch covers many batches, duration / batches
                      'algorithmic_bytes_per_launch': B * algorithmic_bytes_per_triplet(k)},
     }

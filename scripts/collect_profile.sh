@@ -8,7 +8,7 @@
 #   driver           HIP API + kernel trace of the round-end driver's exact command (--steps 20 --warmup 5): what the timed region calls
 # Output: gpurun_out/prof_<tag>/...; summarise afterwards with `python scripts/summarize_profile.py gpurun_out/prof_<tag> <tag>`.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

@@ -3,7 +3,7 @@ under profiles/: <round>_bench_kernel_stats.csv, <round>_kernel_summary.csv, <ro
 import csv, json, os, re, sys
 import pandas as pd
 src, tag = sys.argv[1], sys.argv[2]
-KERN = ('bpr_flow_kernel', 'bpr_step_kernel', 'sample_plan_kernel', 'resolve_flow_kernel', 'resolve_kernel', 'commit_kernel', 'rollback_kernel',
+KERN = ('bpr_own_kernel', 'bpr_flow_kernel', 'bpr_step_kernel', 'sample_plan_kernel', 'resolve_flow_kernel', 'resolve_kernel', 'commit_kernel', 'rollback_kernel',
         'big_draw_kernel', 'big_flag_kernel', 'big_emit_kernel', 'big_count_kernel', 'big_fill_kernel', 'big_parity_kernel', 'big_record_kernel',
         'DeviceRadixSort', 'radix_sort', 'DeviceScan', 'scan', 'vbpr_pair_kernel', 'score_topk_bf16_kernel', 'score_topk_kernel', 'merge_topk_kernel', 'topk_bounds_kernel',
         'raw_rank_kernel', 'count_hits_rr_kernel',
@@ -54,14 +54,14 @@ res = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
 def total(tagdir, pat):
     f, w = counter(tagdir, 'FETCH_SIZE', pat), counter(tagdir, 'WRITE_SIZE', pat)
     return float(f.Counter_Value.sum()) * 1024 * fr, float(w.Counter_Value.sum()) * 1024 * fw, len(f)
-rd, wr, n = total('headline', 'bpr_flow_kernel')
+rd, wr, n = total('headline', 'bpr_own_kernel|bpr_flow_kernel')      # the persistent step: K2o where the item table fits the CUs' LDS, else K2f
 batches = 2048 + 256
 batches += (3906 - batches % 3906) % 3906 + 2 * 3906          # bench.py's epoch_mode leg of the same process: to the epoch boundary, then two reference epochs
 res['bpr_flow_B256'] = {'launches': n, 'batches': batches, 'hbm_read_bytes_per_batch': rd / batches, 'hbm_write_bytes_per_batch': wr / batches,
                         'hbm_bytes_per_launch_corrected': (rd + wr) / batches,
                         'note': 'per BATCH (a launch of the persistent kernel covers up to 512 batches); algorithmic 1,587,200 B; the granule '
                                 'tables move 8 bytes per fp32 (value + version tag)'}
-res['bpr_step_B256'] = res['bpr_flow_B256']          # the key bench.py looks up for the headline
+res['bpr_step_B256'] = res['bpr_own_B256'] = res['bpr_flow_B256']          # the keys bench.py looks up for the headline
 rd, wr, n = total('b8192', 'bpr_step_kernel')
 res['bpr_step_B8192'] = {'launches': n, 'hbm_bytes_per_launch_corrected': (rd + wr) / max(n, 1), 'hbm_read_bytes_per_launch': rd / max(n, 1),
                          'hbm_write_bytes_per_launch': wr / max(n, 1)}
@@ -96,7 +96,7 @@ try:
     shutil.copy(os.path.join(src, 'driver_cmd.json'), 'profiles/%s_driver_cmd.json' % tag)
     ht = pd.read_csv(find('driver', 'd_hip_api_trace.csv*'))
     kt = pd.read_csv(find('driver', 'd_kernel_trace.csv*'))
-    flow = kt[kt.Kernel_Name.str.contains('bpr_flow_kernel')].sort_values('Start_Timestamp')
+    flow = kt[kt.Kernel_Name.str.contains('bpr_own_kernel|bpr_flow_kernel')].sort_values('Start_Timestamp')
     last = flow.iloc[1]                                             # warm-up (5 batches), then the timed 20 batches; the epoch_mode leg follows
     prev_end = flow.iloc[0].End_Timestamp
     win = ht[(ht.Start_Timestamp > prev_end) & (ht.Start_Timestamp < last.End_Timestamp)]

@@ -604,7 +604,14 @@ class BprEngine(PlanMixin):
             return 0
         n = getattr(self, '_owners', None)
         if n is None:                                  # once per engine: a property of the device and the table shape
-            n = self._owners = tkr_hip.bpr_own_owners(self.n_items, self.k, self.device)
+            n = tkr_hip.bpr_own_owners(self.n_items, self.k, self.device)
+            # K2o wants one workgroup of 12 waves on EVERY CU: two processes on one GPU (the multi-rank tests of a one-GPU box, a
+            # launcher that packs ranks) cannot both have that -- K2f (4 waves per CU) shares.  TKR_OWN=2 overrides.
+            import torch.distributed as tdist
+            if (n and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > torch.cuda.device_count()
+                    and __import__('os').environ.get('TKR_OWN', '1') != '2'):
+                n = 0
+            self._owners = n
         return n
 
     def wants_flow(self, B):
