@@ -526,7 +526,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3906 * 2)          # two reference epochs (10^6 // 256 batches each)
-    ap.add_argument('--warmup', type=int, default=512)
+    ap.add_argument('--warmup', type=int, default=1536)             # three chunks: both plan buffers and the side stream have been through a full cycle
     ap.add_argument('--batch-size', type=int, default=256)          # train.py / single/bpr.py:103 default
     ap.add_argument('--k', type=int, default=128)
     ap.add_argument('--shape', default='ml10m', choices=['ml10m', 'netflix'])

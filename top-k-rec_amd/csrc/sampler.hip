@@ -336,9 +336,9 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_flow_kernel(
     int B, const int4* __restrict__ task_all, const int2* __restrict__ occ_all, const int32_t* __restrict__ ucnt,
     const int32_t* __restrict__ icnt, const uint32_t* __restrict__ touch_u, const uint32_t* __restrict__ touch_i,
     int4* __restrict__ pocc_all, int4* __restrict__ prec_all, int n_owner, int32_t* __restrict__ ohdr, int ohdr_stride,
-    const int32_t* __restrict__ occt_all) {
+    const int32_t* __restrict__ occt_all, int own_words /*32-row words of an owner's bitmap: ceil(ceil(n_items / n_owner) / 32)*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_first_item, s_end, s_wave[kPlanThreads / TKR_WAVE];
+    __shared__ int s_first_item, s_wave[kPlanThreads / TKR_WAVE];
     const int b = blockIdx.x;
     const int4* task = task_all + (size_t)b * 3 * B;
     const int2* occ = occ_all + (size_t)b * 3 * B;
@@ -354,35 +354,32 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_flow_kernel(
         pocc[B + p] = make_int4(o.x, version_of(ucnt, touch_u, o.x, b), o.y,
                                 version_of(icnt, touch_i, o.y & 0x3fffffff, b));
     }
-    // ---- owner order of the item tasks: slot of item task q (q-th in row order) = first item slot + its rank by (owner, row)
-    uint16_t* own_of = reinterpret_cast<uint16_t*>(smem);                              // [2B]
-    uint32_t* own_cnt = reinterpret_cast<uint32_t*>(smem + (((size_t)4 * B + 15) & ~(size_t)15));   // [n_owner] tasks, then first rank
-    int first_item = 0, n_item = 0;
+    // ---- owner order of the item tasks: slot of an item task = first item slot + its rank by (owner, row).  Every owner keeps a
+    // bitmap of the rows it meets in this batch (row = owner + n_owner * bit): the rank inside an owner is a popcount below the
+    // row's bit -- the same whatever the order in which the tasks set their bits -- and the owners' first ranks a scan of the counts.
+    uint32_t* own_mask = reinterpret_cast<uint32_t*>(smem);                            // [n_owner][own_words]
+    uint32_t* own_start = own_mask + (size_t)n_owner * own_words;                      // [n_owner]
+    int first_item = 0;
     if (n_owner > 0) {
-        if (threadIdx.x == 0) { s_first_item = 3 * B; s_end = 0; }
-        for (int w = threadIdx.x; w < n_owner; w += kPlanThreads) own_cnt[w] = 0u;
+        if (threadIdx.x == 0) s_first_item = 3 * B;
+        for (int w = threadIdx.x; w < n_owner * own_words; w += kPlanThreads) own_mask[w] = 0u;
         __syncthreads();
         for (int s = threadIdx.x; s < 3 * B; s += kPlanThreads) {   // tasks are [users][items][-1 ...]
             const int x = task[s].x;
             if (x < 0 && x != -1) {
                 if (s == 0 || task[s - 1].x >= 0) s_first_item = s;
-                if (s == 3 * B - 1 || task[s + 1].x == -1) s_end = s + 1;
+                const int row = x & 0x7fffffff, bit = row / n_owner;
+                atomicOr(&own_mask[(size_t)(row % n_owner) * own_words + (bit >> 5)], 1u << (bit & 31));
             }
         }
         __syncthreads();
         first_item = s_first_item;
-        n_item = s_end - first_item;
-        for (int q = threadIdx.x; q < n_item; q += kPlanThreads) {
-            const int w = (task[first_item + q].x & 0x7fffffff) % n_owner;
-            own_of[q] = (uint16_t)w;
-            atomicAdd(&own_cnt[w], 1u);                             // a count: the same whatever the order of arrival
-        }
-        __syncthreads();
         // exclusive scan of the counts over the owners (each thread a run of consecutive owners), header words on the way
         const int per = (n_owner + kPlanThreads - 1) / kPlanThreads;
         const int w0 = min((int)threadIdx.x * per, n_owner), w1 = min(w0 + per, n_owner);
         int mine = 0;
-        for (int w = w0; w < w1; ++w) mine += (int)own_cnt[w];
+        for (int w = w0; w < w1; ++w)
+            for (int j = 0; j < own_words; ++j) mine += __popc(own_mask[(size_t)w * own_words + j]);
         const int lane = threadIdx.x & (TKR_WAVE - 1), wave = threadIdx.x / TKR_WAVE;
         int incl = mine;
 #pragma unroll
@@ -395,9 +392,10 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_flow_kernel(
         int run = incl - mine;
         for (int w = 0; w < wave; ++w) run += s_wave[w];
         for (int w = w0; w < w1; ++w) {
-            const int c = (int)own_cnt[w];
+            int c = 0;
+            for (int j = 0; j < own_words; ++j) c += __popc(own_mask[(size_t)w * own_words + j]);
             ohdr[(size_t)w * ohdr_stride + b] = (first_item + run) | (c << 16);
-            own_cnt[w] = (uint32_t)run;
+            own_start[w] = (uint32_t)run;
             run += c;
         }
     }
@@ -406,12 +404,12 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_flow_kernel(
     for (int s = threadIdx.x; s < 3 * B; s += kPlanThreads) {
         const int4 t = task[s];
         int dst = s;
-        if (n_owner > 0 && t.x < 0 && t.x != -1) {                   // rank among the tasks of the same owner: those before it in row order
-            const int q = s - first_item;
-            const uint16_t w = own_of[q];
-            int before = 0;
-            for (int e = 0; e < q; ++e) before += own_of[e] == w;
-            dst = first_item + (int)own_cnt[w] + before;
+        if (n_owner > 0 && t.x < 0 && t.x != -1) {                   // rank inside its owner: the rows of that owner below this one
+            const int row = t.x & 0x7fffffff, w = row % n_owner, bit = row / n_owner;
+            const uint32_t* m = own_mask + (size_t)w * own_words;
+            int before = __popc(m[bit >> 5] & ((1u << (bit & 31)) - 1u));
+            for (int j = 0; j < (bit >> 5); ++j) before += __popc(m[j]);
+            dst = first_item + (int)own_start[w] + before;
         }
         int4* r = prec + (size_t)dst * 8;
         if (t.x == -1) {
@@ -493,7 +491,8 @@ static int sample_plan_impl(const int32_t* tr_users, int32_t n_tr, const int32_t
                                int32_t* occt, int32_t* tpar, int32_t* prec, int32_t* pocc, void* workspace,
                                int64_t workspace_bytes, int32_t n_owner, int32_t* ohdr, int32_t ohdr_stride, void* stream) {
     if (n_owner < 0 || n_owner > 65535 || (n_owner > 0 && (!prec || !ohdr || ohdr_stride < n_batches))) return TKR_EINVAL;
-    if (n_owner > 0 && batch_size > 1024) return TKR_EUNSUPPORTED;      // the owner order is ranked by a walk over a batch's item tasks
+    const int own_words = n_owner > 0 ? ((n_items + n_owner - 1) / n_owner + 31) / 32 : 0;
+    if (n_owner > 0 && (size_t)4 * n_owner * (own_words + 1) > 60 * 1024) return TKR_EUNSUPPORTED;      // the owners' row bitmaps live in LDS
     if (n_tr <= 0 || n_items <= 0 || n_users <= 0 || batch_size <= 0 || n_batches < 0) return TKR_EINVAL;
     if (n_users >= (1 << 30) || n_items >= (1 << 30)) return TKR_EUNSUPPORTED;   // id bits 30/31 carry flags
     if (n_batches > 32 * tkr::kTouchWords) return TKR_EUNSUPPORTED;
@@ -544,9 +543,9 @@ static int sample_plan_impl(const int32_t* tr_users, int32_t n_tr, const int32_t
     TKR_LAUNCH_CHECK();
     if (flow)
         hipLaunchKernelGGL(tkr::resolve_flow_kernel, dim3(n_batches), dim3(tkr::kPlanThreads),
-                           n_owner > 0 ? (((size_t)4 * batch_size + 15) & ~(size_t)15) + (size_t)4 * n_owner : 0, s, batch_size,
+                           n_owner > 0 ? (size_t)4 * n_owner * (own_words + 1) : 0, s, batch_size,
                            reinterpret_cast<const int4*>(task), reinterpret_cast<const int2*>(occ), ucnt, icnt, touch_u,
-                           touch_i, reinterpret_cast<int4*>(pocc), reinterpret_cast<int4*>(prec), n_owner, ohdr, ohdr_stride, occt);
+                           touch_i, reinterpret_cast<int4*>(pocc), reinterpret_cast<int4*>(prec), n_owner, ohdr, ohdr_stride, occt, own_words);
     else
         hipLaunchKernelGGL(tkr::resolve_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), 0, s, batch_size,
                            tkr_plan_max_blocks(batch_size) * tkr::team_for(batch_size), reinterpret_cast<int4*>(task),
