@@ -474,7 +474,7 @@ def vbpr_bench(r, csr, k, device, B=256, d=20000, steps=256, warmup=32):
     return res
 
 
-def netflix_train_bench(k, device, B=256, steps=2048, warmup=512):
+def netflix_train_bench(k, device, B=256, steps=4096, warmup=1536):
     """BASELINE.json configs[3] shape on ONE GPU (the 8-GPU run shards these users): 480,189 users x 17,770 items, ~3.5e7
     train positives generated straight as CSR (synth.train_csr_shape), BPR defaults, batch 256"""
     import synth
@@ -490,8 +490,8 @@ def netflix_train_bench(k, device, B=256, steps=2048, warmup=512):
     return {'value': steps * B / wall, 'unit': 'triplets/s', 'steps': steps, 'ms_per_step': wall * 1e3 / steps,
             'config': {'workload': 'BPR Netflix shape (%d users x %d items, %d train positives), k=%d, batch_size=%d, one GPU'
                                    % (n_users, n_items, int(row_ptr[-1]), k, B)},
-            'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'launch_us': us,
-                         'traffic': None}}
+            'roofline': {'kernel': step_kernel(eng, B)[0], 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': gbs / HBM_PEAK_GBS, 'launch_us': us, 'traffic': None}}
 
 
 def topk_cpu_baseline(r, k, K=30, budget_s=12.0, slice_users=2000):

@@ -324,32 +324,47 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
 // ITEM tasks are laid out in (owner, row) order instead of row order -- still the slots [users, users + items) of the batch, the
 // order of tasks inside a batch means nothing to the step -- and ohdr[owner * ohdr_stride + batch] = first slot | tasks << 16
 // names every owner's run.
-__device__ __forceinline__ int prev_batch_of(const uint32_t* __restrict__ touch, int row, int batch) {
-    const uint32_t* w = touch + (size_t)row * kTouchWords;
-    int q = batch >> 5;
-    uint32_t bits = w[q] & ((1u << (batch & 31)) - 1u);
-    while (bits == 0u && q > 0) bits = w[--q];
-    return bits ? q * 32 + 31 - __clz(bits) : -1;
+// version of `row` at `batch` (as version_of) and the last batch < `batch` of this call that touched it (-1: none), from ONE
+// round trip: the row's 16 bitmap words as four 16-byte loads (a walk down the words was up to 16 DEPENDENT loads per task: the
+// planner of a 512-batch chunk took 1.08 ms beside the persistent step instead of 0.07)
+__device__ __forceinline__ void row_history(const int32_t* __restrict__ cnt, const uint32_t* __restrict__ touch, int row, int batch, int& ver,
+                                            int& prev) {
+    const uint4* w4 = reinterpret_cast<const uint4*>(touch + (size_t)row * kTouchWords);
+    const uint4 a = w4[0], b = w4[1], c = w4[2], d = w4[3];
+    const uint32_t w[kTouchWords] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    static_assert(kTouchWords == 16, "four uint4 per row");
+    const int full = batch >> 5;
+    const uint32_t below = (1u << (batch & 31)) - 1u;
+    int v = cnt[row], p = -1;
+#pragma unroll
+    for (int q = 0; q < kTouchWords; ++q) {
+        const uint32_t bits = q < full ? w[q] : q == full ? (w[q] & below) : 0u;
+        v += __popc(bits);
+        if (bits) p = q * 32 + 31 - __clz(bits);
+    }
+    ver = v;
+    prev = p;
 }
 
-__global__ __launch_bounds__(kPlanThreads) void resolve_flow_kernel(
+template <int T>
+__global__ __launch_bounds__(T) void resolve_flow_kernel(
     int B, const int4* __restrict__ task_all, const int2* __restrict__ occ_all, const int32_t* __restrict__ ucnt,
     const int32_t* __restrict__ icnt, const uint32_t* __restrict__ touch_u, const uint32_t* __restrict__ touch_i,
     int4* __restrict__ pocc_all, int4* __restrict__ prec_all, int n_owner, int32_t* __restrict__ ohdr, int ohdr_stride,
     const int32_t* __restrict__ occt_all, int own_words /*32-row words of an owner's bitmap: ceil(ceil(n_items / n_owner) / 32)*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_first_item, s_wave[kPlanThreads / TKR_WAVE];
+    __shared__ int s_first_item, s_wave[T / TKR_WAVE];
     const int b = blockIdx.x;
     const int4* task = task_all + (size_t)b * 3 * B;
     const int2* occ = occ_all + (size_t)b * 3 * B;
     int4* pocc = pocc_all + (size_t)b * 3 * B;
     int4* prec = prec_all + (size_t)b * 3 * B * 8;
 
-    for (int p = threadIdx.x; p < B; p += kPlanThreads) {           // user occurrences: (i, j)
+    for (int p = threadIdx.x; p < B; p += T) {           // user occurrences: (i, j)
         const int2 o = occ[p];
         pocc[p] = make_int4(o.x, version_of(icnt, touch_i, o.x, b), o.y, version_of(icnt, touch_i, o.y, b));
     }
-    for (int p = threadIdx.x; p < 2 * B; p += kPlanThreads) {       // item occurrences: (u, other|role<<31)
+    for (int p = threadIdx.x; p < 2 * B; p += T) {       // item occurrences: (u, other|role<<31)
         const int2 o = occ[B + p];
         pocc[B + p] = make_int4(o.x, version_of(ucnt, touch_u, o.x, b), o.y,
                                 version_of(icnt, touch_i, o.y & 0x3fffffff, b));
@@ -362,9 +377,9 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_flow_kernel(
     int first_item = 0;
     if (n_owner > 0) {
         if (threadIdx.x == 0) s_first_item = 3 * B;
-        for (int w = threadIdx.x; w < n_owner * own_words; w += kPlanThreads) own_mask[w] = 0u;
+        for (int w = threadIdx.x; w < n_owner * own_words; w += T) own_mask[w] = 0u;
         __syncthreads();
-        for (int s = threadIdx.x; s < 3 * B; s += kPlanThreads) {   // tasks are [users][items][-1 ...]
+        for (int s = threadIdx.x; s < 3 * B; s += T) {   // tasks are [users][items][-1 ...]
             const int x = task[s].x;
             if (x < 0 && x != -1) {
                 if (s == 0 || task[s - 1].x >= 0) s_first_item = s;
@@ -375,7 +390,7 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_flow_kernel(
         __syncthreads();
         first_item = s_first_item;
         // exclusive scan of the counts over the owners (each thread a run of consecutive owners), header words on the way
-        const int per = (n_owner + kPlanThreads - 1) / kPlanThreads;
+        const int per = (n_owner + T - 1) / T;
         const int w0 = min((int)threadIdx.x * per, n_owner), w1 = min(w0 + per, n_owner);
         int mine = 0;
         for (int w = w0; w < w1; ++w)
@@ -401,7 +416,7 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_flow_kernel(
     }
     __threadfence_block();
     __syncthreads();
-    for (int s = threadIdx.x; s < 3 * B; s += kPlanThreads) {
+    for (int s = threadIdx.x; s < 3 * B; s += T) {
         const int4 t = task[s];
         int dst = s;
         if (n_owner > 0 && t.x < 0 && t.x != -1) {                   // rank inside its owner: the rows of that owner below this one
@@ -419,8 +434,9 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_flow_kernel(
             continue;
         }
         const int row = t.x & 0x7fffffff;
-        const int ver = (t.x < 0) ? version_of(icnt, touch_i, row, b) : version_of(ucnt, touch_u, row, b);
-        const int prev = (t.x < 0) ? prev_batch_of(touch_i, row, b) : prev_batch_of(touch_u, row, b);
+        int ver, prev;
+        if (t.x < 0) row_history(icnt, touch_i, row, b, ver, prev);
+        else row_history(ucnt, touch_u, row, b, ver, prev);
         r[0] = make_int4(t.x, ver, t.z, b * 3 * B + t.y);
         r[1] = make_int4(b, prev, 0, 0);
 #pragma unroll
@@ -541,8 +557,13 @@ static int sample_plan_impl(const int32_t* tr_users, int32_t n_tr, const int32_t
                            reinterpret_cast<int2*>(occ), occt, touch_u, touch_i);
     }
     TKR_LAUNCH_CHECK();
-    if (flow)
-        hipLaunchKernelGGL(tkr::resolve_flow_kernel, dim3(n_batches), dim3(tkr::kPlanThreads),
+    if (flow && 3 * batch_size > 2 * tkr::kPlanThreads)         // one slot per thread: a short call is the latency of this kernel's dependent loads
+        hipLaunchKernelGGL(tkr::resolve_flow_kernel<1024>, dim3(n_batches), dim3(1024),
+                           n_owner > 0 ? (size_t)4 * n_owner * (own_words + 1) : 0, s, batch_size,
+                           reinterpret_cast<const int4*>(task), reinterpret_cast<const int2*>(occ), ucnt, icnt, touch_u,
+                           touch_i, reinterpret_cast<int4*>(pocc), reinterpret_cast<int4*>(prec), n_owner, ohdr, ohdr_stride, occt, own_words);
+    else if (flow)
+        hipLaunchKernelGGL(tkr::resolve_flow_kernel<tkr::kPlanThreads>, dim3(n_batches), dim3(tkr::kPlanThreads),
                            n_owner > 0 ? (size_t)4 * n_owner * (own_words + 1) : 0, s, batch_size,
                            reinterpret_cast<const int4*>(task), reinterpret_cast<const int2*>(occ), ucnt, icnt, touch_u,
                            touch_i, reinterpret_cast<int4*>(pocc), reinterpret_cast<int4*>(prec), n_owner, ohdr, ohdr_stride, occt, own_words);
