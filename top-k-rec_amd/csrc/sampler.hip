@@ -557,12 +557,10 @@ static int sample_plan_impl(const int32_t* tr_users, int32_t n_tr, const int32_t
                            reinterpret_cast<int2*>(occ), occt, touch_u, touch_i);
     }
     TKR_LAUNCH_CHECK();
-    if (flow && 3 * batch_size > 2 * tkr::kPlanThreads)         // one slot per thread: a short call is the latency of this kernel's dependent loads
-        hipLaunchKernelGGL(tkr::resolve_flow_kernel<1024>, dim3(n_batches), dim3(1024),
-                           n_owner > 0 ? (size_t)4 * n_owner * (own_words + 1) : 0, s, batch_size,
-                           reinterpret_cast<const int4*>(task), reinterpret_cast<const int2*>(occ), ucnt, icnt, touch_u,
-                           touch_i, reinterpret_cast<int4*>(pocc), reinterpret_cast<int4*>(prec), n_owner, ohdr, ohdr_stride, occt, own_words);
-    else if (flow)
+    // (256 threads: a 1024-thread workgroup does not fit beside the persistent step's 12 waves per CU -- 4 waves per SIMD against the
+    // one that its registers leave -- and the planner of the next chunk then waits for the running chunk to END: measured 1.06 ms per
+    // launch of this kernel in the profiled bench, -2 % on the steady state)
+    if (flow)
         hipLaunchKernelGGL(tkr::resolve_flow_kernel<tkr::kPlanThreads>, dim3(n_batches), dim3(tkr::kPlanThreads),
                            n_owner > 0 ? (size_t)4 * n_owner * (own_words + 1) : 0, s, batch_size,
                            reinterpret_cast<const int4*>(task), reinterpret_cast<const int2*>(occ), ucnt, icnt, touch_u,
