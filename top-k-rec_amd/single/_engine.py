@@ -492,9 +492,9 @@ def _generators(device, seed, user_seed):
 FLOW_MAX_BATCH = int(__import__('os').environ.get('TKR_FLOW_MAX_BATCH', 512))     # batch sizes up to this take the persistent dataflow step (K2f);
                                    # measured per batch, K2f vs K2: 64: 1.3 vs 3.9 us, 128: 1.8 vs 4.1, 256: 2.6 vs 4.5, 512: 5.1 vs 5.2, 1024: 8.8 vs 6.8
 FLOW_WAVES_PER_CU = int(__import__('os').environ.get('TKR_FLOW_WAVES_PER_CU', 0))    # 0 = the library default
-OWN_MAX_BATCH = int(__import__('os').environ.get('TKR_OWN_MAX_BATCH', 320))    # batch sizes up to this take K2o (item rows owned by one workgroup each, resident
+OWN_MAX_BATCH = int(__import__('os').environ.get('TKR_OWN_MAX_BATCH', 256))    # batch sizes up to this take K2o (item rows owned by one workgroup each, resident
                                    # in its LDS) where the item table fits the CUs' LDS; TKR_OWN=0: always K2f.  Measured per batch, K2o vs K2f (ML-10M
-                                   # shape, same box): 128: 1.32 vs 2.03 us, 256: 2.18 vs 2.75, 512: 6.4 vs 4.07 (two ticket waves per workgroup starve)
+                                   # shape, same box): 64: 0.90 vs 1.47 us, 128: 1.32 vs 2.03, 256: 2.18 vs 2.75, 384: 3.79 vs 3.33, 512: 5.95 vs 3.98 (whatever the wave split)
 OWN_WAVES = int(__import__('os').environ.get('TKR_OWN_WAVES', 0))               # owner waves per workgroup, 0 = the library default
 FLOW_ITEM_BUFS = int(__import__('os').environ.get('TKR_FLOW_ITEM_BUFS', 4))     # buffers per item row of the granule tables (2 or 4; include/tkr.h)
 
