@@ -173,7 +173,14 @@ struct LdsOwnStep {
     uint32_t* ctl;
     uint32_t& spins;
     __device__ __forceinline__ bool operator()(float (&own)[2 * NP], float (&ms)[2 * NP], Own& o) {
+#ifdef TKR_OWN_PROF
+        o.t_own0 = __builtin_amdgcn_s_memtime();
+        const bool ok = item_own_wait<NP>(T, lane, r, sgd, own, ms, o, ctl, spins);
+        o.t_own1 = __builtin_amdgcn_s_memtime();
+        return ok;
+#else
         return item_own_wait<NP>(T, lane, r, sgd, own, ms, o, ctl, spins);
+#endif
     }
 };
 struct NoFeed {
@@ -199,13 +206,25 @@ __device__ __forceinline__ bool item_round(const tkr_flow_state& st, const FlowT
     static_assert(G == 4 || G == 8, "occurrences per round");
     v4u xa[G][NP];
     uint32_t waited = 0;
-    for (;;) {                                    // one pass ISSUES every user row of the round and only then looks at tags
+    // the scalars of this round: the first lane of every group speaks for one occurrence
+    const int myq = lane >> SH;
+    const bool live = (lane & ((1 << SH) - 1)) == 0 && myq < n;
+    const bool role = __shfl(d.z, myq) < 0;                        // this row is the NEGATIVE item of the triplet
+    const int slot = (2 * __shfl(tq, myq) + (role ? 1 : 0)) * 8;   // bytes: granule (triplet, role)
+    const __amdgpu_buffer_rsrc_t xr = row_rsrc(xch_batch, xch_bytes);
+    v2u pvo;                                      // the PARTNER's scalar, asked for together with the user rows: a scout (or the partner
+    pvo.x = 0u; pvo.y = epoch;                    // itself) has usually published it long before this task has its own row, and the round
+    for (;;) {                                    // trip of the poll below would sit on the chain through a popular item.
+        // one pass ISSUES every user row of the round and only then looks at tags
 #pragma unroll
         for (int q = 0; q < G; ++q) {
             const int src = (q < n) ? q : 0;      // straight-line loads: idle slots repeat occurrence 0 (flow_fetch has the reason)
             const int a = bcast_i(d.x, src);
             const uint32_t va = (uint32_t)bcast_i(d.y, src);
             issue_row<NP>(T.U + (va & 1u) * T.ustride + (size_t)a * T.kp, lane, xa[q]);
+        }
+        if constexpr (MODE == kFull) {
+            if (live) pvo = __builtin_amdgcn_raw_buffer_load_b64(xr, slot ^ 8, 0, kAuxLoad);
         }
         bool lane_ok = true, far = false;
 #pragma unroll
@@ -246,24 +265,19 @@ __device__ __forceinline__ bool item_round(const tkr_flow_state& st, const FlowT
         part[q] = q < n ? acc : 0.f;
     }
     const float dme = reduce_multi<G>(part, lane) + o.b;
-    // publish mine, poll the partner's: the first lane of every group, for the occurrence it speaks for
-    const int myq = lane >> SH;
-    const bool live = (lane & ((1 << SH) - 1)) == 0 && myq < n;
-    const bool role = __shfl(d.z, myq) < 0;                        // this row is the NEGATIVE item of the triplet
-    const int slot = (2 * __shfl(tq, myq) + (role ? 1 : 0)) * 8;   // bytes: granule (triplet, role)
-    const __amdgpu_buffer_rsrc_t xr = row_rsrc(xch_batch, xch_bytes);
+    // publish mine; poll the partner's only where the early load did not find it
     if (live) {
         v2u pv;
         pv.x = __float_as_uint(dme); pv.y = epoch;
         __builtin_amdgcn_raw_buffer_store_b64(pv, xr, slot, 0, kAuxStore);
     }
     if constexpr (MODE != kFull) return true;
-    float dother = 0.f;
+    float dother = __uint_as_float(pvo.x);
     waited = 0;
-    for (;;) {
-        v2u pv;
-        pv.x = 0u; pv.y = epoch;
-        if (live) pv = __builtin_amdgcn_raw_buffer_load_b64(xr, slot ^ 8, 0, kAuxLoad);
+    const bool early = __all(pvo.y == epoch);
+    while (!early) {
+        v2u pv = pvo;
+        if (live && pvo.y != epoch) pv = __builtin_amdgcn_raw_buffer_load_b64(xr, slot ^ 8, 0, kAuxLoad);
 #ifdef TKR_OWN_PROF
         if (tune & 4u) pv.y = epoch;              // timing experiment only (wrong results): the partner's scalar is never waited for
 #endif
@@ -602,7 +616,9 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
                                     mn, bn, mbn, ctl, spins, kItemReaders);
 #ifdef TKR_OWN_PROF
             tprev = __builtin_amdgcn_s_memtime();
-            prof[0] += t1 - t0; prof[3] += o.t_ack - t1; prof[4] += tprev - o.t_ack; prof[6] += 1; prof[7] += r.from_lds ? 1 : 0;
+            if constexpr (SCALAR) prof[0] += t1 - t0;
+            else { prof[0] += o.t_own0 - t0; prof[1] += o.t_own1 - o.t_own0; prof[2] += t1 - o.t_own1; }
+            prof[3] += o.t_ack - t1; prof[4] += tprev - o.t_ack; prof[6] += 1; prof[7] += r.from_lds ? 1 : 0;
 #endif
         }
     } else {
