@@ -172,7 +172,7 @@ int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, const int32_
  * other's rows (csrc/bpr_own.hip has the protocol).  User tasks are handed out by tickets as in K2f.
  *   tkr_bpr_own_owners(n_items, k)   n_owner for the current device (its CU count), or 0 when ceil(n_items / CUs) rows of
  *                                    8*kp + 16 bytes do not fit one CU's 160 KB of LDS (use K2f then)
- *   tkr_sample_plan_owned            tkr_sample_plan's dataflow form (prec, pocc; batch_size <= 1024) with the records of every
+ *   tkr_sample_plan_owned            tkr_sample_plan's dataflow form (prec, pocc; batch_size <= 8192) with the records of every
  *                                    batch's ITEM tasks in (row % n_owner, row) order -- same slots -- and
  *                                    ohdr[owner * ohdr_stride + batch] = first slot | tasks << 16 (ohdr_stride >= n_batches).
  *                                    (K2f runs such a plan too: the order of tasks inside a batch means nothing to it.)

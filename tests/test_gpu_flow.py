@@ -374,3 +374,37 @@ def test_fused_exchange_of_the_granule_tables(monkeypatch, bufs):
             eng.V.assign(newV, torch.ones(n_items, k, device=dev))
         sync.begin()
         assert torch.equal(sync.start_flat[:n_items * k].view(n_items, k), newV), how
+
+
+def test_engine_picks_the_persistent_step_by_shape_and_batch():
+    """BprEngine: K2o (owned item rows) up to batch 256 where the item table fits the CUs' LDS, K2f above that batch size and for
+    item tables that do not fit, K2 (plain layout) for large batches -- and every one of them trains the same model"""
+    import tkr_hip
+    from single import _engine
+    dev = torch.device('cuda')
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.02, mode='l2')
+    assert tkr_hip.bpr_own_owners(10380, 128) > 0 and tkr_hip.bpr_own_owners(17770, 128) > 0        # the benchmark shapes fit
+    assert tkr_hip.bpr_own_owners(400000, 128) == 0 and tkr_hip.bpr_own_owners(40000, 256) == 0       # ... these do not: K2f
+    n_users, n_items, k = 900, 300, 64
+    tr, tr_users = _toy(n_users, n_items, seed=4)
+    row_ptr, pos, srt = P.build_csr(tr, n_users)
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
+    eng = _engine.BprEngine(n_users, n_items, k, hp, dev, seed=5)
+    init = {n: eng.get(n)[0].cpu().numpy() for n in ('U', 'V', 'b')}
+    eng.run_batches(csr, 6, 256, want_loss=False)
+    assert eng.layout == 'flow' and eng._plan_owners(256) > 0 and eng.plan.owners > 0          # K2o
+    eng.run_batches(csr, 3, 512, want_loss=False)
+    assert eng.layout == 'flow' and eng._plan_owners(512) == 0 and eng.plan.owners == 0        # K2f
+    eng.run_batches(csr, 4, 128, want_loss=False)
+    assert eng.plan.owners > 0                                                                 # K2o again, same tables
+    eng.check()
+    u, i, j = P.sample_triplets(tr_users, row_ptr, pos, srt, n_items, 5, 0, 6 * 256 + 3 * 512 + 4 * 128)
+    ref = dict(U=init['U'].copy(), V=init['V'].copy(), b=init['b'].copy(), msU=np.ones_like(init['U']), msV=np.ones_like(init['V']),
+               msb=np.ones_like(init['b']))
+    at = 0
+    for nb, B in ((6, 256), (3, 512), (4, 128)):
+        for _ in range(nb):
+            R.bpr_step(ref, u[at:at + B], i[at:at + B], j[at:at + B], hp)
+            at += B
+    for n in ('U', 'V', 'b'):
+        np.testing.assert_allclose(eng.get(n)[0].cpu().numpy(), ref[n], rtol=3e-4, atol=2e-5, err_msg=n)
