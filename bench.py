@@ -616,7 +616,9 @@ def main():
                                   'roofline': {'bound': 'hbm', 'achieved': a2, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                                'frac': a2 / HBM_PEAK_GBS, 'launch_us': s2 * 1e3 / T2,
                                                'traffic': None,
-                                               'traffic_from_profile': pmc_traffic('bpr_step_B8192') if (k == 128 and args.shape == 'ml10m') else None}}
+                                               'traffic_from_profile': pmc_traffic('bpr_step_B8192') if (k == 128 and args.shape == 'ml10m') else None,
+                                               'hbm_utilisation_from_profile': (pmc_traffic('bpr_step_B8192') / (s2 * 1e-3 / T2) / 1e9 / HBM_PEAK_GBS)
+                                               if (k == 128 and args.shape == 'ml10m' and pmc_traffic('bpr_step_B8192')) else None}}
         del eng2
         # batch_size 65,536 and 1,048,576 (planned grid-wide: csrc/planner_big.hip)
         for Bb, Tb in ((65536, 128), (1048576, 8)):
@@ -627,6 +629,10 @@ def main():
                                                'roofline': {'bound': 'hbm', 'achieved': ab, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ab / HBM_PEAK_GBS,
                                                             'launch_us': sb * 1e3 / Tb, 'traffic': None,
                                                             'traffic_from_profile': pmc_traffic('bpr_step_B%d' % Bb) if (k == 128 and args.shape == 'ml10m') else None,
+                                                            # the REAL utilisation: counter bytes of the committed profile over this run's launch time
+                                                            # (duplicate draws of a large batch hit in cache: the algorithmic fraction overstates it)
+                                                            'hbm_utilisation_from_profile': (pmc_traffic('bpr_step_B%d' % Bb) / (sb * 1e-3 / Tb) / 1e9 / HBM_PEAK_GBS)
+                                                            if (k == 128 and args.shape == 'ml10m' and pmc_traffic('bpr_step_B%d' % Bb)) else None,
                                                             'note': 'algorithmic bytes give no credit for in-batch duplicates: %d item draws over %d items'
                                                                     % (2 * Bb, eng.n_items)}}
             del engb
