@@ -408,3 +408,49 @@ def test_engine_picks_the_persistent_step_by_shape_and_batch():
             at += B
     for n in ('U', 'V', 'b'):
         np.testing.assert_allclose(eng.get(n)[0].cpu().numpy(), ref[n], rtol=3e-4, atol=2e-5, err_msg=n)
+
+
+def test_a_timed_out_spin_steps_down_k2o_k2f_k2():
+    """a bounded spin that runs out (injected through the status word) is reported at the next check and moves the engine one step
+    down: K2o (a 12-wave workgroup resident on every CU) -> K2f (4 waves per CU) -> K2 (one launch per batch); the engine stays
+    usable once the caller has put valid tables back (a launch is not transactional)"""
+    import tkr_hip
+    from single import _engine
+    dev = torch.device('cuda')
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.02, mode='l2')
+    n_users, n_items, k = 700, 250, 64
+    tr, tr_users = _toy(n_users, n_items, seed=6)
+    row_ptr, pos, srt = P.build_csr(tr, n_users)
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
+    eng = _engine.BprEngine(n_users, n_items, k, hp, dev, seed=8)
+    keep = {n: [t.clone() for t in eng.get(n)] for n in ('U', 'V', 'b')}
+
+    def restore():
+        eng.set_users(U=keep['U'][0], msU=keep['U'][1])
+        eng.set_items(V=keep['V'][0], b=keep['b'][0], msV=keep['V'][1], msb=keep['b'][1])
+
+    def inject():
+        eng._flow_ran = True
+        eng.ctl[tkr_hip.FLOW_CTL_STATUS] = 1
+        with pytest.raises(tkr_hip.TkrError):
+            eng.check()
+        restore()
+    eng.run_batches(csr, 5, 256, want_loss=False)
+    eng.check()
+    assert eng.layout == 'flow' and eng.plan.owners > 0
+    inject()
+    eng.run_batches(csr, 5, 256, want_loss=False)
+    eng.check()
+    assert eng.layout == 'flow' and eng.plan.owners == 0                 # K2f
+    inject()
+    eng.run_batches(csr, 5, 256, want_loss=False)
+    eng.check()
+    assert eng.layout == 'bulk'                                          # K2
+    # ... and what it trains from the restored tables is the model: against the oracle on the stream the engine drew last
+    ref = dict(U=keep['U'][0].cpu().numpy().copy(), V=keep['V'][0].cpu().numpy().copy(), b=keep['b'][0].cpu().numpy().copy(),
+               msU=keep['U'][1].cpu().numpy().copy(), msV=keep['V'][1].cpu().numpy().copy(), msb=keep['b'][1].cpu().numpy().copy())
+    u, i, j = (eng.plan.u[:5 * 256].cpu().numpy(), eng.plan.i[:5 * 256].cpu().numpy(), eng.plan.j[:5 * 256].cpu().numpy())
+    for q in range(5):
+        R.bpr_step(ref, u[q * 256:(q + 1) * 256], i[q * 256:(q + 1) * 256], j[q * 256:(q + 1) * 256], hp)
+    for n in ('U', 'V', 'b'):
+        np.testing.assert_allclose(eng.get(n)[0].cpu().numpy(), ref[n], rtol=3e-4, atol=2e-5, err_msg=n)

@@ -671,9 +671,17 @@ class BprEngine(PlanMixin):
         # never ends) every later launch would time out the same way.  The tables of THIS run are lost -- a launch is not
         # transactional -- but the engine stays usable: from here on it steps with K2 (one launch per batch, no co-residency
         # assumption), e.g. after the caller re-imports a checkpoint.
-        self._flow_disabled = True
-        raise tkr_hip.TkrError('persistent BPR step gave up waiting for a row version (status %d): tables are invalid; this engine uses the '
-                               'per-batch step (K2) from now on; post-mortem words (csrc/bpr_flow.hip kCtlDebug) %r' % (code, post))
+        # K2o asks for more than K2f -- a 12-wave workgroup resident on EVERY CU: where that is what failed (the GPU is shared), the
+        # next thing to try is K2f (4 waves per CU), and only if that gives up as well the per-batch step.
+        if getattr(self, '_owners', 0):
+            self._owners = 0
+            nxt = 'the persistent step without owned rows (K2f)'
+        else:
+            self._flow_disabled = True
+            nxt = 'the per-batch step (K2)'
+        self._step_key = None
+        raise tkr_hip.TkrError('persistent BPR step gave up waiting for a row version (status %d): tables are invalid; this engine uses %s '
+                               'from now on; post-mortem words (csrc/bpr_flow.hip kCtlDebug) %r' % (code, nxt, post))
 
     def _raise_pending(self):
         ev, self._status_event = self._status_event, None
