@@ -168,8 +168,9 @@ int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, const int32_
  * in the same state as K2f does: the two kernels, the exchange and get / set may be mixed freely between launches.  Item row r is
  * served by workgroup r % n_owner, which keeps the row, its slot, bias and acknowledge totals in LDS from the row's first update
  * in a launch on: the task of batch t+1 finds the row of batch t there instead of polling memory for it (what bounded K2f at
- * batch 256), and the two item tasks of a triplet exchange the scalars <u, v> + b through an 8-byte slot instead of reading each
- * other's rows (csrc/bpr_own.hip has the protocol).  User tasks are handed out by tickets as in K2f.
+ * batch 256).  Partner rows are read from the tables as in K2f; `owner_waves` bit 15 selects the form in which the two item tasks
+ * of a triplet exchange the scalars <u, v> + b through an 8-byte slot of `xch` instead of reading each other's rows (measured
+ * slower: csrc/bpr_own.hip has both protocols and the numbers).  User tasks are handed out by tickets as in K2f.
  *   tkr_bpr_own_owners(n_items, k)   n_owner for the current device (its CU count), or 0 when ceil(n_items / CUs) rows of
  *                                    8*kp + 16 bytes do not fit one CU's 160 KB of LDS (use K2f then)
  *   tkr_sample_plan_owned            tkr_sample_plan's dataflow form (prec, pocc; batch_size <= 8192) with the records of every
@@ -179,11 +180,11 @@ int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, const int32_
  *   tkr_bpr_own_run                  batches [first_batch, first_batch + n_batches) of such a plan in ONE launch of n_owner
  *                                    workgroups (all resident: n_owner <= CUs).  prec / pocc / occt / ohdr / loss_out point at
  *                                    batch 0 of the plan call; owner_waves: waves per workgroup that serve the owner queue, 0 =
- *                                    default (9 of 16 at k <= 128, 4 of 8 above; one more wave is the scout, the rest run user
- *                                    tasks); ctl as for tkr_bpr_flow_run (same words, same status).
+ *                                    default (workgroups of 12 waves at k <= 128: 10 on the owner queue, 2 on user tickets; 8
+ *                                    waves above: 7 + 1; bits 13 / 14: 8 / 16 waves at k <= 128); ctl as for tkr_bpr_flow_run.
  *                                    xch: 16 * batch_size bytes per batch of the plan (the scalar slots {value, epoch} of every
- *                                    (triplet, role)), caller-owned, zeroed once; epoch: a number > 0 that no earlier launch on
- *                                    this xch used (a counter per plan buffer does).
+ *                                    (triplet, role); only the scalar form writes them), caller-owned, zeroed once; epoch: a
+ *                                    number > 0 that no earlier launch on this xch used (a counter per plan buffer does).
  * k <= 256, n_batches <= 512. */
 int32_t tkr_bpr_own_owners(int32_t n_items, int32_t k);
 int tkr_sample_plan_owned(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,

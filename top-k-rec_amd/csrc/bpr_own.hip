@@ -1,39 +1,45 @@
 // K2o -- the persistent BPR step with OWNED item rows (round 4): the tables, versions and acknowledge protocol of K2f
 // (csrc/bpr_flow.hip; sess.run([solver, obj]) of single/bpr.py:141 inside the loop of single/bpr.py:139-147, batch t+1 reads what
-// batch t wrote), with the two dependencies that set K2f's pace taken out of memory.
+// batch t wrote), with the own-row chain that set K2f's pace taken out of memory.
 //
-// (1) The own-row chain.  A popular item is updated in (nearly) every batch; under K2f the task of batch t+1 starts its arithmetic
-//     once the row written by the task of batch t has made the trip write-through store -> memory -> polling load of another CU.  Here
-//     every item row r has an OWNER: the workgroup with arrival number r % n_owner (one workgroup per CU, all resident).  K1 lays
-//     the item tasks of a batch out in (owner, row) order and names every owner's run (tkr_sample_plan_owned: `ohdr`); the owner's
-//     waves take them in plan order from a queue in LDS, and the row, its RMSProp slot, bias and acknowledge totals stay in the
-//     owner's LDS from the row's first update of a launch on: the task of batch t+1 finds what the task of batch t left there --
-//     before that task's acknowledge wait and write-through stores, which now only serve the USER tasks.
-// (2) The item -> item edges.  x_uij = (<u, v_i> + b_i) - (<u, v_j> + b_j) (single/bpr.py:87-89): the task of item i needs the
-//     other item of a triplet only through the scalar <u, v_j> + b_j, which the task of item j computes anyway.  Under K2f (and
-//     the first form of this kernel) it read the whole row v_j at its exact version, through memory -- with the own-row chain in
-//     LDS those edges were the critical path of a batch (measured: 4.6 us of an item task's 8 us waiting for partner rows).  Here
-//     the two item tasks of a triplet never read each other's rows: each publishes d = <u, v_own> + b_own as ONE 8-byte granule
-//     {d, epoch} in the slot of (batch, triplet, role) and polls the partner's slot.  A scalar depends only on its own row's
-//     previous update and the user row, so it can be published EARLY: one wave of every workgroup (the "scout") runs ahead of
-//     the queue's head and publishes the scalars of every task whose rows are final, without waiting for anything.  The chain
-//     through a popular item is then: row from LDS -> dots -> partner scalars (already there) -> update -> row to LDS.  Half the
-//     partner traffic as well: only the user rows are read (one acknowledged reader per occurrence of an item row: the user task).
+// The own-row chain.  A popular item is updated in (nearly) every batch; under K2f the task of batch t+1 starts its arithmetic
+// once the row written by the task of batch t has made the trip write-through store -> memory -> polling load of another CU.  Here
+// every item row r has an OWNER: the workgroup with arrival number r % n_owner (one workgroup per CU, all resident).  K1 lays the
+// item tasks of a batch out in (owner, row) order and names every owner's run (tkr_sample_plan_owned: `ohdr`); the owner's waves
+// take them in plan order from a queue in LDS (one LDS atomic per task), and the row, its RMSProp slot, bias and acknowledge totals
+// stay in the owner's LDS from the row's first update of a launch on: the task of batch t+1 finds what the task of batch t left
+// there -- before that task's acknowledge wait and write-through stores, which now only serve the row's PARTNERS.
+//
+// Two forms of an item task (template parameter SCALAR; `owner_waves` bit 15 of tkr_bpr_own_run):
+//   * row-read (the default): the partner rows of an occurrence -- the user row and the OTHER item's row -- are read from the granule
+//     tables at their exact versions, as in K2f (flow_task.h run_task).  Measured 2.18 us per batch at the ML-10M shape against
+//     2.75 for K2f on the same box.  What bounds it: the item -> item edges, one hand-off through memory per batch.
+//   * scalar exchange: x_uij = (<u, v_i> + b_i) - (<u, v_j> + b_j) (single/bpr.py:87-89), so the task of item i needs the other item of
+//     a triplet only through the scalar <u, v_j> + b_j, which the task of item j computes anyway.  Each publishes d = <u, v_own> +
+//     b_own as ONE 8-byte granule {d, epoch} in the slot of (batch, triplet, role) and reads the partner's slot (asked for together
+//     with the user rows: the partner has usually published before this task has its own row); the two never read each other's rows
+//     (half the partner traffic; one acknowledged reader per occurrence of an item row: the user task).  One wave of every workgroup,
+//     the "scout", runs ahead of the queue's head and publishes the scalars of every task whose rows are final, without waiting for
+//     anything: that is also what keeps the same-batch rendezvous free of deadlock (below).  Measured 2.74 us per batch: the
+//     dependence between the two item tasks of a triplet becomes mutual and same-batch, two hand-offs per batch on the worst path
+//     instead of one.  Kept selectable; every test of tests/test_gpu_flow.py runs both forms.
 //
 // User tasks are handed out by tickets as in K2f, to the remaining waves of every workgroup.  The granule tables are written
 // through at every update exactly as by K2f, so a launch leaves them complete (get / set, the exchange of csrc/sync.hip, a K2f
-// launch on a plan of its own all work on the same state), and a chunk may be cut into launches anywhere: a task whose row was
-// not yet updated in THIS launch (prec[5] < first batch of the launch) loads it from the tables like K2f does.
+// launch all work on the same state), and a chunk may be cut into launches anywhere: a task whose row was not yet updated in THIS
+// launch (prec[5] < first batch of the launch) loads it from the tables like K2f does.
 //
-// Progress.  Producers of a task sit in earlier batches, except the partner scalars of the SAME batch.  Owner queues are taken
-// in plan order by their own waves, tickets in plan order by the ticket waves, one task per wave at a time; the scout never
-// waits.  Take the oldest batch with an unfinished task: all rows its tasks read are final (their writers sit in earlier
-// batches, which are done), so the scouts -- which scan from their queue's head on and skip only what is not final yet -- publish
-// every scalar of that batch that a taken task has not published itself; the tasks of that batch that hold a wave then finish,
-// the heads move.  Needs every workgroup resident (grid = n_owner <= CUs); every spin is bounded (status word).
+// Progress.  Producers of a task sit in earlier batches -- in the scalar form except the partner scalars of the SAME batch.  Owner
+// queues are taken in plan order by their own waves, tickets in plan order by the ticket waves, one task per wave at a time (no
+// claim-ahead: a claimed task that nobody works on blocked the waves behind it); the scout never waits.  Scalar form: take the oldest
+// batch with an unfinished task: all rows its tasks read are final (their writers sit in earlier batches, which are done), so the
+// scouts -- which scan from their queue's head on and skip only what is not final yet -- publish every scalar of that batch that a
+// taken task has not published itself (a task of several rounds announces ALL its scalars before it waits for any); the tasks of
+// that batch that hold a wave then finish, the heads move.  Needs every workgroup resident (grid = n_owner <= CUs); every spin is
+// bounded (status word), and the engine steps down to K2f when one runs out.
 //
-// Results are bitwise reproducible run to run and whatever publishes a scalar first (scout and task run the same code on the same
-// versions); against K2f the sums differ in the last bits (x is the difference of two rounded dots): same tolerance to the oracle.
+// Results are bitwise reproducible run to run (scout and task run the same code on the same versions; the row-read form sums like
+// K2f); the scalar form differs from K2f in the last bits (x is the difference of two rounded dots): same tolerance to the oracle.
 #include "flow_task.h"
 
 namespace tkr {
