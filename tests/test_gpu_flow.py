@@ -454,3 +454,26 @@ def test_a_timed_out_spin_steps_down_k2o_k2f_k2():
         R.bpr_step(ref, u[q * 256:(q + 1) * 256], i[q * 256:(q + 1) * 256], j[q * 256:(q + 1) * 256], hp)
     for n in ('U', 'V', 'b'):
         np.testing.assert_allclose(eng.get(n)[0].cpu().numpy(), ref[n], rtol=3e-4, atol=2e-5, err_msg=n)
+
+
+def test_k2o_at_netflix_width_and_k256(monkeypatch):
+    """17,770 items x k = 256: 70 rows of 2 KB per owner = 154 KB of a CU's 160 KB of LDS, the 8-wave form of K2o (k > 128) -- against
+    K2f on the same stream (the two group the occurrences of a heavy row differently: equal to rounding)"""
+    import synth
+    from single import _engine
+    dev = torch.device('cuda')
+    n_users, n_items, k = 30000, 17770, 256
+    row_ptr, pos, _, tr_users = synth.train_csr_shape(n_users, n_items, mean_pos=30.0, seed=3)
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, tr_users, dev)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.01, mode='l2')
+    outs = []
+    for own in ('1', '0'):
+        monkeypatch.setenv('TKR_OWN', own)
+        eng = _engine.BprEngine(n_users, n_items, k, hp, dev, seed=11)
+        eng.run_batches(csr, 300, 256, want_loss=False)
+        eng.check()
+        assert eng.layout == 'flow' and (eng.plan.owners > 0) == (own == '1')
+        outs.append([eng.get(n)[0].clone() for n in ('U', 'V', 'b')])
+        del eng
+    for a, b, n in zip(outs[0], outs[1], 'UVb'):
+        assert torch.allclose(a, b, rtol=2e-4, atol=1e-6), n
