@@ -13,16 +13,18 @@
 // Two forms of an item task (template parameter SCALAR; `owner_waves` bit 15 of tkr_bpr_own_run):
 //   * row-read (the default): the partner rows of an occurrence -- the user row and the OTHER item's row -- are read from the granule
 //     tables at their exact versions, as in K2f (flow_task.h run_task).  Measured 2.18 us per batch at the ML-10M shape against
-//     2.75 for K2f on the same box.  What bounds it: the item -> item edges, one hand-off through memory per batch.
+//     2.75 for K2f on the same box.  What bounds it: throughput -- two to three memory round trips per task in series at 2-3 us
+//     apiece, ~700 tasks per batch over 3,072 waves; the dependency structure alone forces only 0.38 hand-offs per batch against
+//     K2f's 1.14 (scripts/chain_model.py).
 //   * scalar exchange: x_uij = (<u, v_i> + b_i) - (<u, v_j> + b_j) (single/bpr.py:87-89), so the task of item i needs the other item of
 //     a triplet only through the scalar <u, v_j> + b_j, which the task of item j computes anyway.  Each publishes d = <u, v_own> +
 //     b_own as ONE 8-byte granule {d, epoch} in the slot of (batch, triplet, role) and reads the partner's slot (asked for together
 //     with the user rows: the partner has usually published before this task has its own row); the two never read each other's rows
 //     (half the partner traffic; one acknowledged reader per occurrence of an item row: the user task).  One wave of every workgroup,
 //     the "scout", runs ahead of the queue's head and publishes the scalars of every task whose rows are final, without waiting for
-//     anything: that is also what keeps the same-batch rendezvous free of deadlock (below).  Measured 2.74 us per batch: the
-//     dependence between the two item tasks of a triplet becomes mutual and same-batch, two hand-offs per batch on the worst path
-//     instead of one.  Kept selectable; every test of tests/test_gpu_flow.py runs both forms.
+//     anything: that is also what keeps the same-batch rendezvous free of deadlock (below).  Measured 2.74 us per batch: one more
+//     serial round trip per item task (publish, then the partner's slot where the early load missed it) and one wave of twelve
+//     spent on the scout.  Kept selectable; every test of tests/test_gpu_flow.py runs both forms.
 //
 // User tasks are handed out by tickets as in K2f, to the remaining waves of every workgroup.  The granule tables are written
 // through at every update exactly as by K2f, so a launch leaves them complete (get / set, the exchange of csrc/sync.hip, a K2f
