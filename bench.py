@@ -200,8 +200,11 @@ def timed_run(eng, csr, B, steps, warmup, sync_every, world, names=None, loop=No
     before = loop.exchanges
     t0 = time.perf_counter()
     loop.run(steps)
+    t_host = time.perf_counter()
     _fence(world)
     wall = time.perf_counter() - t0
+    if os.environ.get('TKR_BENCH_TRACE') == '1':
+        print('timed region: host returned at %.1f us, fence at %.1f us' % ((t_host - t0) * 1e6, wall * 1e6), file=sys.stderr, flush=True)
     step_ms = sum(a.elapsed_time(b) for a, b, _ in eng.step_events)
     launches = sum(n for _, _, n in eng.step_events)
     loop.last_step_events = eng.step_events

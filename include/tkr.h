@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TKR_VERSION 111 /* 0.1.11: K2o (tkr_sample_plan_owned, tkr_bpr_own_run: item rows owned by one workgroup each, resident in its LDS); prec[5] = last batch of the call that updated the row. 0.1.10: tkr_topk_workspace_bytes_for (K4 stages pre-converted fp16 tiles). 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
+#define TKR_VERSION 112 /* 0.1.12: tkr_bpr_own_run_between. 0.1.11: K2o (tkr_sample_plan_owned, tkr_bpr_own_run: item rows owned by one workgroup each, resident in its LDS); prec[5] = last batch of the call that updated the row. 0.1.10: tkr_topk_workspace_bytes_for (K4 stages pre-converted fp16 tiles). 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
 #define TKR_OK 0
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
@@ -196,6 +196,11 @@ int tkr_sample_plan_owned(const int32_t* tr_users, int32_t n_tr, const int32_t* 
 int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, const int32_t* occt, const int32_t* ohdr,
                     int32_t ohdr_stride, int32_t n_owner, int32_t batch_size, int32_t first_batch, int32_t n_batches, uint32_t* ctl, float* loss_out,
                     int32_t owner_waves, void* xch, uint32_t epoch, void* stream);
+/* tkr_bpr_own_run between two events of the caller (hipEvent_t or NULL), recorded on `stream` right around the launch */
+int tkr_bpr_own_run_between(void* ev_before, void* ev_after, const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc,
+                            const int32_t* occt, const int32_t* ohdr, int32_t ohdr_stride, int32_t n_owner, int32_t batch_size,
+                            int32_t first_batch, int32_t n_batches, uint32_t* ctl, float* loss_out, int32_t owner_waves, void* xch,
+                            uint32_t epoch, void* stream);
 
 /* ---- K3: VBPR mini-batch step -------------------------------------------------------------
  * Replaces sess.run([solver, obj]) of single/vbpr.py:114 on the graph of single/vbpr.py:50-73 and the

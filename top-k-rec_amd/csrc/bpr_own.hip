@@ -798,3 +798,17 @@ extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, co
     TKR_LAUNCH_CHECK();
     return TKR_OK;
 }
+
+// the same launch between two HIP events of the caller (nullable hipEvent_t, recorded on `stream`): whoever times the launch --
+// bench.py's roofline -- does not come back through the host language between K1's launches, the event and this launch (a short
+// call is ~130 us of device work; 20 us of interpreter between its launches leave the device idle)
+extern "C" int tkr_bpr_own_run_between(void* ev_before, void* ev_after, const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc,
+                                       const int32_t* occt, const int32_t* ohdr, int32_t ohdr_stride, int32_t n_owner, int32_t batch_size,
+                                       int32_t first_batch, int32_t n_batches, uint32_t* ctl, float* loss_out, int32_t owner_waves, void* xch,
+                                       uint32_t epoch, void* stream) {
+    if (ev_before) TKR_CHECK(hipEventRecord((hipEvent_t)ev_before, (hipStream_t)stream));
+    const int rc = tkr_bpr_own_run(st, prec, pocc, occt, ohdr, ohdr_stride, n_owner, batch_size, first_batch, n_batches, ctl, loss_out, owner_waves,
+                                   xch, epoch, stream);
+    if (ev_after) TKR_CHECK(hipEventRecord((hipEvent_t)ev_after, (hipStream_t)stream));
+    return rc;
+}

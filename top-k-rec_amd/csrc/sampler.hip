@@ -27,6 +27,13 @@
 
 namespace tkr {
 
+#ifdef TKR_K1_PROF            // scripts/probe_short.py: s_memtime at the phase boundaries of workgroup 0 (100 MHz ticks)
+__device__ unsigned long long k1_prof[32];
+#define K1_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) k1_prof[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define K1_STAMP(i) do { } while (0)
+#endif
+
 constexpr int kPlanThreads = 256;      // resolve/commit kernels, and sample_plan for B <= 1024
 constexpr int kPlanThreadsBig = 1024;  // sample_plan for larger batches (the LDS sort dominates there)
 constexpr int kLightMax = 4;     // oracle/plan_np.py LIGHT_MAX: occurrences one wave handles, B <= 4096
@@ -53,6 +60,109 @@ __device__ __forceinline__ void bitonic_sort(uint64_t* keys, int n) {
                 if ((a > b) == asc) { keys[lo] = b; keys[hi] = a; }
             }
         }
+    }
+    __syncthreads();
+}
+
+// ---- the same sort in registers ------------------------------------------------------------------------------------------------
+// The LDS sort above pays one barrier + one LDS round trip per compare-exchange step (45 steps for 512 keys: 8.3 us of a 24 us
+// kernel that sits in front of every short call).  Here thread t holds keys R*t .. R*t + R - 1 (32-bit: row << OB | occurrence):
+// strides below R exchange registers of one thread, strides below 64 R lanes of one wave -- DPP moves and v_permlane{16,32}_swap,
+// vector-ALU instructions, no LDS, no barrier -- and only the strides from 64 R on (3 steps of 45 at 512 keys over 4 waves) go
+// through LDS.  Same network, same result.
+typedef uint32_t lane_pair __attribute__((ext_vector_type(2)));
+template <int M>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int lane) {
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "xor mask inside a wave");
+    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);          // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) {                                                                                     // i -> 7 - i -> its quad reversed = i ^ 4
+        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);                               // row_half_mirror
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, t, 0x1b, 0xf, 0xf, false);                                  // quad_perm [3,2,1,0]
+    } else if constexpr (M == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);  // row_ror:8
+    else if constexpr (M == 16) {
+        const lane_pair r = __builtin_amdgcn_permlane16_swap(v, v, false, false);     // x = rows [0,0,2,2] of v, y = rows [1,1,3,3]
+        return (lane & 16) ? r.x : r.y;
+    } else {
+        const lane_pair r = __builtin_amdgcn_permlane32_swap(v, v, false, false);     // x = [lower half, lower half], y = [upper, upper]
+        return (lane & 32) ? r.x : r.y;
+    }
+}
+template <int R, int M>
+__device__ __forceinline__ void lane_step(uint32_t (&k)[R], int lane, bool keep_min) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t o = lane_xor<M>(k[r], lane);
+        k[r] = keep_min ? min(k[r], o) : max(k[r], o);
+    }
+}
+// n = R * T keys, ascending over e = R * thread + r; `xbuf`: n words of LDS, free on entry (barrier inside before its first use)
+template <int T, int R>
+__device__ __forceinline__ void register_sort(uint32_t (&k)[R], uint32_t* xbuf) {
+    const int tid = threadIdx.x, lane = tid & (TKR_WAVE - 1);
+    constexpr int n = R * T;
+    constexpr int LOGN = __builtin_ctz(n);
+    static_assert((n & (n - 1)) == 0, "power of two");
+    // fully unrolled: sizes, strides and register indices are compile-time constants (a register array indexed by a run-time
+    // stride would live in scratch memory)
+#pragma unroll
+    for (int ls = 1; ls <= LOGN; ++ls) {
+#pragma unroll
+        for (int lj = ls - 1; lj >= 0; --lj) {
+            const int size = 1 << ls, stride = 1 << lj;
+            if (stride < R) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int q = r ^ stride;
+                    if (q > r) {
+                        const bool asc = (((tid * R + r) & size) == 0);
+                        const uint32_t a = k[r], b = k[q];
+                        const bool sw = (a > b) == asc;
+                        k[r] = sw ? b : a;
+                        k[q] = sw ? a : b;
+                    }
+                }
+            } else {
+                const int m = stride / R;                            // lane / thread distance
+                const bool asc = (((tid * R) & size) == 0);
+                const bool lower = (tid & m) == 0;
+                const bool keep_min = lower == asc;
+                if (m == 1) lane_step<R, 1>(k, lane, keep_min);
+                else if (m == 2) lane_step<R, 2>(k, lane, keep_min);
+                else if (m == 4) lane_step<R, 4>(k, lane, keep_min);
+                else if (m == 8) lane_step<R, 8>(k, lane, keep_min);
+                else if (m == 16) lane_step<R, 16>(k, lane, keep_min);
+                else if (m == 32) lane_step<R, 32>(k, lane, keep_min);
+                else {                                               // across waves: through LDS
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < R; ++r) xbuf[tid * R + r] = k[r];
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t o = xbuf[(tid ^ m) * R + r];
+                        k[r] = keep_min ? min(k[r], o) : max(k[r], o);
+                    }
+                }
+            }
+        }
+    }
+}
+// a whole sort of this kernel through registers: keys of element e from `make(e)` (row << ob | occurrence, ~0 = padding), result
+// into keys[] in the 64-bit form the rest of the kernel reads (row << 32 | occurrence)
+template <int T, int R, class Make>
+__device__ __forceinline__ void sort_via_registers(uint64_t* keys, int ob, Make make) {
+    uint32_t k[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) k[r] = make((int)threadIdx.x * R + r);
+    // the exchange buffer: the upper half of keys[] (n 64-bit slots = 2n words; the lower n words stay clear of the 64-bit result
+    // only after the barrier below)
+    register_sort<T, R>(k, reinterpret_cast<uint32_t*>(keys));
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t v = k[r];
+        keys[(int)threadIdx.x * R + r] = v == 0xffffffffu ? ~0ull : (((uint64_t)(v >> ob) << 32) | (uint64_t)(v & ((1u << ob) - 1u)));
     }
     __syncthreads();
 }
@@ -110,7 +220,7 @@ __global__ __launch_bounds__(T) void sample_plan_kernel(
     uint64_t seed, uint64_t first_triplet, const int64_t* __restrict__ ctl, int B, int npad_items,
     int32_t* __restrict__ out_u, int32_t* __restrict__ out_i, int32_t* __restrict__ out_j,
     int4* __restrict__ task_all, int2* __restrict__ occ_all, int32_t* __restrict__ occt_all,
-    uint32_t* __restrict__ touch_u, uint32_t* __restrict__ touch_i) {
+    uint32_t* __restrict__ touch_u, uint32_t* __restrict__ touch_i, bool reg_sort_ok /*row ids leave room for the occurrence bits in 32-bit keys*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                       // [npad_items]
     int* scan = reinterpret_cast<int*>(smem + (size_t)npad_items * 8);        // [T+1]
@@ -125,6 +235,7 @@ __global__ __launch_bounds__(T) void sample_plan_kernel(
     int2* occ = occ_all + (size_t)b * 3 * B;
     int32_t* occt = occt_all + (size_t)b * 3 * B;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    K1_STAMP(0);
 
     // ---- draw; item keys go to LDS, triplets to HBM ---------------------------------
     for (int t = threadIdx.x; t < B; t += T) {
@@ -134,30 +245,56 @@ __global__ __launch_bounds__(T) void sample_plan_kernel(
     }
     __threadfence_block();
     __syncthreads();
+    K1_STAMP(1);
 
     // ---- users: sort (u<<32 | t) ----------------------------------------------------------
     int npad_u = 1;
     while (npad_u < B) npad_u <<= 1;
-    for (int t = threadIdx.x; t < npad_u; t += T)
-        keys[t] = (t < B) ? (((uint64_t)(uint32_t)bu[t] << 32) | (uint32_t)t) : ~0ull;
-    bitonic_sort<T>(keys, npad_u);
+    // registers when the sizes allow (npad_u = T or 2T or 4T keys, 32-bit keys: row ids and occurrence numbers fit one word)
+    int ob = 1;
+    while ((1 << ob) < npad_items) ++ob;
+    const bool in_regs = reg_sort_ok && npad_items == 2 * npad_u && (npad_u == T || npad_u == 2 * T || npad_u == 4 * T);
+    if (in_regs) {
+        auto make = [&](int t) { return t < B ? (((uint32_t)bu[t] << ob) | (uint32_t)t) : 0xffffffffu; };
+        if (npad_u == T) sort_via_registers<T, 1>(keys, ob, make);
+        else if (npad_u == 2 * T) sort_via_registers<T, 2>(keys, ob, make);
+        else sort_via_registers<T, 4>(keys, ob, make);
+    } else {
+        for (int t = threadIdx.x; t < npad_u; t += T)
+            keys[t] = (t < B) ? (((uint64_t)(uint32_t)bu[t] << 32) | (uint32_t)t) : ~0ull;
+        bitonic_sort<T>(keys, npad_u);
+    }
+    K1_STAMP(2);
     const int n_uq = emit_tasks<T>(keys, B, task, 0, 0, 0, scan, touch_u, b);
+    K1_STAMP(3);
     for (int p = threadIdx.x; p < B; p += T) {
         const int t = (int)(uint32_t)keys[p];
         occ[p] = make_int2(bi[t], bj[t]);
         occt[p] = t;
     }
     __syncthreads();
+    K1_STAMP(4);
 
     // ---- items: sort (item<<32 | o), o<B: i-role of triplet o, else j-role of o-B ---------
-    for (int o = threadIdx.x; o < npad_items; o += T) {
-        uint64_t key = ~0ull;
-        if (o < B) key = ((uint64_t)(uint32_t)bi[o] << 32) | (uint32_t)o;
-        else if (o < 2 * B) key = ((uint64_t)(uint32_t)bj[o - B] << 32) | (uint32_t)o;
-        keys[o] = key;
+    if (in_regs) {
+        auto make = [&](int o) {
+            return o < B ? (((uint32_t)bi[o] << ob) | (uint32_t)o) : o < 2 * B ? (((uint32_t)bj[o - B] << ob) | (uint32_t)o) : 0xffffffffu;
+        };
+        if (npad_u == T) sort_via_registers<T, 2>(keys, ob, make);
+        else if (npad_u == 2 * T) sort_via_registers<T, 4>(keys, ob, make);
+        else sort_via_registers<T, 8>(keys, ob, make);
+    } else {
+        for (int o = threadIdx.x; o < npad_items; o += T) {
+            uint64_t key = ~0ull;
+            if (o < B) key = ((uint64_t)(uint32_t)bi[o] << 32) | (uint32_t)o;
+            else if (o < 2 * B) key = ((uint64_t)(uint32_t)bj[o - B] << 32) | (uint32_t)o;
+            keys[o] = key;
+        }
+        bitonic_sort<T>(keys, npad_items);
     }
-    bitonic_sort<T>(keys, npad_items);
+    K1_STAMP(5);
     const int n_iq = emit_tasks<T>(keys, 2 * B, task, n_uq, B, 1, scan, touch_i, b);
+    K1_STAMP(6);
     for (int p = threadIdx.x; p < 2 * B; p += T) {
         const int o = (int)(uint32_t)keys[p];
         const bool role = o >= B;
@@ -167,6 +304,8 @@ __global__ __launch_bounds__(T) void sample_plan_kernel(
         occt[B + p] = t;
     }
     for (int s = n_uq + n_iq + threadIdx.x; s < 3 * B; s += T) task[s] = make_int4(-1, 0, 0, 0);
+    __syncthreads();
+    K1_STAMP(7);
 }
 
 // ---- K1b: parities + per-wave launch records ------------------------------------------------
@@ -359,6 +498,7 @@ __global__ __launch_bounds__(T) void resolve_flow_kernel(
     const int2* occ = occ_all + (size_t)b * 3 * B;
     int4* pocc = pocc_all + (size_t)b * 3 * B;
     int4* prec = prec_all + (size_t)b * 3 * B * 8;
+    K1_STAMP(8);
 
     for (int p = threadIdx.x; p < B; p += T) {           // user occurrences: (i, j)
         const int2 o = occ[p];
@@ -375,6 +515,10 @@ __global__ __launch_bounds__(T) void resolve_flow_kernel(
     uint32_t* own_mask = reinterpret_cast<uint32_t*>(smem);                            // [n_owner][own_words]
     uint32_t* own_start = own_mask + (size_t)n_owner * own_words;                      // [n_owner]
     int first_item = 0;
+#ifdef TKR_K1_PROF
+    __syncthreads();
+    K1_STAMP(9);
+#endif
     if (n_owner > 0) {
         if (threadIdx.x == 0) s_first_item = 3 * B;
         for (int w = threadIdx.x; w < n_owner * own_words; w += T) own_mask[w] = 0u;
@@ -416,6 +560,7 @@ __global__ __launch_bounds__(T) void resolve_flow_kernel(
     }
     __threadfence_block();
     __syncthreads();
+    K1_STAMP(10);
     for (int s = threadIdx.x; s < 3 * B; s += T) {
         const int4 t = task[s];
         int dst = s;
@@ -445,6 +590,10 @@ __global__ __launch_bounds__(T) void resolve_flow_kernel(
         r[6] = make_int4(tt[0], t.z > 1 ? tt[1] : 0, t.z > 2 ? tt[2] : 0, t.z > 3 ? tt[3] : 0);
         r[7] = make_int4(0, 0, 0, 0);
     }
+#ifdef TKR_K1_PROF
+    __syncthreads();
+    K1_STAMP(11);
+#endif
 }
 
 // ---- K1c: fold the chunk's touch bitmap into the update counters and clear it --------------
@@ -532,15 +681,18 @@ static int sample_plan_impl(const int32_t* tr_users, int32_t n_tr, const int32_t
         TKR_LAUNCH_CHECK();
         return TKR_OK;
     }
-    int npad = 1;
-    while (npad < 2 * batch_size) npad <<= 1;
+    int npad = 1, npad_bits = 0;
+    while (npad < 2 * batch_size) { npad <<= 1; ++npad_bits; }
+    // 32-bit sort keys (row << bits | occurrence) when the row ids leave the room; TKR_PLAN_LDS_SORT=1: the LDS sort always
+    static const bool lds_sort = [] { const char* e = getenv("TKR_PLAN_LDS_SORT"); return e && atoi(e) != 0; }();
+    const bool reg_sort_ok = !lds_sort && npad_bits < 31 && (uint64_t)(n_users > n_items ? n_users : n_items) < (1ull << (32 - npad_bits)) - 1ull;
     hipStream_t s = (hipStream_t)stream;
     if (batch_size <= 1024) {
         const size_t lds = (size_t)npad * 8 + (tkr::kPlanThreads + 1) * sizeof(int);
         hipLaunchKernelGGL(tkr::sample_plan_kernel<tkr::kPlanThreads>, dim3(n_batches), dim3(tkr::kPlanThreads), lds, s,
                            tr_users, (uint32_t)n_tr, row_ptr, pos_cols, cols_sorted, (uint32_t)n_items, seed,
                            first_triplet, ctl, batch_size, npad, out_u, out_i, out_j, reinterpret_cast<int4*>(task),
-                           reinterpret_cast<int2*>(occ), occt, touch_u, touch_i);
+                           reinterpret_cast<int2*>(occ), occt, touch_u, touch_i, reg_sort_ok);
     } else {
         const size_t lds = (size_t)npad * 8 + (tkr::kPlanThreadsBig + 1) * sizeof(int);
         static bool attr_set[64] = {};                 // per device: the attribute belongs to the device's code object
@@ -554,7 +706,7 @@ static int sample_plan_impl(const int32_t* tr_users, int32_t n_tr, const int32_t
         hipLaunchKernelGGL(tkr::sample_plan_kernel<tkr::kPlanThreadsBig>, dim3(n_batches), dim3(tkr::kPlanThreadsBig), lds,
                            s, tr_users, (uint32_t)n_tr, row_ptr, pos_cols, cols_sorted, (uint32_t)n_items, seed,
                            first_triplet, ctl, batch_size, npad, out_u, out_i, out_j, reinterpret_cast<int4*>(task),
-                           reinterpret_cast<int2*>(occ), occt, touch_u, touch_i);
+                           reinterpret_cast<int2*>(occ), occt, touch_u, touch_i, reg_sort_ok);
     }
     TKR_LAUNCH_CHECK();
     // (256 threads: a 1024-thread workgroup does not fit beside the persistent step's 12 waves per CU -- 4 waves per SIMD against the
@@ -613,3 +765,9 @@ extern "C" int tkr_plan_rollback(const int32_t* task, int32_t batch_size, int32_
     TKR_LAUNCH_CHECK();
     return TKR_OK;
 }
+
+#ifdef TKR_K1_PROF
+extern "C" int tkr_debug_k1_prof(unsigned long long* out /*[32] host*/) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tkr::k1_prof), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -100;
+}
+#endif

@@ -212,6 +212,14 @@ def _event_pair():
     return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
 
+def _recorded_event_pair():
+    """a pair that exists on the device (a torch event is created by its first record())"""
+    pair = _event_pair()
+    for e in pair:
+        e.record()
+    return pair
+
+
 class PlanMixin:
     """Sample stream position + plans of an engine.
 
@@ -286,10 +294,7 @@ class PlanMixin:
         """n event pairs for step_events, created NOW: a torch event is only created on the device by its first record(),
         tens of microseconds that would otherwise land between the launches of a short timed run"""
         while len(self._event_pool) < n:
-            pair = _event_pair()
-            for e in pair:
-                e.record()
-            self._event_pool.append(pair)
+            self._event_pool.append(_recorded_event_pair())
 
     def settle(self, check=True, keep_epoch_ahead=False):
         """drop what is planned but has not run; afterwards the counters describe the tables.  Everything that takes results
@@ -397,12 +402,16 @@ class PlanMixin:
             if want_loss:
                 plan.loss[lo:lo + m].zero_()
             if self.step_events is not None:          # bench: HIP events around the step launches
-                e0, e1 = self._event_pool.pop() if self._event_pool else _event_pair()
-                e0.record()
-            step_fn(plan, lo, m, plan.loss if want_loss else None)
-            if self.step_events is not None:
-                e1.record()
+                e0, e1 = self._event_pool.pop() if self._event_pool else _recorded_event_pair()
+                if getattr(step_fn, 'takes_events', False):         # recorded in C, right around the launch
+                    step_fn(plan, lo, m, plan.loss if want_loss else None, (e0, e1))
+                else:
+                    e0.record()
+                    step_fn(plan, lo, m, plan.loss if want_loss else None)
+                    e1.record()
                 self.step_events.append((e0, e1, m))
+            else:
+                step_fn(plan, lo, m, plan.loss if want_loss else None)
             ch.used += m
             left -= m
             self._drawn += m * B

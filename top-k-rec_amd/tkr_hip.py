@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TKR_HIP_LIB') or os.path.join(_HERE, 'libtkr_hip.so')      # the override is for A/B builds of the kernels (scripts/)
 
 _lib = None
-VERSION = 111          # TKR_VERSION of include/tkr.h this binding was written against
+VERSION = 112          # TKR_VERSION of include/tkr.h this binding was written against
 
 
 class TkrError(RuntimeError):
@@ -46,7 +46,7 @@ class VbprState(C.Structure):
                [(n, C.c_void_p) for n in ('f_ptr', 'f_col', 'f_val', 'c_ptr', 'c_item', 'c_val', 'item_tag')]
 
 
-EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_sample_plan_owned', 'tkr_plan_rollback', 'tkr_bpr_run', 'tkr_bpr_flow_run', 'tkr_bpr_own_run', 'tkr_bpr_own_owners', 'tkr_flow_row_granules', 'tkr_flow_ctl_words',
+EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_sample_plan_owned', 'tkr_plan_rollback', 'tkr_bpr_run', 'tkr_bpr_flow_run', 'tkr_bpr_own_run', 'tkr_bpr_own_run_between', 'tkr_bpr_own_owners', 'tkr_flow_row_granules', 'tkr_flow_ctl_words',
            'tkr_vbpr_run', 'tkr_vbpr_colplan', 'tkr_vbpr_run_cols', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy',
            'tkr_idmap_create', 'tkr_idmap_destroy', 'tkr_ratings_parse', 'tkr_ratings_sizes', 'tkr_ratings_copy',
            'tkr_ratings_destroy', 'tkr_matrix_read', 'tkr_matrix_sizes', 'tkr_matrix_copy', 'tkr_matrix_destroy',
@@ -299,22 +299,26 @@ def bpr_own_run(state, plan, B, n_batches, ctl, loss_out=None, first=0, owner_wa
 
 
 def own_stepper(state, B, ctl, owner_waves=0):
-    """-> step(plan, first, n_batches, loss_out): bpr_own_run with the fixed arguments bound once (as flow_stepper)"""
-    fn = lib().tkr_bpr_own_run
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
-                   C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p]
+    """-> step(plan, first, n_batches, loss_out, events=None): bpr_own_run with the fixed arguments bound once (as flow_stepper);
+    events = (before, after): two torch events that have been recorded once (so they exist), recorded around the launch in C"""
+    fn = lib().tkr_bpr_own_run_between
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                   C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p]
     device, st, ctl_ptr = ctl.device, C.addressof(state), ctl.data_ptr()
 
-    def step(plan, first, n_batches, loss_out):
+    def step(plan, first, n_batches, loss_out, events=None):
         if torch.cuda.current_device() != device.index:
+            assert events is None
             return bpr_own_run(state, plan, B, n_batches, ctl, loss_out, first, owner_waves)
         plan.epoch += 1
-        rc = fn(st, plan.prec.data_ptr(), plan.pocc.data_ptr(), plan.occt.data_ptr(), plan.ohdr.data_ptr(), plan.cap, plan.owners, B, first, n_batches, ctl_ptr,
-                None if loss_out is None else loss_out.data_ptr(), owner_waves, plan.xch.data_ptr(), plan.epoch & 0xffffffff or 1,
+        rc = fn(None if events is None else events[0].cuda_event, None if events is None else events[1].cuda_event,
+                st, plan.prec.data_ptr(), plan.pocc.data_ptr(), plan.occt.data_ptr(), plan.ohdr.data_ptr(), plan.cap, plan.owners, B, first, n_batches,
+                ctl_ptr, None if loss_out is None else loss_out.data_ptr(), owner_waves, plan.xch.data_ptr(), plan.epoch & 0xffffffff or 1,
                 torch.cuda.current_stream(device).cuda_stream)
         if rc:
-            _check(rc, 'tkr_bpr_own_run')
+            _check(rc, 'tkr_bpr_own_run_between')
     step.state = state
+    step.takes_events = True
     return step
 
 
