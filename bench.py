@@ -192,8 +192,17 @@ def timed_run(eng, csr, B, steps, warmup, sync_every, world, names=None, loop=No
     What the timed region contains: for each batch its (u, i, j) draw + plan (K1) AND its step -- settle() drops
     whatever an earlier call planned but did not run, and run_batches plans exactly what it is asked to run."""
     loop = loop or Loop(eng, csr, B, sync_every, world, names)
-    eng.reserve_events(-(-(steps + warmup) // sync_every) + _chunk_crossings(eng, steps, B) + 2)      # created now, not between the timed launches
-    loop.run(warmup)
+    singles = min(warmup, 8)
+    eng.reserve_events(-(-(steps + warmup) // sync_every) + _chunk_crossings(eng, steps + warmup, B) + singles + 2)   # created now, not between the timed launches
+    # The warm-up goes down the SAME host path as the timed call -- events around the step launches included -- and its first
+    # batches as calls of their own: the first two or three passes of the runtime through a launch path (kernel arguments,
+    # signals of timed events) cost tens of microseconds each, which a 20-step timed call (~130 us) would otherwise carry.
+    eng.step_events = []
+    for _ in range(singles):
+        loop.run(1)
+    if warmup > singles:
+        loop.run(warmup - singles)
+    eng.step_events = None
     eng.settle()                 # nothing planned ahead: the timed batches sample and plan themselves (also reports a failed step)
     _fence(world)
     eng.step_events = []

@@ -64,7 +64,10 @@ def _plan(hip, tr, tr_users, n_users, n_items, seed, first, nb, B, chunks=1, own
 
 @pytest.mark.parametrize('owners', [0, 1, 7, 256])
 @pytest.mark.parametrize('n_users,n_items,B,nb,chunks', [(60, 40, 32, 5, 1), (300, 150, 256, 7, 3), (300, 150, 100, 3, 2),
-                                                         (5000, 900, 1024, 3, 1), (40, 30, 1, 4, 1), (300, 150, 64, 512, 2)])
+                                                         (5000, 900, 1024, 3, 1), (40, 30, 1, 4, 1), (300, 150, 64, 512, 2),
+                                                         # K1's forms: sorts in registers (128 < B, keys per thread 1+2 / 2+4 / 4+8) or in LDS; the
+                                                         # records of a short call (<= 64 batches of <= 256: one thread per slot) or of a long one
+                                                         (300, 150, 256, 80, 1), (2000, 600, 512, 4, 2), (2000, 600, 200, 5, 1), (700, 300, 129, 66, 1)])
 def test_flow_plan_bit_exact(hip, n_users, n_items, B, nb, chunks, owners):
     tr, tr_users = _toy(n_users, n_items, seed=n_users + B)
     plan, exp, cnt, (ucnt, icnt) = _plan(hip, tr, tr_users, n_users, n_items, 0x1234567890ABCDEF, (1 << 33) + 17, nb, B, chunks, owners)

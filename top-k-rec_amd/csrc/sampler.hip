@@ -596,6 +596,122 @@ __global__ __launch_bounds__(T) void resolve_flow_kernel(
 #endif
 }
 
+// ---- K1b'' : the same records for a SHORT call (B <= 256, one thread per task slot and per occurrence) ---------------------------
+// resolve_flow_kernel is written to run BESIDE the persistent step (256 threads, ~50 registers, a few KB of LDS) and walks three
+// slots per thread through chains of dependent loads: occurrence -> its versions, then task -> its history -> its occurrences.
+// In front of a short call nothing runs beside the planner and those ~14 us are all exposed.  Here every thread takes ONE slot:
+// the occurrence and the task of its slot are loaded together, their version words together, the occurrences of a task come from
+// LDS -- two trips through memory instead of five.  Same output, bit for bit.
+constexpr int kWideThreads = 768;
+__global__ __launch_bounds__(kWideThreads) void resolve_flow_wide_kernel(
+    int B, const int4* __restrict__ task_all, const int2* __restrict__ occ_all, const int32_t* __restrict__ ucnt,
+    const int32_t* __restrict__ icnt, const uint32_t* __restrict__ touch_u, const uint32_t* __restrict__ touch_i,
+    int4* __restrict__ pocc_all, int4* __restrict__ prec_all, int n_owner, int32_t* __restrict__ ohdr, int ohdr_stride,
+    const int32_t* __restrict__ occt_all, int own_words) {
+    constexpr int T = kWideThreads;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_first_item, s_wave[T / TKR_WAVE];
+    const int b = blockIdx.x, n = 3 * B, s = threadIdx.x;
+    int4* lp = reinterpret_cast<int4*>(smem);                                          // [3B] the batch's pocc
+    int32_t* lt = reinterpret_cast<int32_t*>(lp + n);                                  // [3B] its occt
+    uint32_t* own_mask = reinterpret_cast<uint32_t*>(lt + n);                          // [n_owner][own_words]
+    uint32_t* own_start = own_mask + (size_t)n_owner * own_words;                      // [n_owner]
+    int4* pocc = pocc_all + (size_t)b * n;
+    int4* prec = prec_all + (size_t)b * n * 8;
+    K1_STAMP(8);
+    if (s == 0) s_first_item = n;
+    for (int w = s; w < n_owner * own_words; w += T) own_mask[w] = 0u;
+    int4 t = make_int4(-1, 0, 0, 0);
+    int ver = 0, prev = -1;
+    if (s < n) {
+        t = task_all[(size_t)b * n + s];
+        const int2 o = occ_all[(size_t)b * n + s];
+        const int tt = occt_all[(size_t)b * n + s];
+        const bool user_occ = s < B;                                                   // user occurrences: (i, j); item occurrences: (u, other | role << 31)
+        const int va = user_occ ? version_of(icnt, touch_i, o.x, b) : version_of(ucnt, touch_u, o.x, b);
+        const int vb = version_of(icnt, touch_i, o.y & 0x3fffffff, b);
+        if (t.x != -1) {
+            if (t.x < 0) row_history(icnt, touch_i, t.x & 0x7fffffff, b, ver, prev);
+            else row_history(ucnt, touch_u, t.x, b, ver, prev);
+        }
+        const int4 po = make_int4(o.x, va, o.y, vb);
+        pocc[s] = po;
+        lp[s] = po;
+        lt[s] = tt;
+    }
+    __syncthreads();
+    K1_STAMP(9);
+    const bool item_task = t.x < 0 && t.x != -1;
+    int first_item = 0;
+    if (n_owner > 0) {
+        if (item_task) {
+            atomicMin(&s_first_item, s);
+            const int row = t.x & 0x7fffffff, bit = row / n_owner;
+            atomicOr(&own_mask[(size_t)(row % n_owner) * own_words + (bit >> 5)], 1u << (bit & 31));
+        }
+        __syncthreads();
+        first_item = s_first_item;
+        const int per = (n_owner + T - 1) / T;
+        const int w0 = min(s * per, n_owner), w1 = min(w0 + per, n_owner);
+        int mine = 0;
+        for (int w = w0; w < w1; ++w)
+            for (int j = 0; j < own_words; ++j) mine += __popc(own_mask[(size_t)w * own_words + j]);
+        const int lane = s & (TKR_WAVE - 1), wave = s / TKR_WAVE;
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < TKR_WAVE; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == TKR_WAVE - 1) s_wave[wave] = incl;
+        __syncthreads();
+        int run = incl - mine;
+        for (int w = 0; w < wave; ++w) run += s_wave[w];
+        for (int w = w0; w < w1; ++w) {
+            int c = 0;
+            for (int j = 0; j < own_words; ++j) c += __popc(own_mask[(size_t)w * own_words + j]);
+            ohdr[(size_t)w * ohdr_stride + b] = (first_item + run) | (c << 16);
+            own_start[w] = (uint32_t)run;
+            run += c;
+        }
+        __syncthreads();
+    }
+    K1_STAMP(10);
+    if (s < n) {
+        int dst = s;
+        if (n_owner > 0 && item_task) {
+            const int row = t.x & 0x7fffffff, w = row % n_owner, bit = row / n_owner;
+            const uint32_t* m = own_mask + (size_t)w * own_words;
+            int before = __popc(m[bit >> 5] & ((1u << (bit & 31)) - 1u));
+            for (int j = 0; j < (bit >> 5); ++j) before += __popc(m[j]);
+            dst = first_item + (int)own_start[w] + before;
+        }
+        int4* r = prec + (size_t)dst * 8;
+        if (t.x == -1) {
+            r[0] = make_int4(-1, 0, 0, 0);
+#pragma unroll
+            for (int q = 1; q < 8; ++q) r[q] = make_int4(0, 0, 0, 0);
+        } else {
+            r[0] = make_int4(t.x, ver, t.z, b * n + t.y);
+            r[1] = make_int4(b, prev, 0, 0);
+            int tq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int at = t.y + min(q, t.z - 1);                                  // (always inside the batch: no branch around the load)
+                const int4 v = lp[at];
+                r[2 + q] = (q < t.z) ? v : make_int4(0, 0, 0, 0);
+                tq[q] = (q < t.z) ? lt[at] : 0;
+            }
+            r[6] = make_int4(tq[0], tq[1], tq[2], tq[3]);
+            r[7] = make_int4(0, 0, 0, 0);
+        }
+    }
+#ifdef TKR_K1_PROF
+    __syncthreads();
+    K1_STAMP(11);
+#endif
+}
+
 // ---- K1c: fold the chunk's touch bitmap into the update counters and clear it --------------
 __global__ void commit_kernel(int n_users, int n_items, int32_t* __restrict__ ucnt, int32_t* __restrict__ icnt,
                               uint32_t* __restrict__ touch_u, uint32_t* __restrict__ touch_i) {
@@ -712,11 +828,19 @@ static int sample_plan_impl(const int32_t* tr_users, int32_t n_tr, const int32_t
     // (256 threads: a 1024-thread workgroup does not fit beside the persistent step's 12 waves per CU -- 4 waves per SIMD against the
     // one that its registers leave -- and the planner of the next chunk then waits for the running chunk to END: measured 1.06 ms per
     // launch of this kernel in the profiled bench, -2 % on the steady state)
-    if (flow)
-        hipLaunchKernelGGL(tkr::resolve_flow_kernel<tkr::kPlanThreads>, dim3(n_batches), dim3(tkr::kPlanThreads),
-                           n_owner > 0 ? (size_t)4 * n_owner * (own_words + 1) : 0, s, batch_size,
-                           reinterpret_cast<const int4*>(task), reinterpret_cast<const int2*>(occ), ucnt, icnt, touch_u,
-                           touch_i, reinterpret_cast<int4*>(pocc), reinterpret_cast<int4*>(prec), n_owner, ohdr, ohdr_stride, occt, own_words);
+    if (flow) {
+        // a short call (its plan sits in front of its step, nothing runs beside it): one thread per task instead of three tasks per thread
+        static const int wide_upto = [] { const char* e = getenv("TKR_PLAN_WIDE_UPTO"); return e ? atoi(e) : 64; }();
+        const size_t lds_r = n_owner > 0 ? (size_t)4 * n_owner * (own_words + 1) : 0;
+        if (n_batches <= wide_upto && 3 * batch_size <= tkr::kWideThreads)
+            hipLaunchKernelGGL(tkr::resolve_flow_wide_kernel, dim3(n_batches), dim3(tkr::kWideThreads), lds_r + (size_t)3 * batch_size * 20, s,
+                               batch_size, reinterpret_cast<const int4*>(task), reinterpret_cast<const int2*>(occ), ucnt, icnt, touch_u,
+                               touch_i, reinterpret_cast<int4*>(pocc), reinterpret_cast<int4*>(prec), n_owner, ohdr, ohdr_stride, occt, own_words);
+        else
+            hipLaunchKernelGGL(tkr::resolve_flow_kernel<tkr::kPlanThreads>, dim3(n_batches), dim3(tkr::kPlanThreads), lds_r, s, batch_size,
+                               reinterpret_cast<const int4*>(task), reinterpret_cast<const int2*>(occ), ucnt, icnt, touch_u,
+                               touch_i, reinterpret_cast<int4*>(pocc), reinterpret_cast<int4*>(prec), n_owner, ohdr, ohdr_stride, occt, own_words);
+    }
     else
         hipLaunchKernelGGL(tkr::resolve_kernel, dim3(n_batches), dim3(tkr::kPlanThreads), 0, s, batch_size,
                            tkr_plan_max_blocks(batch_size) * tkr::team_for(batch_size), reinterpret_cast<int4*>(task),
