@@ -309,7 +309,9 @@ int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i, const int3
  *   On gfx950 the fp32 MFMA runs at the vector-ALU rate and overlaps nothing; mode 0 is 1.4-1.6x faster than mode 1,
  *   mode 2 1.5-2.1x.
  * K <= 32 per launch (larger K: rank 32, add the found columns to the mask with tkr_build_rated_mask, rank
- * again -- top-k-rec_amd/tkr_hip.py score_topk does this), k <= 256. */
+ * again -- top-k-rec_amd/tkr_hip.py score_topk does this), k <= 768 (above 256: mode 1 with the k dimension in slabs of 256 --
+ * the chain of a score runs slab after slab, halves [256 s, 256 s + 128) and [256 s + 128, 256 s + 256) in place of the two
+ * halves of k; 63 % of the fp32-MFMA peak at k = 512, register spills above 512). */
 int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K);
 /* the same + room for the item factors of mode 2 pre-converted to scaled fp16 (k <= 128), laid out as the LDS image of every
  * 32-item tile: with a workspace of at least this size a K4 call converts V once (a ~5 us pre-pass) and every workgroup stages

@@ -302,5 +302,10 @@ def test_wide_factors_through_the_class_and_the_stated_limits(tmp_path):
         eng = _engine.BprEngine(m.n_users, m.n_items, kk, hp, dev, seed=1)
         with pytest.raises(ValueError, match='k <= 512'):
             eng.run_batches(csr, 1, BB)
-    with pytest.raises(ValueError, match='up to 256'):
-        tkr_hip.score_topk(torch.zeros((4, 300), device=dev), torch.zeros((8, 300), device=dev), 3)
+    with pytest.raises(ValueError, match='up to 768'):
+        tkr_hip.score_topk(torch.zeros((4, 800), device=dev), torch.zeros((8, 800), device=dev), 3)
+    # ... and what the trainer holds, the scorer ranks (evaluate.py:78 on the k = 300 model above)
+    ids = tkr_hip.score_topk(torch.from_numpy(m.fue).to(dev), torch.from_numpy(m.fie).to(dev), 5, bias=torch.from_numpy(m.fib.ravel().copy()).to(dev))
+    s = m.fue.astype(np.float64) @ m.fie.astype(np.float64).T + m.fib.ravel()
+    best = np.argsort(-s, axis=1, kind='stable')[:, :5]
+    assert (ids.cpu().numpy() == best).mean() > 0.98                      # fp32 near-ties aside

@@ -253,12 +253,13 @@ __global__ __launch_bounds__(T) void sample_plan_kernel(
     // registers when the sizes allow (npad_u = T or 2T or 4T keys, 32-bit keys: row ids and occurrence numbers fit one word)
     int ob = 1;
     while ((1 << ob) < npad_items) ++ob;
-    const bool in_regs = reg_sort_ok && npad_items == 2 * npad_u && (npad_u == T || npad_u == 2 * T || npad_u == 4 * T);
+    const bool in_regs = reg_sort_ok && npad_items == 2 * npad_u && (npad_u == T || npad_u == 2 * T || npad_u == 4 * T || npad_u == 8 * T);
     if (in_regs) {
         auto make = [&](int t) { return t < B ? (((uint32_t)bu[t] << ob) | (uint32_t)t) : 0xffffffffu; };
         if (npad_u == T) sort_via_registers<T, 1>(keys, ob, make);
         else if (npad_u == 2 * T) sort_via_registers<T, 2>(keys, ob, make);
-        else sort_via_registers<T, 4>(keys, ob, make);
+        else if (npad_u == 4 * T) sort_via_registers<T, 4>(keys, ob, make);
+        else sort_via_registers<T, 8>(keys, ob, make);
     } else {
         for (int t = threadIdx.x; t < npad_u; t += T)
             keys[t] = (t < B) ? (((uint64_t)(uint32_t)bu[t] << 32) | (uint32_t)t) : ~0ull;
@@ -282,7 +283,8 @@ __global__ __launch_bounds__(T) void sample_plan_kernel(
         };
         if (npad_u == T) sort_via_registers<T, 2>(keys, ob, make);
         else if (npad_u == 2 * T) sort_via_registers<T, 4>(keys, ob, make);
-        else sort_via_registers<T, 8>(keys, ob, make);
+        else if (npad_u == 4 * T) sort_via_registers<T, 8>(keys, ob, make);
+        else sort_via_registers<T, 16>(keys, ob, make);
     } else {
         for (int o = threadIdx.x; o < npad_items; o += T) {
             uint64_t key = ~0ull;

@@ -831,6 +831,146 @@ __global__ __launch_bounds__((WAVES * TKR_WAVE)) void score_topk_kernel(
     write_rows<IdT>(sm, ws, n_rows, K, thr, out_ids, out_scores, part);
 }
 
+// ---- factor widths above 256: the k dimension in slabs of 256 --------------------------------------------------------------------
+// evaluate.py:78 takes any width and the trainer here goes to k = 512.  score_topk_kernel keeps a lane's half of its user's factor
+// row in registers (128 at k = 256) and a 32-item tile of the full width in LDS (2 x 33 KB at k = 256): neither scales.  Here the
+// user operand of EVERY slab stays in registers (SLABS x 128: the 512-register file of a one-wave-per-SIMD workgroup holds two or
+// three slabs) and the item tiles go through the same two LDS buffers one slab at a time -- unit (tile, slab) is staged while unit
+// (tile, slab - 1) is multiplied; the accumulator runs over a tile's slabs and the filter sees it after the last.  Same fp32 MFMA
+// chain, same lists, trims and merge as score_topk_kernel.
+template <int SLABS, typename IdT>
+__global__ __launch_bounds__(256) void score_topk_slab_kernel(
+    const float* __restrict__ U, const int32_t* __restrict__ uidx, int n_rows, const float* __restrict__ Vt,
+    const float* __restrict__ bias, int n_cols, int k, const uint32_t* __restrict__ mask, int mask_pitch, int K,
+    int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int tiles_per_split, uint64_t* __restrict__ part,
+    uint32_t* __restrict__ thr_shared, const int4* __restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int KHP = 128, SW = 2 * KHP;                       // a slab: 256 factors, 128 per half-wave
+    constexpr int KP = SW + 4;
+    constexpr int W = 4, users = W * 32, NT_ = W * 64;
+    TopkSmem<IdT> sm;
+    sm.tile = reinterpret_cast<float*>(smem_raw);
+    sm.tbias = sm.tile + 2 * 32 * KP;
+    sm.cnt = reinterpret_cast<int*>(sm.tbias + 64);
+    sm.cs = reinterpret_cast<float*>(sm.cnt + users);
+    sm.ci = reinterpret_cast<IdT*>(sm.cs + (size_t)users * kCap);
+    sm.users = users;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ul = lane & 31, h = lane >> 5;
+    const int uw = wave * 32 + ul;
+    int4 it = make_int4((int)blockIdx.x, (int)blockIdx.y * tiles_per_split, 0, (int)blockIdx.y | ((int)gridDim.y << 16));
+    if (items) it = items[blockIdx.x];
+    const TopkSlot ws = {it.x, it.w & 0xffff, it.w >> 16};
+    const int row = ws.block * users + uw;
+    const bool user_ok = row < n_rows;
+
+    float breg[SLABS * KHP];                                     // element (slab s, kk) = factor 256 s + 128 h + kk of this lane's user
+    {
+        const int urow = user_ok ? (uidx ? uidx[row] : row) : 0;
+        const float* up = U + (size_t)urow * k;
+#pragma unroll
+        for (int sl = 0; sl < SLABS; ++sl)
+#pragma unroll
+            for (int kk = 0; kk < KHP; ++kk) {
+                const int e = sl * SW + h * KHP + kk;
+                breg[sl * KHP + kk] = (user_ok && e < k) ? up[e] : 0.f;
+            }
+    }
+    for (int s = tid; s < users; s += NT_) sm.cnt[s] = 0;
+    float thr = (thr_shared && user_ok) ? unordered_bits(thr_shared[row]) : -INFINITY;
+    const int n_tiles_all = (n_cols + 31) >> 5;
+    const int t_begin = it.y;
+    const int n_tiles = items ? it.z : min(n_tiles_all, t_begin + tiles_per_split);
+
+    // ---- staging of unit (tile t, slab sl): global -> registers -> LDS buffer (unit index & 1)
+    constexpr int NC = 32 * SW / 4 / NT_;                        // 8 float4 per thread
+    const bool vec = (k & 3) == 0;                               // every item row and slab starts 16-byte aligned
+    float4 stg[NC];
+    float stg_bias = 0.f;
+    auto stage_load = [&](int t, int sl) {
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int c = tid + q * NT_, item = c >> 6, e = sl * SW + (c & 63) * 4;
+                stg[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < k && t * 32 + item < n_cols) stg[q] = *reinterpret_cast<const float4*>(Vt + (size_t)(t * 32 + item) * k + e);
+            }
+        }
+        if (sl == 0 && tid < 32) {
+            const int col = t * 32 + tid;
+            stg_bias = (bias && col < n_cols) ? bias[col] : 0.f;
+        }
+    };
+    auto stage_store = [&](int t, int sl, int buf) {
+        float* dst = sm.tile + buf * 32 * KP;
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int c = tid + q * NT_;
+                *reinterpret_cast<float4*>(dst + (c >> 6) * KP + (c & 63) * 4) = stg[q];
+            }
+        } else {
+            for (int c = tid; c < 32 * SW; c += NT_) {
+                const int item = c / SW, e = sl * SW + c % SW, col = t * 32 + item;
+                dst[item * KP + c % SW] = (e < k && col < n_cols) ? Vt[(size_t)col * k + e] : 0.f;
+            }
+        }
+        if (sl == 0 && tid < 32) sm.tbias[(t & 1) * 32 + tid] = stg_bias;
+    };
+    // unit n = (t - t_begin) * SLABS + sl; the one after (t, sl):
+    auto next_unit = [&](int& t, int& sl) { if (++sl == SLABS) { sl = 0; ++t; } };
+
+    stage_load(t_begin, 0);
+    stage_store(t_begin, 0, 0);
+    __syncthreads();
+    {
+        int t1 = t_begin, s1 = 0;
+        next_unit(t1, s1);
+        if (t1 < n_tiles) stage_load(t1, s1);
+    }
+    const uint32_t tail_mask = (n_cols & 31) ? (0xffffffffu << (n_cols & 31)) : 0u;
+    int next_sched = t_begin + 2;
+    int unit = 0;
+    for (int t = t_begin; t < n_tiles; ++t) {
+        uint32_t maskw = (mask && user_ok) ? mask[(size_t)t * mask_pitch + row] : 0u;
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int sl = 0; sl < SLABS; ++sl, ++unit) {
+            const int buf = unit & 1;
+            const float* arow = sm.tile + buf * 32 * KP + ul * KP + h * KHP;
+#pragma unroll
+            for (int kk = 0; kk < KHP; kk += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + kk);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, breg[sl * KHP + kk + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, breg[sl * KHP + kk + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, breg[sl * KHP + kk + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, breg[sl * KHP + kk + 3], acc, 0, 0, 0);
+            }
+            // the next unit: registers -> the other buffer (free since the barrier before this unit); the one after it -> registers
+            int t1 = t, s1 = sl;
+            next_unit(t1, s1);
+            if (t1 < n_tiles) stage_store(t1, s1, buf ^ 1);
+            int t2 = t1, s2 = s1;
+            next_unit(t2, s2);
+            if (t1 < n_tiles && t2 < n_tiles) stage_load(t2, s2);
+            if (sl + 1 < SLABS) __syncthreads();
+        }
+        if (!user_ok) maskw = 0xffffffffu;
+        if (t == n_tiles_all - 1) maskw |= tail_mask;
+        if (t == next_sched) {
+            if (__ballot(sm.cnt[uw] > kCap / 2) != 0) {
+                thr = trim_all_users<IdT>(sm, uw, h, K, thr);
+                thr = share_threshold(thr_shared, row, user_ok && h == 0, thr);
+            }
+            next_sched = t + ((t - t_begin + 1) >> 1);
+        }
+        filter_tile<IdT>(sm, acc, sm.tbias + (t & 1) * 32, maskw, t, K, thr);
+        __syncthreads();
+    }
+    write_rows<IdT>(sm, ws, n_rows, K, thr, out_ids, out_scores, part);
+}
+
 // ---- K4 on the dense matrix pipe: 6-product bf16 split of the fp32 factors ------------------------------------
 // Every fp32 factor is split EXACTLY into three bf16 parts a = a1 + a2 + a3 (8 significant bits each, round to
 // nearest at each step; bf16 has fp32's exponent range).  The product a*b is taken as the six partial products
@@ -1641,6 +1781,25 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
     return merge_planned(p, users, n_rows, K, out_ids, out_scores, stream);
 }
 
+template <int SLABS, typename IdT>
+static int launch_topk_slabs(const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias, int n_cols, int k,
+                             const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores, void* workspace,
+                             size_t workspace_bytes, hipStream_t stream) {
+    constexpr int users = 128, KP = 260;
+    TopkPlan p;
+    int rc = plan_topk(users, n_rows, n_cols, K, workspace, workspace_bytes, 0, stream, p);
+    if (rc != TKR_OK) return rc;
+    const size_t lds = (size_t)(2 * 32 * KP + 64) * 4 + (size_t)users * 4 + (size_t)users * kCap * (4 + sizeof(IdT));
+    auto kern = score_topk_slab_kernel<SLABS, IdT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, p.grid, dim3(256), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores,
+                       p.tps, p.part, p.thr_shared, p.items);
+    rc = (int)hipGetLastError();
+    if (rc != TKR_OK) return rc;
+    return merge_planned(p, users, n_rows, K, out_ids, out_scores, stream);
+}
+
 // arithmetic of the score block: 2 = bound-and-refine (default; k <= 128 and a workspace, else it runs as 1), 0 = bf16-split
 // products on the dense matrix pipe (k <= 128), 1 = fp32 MFMA for every k.
 // Initial value from TKR_TOPK_MATH=refine|bf16x3|fp32; tkr_topk_set_math changes it for the process.
@@ -1696,6 +1855,10 @@ static int dispatch_topk(const float* U, const int32_t* uidx, int n_rows, const 
     TKR_TOPK_CASE(100)
     TKR_TOPK_CASE(128)
 #undef TKR_TOPK_CASE
+    if (k <= 512)
+        return launch_topk_slabs<2, IdT>(U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores, workspace, workspace_bytes, stream);
+    if (k <= 768)
+        return launch_topk_slabs<3, IdT>(U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores, workspace, workspace_bytes, stream);
     return TKR_EUNSUPPORTED;
 }
 
@@ -1752,7 +1915,7 @@ extern "C" int tkr_score_topk(const float* U, const int32_t* user_idx, int32_t n
                               int64_t workspace_bytes, void* stream) {
     if (!U || !Vt || !out_ids || n_rows <= 0 || n_cols <= 0 || k <= 0 || K <= 0) return TKR_EINVAL;
     if (mask && mask_pitch < n_rows) return TKR_EINVAL;
-    if (K > tkr::kMaxK || k > 256) return TKR_EUNSUPPORTED;
+    if (K > tkr::kMaxK || k > 768) return TKR_EUNSUPPORTED;
     if (n_cols <= 65535)
         return tkr::dispatch_topk<uint16_t>(U, user_idx, n_rows, Vt, bias, n_cols, k, mask, mask_pitch, K, out_ids,
                                             out_scores, workspace, (size_t)(workspace_bytes > 0 ? workspace_bytes : 0),
