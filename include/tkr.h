@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TKR_VERSION 112 /* 0.1.12: tkr_bpr_own_run_between. 0.1.11: K2o (tkr_sample_plan_owned, tkr_bpr_own_run: item rows owned by one workgroup each, resident in its LDS); prec[5] = last batch of the call that updated the row. 0.1.10: tkr_topk_workspace_bytes_for (K4 stages pre-converted fp16 tiles). 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
+#define TKR_VERSION 113 /* 0.1.13: tkr_bpr_own_plan_run, K4 to k = 768. 0.1.12: tkr_bpr_own_run_between. 0.1.11: K2o (tkr_sample_plan_owned, tkr_bpr_own_run: item rows owned by one workgroup each, resident in its LDS); prec[5] = last batch of the call that updated the row. 0.1.10: tkr_topk_workspace_bytes_for (K4 stages pre-converted fp16 tiles). 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
 #define TKR_OK 0
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
@@ -196,6 +196,21 @@ int tkr_sample_plan_owned(const int32_t* tr_users, int32_t n_tr, const int32_t* 
 int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, const int32_t* occt, const int32_t* ohdr,
                     int32_t ohdr_stride, int32_t n_owner, int32_t batch_size, int32_t first_batch, int32_t n_batches, uint32_t* ctl, float* loss_out,
                     int32_t owner_waves, void* xch, uint32_t epoch, void* stream);
+/* One call for a SHORT training call -- K1 of a chunk and the persistent step on it, back to back: tkr_sample_plan_owned with the
+ * arguments of `plan` (a struct: a caller fills it once per plan buffer and changes first_triplet / n_batches per call), then
+ * tkr_bpr_own_run on batches [first_batch, first_batch + n_batches) of that plan, with the caller's two events (hipEvent_t or NULL)
+ * recorded around the step launch.  Four launches without a trip back through the host language between them: a 20-batch call
+ * is ~105 us of device work, and an interpreter between the launches leaves the device waiting for the host. */
+typedef struct tkr_plan_call {
+    const int32_t *tr_users, *row_ptr, *pos_cols, *cols_sorted;
+    int32_t *ucnt, *icnt;
+    uint32_t *touch_u, *touch_i;
+    int32_t *out_u, *out_i, *out_j, *task, *occ, *occt, *prec, *pocc, *ohdr;
+    uint64_t seed, first_triplet;
+    int32_t n_tr, n_users, n_items, n_batches, batch_size, n_owner, ohdr_stride, reserved;
+} tkr_plan_call;
+int tkr_bpr_own_plan_run(const tkr_plan_call* plan, const tkr_flow_state* st, int32_t first_batch, int32_t n_batches, uint32_t* ctl,
+                         float* loss_out, int32_t owner_waves, void* xch, uint32_t epoch, void* ev_before, void* ev_after, void* stream);
 /* tkr_bpr_own_run between two events of the caller (hipEvent_t or NULL), recorded on `stream` right around the launch */
 int tkr_bpr_own_run_between(void* ev_before, void* ev_after, const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc,
                             const int32_t* occt, const int32_t* ohdr, int32_t ohdr_stride, int32_t n_owner, int32_t batch_size,

@@ -812,3 +812,16 @@ extern "C" int tkr_bpr_own_run_between(void* ev_before, void* ev_after, const tk
     if (ev_after) TKR_CHECK(hipEventRecord((hipEvent_t)ev_after, (hipStream_t)stream));
     return rc;
 }
+
+extern "C" int tkr_bpr_own_plan_run(const tkr_plan_call* plan, const tkr_flow_state* st, int32_t first_batch, int32_t n_batches, uint32_t* ctl,
+                                    float* loss_out, int32_t owner_waves, void* xch, uint32_t epoch, void* ev_before, void* ev_after,
+                                    void* stream) {
+    if (!plan || first_batch < 0 || n_batches < 0 || first_batch + n_batches > plan->n_batches) return TKR_EINVAL;
+    const int rc = tkr_sample_plan_owned(plan->tr_users, plan->n_tr, plan->row_ptr, plan->pos_cols, plan->cols_sorted, plan->n_users,
+                                         plan->n_items, plan->seed, plan->first_triplet, plan->n_batches, plan->batch_size, plan->ucnt,
+                                         plan->icnt, plan->touch_u, plan->touch_i, plan->out_u, plan->out_i, plan->out_j, plan->task,
+                                         plan->occ, plan->occt, plan->prec, plan->pocc, plan->n_owner, plan->ohdr, plan->ohdr_stride, stream);
+    if (rc != TKR_OK) return rc;
+    return tkr_bpr_own_run_between(ev_before, ev_after, st, plan->prec, plan->pocc, plan->occt, plan->ohdr, plan->ohdr_stride, plan->n_owner,
+                                   plan->batch_size, first_batch, n_batches, ctl, loss_out, owner_waves, xch, epoch, stream);
+}

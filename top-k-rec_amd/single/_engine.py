@@ -178,6 +178,7 @@ class PlanPipeline:
             self._side_dirty = False
 
 
+FUSE_SHORT_CALLS = __import__('os').environ.get('TKR_FUSE_SHORT', '1') != '0'     # K1 + step of a short call in ONE C call (tkr_bpr_own_plan_run)
 OVERLAP_MIN_BATCH = int(__import__('os').environ.get('TKR_OVERLAP_MIN_BATCH', 2048))     # below this the planner is < 5 % of the time and a second active queue slows
                              # the dependent launch cadence of the step kernels (measured: 5.8 -> 6.8 us at B=256)
 
@@ -194,11 +195,12 @@ class _Chunk:
     """a planned chunk: batches [used, nb) of plan buffer `idx` have not run yet; batch 0 starts at triplet `first`.
     ``shadow``: the chunk was planned AHEAD OF AN EXCHANGE against a zeroed copy of the item counters (this tensor); it only
     becomes runnable once the exchange has zeroed the real ones (PlanMixin.after_exchange)."""
-    __slots__ = ('idx', 'nb', 'used', 'B', 'first', 'csr', 'shadow', 'epoch_ahead')
+    __slots__ = ('idx', 'nb', 'used', 'B', 'first', 'csr', 'shadow', 'epoch_ahead', 'pending')
 
     def __init__(self, idx, nb, B, first, csr, shadow=None):
         self.idx, self.nb, self.used, self.B, self.first, self.csr = idx, nb, 0, B, first, csr
         self.shadow, self.epoch_ahead = shadow, shadow is not None
+        self.pending = None             # a tkr_hip.PlanCall: K1 of this chunk has NOT been launched yet -- the step's call launches it (short calls)
 
 
 class _ShadowCounters:
@@ -311,7 +313,7 @@ class PlanMixin:
             return
         self.pipe.drain()
         for ch in (self._ahead, self._cur):          # newest first, like unwinding
-            if ch is not None and ch.used < ch.nb:
+            if ch is not None and ch.used < ch.nb and ch.pending is None:
                 buf = self.pipe.bufs[ch.idx]
                 cnt = self._cnt if ch.shadow is None else _ShadowCounters(self._cnt, ch.shadow)
                 tkr_hip.plan_rollback(buf, ch.B, ch.used, ch.nb - ch.used, cnt)
@@ -329,9 +331,24 @@ class PlanMixin:
         self._cnt.icnt.copy_(ah.shadow)
         ah.shadow = None
 
-    def _plan_chunk(self, idx, csr, B, first, overlap, want, shadow=None):
+    def _plan_chunk(self, idx, csr, B, first, overlap, want, shadow=None, fuse=False):
         nb = max(1, min(self._cap(B), want))
         cnt = self._cnt if shadow is None else _ShadowCounters(self._cnt, shadow)
+        if fuse:            # K1 rides in the step's C call (tkr_bpr_own_plan_run): nothing is launched here
+            self.pipe.drain()
+            buf = self.pipe.bufs[idx]
+            key = ('fused', id(csr), id(cnt.ucnt), id(cnt.icnt), self.seed)
+            callers = buf.__dict__.setdefault('_callers', {})
+            call = callers.get(key)
+            if call is None:
+                if len(callers) > 4:
+                    callers.clear()
+                call = callers[key] = tkr_hip.plan_call(csr, self.n_users, self.n_items, self.seed, B, cnt, buf)
+            call.first_triplet, call.n_batches = first, nb
+            self.pipe.planned[idx] = None
+            ch = _Chunk(idx, nb, B, first, csr, shadow)
+            ch.pending = call
+            return ch
 
         def fn(buf):
             if shadow is not None:
@@ -377,7 +394,10 @@ class PlanMixin:
         if cur is not None and self._ahead is not None:
             nxt, self._ahead = self._ahead, None
         else:
-            nxt = self._plan_chunk(0 if cur is None else cur.idx ^ 1, csr, B, self._drawn, False, want)
+            # a short call (this chunk holds all that is left of it, nothing is planned beside it): K1 goes out in the step's call
+            fuse = (FUSE_SHORT_CALLS and not overlap and then_exchange == 0 and want <= self._cap(B) and
+                    getattr(getattr(self, '_step', None), 'plan_and_run', None) is not None and self._plan_owners(B) > 0)
+            nxt = self._plan_chunk(0 if cur is None else cur.idx ^ 1, csr, B, self._drawn, False, want, fuse=fuse)
         if overlap and want > nxt.nb:                 # the chunk after it, behind the steps of this one
             self._ahead = self._plan_chunk(nxt.idx ^ 1, csr, B, nxt.first + nxt.nb * B, True, want - nxt.nb)
         elif then_exchange > 0 and want <= nxt.nb and self._epoch_ahead_ok(B):
@@ -401,7 +421,14 @@ class PlanMixin:
             lo = ch.used
             if want_loss:
                 plan.loss[lo:lo + m].zero_()
-            if self.step_events is not None:          # bench: HIP events around the step launches
+            if ch.pending is not None:                # K1 of this chunk and the step on its first m batches: one C call
+                call, ch.pending = ch.pending, None
+                ev = None
+                if self.step_events is not None:
+                    ev = self._event_pool.pop() if self._event_pool else _recorded_event_pair()
+                    self.step_events.append((ev[0], ev[1], m))
+                step_fn.plan_and_run(plan, call, lo, m, plan.loss if want_loss else None, ev)
+            elif self.step_events is not None:        # bench: HIP events around the step launches
                 e0, e1 = self._event_pool.pop() if self._event_pool else _recorded_event_pair()
                 if getattr(step_fn, 'takes_events', False):         # recorded in C, right around the launch
                     step_fn(plan, lo, m, plan.loss if want_loss else None, (e0, e1))

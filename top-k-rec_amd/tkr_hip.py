@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TKR_HIP_LIB') or os.path.join(_HERE, 'libtkr_hip.so')      # the override is for A/B builds of the kernels (scripts/)
 
 _lib = None
-VERSION = 112          # TKR_VERSION of include/tkr.h this binding was written against
+VERSION = 113          # TKR_VERSION of include/tkr.h this binding was written against
 
 
 class TkrError(RuntimeError):
@@ -29,6 +29,32 @@ class BprState(C.Structure):
                 ('n_users', C.c_int32), ('n_items', C.c_int32), ('k', C.c_int32), ('mode', C.c_int32),
                 ('lu', C.c_float), ('li', C.c_float), ('lj', C.c_float), ('lb', C.c_float),
                 ('lr', C.c_float), ('rho', C.c_float), ('eps', C.c_float), ('opt', C.c_int32)]
+
+
+class PlanCall(C.Structure):
+    """tkr_plan_call of include/tkr.h: the arguments of tkr_sample_plan_owned"""
+    _fields_ = [(n, C.c_void_p) for n in ('tr_users', 'row_ptr', 'pos_cols', 'cols_sorted', 'ucnt', 'icnt', 'touch_u', 'touch_i', 'out_u', 'out_i',
+                                           'out_j', 'task', 'occ', 'occt', 'prec', 'pocc', 'ohdr')] + \
+               [('seed', C.c_uint64), ('first_triplet', C.c_uint64)] + \
+               [(n, C.c_int32) for n in ('n_tr', 'n_users', 'n_items', 'n_batches', 'batch_size', 'n_owner', 'ohdr_stride', 'reserved')]
+
+
+def plan_call(csr, n_users, n_items, seed, B, cnt, plan):
+    """-> PlanCall for K1 into `plan` (an owner-ordered dataflow plan buffer); first_triplet / n_batches are the caller's to set"""
+    assert plan.owners > 0
+    for t in (csr.tr_users, csr.row_ptr, csr.pos_cols, csr.cols_sorted, cnt.ucnt, cnt.icnt, cnt.touch_u, cnt.touch_i, plan.u, plan.task):
+        assert t.is_cuda and t.is_contiguous()
+    assert cnt.ucnt.numel() == n_users and cnt.icnt.numel() == n_items
+    pc = PlanCall()
+    for name, t in (('tr_users', csr.tr_users), ('row_ptr', csr.row_ptr), ('pos_cols', csr.pos_cols), ('cols_sorted', csr.cols_sorted),
+                    ('ucnt', cnt.ucnt), ('icnt', cnt.icnt), ('touch_u', cnt.touch_u), ('touch_i', cnt.touch_i), ('out_u', plan.u),
+                    ('out_i', plan.i), ('out_j', plan.j), ('task', plan.task), ('occ', plan.occ), ('occt', plan.occt), ('prec', plan.prec),
+                    ('pocc', plan.pocc), ('ohdr', plan.ohdr)):
+        setattr(pc, name, t.data_ptr())
+    pc.seed, pc.n_tr, pc.n_users, pc.n_items, pc.batch_size = seed, int(csr.tr_users.numel()), n_users, n_items, B
+    pc.n_owner, pc.ohdr_stride = plan.owners, plan.cap
+    pc.keep = (csr, cnt)                  # the tensors behind the pointers live as long as the struct
+    return pc
 
 
 class FlowState(C.Structure):
@@ -46,7 +72,7 @@ class VbprState(C.Structure):
                [(n, C.c_void_p) for n in ('f_ptr', 'f_col', 'f_val', 'c_ptr', 'c_item', 'c_val', 'item_tag')]
 
 
-EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_sample_plan_owned', 'tkr_plan_rollback', 'tkr_bpr_run', 'tkr_bpr_flow_run', 'tkr_bpr_own_run', 'tkr_bpr_own_run_between', 'tkr_bpr_own_owners', 'tkr_flow_row_granules', 'tkr_flow_ctl_words',
+EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_sample_plan_owned', 'tkr_plan_rollback', 'tkr_bpr_run', 'tkr_bpr_flow_run', 'tkr_bpr_own_run', 'tkr_bpr_own_run_between', 'tkr_bpr_own_plan_run', 'tkr_bpr_own_owners', 'tkr_flow_row_granules', 'tkr_flow_ctl_words',
            'tkr_vbpr_run', 'tkr_vbpr_colplan', 'tkr_vbpr_run_cols', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy',
            'tkr_idmap_create', 'tkr_idmap_destroy', 'tkr_ratings_parse', 'tkr_ratings_sizes', 'tkr_ratings_copy',
            'tkr_ratings_destroy', 'tkr_matrix_read', 'tkr_matrix_sizes', 'tkr_matrix_copy', 'tkr_matrix_destroy',
@@ -317,8 +343,22 @@ def own_stepper(state, B, ctl, owner_waves=0):
                 torch.cuda.current_stream(device).cuda_stream)
         if rc:
             _check(rc, 'tkr_bpr_own_run_between')
+    fused = lib().tkr_bpr_own_plan_run
+    fused.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p,
+                      C.c_void_p, C.c_void_p]
+
+    def plan_and_run(plan, call, first, n_batches, loss_out, events=None):
+        """K1 of the chunk described by `call` (a PlanCall into `plan`) and the step on its batches [first, first + n_batches): one C call"""
+        assert torch.cuda.current_device() == device.index and 0 < call.n_batches <= min(plan.cap, PLAN_MAX_BATCHES)
+        plan.epoch += 1
+        rc = fused(C.addressof(call), st, first, n_batches, ctl_ptr, None if loss_out is None else loss_out.data_ptr(), owner_waves,
+                   plan.xch.data_ptr(), plan.epoch & 0xffffffff or 1, None if events is None else events[0].cuda_event,
+                   None if events is None else events[1].cuda_event, torch.cuda.current_stream(device).cuda_stream)
+        if rc:
+            _check(rc, 'tkr_bpr_own_plan_run')
     step.state = state
     step.takes_events = True
+    step.plan_and_run = plan_and_run
     return step
 
 
