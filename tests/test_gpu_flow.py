@@ -316,6 +316,32 @@ def test_engine_layouts_and_piecewise_plans():
         np.testing.assert_allclose(a.get(n)[0].cpu().numpy(), ref[n], rtol=3e-4, atol=2e-5, err_msg=n)
 
 
+def test_short_calls_in_one_c_call_equal_two(monkeypatch):
+    """a short call sends K1 and the step out in ONE C call (tkr_bpr_own_plan_run); a long one plans and steps separately: the same
+    tables bit for bit, the same losses (to the order of their atomic sums), the same counters -- also across a settle() that finds a chunk whose K1 never left"""
+    from single import _engine
+    n_users, n_items, k = 900, 200, 64
+    tr, tr_users = _toy(n_users, n_items, seed=3)
+    row_ptr, pos, srt = P.build_csr(tr, n_users)
+    dev = torch.device('cuda')
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.02, mode='l2')
+    out = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(_engine, 'FUSE_SHORT_CALLS', fuse)
+        e = _engine.BprEngine(n_users, n_items, k, hp, dev, seed=21)
+        losses = []
+        for m in (1, 20, 7, 3):
+            losses.append(e.run_batches(csr, m, 256, want_loss=True).clone())
+            e.settle()
+        assert e._plan_owners(256) > 0
+        out[fuse] = ([t.clone() for n in ('U', 'V', 'b') for t in e.get(n)], torch.cat(losses), e.cnt.ucnt.clone(), e.cnt.icnt.clone())
+    for x, y in zip(out[True][0], out[False][0]):
+        assert torch.equal(x, y)
+    torch.testing.assert_close(out[True][1], out[False][1], rtol=1e-5, atol=1e-4)          # per-batch sums of atomic adds: order-dependent bits
+    assert torch.equal(out[True][2], out[False][2]) and torch.equal(out[True][3], out[False][3])
+
+
 @pytest.mark.parametrize('bufs', [2, 4])
 def test_fused_exchange_of_the_granule_tables(monkeypatch, bufs):
     """dist.ItemSync on the dataflow layout (tkr_sync_flow_snapshot / pack / unpack) against the same exchange through get /
