@@ -4,7 +4,7 @@
 //
 // The own-row chain.  A popular item is updated in (nearly) every batch; under K2f the task of batch t+1 starts its arithmetic
 // once the row written by the task of batch t has made the trip write-through store -> memory -> polling load of another CU.  Here
-// every item row r has an OWNER: the workgroup with arrival number r % n_owner (one workgroup per CU, all resident).  K1 lays the
+// every item row r has an OWNER: workgroup r % n_owner (one workgroup per CU, all resident).  K1 lays the
 // item tasks of a batch out in (owner, row) order and names every owner's run (tkr_sample_plan_owned: `ohdr`); the owner's waves
 // take them in plan order from a queue in LDS (one LDS atomic per task), and the row, its RMSProp slot, bias and acknowledge totals
 // stay in the owner's LDS from the row's first update of a launch on: the task of batch t+1 finds what the task of batch t left
@@ -459,9 +459,16 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     uint32_t* dotmark = tags + rows_here;                                              // [kDotWin]: position + 1 of the task whose scalars are out
     float* rows = reinterpret_cast<float*>(smem + ((sizeof(OwnQueue) + (size_t)4 * (2 * nb + 1 + TKR_WAVE + rows_here + kDotWin) + 15) & ~(size_t)15));
 
-    if (threadIdx.x == 0) q->arrival = __hip_atomic_fetch_add(ctl + kCtlArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const uint32_t me = q->arrival;                                                    // owner number: arrival order, whatever the placement
+    // owner number = workgroup number (every workgroup is resident: which CU it sits on means nothing).  The first ticket of a user-task
+    // wave goes out NOW, beside the loads of the queue header: a launch used to start with three trips in series -- an arrival
+    // counter, the header, the first ticket -- in front of every short call.
+    const uint32_t me = blockIdx.x;
+    const bool ticket_wave = wave > owner_waves;
+    const int tw = wave - owner_waves - 1, n_tw = TPB / TKR_WAVE - owner_waves - 1;
+    const int queues = min(kQueues, max(n_tw, 1) * (int)gridDim.x);
+    const int home = ticket_wave ? (int)((me * (uint32_t)n_tw + (uint32_t)tw) % (uint32_t)queues) : 0;
+    uint32_t ticket = 0;
+    if (ticket_wave) ticket = grab_issue(ctl, lane, home);
     for (int b = threadIdx.x; b < nb; b += TPB) {
         const uint32_t h = me < (uint32_t)n_owner ? (uint32_t)ohdr[(size_t)me * ohdr_stride + b] : 0u;
         start[b] = h & 0xffffu;
@@ -631,11 +638,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
         }
     } else {
         // ================= user tasks, by ticket =================
-        const int tw = wave - owner_waves - 1, n_tw = TPB / TKR_WAVE - owner_waves - 1;
-        const int queues = min(kQueues, n_tw * (int)gridDim.x);
-        const int home = (int)((me * (uint32_t)n_tw + (uint32_t)tw) % (uint32_t)queues);
         const uint32_t total = (uint32_t)nb * (uint32_t)B;
-        uint32_t ticket = grab_issue(ctl, lane, home);
         NextTask nx;
         nx.idx = 0u; nx.w = make_int4(0, 0, 0, 0); nx.have = false;
         while (alive) {
