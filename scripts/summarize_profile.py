@@ -3,7 +3,7 @@ under profiles/: <round>_bench_kernel_stats.csv, <round>_kernel_summary.csv, <ro
 import csv, json, os, re, sys
 import pandas as pd
 src, tag = sys.argv[1], sys.argv[2]
-KERN = ('bpr_own_kernel', 'bpr_flow_kernel', 'bpr_step_kernel', 'sample_plan_kernel', 'resolve_flow_kernel', 'resolve_kernel', 'commit_kernel', 'rollback_kernel',
+KERN = ('bpr_own_kernel', 'bpr_flow_kernel', 'bpr_step_kernel', 'sample_plan_kernel', 'resolve_flow_wide_kernel', 'resolve_flow_kernel', 'score_topk_slab_kernel', 'resolve_kernel', 'commit_kernel', 'rollback_kernel',
         'big_draw_kernel', 'big_flag_kernel', 'big_emit_kernel', 'big_count_kernel', 'big_fill_kernel', 'big_parity_kernel', 'big_record_kernel',
         'DeviceRadixSort', 'radix_sort', 'DeviceScan', 'scan', 'vbpr_pair_kernel', 'score_topk_bf16_kernel', 'score_topk_kernel', 'merge_topk_kernel', 'topk_bounds_kernel',
         'raw_rank_kernel', 'count_hits_rr_kernel',
@@ -97,8 +97,11 @@ try:
     ht = pd.read_csv(find('driver', 'd_hip_api_trace.csv*'))
     kt = pd.read_csv(find('driver', 'd_kernel_trace.csv*'))
     flow = kt[kt.Kernel_Name.str.contains('bpr_own_kernel|bpr_flow_kernel')].sort_values('Start_Timestamp')
-    last = flow.iloc[1]                                             # warm-up (5 batches), then the timed 20 batches; the epoch_mode leg follows
-    prev_end = flow.iloc[0].End_Timestamp
+    # the warm-up (5 single-batch calls since round 4's short-call work), then the timed 20 batches; the epoch_mode leg follows
+    n_warm = 5 if (flow.iloc[:5].Grid_Size_X == flow.iloc[0].Grid_Size_X).all() and \
+        (flow.iloc[:5].End_Timestamp - flow.iloc[:5].Start_Timestamp).max() < 0.7 * (flow.iloc[5].End_Timestamp - flow.iloc[5].Start_Timestamp) else 1
+    last = flow.iloc[n_warm]
+    prev_end = flow.iloc[n_warm - 1].End_Timestamp
     win = ht[(ht.Start_Timestamp > prev_end) & (ht.Start_Timestamp < last.End_Timestamp)]
     calls = win.Function.value_counts().to_dict()
     json.dump({'window': 'HIP API calls between the end of the warm-up launch and the end of the timed launch of `bench.py --steps 20 --warmup 5`',
