@@ -162,12 +162,12 @@ mine = tdist.shard_users(users, rank, world)
 allu = [None] * world
 dist.all_gather_object(allu, mine)
 assert sorted(sum(allu, [])) == users and len(set(sum(allu, []))) == len(users)
-assert tdist.batches_per_rank(3906, world) == 1953
+assert tdist.batches_per_rank(3906, world) == 3906 // world            # (epoch_sample_limit // B) // N of north_star
 
 class Eng:                      # the engine surface ItemSync needs (device-agnostic tensors)
     def __init__(self):
         g = torch.Generator().manual_seed(0)
-        self.t = {'V': [torch.randn(6, 4, generator=g), torch.ones(6, 4)], 'b': [torch.zeros(6), torch.ones(6)]}
+        self.t = {'V': [torch.randn(9, 4, generator=g), torch.ones(9, 4)], 'b': [torch.zeros(9), torch.ones(9)]}
     def get(self, n): return self.t[n][0], self.t[n][1]
     def set_replicated(self, new):
         for n, (p, ms) in new.items(): self.t[n] = [p.clone(), ms.clone()]
@@ -180,9 +180,9 @@ e.t['V'][1] *= (rank + 1)
 e.t['b'][0][rank] = 1.0                  # disjoint bias updates
 sync.end()
 assert torch.allclose(e.t['V'][0], V0 + 0.5 * sum(range(1, world + 1)))        # P0 + sum of deltas
-assert torch.allclose(e.t['V'][1], torch.full((6, 4), sum(range(1, world + 1)) / world))   # slots: mean
+assert torch.allclose(e.t['V'][1], torch.full((9, 4), sum(range(1, world + 1)) / world))   # slots: mean
 assert torch.allclose(e.t['b'][0][:world], torch.ones(world))
-# user rows: every rank holds ONLY the rows of its users (5 users dealt round-robin -> shards of 3 and 2) and they are gathered once
+# user rows: every rank holds ONLY the rows of its users (5 users dealt round-robin -> shards of 3 and 2; of 1 and 0 on 8 ranks) and they are gathered once
 owned = tdist.shard_users(list(range(5)), rank, world)
 rows = torch.full((len(owned), 2), float(rank + 1)); slots = rows * 10
 full, full_ms = np.zeros((5, 2), np.float32), np.zeros((5, 2), np.float32)
@@ -197,14 +197,15 @@ print('ok', rank)
 '''
 
 
-def test_item_sync_world_size_2_gloo(tmp_path):
+@pytest.mark.parametrize('world', [2, 8])          # 8: the north_star node (one process per GPU), here on gloo
+def test_item_sync_world_size_2_gloo(tmp_path, world):
     script = tmp_path / 'worker.py'
     script.write_text(_GLOO_WORKER % dict(root=ROOT, pkg=os.path.join(ROOT, 'top-k-rec_amd')))
-    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-                          '--master-addr', '127.0.0.1', '--master-port', '29631', str(script)],
-                         capture_output=True, text=True, timeout=240)
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
+                          '--master-addr', '127.0.0.1', '--master-port', str(29631 + world), str(script)],
+                         capture_output=True, text=True, timeout=400, env=dict(os.environ, OMP_NUM_THREADS='1'))
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count('ok') == 2
+    assert out.stdout.count('ok') == world
 
 
 # ---------------------------------------------------------------- native text I/O (csrc/textio.hip)
