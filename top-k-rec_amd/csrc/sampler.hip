@@ -834,7 +834,7 @@ static int sample_plan_impl(const int32_t* tr_users, int32_t n_tr, const int32_t
         // a short call (its plan sits in front of its step, nothing runs beside it): one thread per task instead of three tasks per thread
         static const int wide_upto = [] { const char* e = getenv("TKR_PLAN_WIDE_UPTO"); return e ? atoi(e) : 64; }();
         const size_t lds_r = n_owner > 0 ? (size_t)4 * n_owner * (own_words + 1) : 0;
-        if (n_batches <= wide_upto && 3 * batch_size <= tkr::kWideThreads)
+        if (n_batches <= wide_upto && 3 * batch_size <= tkr::kWideThreads && lds_r + (size_t)3 * batch_size * 20 <= 64 * 1024)
             hipLaunchKernelGGL(tkr::resolve_flow_wide_kernel, dim3(n_batches), dim3(tkr::kWideThreads), lds_r + (size_t)3 * batch_size * 20, s,
                                batch_size, reinterpret_cast<const int4*>(task), reinterpret_cast<const int2*>(occ), ucnt, icnt, touch_u,
                                touch_i, reinterpret_cast<int4*>(pocc), reinterpret_cast<int4*>(prec), n_owner, ohdr, ohdr_stride, occt, own_words);
