@@ -169,3 +169,87 @@ def test_integration_md_persistent_sequence():
     np.testing.assert_allclose(fie, ref['V'], rtol=2e-4, atol=1e-5)
     np.testing.assert_allclose(fib, ref['b'], rtol=2e-4, atol=1e-5)
     np.testing.assert_allclose(loss.cpu().numpy()[:run], np.array(ref_loss), rtol=1e-4)
+
+
+class tkr_plan_call(C.Structure):                   # include/tkr.h, field for field
+    _fields_ = [(n, C.c_void_p) for n in ('tr_users', 'row_ptr', 'pos_cols', 'cols_sorted', 'ucnt', 'icnt', 'touch_u', 'touch_i', 'out_u', 'out_i',
+                                           'out_j', 'task', 'occ', 'occt', 'prec', 'pocc', 'ohdr')] + \
+               [('seed', C.c_uint64), ('first_triplet', C.c_uint64)] + \
+               [(n, C.c_int32) for n in ('n_tr', 'n_users', 'n_items', 'n_batches', 'batch_size', 'n_owner', 'ohdr_stride', 'reserved')]
+
+
+def test_integration_md_owned_rows_in_one_call():
+    """INTEGRATION.md §B.1b (its K2o part) with raw ctypes: K1 of a short chunk and the persistent step with owned item rows (K2o) in ONE C call
+    (tkr_bpr_own_plan_run over a tkr_plan_call), twice in a row on the same tables, two HIP events of the caller recorded around the
+    step launch -- against the oracle"""
+    lib = C.CDLL(os.path.join(ROOT, 'top-k-rec_amd', 'libtkr_hip.so'))
+    lib.tkr_flow_row_granules.restype = C.c_int32
+    lib.tkr_flow_ctl_words.restype = C.c_int32
+    lib.tkr_bpr_own_owners.restype = C.c_int32
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    dev = 'cuda'
+    rng = np.random.Generator(np.random.PCG64(2))
+    n_users, n_items, k, B, nb, seed = 500, 200, 50, 128, 5, 777
+    tr = {u: [int(x) for x in rng.integers(0, n_items, int(rng.integers(1, 9)))] for u in range(n_users)}
+    tr_users_l = list(tr.keys())
+    row_ptr_n, pos_n, srt_n = P.build_csr(tr, n_users)
+    i32 = dict(dtype=torch.int32, device=dev)
+    tr_users, row_ptr = torch.tensor(tr_users_l, **i32), torch.from_numpy(row_ptr_n).to(dev)
+    pos_cols, cols_sorted = torch.from_numpy(pos_n).to(dev), torch.from_numpy(srt_n).to(dev)
+    ref = R.init_bpr_state(n_users, n_items, k, rng)
+    kp = lib.tkr_flow_row_granules(k)
+    n_owner = lib.tkr_bpr_own_owners(n_items, k)
+    assert n_owner > 0
+
+    def granules(n, w, init=None, pad=0.0):
+        t = torch.zeros(2, n, w, 2, device=dev)
+        t[0, :, :, 0] = pad
+        if init is not None:
+            t[0, :, :init.shape[1], 0] = torch.from_numpy(init).to(dev)
+        t.view(torch.int32)[1, :, :, 1] = -1
+        return t
+    U, msU = granules(n_users, kp, ref['U']), granules(n_users, kp, ref['msU'], pad=1.0)
+    V, msV = granules(n_items, kp, ref['V']), granules(n_items, kp, ref['msV'], pad=1.0)
+    tailU, tailV = granules(n_users, 4), granules(n_items, 4)
+    tailV[0, :, 1, 0] = 1.0
+    rdU, rdV = torch.zeros(2 * n_users, **i32), torch.zeros(2 * n_items, **i32)
+    ctl = torch.zeros(lib.tkr_flow_ctl_words(), **i32)
+    ucnt, icnt = torch.zeros(n_users, **i32), torch.zeros(n_items, **i32)
+    touch_u, touch_i = torch.zeros(n_users * 16, **i32), torch.zeros(n_items * 16, **i32)
+    out_u, out_i, out_j = (torch.empty(nb * B, **i32) for _ in range(3))
+    task, occ, occt = torch.empty(nb * 3 * B * 4, **i32), torch.empty(nb * 3 * B * 2, **i32), torch.empty(nb * 3 * B, **i32)
+    prec, pocc = torch.empty(nb * 3 * B * 32, **i32), torch.empty(nb * 3 * B * 4, **i32)
+    ohdr, xch = torch.zeros(n_owner * nb, **i32), torch.zeros(nb * B * 4, **i32)
+    loss = torch.zeros(nb, device=dev)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.05, mode='l2')
+    st = tkr_flow_state(ptr(U), ptr(msU), ptr(tailU), ptr(rdU), ptr(V), ptr(msV), ptr(tailV), ptr(rdV), n_users, n_items, k, 0,
+                        hp['lu'], hp['li'], hp['lj'], hp['lb'], hp['lr'], 0.9, 1e-10, 0, 2)
+    pc = tkr_plan_call()
+    for name, t in (('tr_users', tr_users), ('row_ptr', row_ptr), ('pos_cols', pos_cols), ('cols_sorted', cols_sorted), ('ucnt', ucnt), ('icnt', icnt),
+                    ('touch_u', touch_u), ('touch_i', touch_i), ('out_u', out_u), ('out_i', out_i), ('out_j', out_j), ('task', task), ('occ', occ),
+                    ('occt', occt), ('prec', prec), ('pocc', pocc), ('ohdr', ohdr)):
+        setattr(pc, name, t.data_ptr())
+    pc.seed, pc.n_tr, pc.n_users, pc.n_items, pc.batch_size, pc.n_owner, pc.ohdr_stride = seed, len(tr_users_l), n_users, n_items, B, n_owner, nb
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for e in ev:
+        e.record()                                  # a torch event exists on the device from its first record() on
+    ref_loss, got_loss, u_all = [], [], []
+    for call, n in enumerate((nb, 3)):              # two short calls: 5 batches, then 3 more from where the stream stands
+        pc.first_triplet, pc.n_batches = sum((nb, 3)[:call]) * B, n
+        assert lib.tkr_bpr_own_plan_run(C.byref(pc), C.byref(st), 0, n, ptr(ctl), ptr(loss), 0, ptr(xch), C.c_uint32(call + 1),
+                                        C.c_void_p(ev[0].cuda_event), C.c_void_p(ev[1].cuda_event), stream) == 0
+        torch.cuda.synchronize()
+        assert int(ctl[1026]) == 0 and ev[0].elapsed_time(ev[1]) > 0.0
+        u, i, j = P.sample_triplets(tr_users_l, row_ptr_n, pos_n, srt_n, n_items, seed, int(pc.first_triplet), n * B)
+        np.testing.assert_array_equal(out_u.cpu().numpy()[:n * B], u)
+        ref_loss += [R.bpr_step(ref, u[q * B:(q + 1) * B], i[q * B:(q + 1) * B], j[q * B:(q + 1) * B], hp) for q in range(n)]
+        got_loss += loss.cpu().numpy()[:n].tolist()
+        loss.zero_()
+    fue = U[(ucnt & 1).long(), torch.arange(n_users, device=dev), :k, 0].cpu().numpy()
+    fie = V[(icnt & 1).long(), torch.arange(n_items, device=dev), :k, 0].cpu().numpy()
+    fib = tailV[(icnt & 1).long(), torch.arange(n_items, device=dev), 0, 0].cpu().numpy()
+    np.testing.assert_allclose(fue, ref['U'], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(fie, ref['V'], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(fib, ref['b'], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(np.array(got_loss), np.array(ref_loss), rtol=1e-4)
