@@ -150,6 +150,11 @@ def _chunk_crossings(eng, steps, B):
     return steps // eng._cap(B) + 1
 
 
+# Every step also produces its batch's loss, as the reference's does (`_, loss = sess.run([solver, obj])`, single/bpr.py:141,
+# vbpr.py:114) -- since round 4 (before: the step without it; TKR_BENCH_LOSS=0 brings that back for comparison)
+WANT_LOSS = os.environ.get('TKR_BENCH_LOSS', '1') != '0'
+
+
 class Loop:
     """The loop of single/bpr.py:136-147 as BPR.train runs it on this rank: batches in stream order and, at N > 1, the exchange
     of the item-side tables at its REAL cadence -- every `sync_every` batches, counted across run() calls (round 2 wrapped
@@ -170,7 +175,7 @@ class Loop:
                 self.isync.begin()
             m = min(n - done, self.sync_every - self.since)
             ends_epoch = self.isync is not None and self.since + m == self.sync_every        # BPR.train: the exchange follows, then another epoch
-            self.eng.run_batches(self.csr, m, self.B, want_loss=False, then_exchange=self.sync_every if ends_epoch else 0)
+            self.eng.run_batches(self.csr, m, self.B, want_loss=WANT_LOSS, then_exchange=self.sync_every if ends_epoch else 0)
             done += m
             self.since += m
             if self.since == self.sync_every:
@@ -597,7 +602,7 @@ def main():
                    'batch_size': B, 'k': k, 'sharding': 'users sharded over %d GPU(s), item tables replicated, '
                                                         'all-reduce every %d steps' % (world, sync_every) if world > 1 else 'single GPU'},
         'timed_region': {'per_batch': ['K1 tkr_sample_plan: (u,i,j) draw + plan of the timed batches (planned inside the region: nothing is left over '
-                                       'from the warm-up)', step_kernel(eng, B)[1]],
+                                       'from the warm-up)', step_kernel(eng, B)[1] + (' with the loss of every batch (the obj of sess.run([solver, obj]))' if WANT_LOSS else ' WITHOUT the per-batch loss')],
                          'exchanges_inside': loop_timed_exchanges,
                          'exchange_share_charged': share, 'exchange_ms_charged_each': exch_ms,
                          'raw': {'wall_ms': raw_wall * 1e3, 'value': world * args.steps * B / raw_wall,

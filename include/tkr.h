@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TKR_VERSION 113 /* 0.1.13: tkr_bpr_own_plan_run, K4 to k = 768. 0.1.12: tkr_bpr_own_run_between. 0.1.11: K2o (tkr_sample_plan_owned, tkr_bpr_own_run: item rows owned by one workgroup each, resident in its LDS); prec[5] = last batch of the call that updated the row. 0.1.10: tkr_topk_workspace_bytes_for (K4 stages pre-converted fp16 tiles). 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
+#define TKR_VERSION 114 /* 0.1.14: per-task loss sums instead of atomics on loss_out (larger tkr_vbpr_workspace_floats; K2 writes word 15 of its records). 0.1.13: tkr_bpr_own_plan_run, K4 to k = 768. 0.1.12: tkr_bpr_own_run_between. 0.1.11: K2o (tkr_sample_plan_owned, tkr_bpr_own_run: item rows owned by one workgroup each, resident in its LDS); prec[5] = last batch of the call that updated the row. 0.1.10: tkr_topk_workspace_bytes_for (K4 stages pre-converted fp16 tiles). 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
 #define TKR_OK 0
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
@@ -113,7 +113,11 @@ typedef struct {
 
 /* n_batches consecutive batches of a plan (the inner loop of single/bpr.py:139-147), one launch
  * each, in plan order; loss_out (nullable) is float[n_batches], pre-zeroed by the caller: the
- * batch objective (single/bpr.py:93-99) is added to loss_out[b] */
+ * batch objective (single/bpr.py:93-99) is added to loss_out[b].  How (all entries with a loss_out): thousands of waves summing
+ * into one word with atomics cost 10 ns apiece, one after the other (4-5x the step at batch 8192).  Every user task therefore
+ * leaves its sum in a place of its own -- here word 15 of its launch record in `rec` (K1 leaves it zero; `rec` is written in that
+ * one word although it is declared const), under K2o a {sum, epoch} slot of `xch`, under K2f its workgroup's LDS, under K3 one of
+ * 64 slots behind the workspace -- and one small launch per CALL adds them up into loss_out. */
 /* k <= 512; 256 < k <= 512 only for batch_size <= 1024 (TKR_E_UNSUPPORTED otherwise) */
 int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ, const int32_t* hdr,
                 int32_t batch_size, int32_t n_batches, float* loss_out, void* stream);

@@ -27,6 +27,13 @@ eng.run_batches(csr, nb, B, want_loss=False)
 torch.cuda.synchronize()
 print('B=%d d=%d cols=%s cpb=%s: %.1f us/batch' % (B, d, eng.wants_cols(B), eng.cols_per_block(B) if eng.sparse is not None else None,
                                                    (time.perf_counter() - t0) / nb * 1e6))
+if os.environ.get('LOSS') == '1':           # what does the per-batch loss (vbpr.py:114 returns obj every batch) cost?
+    for wl in (True, False, True, False):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.run_batches(csr, nb, B, want_loss=wl)
+        torch.cuda.synchronize()
+        print('  want_loss %s: %.1f us/batch' % (wl, (time.perf_counter() - t0) / nb * 1e6), flush=True)
 if os.environ.get('GRAPH') == '1':          # the same step launches replayed from a captured graph: is the loop host-bound?
     plan = eng.plan
     step = eng.step_fn(B)

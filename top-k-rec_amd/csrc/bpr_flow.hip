@@ -56,7 +56,8 @@ __device__ unsigned long long* g_flow_trace;
 template <int NP, bool PROF = false>
 __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_flow_state st, const int4* __restrict__ prec,
                                                        const int4* __restrict__ pocc, uint32_t total,
-                                                       uint32_t* __restrict__ ctl, float* __restrict__ loss_out, uint32_t tune) {
+                                                       uint32_t* __restrict__ ctl, float* __restrict__ loss_out, uint32_t tune,
+                                                       uint32_t per_batch /*records of a batch: 3 * batch_size*/) {
     constexpr int NE = 2 * NP;
     const int lane = threadIdx.x & (TKR_WAVE - 1);
     FlowTables T;
@@ -77,7 +78,15 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
     // queue of this wave = (arrival number of its workgroup * 4 + wave) & 31: one atomic per workgroup (a word takes ~12 ns
     // per atomic: per wave that was 12 us of start-up), and still independent of block index, placement and residency
     __shared__ uint32_t wg_arrival;
+    // A batch's loss is the sum over its ~250 user tasks.  As atomics on loss_out[batch] -- one word, one memory channel -- they cost
+    // 0.6 us of a 2.8 us batch: each is a memory operation the next task's first load waits behind.  The workgroup adds its tasks'
+    // sums up in LDS (ds_add_f32: not a memory operation) and hands loss_out ONE atomic per batch it met, on its way out.
+    constexpr int kLossSlots = 512;
+    __shared__ float wg_loss[kLossSlots];
+    __shared__ int wg_loss_base;                                    // index in loss_out of the first batch of this launch
     if (threadIdx.x == 0) wg_arrival = __hip_atomic_fetch_add(ctl + kCtlArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) wg_loss_base = -1;
+    for (int q = threadIdx.x; q < kLossSlots; q += blockDim.x) wg_loss[q] = 0.f;
     __syncthreads();
     const int home = (int)((wg_arrival * (blockDim.x / TKR_WAVE) + (threadIdx.x / TKR_WAVE)) & (kQueues - 1));
     uint32_t spins = 0;
@@ -159,7 +168,15 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
 
         if (!is_item && want_loss) {
             const float tot = wave_sum(loss_lane) + loss_x;
-            if (lane == 0) atomicAdd(loss_out + batch, tot);
+            const uint32_t lb = idx / per_batch;                     // batch of this task, counted from the first of the launch
+            if (lane == 0) {
+                if (lb < (uint32_t)kLossSlots) {
+                    atomicAdd(&wg_loss[lb], tot);
+                    wg_loss_base = batch - (int)lb;                 // (every task writes the same number)
+                } else {
+                    loss_add(loss_out + batch, tot);
+                }
+            }
         }
 
         // the new row first (nothing in it depends on the acknowledgements): behind the wait only the stores are left
@@ -234,6 +251,13 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 1)) void bpr_flow_kernel(tkr_fl
     // out on the value (the vmcnt covers the give-up path, where the prefetched ticket is never looked at).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (want_loss && wg_loss_base >= 0) {
+        const int n_here = (int)min((total + per_batch - 1u) / per_batch, (uint32_t)kLossSlots);
+        for (int q = threadIdx.x; q < n_here; q += blockDim.x) {
+            const float v = wg_loss[q];
+            if (v != 0.f) loss_add(loss_out + wg_loss_base + q, v);
+        }
+    }
     if (threadIdx.x == 0 &&
         __hip_atomic_fetch_add(ctl + kCtlLeave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
         for (int q = 0; q < kQueues; ++q) ctl[q * kQueueStride] = 0u;
@@ -299,10 +323,10 @@ extern "C" int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, c
     const int4* o4 = reinterpret_cast<const int4*>(pocc);
     static const bool prof = getenv("TKR_FLOW_PROFILE") && getenv("TKR_FLOW_PROFILE")[0] == '1';     // cycle sums into ctl (scripts/probe_flow_bench.py)
     if (prof) {
-        if (np == 1) hipLaunchKernelGGL((tkr::bpr_flow_kernel<1, true>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out, tune);
-        else hipLaunchKernelGGL((tkr::bpr_flow_kernel<2, true>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out, tune);
-    } else if (np == 1) hipLaunchKernelGGL((tkr::bpr_flow_kernel<1, false>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out, tune);
-    else hipLaunchKernelGGL((tkr::bpr_flow_kernel<2, false>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out, tune);
+        if (np == 1) hipLaunchKernelGGL((tkr::bpr_flow_kernel<1, true>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out, tune, 3u * (uint32_t)batch_size);
+        else hipLaunchKernelGGL((tkr::bpr_flow_kernel<2, true>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out, tune, 3u * (uint32_t)batch_size);
+    } else if (np == 1) hipLaunchKernelGGL((tkr::bpr_flow_kernel<1, false>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out, tune, 3u * (uint32_t)batch_size);
+    else hipLaunchKernelGGL((tkr::bpr_flow_kernel<2, false>), dim3(grid), dim3(256), 0, s, *st, r4, o4, total, ctl, loss_out, tune, 3u * (uint32_t)batch_size);
     TKR_LAUNCH_CHECK();
     return TKR_OK;
 }

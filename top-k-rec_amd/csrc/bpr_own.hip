@@ -688,8 +688,18 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             const u64 t1 = __builtin_amdgcn_s_memtime();
 #endif
             if (want_loss) {
+                // A batch's loss is the sum over its ~250 user tasks.  As atomics on loss_out[batch] -- one word, one memory channel --
+                // they cost 0.9 us of a 2.2 us batch (hardware fp32 atomics or a compare-and-swap loop alike: each is a memory
+                // operation that the next task's first load waits behind).  The row-read form leaves `xch` alone: the task's sum goes
+                // there as ONE plain 8-byte store {sum, epoch} in the slot of its record, and own_loss_kernel adds the slots of a batch
+                // up after the launch (fixed order: the losses are bitwise reproducible).
                 const float tot = wave_sum(loss_lane);
-                if (lane == 0) atomicAdd(loss_out + batch, tot);
+                if constexpr (SCALAR) {
+                    if (lane == 0) loss_add(loss_out + batch, tot);
+                } else if (lane == 0) {
+                    const uint32_t slot = idx - (uint32_t)(batch - first_batch) * 3u * (uint32_t)B;     // user tasks: the first slots of a batch's 3B
+                    xch[((size_t)batch * B + slot) * 2] = ((u64)epoch << 32) | (u64)__float_as_uint(tot);
+                }
             }
             float pn[NE], mn[NE], bn, mbn;
             own_update<NP>(st, sgd, own, ms, o, g, gb, pn, mn, bn, mbn);
@@ -717,6 +727,22 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
         ctl[kCtlArrive] = 0u;
         ctl[kCtlLeave] = 0u;
     }
+}
+
+// the losses of a launch's batches from the per-task sums its user tasks left in xch (row-read form): loss_out[b] += sum of the slots
+// of batch b that carry this launch's epoch
+__global__ __launch_bounds__(256) void own_loss_kernel(const u64* __restrict__ xch, int first_batch, int B, uint32_t epoch, float* __restrict__ loss_out) {
+    __shared__ float part[4];
+    const int b = first_batch + (int)blockIdx.x, lane = threadIdx.x & (TKR_WAVE - 1), wave = threadIdx.x / TKR_WAVE;
+    float acc = 0.f;
+    for (int s = threadIdx.x; s < B; s += 256) {
+        const u64 g = xch[((size_t)b * B + s) * 2];
+        if ((uint32_t)(g >> 32) == epoch) acc += __uint_as_float((uint32_t)g);
+    }
+    acc = wave_sum(acc);
+    if (lane == TKR_WAVE - 1) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_out[b] += (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 static size_t own_lds_bytes(int np, int nb, int n_items, int n_owner) {
@@ -799,6 +825,11 @@ extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, co
     else { if (scalar) TKR_OWN_LAUNCH(2, 512, true); else TKR_OWN_LAUNCH(2, 512, false); }
 #undef TKR_OWN_LAUNCH
     TKR_LAUNCH_CHECK();
+    if (loss_out && !scalar) {
+        hipLaunchKernelGGL(tkr::own_loss_kernel, dim3(n_batches), dim3(256), 0, s, static_cast<const tkr::u64*>(xch), first_batch, batch_size, epoch,
+                           loss_out);
+        TKR_LAUNCH_CHECK();
+    }
     return TKR_OK;
 }
 

@@ -273,8 +273,12 @@ __global__ __launch_bounds__((kTeam * TKR_WAVE)) void bpr_step_kernel(
         }
 
         if (!is_item && loss_out) {
+            // The loss of a batch is the sum over its user tasks -- thousands of waves.  As atomics on one word they cost 10 ns EACH,
+            // one after the other at the memory side: 90 us on top of a 22 us launch at batch 8192.  Every wave has a 64-byte launch
+            // record of its own whose last word K1 leaves zero: its sum goes THERE (a plain store), and step_loss_kernel adds a
+            // call's records up afterwards.
             const float tot = wave_sum(acc.loss_lane) + acc.loss_x;
-            if (lane == 0) atomicAdd(loss_out, tot);
+            if (lane == 0) const_cast<int32_t*>(rec_all)[((size_t)blk * kTeam + wave) * 16 + 15] = __float_as_int(tot);
         }
 
         if (heavy) {                               // combine the team's partial gradients in wave order
@@ -374,6 +378,29 @@ static int dispatch_step(const tkr_bpr_state& st, const int32_t* rec, const int3
 
 }  // namespace tkr
 
+namespace tkr {
+// loss_out[b] += the sums the user tasks of batch b left in word 15 of their records (zero in every other record); one atomic
+// per (batch, slice: 8 to 128 of them by the batch size)
+__global__ __launch_bounds__(256) void step_loss_kernel(const int32_t* __restrict__ rec, size_t stride_r, const int4* __restrict__ hdr, int team,
+                                                        float* __restrict__ loss_out) {
+    __shared__ float part[4];
+    const int b = blockIdx.x, sl = blockIdx.y, lane = threadIdx.x & (TKR_WAVE - 1), wave = threadIdx.x / TKR_WAVE;
+    const int n_rec = hdr[b].x * team;
+    const int per = (n_rec + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int lo = min(sl * per, n_rec), hi = min(lo + per, n_rec);
+    const int32_t* r = rec + (size_t)b * stride_r;
+    float acc = 0.f;
+    for (int q = lo + (int)threadIdx.x; q < hi; q += 256) acc += __int_as_float(r[(size_t)q * 16 + 15]);
+    acc = wave_sum(acc);
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = (part[0] + part[1]) + (part[2] + part[3]);
+        if (tot != 0.f) loss_add(loss_out + b, tot);
+    }
+}
+}  // namespace tkr
+
 extern "C" int tkr_plan_max_blocks(int32_t batch_size);
 
 static int check_state(const tkr_bpr_state* st) {
@@ -400,6 +427,11 @@ extern "C" int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const in
         const int r = tkr::dispatch_step(*st, rec + b * stride_r, occ + b * stride_o, hdr + (size_t)b * 4, batch_size,
                                          loss_out ? loss_out + b : nullptr, s);
         if (r != 0) return r;
+    }
+    if (loss_out && n_batches > 0) {
+        hipLaunchKernelGGL(tkr::step_loss_kernel, dim3(n_batches, batch_size >= 16384 ? 128 : batch_size >= 2048 ? 32 : 8), dim3(256), 0, s, rec, stride_r,
+                           reinterpret_cast<const int4*>(hdr), tkr_plan_team(batch_size), loss_out);
+        TKR_LAUNCH_CHECK();
     }
     return TKR_OK;
 }

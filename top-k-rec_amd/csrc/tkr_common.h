@@ -16,6 +16,7 @@
         if (_e != hipSuccess) return (int)_e; \
     } while (0)
 
+#define TKR_CHECK_RC(expr) do { const int rc_ = (expr); if (rc_ != TKR_OK) return rc_; } while (0)
 #define TKR_LAUNCH_CHECK()                    \
     do {                                      \
         hipError_t _e = hipGetLastError();    \
@@ -74,6 +75,17 @@ __device__ __forceinline__ void wave_sum2(float& a, float& b) {
     b = wave_sum(b);
 }
 
+// One batch's loss is summed by hundreds of waves on ONE word.  atomicAdd(float*) compiles to a compare-and-swap LOOP here (the
+// compiler must assume fine-grained memory): 250 waves retrying against each other cost 0.85 us of a 2.2 us batch.  The tables of
+// this library live in ordinary device memory, where the hardware's global_atomic_add_f32 is exact enough (an fp32 add in L2).
+__device__ __forceinline__ void loss_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+// ... and where many workgroups of one launch add to one batch's loss (K3): 64 slots, one cache line apart, picked by the
+// workgroup number -- a word takes ~10 ns per atomic, one after the other; 64 words take them side by side.  loss_slots_kernel
+// adds a call's slots up afterwards (csrc/vbpr_step.hip).
+constexpr int kLossSlots = 64, kLossSlotStride = 32;                 // floats
+__device__ __forceinline__ void loss_add_spread(float* slots, float v) {
+    unsafeAtomicAdd(slots + (blockIdx.x & (kLossSlots - 1)) * kLossSlotStride, v);
+}
 __device__ __forceinline__ int bcast_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ float bcast_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));

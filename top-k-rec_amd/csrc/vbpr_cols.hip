@@ -48,6 +48,7 @@
 extern "C" int tkr_plan_team(int32_t batch_size);
 extern "C" int tkr_plan_max_blocks(int32_t batch_size);
 extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d);
+extern "C" int64_t tkr_vbpr_workspace_core_floats(int32_t batch_size, int32_t kh, int32_t d);
 
 namespace tkr {
 
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(W * 64) void vbpr_tproject_kernel(tkr_vbpr_state st
                 loss_lane += (fabsf(ure[e]) + fabsf(uce[e])) * st.lu + fabsf(vi[e]) * st.li + fabsf(vj[e]) * st.lj;
         }
         const float tot = wave_sum(loss_lane) + loss;
-        if (lane == 0) atomicAdd(loss_out, tot);
+        if (lane == 0) loss_add_spread(loss_out, tot);
     }
 }
 
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256) void vbpr_pairsum_kernel(const float* __restri
     if (lane == 0) { sS[t] = s_row; sT[t] = s_col; }
     if (loss_out) {
         loss = wave_sum(loss);
-        if (lane == 0) atomicAdd(loss_out, loss);
+        if (lane == 0) loss_add_spread(loss_out, loss);
     }
 }
 
@@ -492,7 +493,7 @@ __device__ __forceinline__ void col_block(const tkr_vbpr_state& st, const PairSu
     }
     if (loss_out) {
         lpart = wave_sum(lpart);
-        if (lane == 0 && lpart != 0.f) atomicAdd(loss_out, lpart);
+        if (lane == 0 && lpart != 0.f) loss_add_spread(loss_out, lpart);
     }
 }
 
@@ -529,6 +530,15 @@ static void launch_update(const tkr_vbpr_state& st, const int32_t* rec, const in
                        s_buf, t_buf, P, Wm, colh, cent, n_row_blocks, cpb, loss, tune);
 }
 
+}  // namespace tkr
+
+namespace tkr {
+// loss_out[b] += the 64 slots of batch b (as vbpr_step.hip's loss_slots_kernel)
+__global__ __launch_bounds__(64) void loss_slots_sum_kernel(const float* __restrict__ slots, float* __restrict__ loss_out) {
+    const int b = blockIdx.x;
+    const float v = wave_sum(slots[(size_t)b * kLossSlots * kLossSlotStride + threadIdx.x * kLossSlotStride]);
+    if (threadIdx.x == 0) loss_out[b] += v;
+}
 }  // namespace tkr
 
 extern "C" int64_t tkr_vbpr_colplan_lds_bytes(int32_t batch_size, int32_t d) {
@@ -582,7 +592,7 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
     const int B = batch_size, kh = st->kh, tcap = 2 * row_cap;
     const size_t stride_r = (size_t)tkr_plan_max_blocks(B) * tkr_plan_team(B) * 16;
     const size_t stride_o = (size_t)3 * B;
-    if (tkr_vbpr_workspace_floats(B, kh, st->d) < (int64_t)B * (6 + 2 * kh)) return TKR_EINVAL;
+    if (tkr_vbpr_workspace_core_floats(B, kh, st->d) < (int64_t)B * (6 + 2 * kh)) return TKR_EINVAL;
     float* s_buf = workspace;                                        // S_t [B] | T_t [B] | alpha, beta, e^alpha, e^beta [4B] | P [B][kh] | uce rows [B][kh]
     float* t_buf = s_buf + B;
     float* ab2 = t_buf + B;
@@ -597,6 +607,12 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
     int pw = pw_env ? pw_env : (row_cap <= 64 ? 4 : (row_cap <= 128 || B > 256 ? 8 : 16));
     if (NH == 2 && pw > 8) pw = 8;          // kh > 64: two registers per gathered row and wave -- the 16-wave team is not instantiated there:
                                             // two rounds of gathers per wave instead of one (was a silent fall-through)
+    // the loss slots of the call's batches: behind the step's own scratch (tkr_common.h loss_add_spread; LossSlots is vbpr_step.hip's)
+    float* slots = loss_out ? workspace + tkr_vbpr_workspace_core_floats(B, kh, st->d) : nullptr;
+    if (slots) {
+        if (n_batches > 512) return TKR_EUNSUPPORTED;
+        TKR_CHECK(hipMemsetAsync(slots, 0, (size_t)n_batches * tkr::kLossSlots * tkr::kLossSlotStride * sizeof(float), s));
+    }
     for (int b = 0; b < n_batches; ++b) {
         const int32_t* ti = tri_i + (size_t)b * B;
         const int32_t* tj = tri_j + (size_t)b * B;
@@ -610,7 +626,7 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
         const int2* ce = reinterpret_cast<const int2*>(cent) + (size_t)b * B * tcap;
         const int32_t* tc = tcnt + (size_t)b * B;
         const int2* te = reinterpret_cast<const int2*>(tent) + (size_t)b * B * tcap;
-        float* l = loss_out ? loss_out + b : nullptr;
+        float* l = slots ? slots + (size_t)b * tkr::kLossSlots * tkr::kLossSlotStride : nullptr;
         if (tune & 64) {
         } else if (NH == 1 && pw == 4) hipLaunchKernelGGL((tkr::vbpr_tproject_kernel<1, 4>), dim3(B), dim3(256), 0, s, *st, ti, tj, tu, tp, tc, te, tcap, B, P, ab2, Wm, l, tune);
         else if (NH == 1 && pw == 8) hipLaunchKernelGGL((tkr::vbpr_tproject_kernel<1, 8>), dim3(B), dim3(512), 0, s, *st, ti, tj, tu, tp, tc, te, tcap, B, P, ab2, Wm, l, tune);
@@ -628,6 +644,10 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
             default: if (NE <= 3) TKR_UPD(3, 32); else TKR_UPD(4, 32); break;
         }
 #undef TKR_UPD
+        TKR_LAUNCH_CHECK();
+    }
+    if (slots && n_batches > 0) {
+        hipLaunchKernelGGL(tkr::loss_slots_sum_kernel, dim3(n_batches), dim3(64), 0, s, slots, loss_out);
         TKR_LAUNCH_CHECK();
     }
     return TKR_OK;

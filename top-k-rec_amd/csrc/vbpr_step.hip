@@ -47,6 +47,7 @@
 extern "C" int tkr_plan_team(int32_t batch_size);
 extern "C" int tkr_plan_max_blocks(int32_t batch_size);
 extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d);
+extern "C" int64_t tkr_vbpr_workspace_core_floats(int32_t batch_size, int32_t kh, int32_t d);
 
 namespace tkr {
 
@@ -229,7 +230,7 @@ __global__ __launch_bounds__((kVTeam * TKR_WAVE)) void vbpr_occur_kernel(
         }
         if (loss_out) {
             const float tot = wave_sum(loss_lane) + loss;
-            if (lane == 0) atomicAdd(loss_out, tot);
+            if (lane == 0) loss_add_spread(loss_out, tot);
         }
     }
 }
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void vbpr_pair_kernel(const float* __restrict_
         for (int c = lane; c < kh; c += 64) Wm[(size_t)t * kh + c] *= -s_col;
     if (loss_out) {
         loss = wave_sum(loss);
-        if (lane == 0) atomicAdd(loss_out, loss);
+        if (lane == 0) loss_add_spread(loss_out, loss);
     }
 }
 
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256) void vbpr_dense_kernel(tkr_vbpr_state st, cons
     }
     if (loss_out) {
         lpart = wave_sum(lpart);
-        if (lane == 0 && lpart != 0.f) atomicAdd(loss_out, lpart);
+        if (lane == 0 && lpart != 0.f) loss_add_spread(loss_out, lpart);
     }
 }
 
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(256) void vbpr_sproject_kernel(tkr_vbpr_state st, c
                         loss_lane += (fabsf(ure[e]) + fabsf(uce[e])) * st.lu + fabsf(vi[e]) * st.li + fabsf(vj[e]) * st.lj;
                 }
                 const float tot = wave_sum(loss_lane) + loss;
-                if (lane == 0) atomicAdd(loss_out, tot);
+                if (lane == 0) loss_add_spread(loss_out, tot);
             }
         }
     }
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(256) void vbpr_sdense_kernel(tkr_vbpr_state st, con
     }
     if (loss_out) {
         lpart = wave_sum(lpart);
-        if (lane == 0 && lpart != 0.f) atomicAdd(loss_out, lpart);
+        if (lane == 0 && lpart != 0.f) loss_add_spread(loss_out, lpart);
     }
 }
 
@@ -625,7 +626,7 @@ static int launch_vbpr_t(const tkr_vbpr_state& st, const int32_t* ti, const int3
     float* P = s_buf + B;
     float* Wm = P + (size_t)B * kh;
     float* Q = Wm + (size_t)B * kh;
-    float* ab2 = ws + tkr_vbpr_workspace_floats(B, kh, st.d) - 5 * (size_t)B;      // alpha, beta, e^alpha, e^beta [B] of the batch
+    float* ab2 = ws + tkr_vbpr_workspace_core_floats(B, kh, st.d) - 5 * (size_t)B;      // alpha, beta, e^alpha, e^beta [B] of the batch
     float* t_buf = ab2 + 4 * (size_t)B;                                            // T_t (s_buf holds S_t)
     const int2* occ2 = reinterpret_cast<const int2*>(occ);
     const int4* hdr4 = reinterpret_cast<const int4*>(hdr);
@@ -682,11 +683,44 @@ static int launch_vbpr(const tkr_vbpr_state& st, const int32_t* ti, const int32_
 
 extern "C" int tkr_plan_max_blocks(int32_t batch_size);
 
-extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d) {
+// the step's own scratch ...
+extern "C" int64_t tkr_vbpr_workspace_core_floats(int32_t batch_size, int32_t kh, int32_t d) {
     const int64_t S = tkr::vbpr_slices(d);
     const int64_t slots = (int64_t)tkr_plan_max_blocks(batch_size) * tkr_plan_team(batch_size);     // sparse view: A, a per item task
     return S * batch_size * (kh + 1) + 2ll * batch_size + 2ll * batch_size * kh + slots * (kh + 1) + 5ll * batch_size;
 }
+// ... and behind it the loss slots of up to 512 batches of a call (tkr_common.h loss_add_spread)
+extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d) {
+    return tkr_vbpr_workspace_core_floats(batch_size, kh, d) + 512ll * tkr::kLossSlots * tkr::kLossSlotStride;
+}
+
+namespace tkr {
+// loss_out[b] += the 64 slots of batch b
+__global__ __launch_bounds__(64) void loss_slots_kernel(const float* __restrict__ slots, float* __restrict__ loss_out) {
+    const int b = blockIdx.x;
+    const float v = wave_sum(slots[(size_t)b * kLossSlots * kLossSlotStride + threadIdx.x * kLossSlotStride]);
+    if (threadIdx.x == 0) loss_out[b] += v;
+}
+// a call's loss bookkeeping: slots zeroed in front of its batches, added up behind them; batch b's kernels get slots(b) as their loss pointer
+struct LossSlots {
+    float* base;
+    float* out;
+    int n;
+    hipStream_t s;
+    int begin(float* ws_end_of_core, float* loss_out, int n_batches, hipStream_t stream) {
+        base = loss_out ? ws_end_of_core : nullptr; out = loss_out; n = n_batches; s = stream;
+        if (!base || n <= 0) return TKR_OK;
+        if (n > 512) return TKR_EUNSUPPORTED;
+        return hipMemsetAsync(base, 0, (size_t)n * kLossSlots * kLossSlotStride * sizeof(float), s) == hipSuccess ? TKR_OK : TKR_EINVAL;
+    }
+    float* of(int b) const { return base ? base + (size_t)b * kLossSlots * kLossSlotStride : nullptr; }
+    int end() const {
+        if (!base || n <= 0) return TKR_OK;
+        hipLaunchKernelGGL(loss_slots_kernel, dim3(n), dim3(64), 0, s, base, out);
+        return (int)hipGetLastError();
+    }
+};
+}  // namespace tkr
 
 extern "C" int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* tri_j, const int32_t* rec,
                             const int32_t* occ, const int32_t* hdr, const int32_t* occt, const int32_t* tri_u,
@@ -702,6 +736,8 @@ extern "C" int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, cons
     const size_t stride_r = (size_t)tkr_plan_max_blocks(batch_size) * tkr_plan_team(batch_size) * 16;
     const size_t stride_o = (size_t)3 * batch_size;
     const int NT = (st->kh + 31) / 32;
+    tkr::LossSlots ls;
+    TKR_CHECK_RC(ls.begin(workspace + tkr_vbpr_workspace_core_floats(batch_size, st->kh, st->d), loss_out, n_batches, (hipStream_t)stream));
     for (int b = 0; b < n_batches; ++b) {
         const int32_t* ti = tri_i + (size_t)b * batch_size;
         const int32_t* tj = tri_j + (size_t)b * batch_size;
@@ -711,7 +747,7 @@ extern "C" int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, cons
         const int32_t* ot = occt + b * stride_o;
         const int32_t* tu = (tri_u && tpar) ? tri_u + (size_t)b * batch_size : nullptr;
         const int32_t* tp = (tri_u && tpar) ? tpar + (size_t)b * batch_size : nullptr;
-        float* l = loss_out ? loss_out + b : nullptr;
+        float* l = ls.of(b);
         int rc;
         switch (NT) {
             case 1: rc = tkr::launch_vbpr<1>(*st, ti, tj, r, o, h, ot, batch_size, workspace, l, (hipStream_t)stream, tu, tp); break;
@@ -721,5 +757,5 @@ extern "C" int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, cons
         }
         if (rc != 0) return rc;
     }
-    return TKR_OK;
+    return ls.end();
 }

@@ -195,11 +195,12 @@ class _Chunk:
     """a planned chunk: batches [used, nb) of plan buffer `idx` have not run yet; batch 0 starts at triplet `first`.
     ``shadow``: the chunk was planned AHEAD OF AN EXCHANGE against a zeroed copy of the item counters (this tensor); it only
     becomes runnable once the exchange has zeroed the real ones (PlanMixin.after_exchange)."""
-    __slots__ = ('idx', 'nb', 'used', 'B', 'first', 'csr', 'shadow', 'epoch_ahead', 'pending')
+    __slots__ = ('idx', 'nb', 'used', 'B', 'first', 'csr', 'shadow', 'epoch_ahead', 'pending', 'loss_zeroed')
 
     def __init__(self, idx, nb, B, first, csr, shadow=None):
         self.idx, self.nb, self.used, self.B, self.first, self.csr = idx, nb, 0, B, first, csr
         self.shadow, self.epoch_ahead = shadow, shadow is not None
+        self.loss_zeroed = False        # the planner zeroed this chunk's loss words beside K1 (not a launch in front of the step)
         self.pending = None             # a tkr_hip.PlanCall: K1 of this chunk has NOT been launched yet -- the step's call launches it (short calls)
 
 
@@ -362,8 +363,11 @@ class PlanMixin:
                 call = callers[key] = tkr_hip.plan_caller(csr, self.n_users, self.n_items, self.seed, B, cnt, buf)
             call(first, nb)
             self._plan_extra(buf, nb, B)
+            buf.loss[:nb].zero_()                     # where K1 runs (the side stream when it is planned ahead): the step starts without a fill in front of it
         self.pipe.plan(idx, fn, overlap)
-        return _Chunk(idx, nb, B, first, csr, shadow)
+        ch = _Chunk(idx, nb, B, first, csr, shadow)
+        ch.loss_zeroed = True
+        return ch
 
     def _epoch_ahead_ok(self, B):
         """may the first chunk of the epoch AFTER an exchange be planned before it?  Only where the exchange leaves the tables in
@@ -419,7 +423,7 @@ class PlanMixin:
             plan = self.pipe.acquire(ch.idx)
             m = min(left, ch.nb - ch.used)
             lo = ch.used
-            if want_loss:
+            if want_loss and not ch.loss_zeroed:
                 plan.loss[lo:lo + m].zero_()
             if ch.pending is not None:                # K1 of this chunk and the step on its first m batches: one C call
                 call, ch.pending = ch.pending, None

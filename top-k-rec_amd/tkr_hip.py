@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TKR_HIP_LIB') or os.path.join(_HERE, 'libtkr_hip.so')      # the override is for A/B builds of the kernels (scripts/)
 
 _lib = None
-VERSION = 113          # TKR_VERSION of include/tkr.h this binding was written against
+VERSION = 114          # TKR_VERSION of include/tkr.h this binding was written against
 
 
 class TkrError(RuntimeError):
