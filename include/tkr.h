@@ -117,7 +117,8 @@ typedef struct {
  * into one word with atomics cost 10 ns apiece, one after the other (4-5x the step at batch 8192).  Every user task therefore
  * leaves its sum in a place of its own -- here word 15 of its launch record in `rec` (K1 leaves it zero; `rec` is written in that
  * one word although it is declared const), under K2o a {sum, epoch} slot of `xch`, under K2f its workgroup's LDS, under K3 one of
- * 64 slots behind the workspace -- and one small launch per CALL adds them up into loss_out. */
+ * 64 slots behind the workspace -- and one small launch per CALL adds them up into loss_out (tkr_bpr_own_run in its default
+ * form ASSIGNS loss_out[b]: no fill is needed in front of it). */
 /* k <= 512; 256 < k <= 512 only for batch_size <= 1024 (TKR_E_UNSUPPORTED otherwise) */
 int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ, const int32_t* hdr,
                 int32_t batch_size, int32_t n_batches, float* loss_out, void* stream);

@@ -729,7 +729,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     }
 }
 
-// the losses of a launch's batches from the per-task sums its user tasks left in xch (row-read form): loss_out[b] += sum of the slots
+// the losses of a launch's batches from the per-task sums its user tasks left in xch (row-read form): loss_out[b] = sum of the slots
 // of batch b that carry this launch's epoch
 __global__ __launch_bounds__(256) void own_loss_kernel(const u64* __restrict__ xch, int first_batch, int B, uint32_t epoch, float* __restrict__ loss_out) {
     __shared__ float part[4];
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256) void own_loss_kernel(const u64* __restrict__ x
     acc = wave_sum(acc);
     if (lane == TKR_WAVE - 1) part[wave] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) loss_out[b] += (part[0] + part[1]) + (part[2] + part[3]);
+    if (threadIdx.x == 0) loss_out[b] = (part[0] + part[1]) + (part[2] + part[3]);       // ASSIGNED: a batch runs once (no fill in front of a short call)
 }
 
 static size_t own_lds_bytes(int np, int nb, int n_items, int n_owner) {

@@ -423,7 +423,7 @@ class PlanMixin:
             plan = self.pipe.acquire(ch.idx)
             m = min(left, ch.nb - ch.used)
             lo = ch.used
-            if want_loss and not ch.loss_zeroed:
+            if want_loss and not ch.loss_zeroed and not getattr(step_fn, 'assigns_loss', False):
                 plan.loss[lo:lo + m].zero_()
             if ch.pending is not None:                # K1 of this chunk and the step on its first m batches: one C call
                 call, ch.pending = ch.pending, None

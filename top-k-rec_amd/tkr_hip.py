@@ -359,6 +359,7 @@ def own_stepper(state, B, ctl, owner_waves=0):
     step.state = state
     step.takes_events = True
     step.plan_and_run = plan_and_run
+    step.assigns_loss = not ((owner_waves >> 8) & 0x80)      # the row-read form writes loss_out[b] (csrc/bpr_own.hip own_loss_kernel); the scalar form adds
     return step
 
 
