@@ -399,7 +399,7 @@ class PlanMixin:
             nxt, self._ahead = self._ahead, None
         else:
             # a short call (this chunk holds all that is left of it, nothing is planned beside it): K1 goes out in the step's call
-            fuse = (FUSE_SHORT_CALLS and not overlap and then_exchange == 0 and want <= self._cap(B) and
+            fuse = (FUSE_SHORT_CALLS and then_exchange == 0 and want <= self._cap(B) and
                     getattr(getattr(self, '_step', None), 'plan_and_run', None) is not None and self._plan_owners(B) > 0)
             nxt = self._plan_chunk(0 if cur is None else cur.idx ^ 1, csr, B, self._drawn, False, want, fuse=fuse)
         if overlap and want > nxt.nb:                 # the chunk after it, behind the steps of this one
