@@ -142,6 +142,7 @@ def build_problem(shape, k, rank, world, device, seed=42):
         mine = np.asarray(tdist.shard_users(tr_users, rank, world), dtype=np.int64)
         csr = _engine.TrainingCSR.shard(row_ptr, pos, mine, device)
         eng = _engine.BprEngine(len(mine), n_items, k, hp, device, seed=1234, user_seed=99991 * (rank + 1))
+        eng.ranks_on_device = tdist.ranks_sharing_device(device)       # ranks packed on one GPU split its CUs between their K2o launches (as BPR.train)
     return r, csr, eng, int(row_ptr[-1])
 
 
@@ -539,6 +540,29 @@ def topk_cpu_baseline(r, k, K=30, budget_s=12.0, slice_users=2000):
                        '(single thread), oracle restatement of evaluate.py:78-105' % (done, n_items, dt))
 
 
+def summary(out):
+    """the numbers VERDICT tracks, compact, as the last key of the line (the driver's record keeps only the tail of stdout)"""
+    def leg(key, *path):
+        v = out.get(key)
+        for q in path:
+            v = v.get(q) if isinstance(v, dict) else None
+        return round(v, 6) if isinstance(v, float) else v
+    s = {'value_Mtps': round(out['value'] / 1e6, 3), 'ms_per_step': round(out['ms_per_step'], 6), 'kernel': out['roofline']['kernel'].split(' ')[0],
+         'steady_Mtps': (leg('steady_state', 'value') or 0) / 1e6 or None, 'steady_us_per_batch': leg('steady_state', 'roofline', 'launch_us'),
+         'steady_frac': leg('steady_state', 'roofline', 'frac'),
+         'netflix_Mtps': (leg('bpr_netflix_shape', 'value') or 0) / 1e6 or None, 'netflix_us_per_batch': leg('bpr_netflix_shape', 'roofline', 'launch_us'),
+         'B8192_frac': leg('throughput_mode', 'roofline', 'frac'), 'B65536_frac': leg('throughput_mode_B65536', 'roofline', 'frac'),
+         'topk_ms': leg('topk', 'ms_per_pass'), 'topk_frac': leg('topk', 'roofline', 'frac'),
+         'topk_nf_ms': leg('topk_netflix_shape', 'ms_per_pass'), 'topk_nf_frac': leg('topk_netflix_shape', 'roofline', 'frac'),
+         'vbpr_ms': leg('vbpr', 'ms_per_step'), 'vbpr_frac': leg('vbpr', 'roofline', 'frac'),
+         'vbpr_dc128_ms': leg('vbpr', 'dense_dc128', 'ms_per_step'),
+         'cpu_Mtps': (leg('cpu_baseline', 'value') or 0) / 1e6 or None}
+    if out.get('n_gpus', 1) > 1:
+        s['exchange_us'] = leg('epoch_mode', 'exchange_us')
+        s['epoch_Mtps'] = (leg('epoch_mode', 'value') or 0) / 1e6 or None
+    return {k: v for k, v in s.items() if v is not None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -596,9 +620,7 @@ def main():
         'ms_per_step': wall * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'BPR %s k=%d B=%d' % ('ML-10M' if args.shape == 'ml10m' else 'Netflix', k, B),
-                   'detail': 'BPR %s shape (%d users x %d items, %d train positives), k=%d, batch_size=%d, '
-                             'RMSProp lr=1e-4, reference defaults' % ('MovieLens-10M' if args.shape == 'ml10m' else 'Netflix',
-                                                                      r['n_users'], r['n_in'] + r['n_out'], nnz, k, B),
+                   'detail': '%dx%d, %d positives, k=%d, B=%d, RMSProp 1e-4, ref. defaults' % (r['n_users'], r['n_in'] + r['n_out'], nnz, k, B),
                    'batch_size': B, 'k': k, 'sharding': 'users sharded over %d GPU(s), item tables replicated, '
                                                         'all-reduce every %d steps' % (world, sync_every) if world > 1 else 'single GPU'},
         'timed_region': {'per_batch': ['K1 tkr_sample_plan: (u,i,j) draw + plan of the timed batches (planned inside the region: nothing is left over '
@@ -614,6 +636,7 @@ def main():
                      'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                      'traffic_from_profile': pmc_traffic(step_kernel(eng, B)[2]) if (k == 128 and args.shape == 'ml10m') else None,
+                     'owners': eng._plan_owners(B),    # K2o: workgroups that own item rows (the CUs, split between the ranks that share a GPU); 0: K2f / K2
                      'launch_us': launch_us,          # per BATCH: the persistent kernel's launch covers many batches, duration / batches
                      'algorithmic_bytes_per_launch': B * algorithmic_bytes_per_triplet(k)},
     }
@@ -676,6 +699,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(r, k, B)
     if rank == 0:
+        out['summary'] = summary(out)         # LAST key: the driver keeps the tail of the line
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -18,6 +18,10 @@
  *   - `stream` is a hipStream_t passed as void*; all calls are asynchronous and stream-ordered;
  *     scalar results are written to device memory
  *   - ids are int32, parameters fp32
+ *   - device memory means ORDINARY (coarse-grained) device allocations -- hipMalloc, a torch CUDA tensor.  loss_out, the K3
+ *     workspace and every table must not be fine-grained / host-coherent memory (hipHostMalloc, hipMallocManaged,
+ *     hipExtMallocWithFlags(fine-grained)): the loss sums of K2f / K3 use the hardware's global_atomic_add_f32, which such memory
+ *     silently drops on gfx90a and later, and the write-through granule protocol of K2f / K2o assumes device-local lines
  */
 #ifndef TKR_H
 #define TKR_H
@@ -27,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TKR_VERSION 114 /* 0.1.14: per-task loss sums instead of atomics on loss_out (larger tkr_vbpr_workspace_floats; K2 writes word 15 of its records). 0.1.13: tkr_bpr_own_plan_run, K4 to k = 768. 0.1.12: tkr_bpr_own_run_between. 0.1.11: K2o (tkr_sample_plan_owned, tkr_bpr_own_run: item rows owned by one workgroup each, resident in its LDS); prec[5] = last batch of the call that updated the row. 0.1.10: tkr_topk_workspace_bytes_for (K4 stages pre-converted fp16 tiles). 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
+#define TKR_VERSION 115 /* 0.1.15: tkr_bpr_own_owners_shared; tkr_bpr_run takes `rec` non-const. 0.1.14: per-task loss sums instead of atomics on loss_out (larger tkr_vbpr_workspace_floats; K2 writes word 15 of its records). 0.1.13: tkr_bpr_own_plan_run, K4 to k = 768. 0.1.12: tkr_bpr_own_run_between. 0.1.11: K2o (tkr_sample_plan_owned, tkr_bpr_own_run: item rows owned by one workgroup each, resident in its LDS); prec[5] = last batch of the call that updated the row. 0.1.10: tkr_topk_workspace_bytes_for (K4 stages pre-converted fp16 tiles). 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
 #define TKR_OK 0
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
@@ -115,12 +119,12 @@ typedef struct {
  * each, in plan order; loss_out (nullable) is float[n_batches], pre-zeroed by the caller: the
  * batch objective (single/bpr.py:93-99) is added to loss_out[b].  How (all entries with a loss_out): thousands of waves summing
  * into one word with atomics cost 10 ns apiece, one after the other (4-5x the step at batch 8192).  Every user task therefore
- * leaves its sum in a place of its own -- here word 15 of its launch record in `rec` (K1 leaves it zero; `rec` is written in that
- * one word although it is declared const), under K2o a {sum, epoch} slot of `xch`, under K2f its workgroup's LDS, under K3 one of
+ * leaves its sum in a place of its own -- here word 15 of its launch record in `rec` (K1 leaves it zero; that one word of `rec` is
+ * WRITTEN by the step, which is why `rec` is not const; a plan run again with a loss_out overwrites it), under K2o a {sum, epoch} slot of `xch`, under K2f its workgroup's LDS, under K3 one of
  * 64 slots behind the workspace -- and one small launch per CALL adds them up into loss_out (tkr_bpr_own_run in its default
  * form ASSIGNS loss_out[b]: no fill is needed in front of it). */
 /* k <= 512; 256 < k <= 512 only for batch_size <= 1024 (TKR_E_UNSUPPORTED otherwise) */
-int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ, const int32_t* hdr,
+int tkr_bpr_run(const tkr_bpr_state* st, int32_t* rec, const int32_t* occ, const int32_t* hdr,
                 int32_t batch_size, int32_t n_batches, float* loss_out, void* stream);
 
 /* ---- K2f: the same step as ONE persistent launch per chunk (dataflow form; csrc/bpr_flow.hip) ------------------
@@ -192,6 +196,9 @@ int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, const int32_
  *                                    number > 0 that no earlier launch on this xch used (a counter per plan buffer does).
  * k <= 256, n_batches <= 512. */
 int32_t tkr_bpr_own_owners(int32_t n_items, int32_t k);
+/* the same when `share` processes split one device's CUs between them (ranks packed on one GPU: each runs CUs / share owners, so
+ * that the workgroups of all of them are resident together); 0 when ceil(n_items / (CUs / share)) rows do not fit an owner's LDS */
+int32_t tkr_bpr_own_owners_shared(int32_t n_items, int32_t k, int32_t share);
 int tkr_sample_plan_owned(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,
                           const int32_t* cols_sorted, int32_t n_users, int32_t n_items, uint64_t seed, uint64_t first_triplet,
                           int32_t n_batches, int32_t batch_size, int32_t* ucnt, int32_t* icnt, uint32_t* touch_u,

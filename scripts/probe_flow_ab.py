@@ -13,7 +13,7 @@ shape = sys.argv[4] if len(sys.argv) > 4 else 'ml10m'
 dev = torch.device('cuda', 0)
 r, csr, eng, nnz = bench.build_problem(shape, 128, 0, 1, dev)
 for w in waves:
-    _engine.FLOW_WAVES_PER_CU = w
+    eng.cfg.flow_waves_per_cu = w
     eng.run_batches(csr, 1024, B, want_loss=False)
     torch.cuda.synchronize()
     eng.check()

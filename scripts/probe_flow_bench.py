@@ -12,7 +12,7 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 dev = torch.device('cuda', 0)
 r, csr, eng, nnz = bench.build_problem('ml10m', 128, 0, 1, dev)
 for w in waves:
-    _engine.FLOW_WAVES_PER_CU = w
+    eng.cfg.flow_waves_per_cu = w
     eng.run_batches(csr, 512, B, want_loss=False)
     torch.cuda.synchronize()
     eng.ctl[tkr_hip.FLOW_CTL_SPINS] = 0

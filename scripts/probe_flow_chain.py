@@ -16,7 +16,7 @@ hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=1e-4, mode='l2')
 eng = _engine.BprEngine(n_users, n_items, 128, hp, dev, seed=5)
 for B in (1, 4, 8, 12, 16):
     for w in waves:
-        _engine.FLOW_WAVES_PER_CU = w
+        eng.cfg.flow_waves_per_cu = w
         eng.run_batches(csr, 512, B, want_loss=False); torch.cuda.synchronize()
         t0 = time.perf_counter()
         eng.run_batches(csr, 2048, B, want_loss=False); torch.cuda.synchronize()

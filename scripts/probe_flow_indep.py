@@ -16,7 +16,7 @@ csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.arange(n_users, dtype=np.
 hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=1e-4, mode='l2')
 eng = _engine.BprEngine(n_users, n_items, k, hp, dev, seed=5)
 for w in waves:
-    _engine.FLOW_WAVES_PER_CU = w
+    eng.cfg.flow_waves_per_cu = w
     eng.run_batches(csr, 512, B, want_loss=False)
     torch.cuda.synchronize()
     eng.ctl[tkr_hip.FLOW_CTL_SPINS] = 0

@@ -14,8 +14,8 @@ shape = sys.argv[4] if len(sys.argv) > 4 else 'ml10m'
 dev = torch.device('cuda', 0)
 r, csr, eng, nnz = bench.build_problem(shape, 128, 0, 1, dev)
 for v in variants:
-    os.environ['TKR_OWN'] = '0' if v == 'f' else '1'
-    _engine.OWN_WAVES = int(v[1:], 0) if v != 'f' else 0
+    eng.cfg.own = '0' if v == 'f' else '1'
+    eng.cfg.own_waves = int(v[1:], 0) if v != 'f' else 0
     eng.run_batches(csr, 512, B, want_loss=False)
     torch.cuda.synchronize()
     eng.check()

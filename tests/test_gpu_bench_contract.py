@@ -58,8 +58,9 @@ def test_driver_command_measures_the_steady_state():
     assert d['steady_state']['value'] > 85e6 and d['steady_state']['steps'] == 7812, d['steady_state']
 
 
-def test_two_rank_line():
-    env = dict(os.environ, TKR_BENCH_SINGLE_DEVICE='1', TKR_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+@pytest.mark.parametrize('own', ['1', '0'])
+def test_two_rank_line(own):
+    env = dict(os.environ, TKR_BENCH_SINGLE_DEVICE='1', TKR_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1', TKR_OWN=own)
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
                           '--master-port', '29611', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '256', '--warmup', '32',
                           '--no-extras', '--epoch-sample-limit', '65536'],
@@ -69,6 +70,8 @@ def test_two_rank_line():
     for key in REQUIRED:
         assert key in d, key
     assert d['n_gpus'] == 2 and d['steps'] == 256 and 'cpu_baseline' not in d      # rank 0 at N = 1 only
+    # the headline kernel runs under two ranks on ONE GPU as well: each takes half the CUs as owners
+    assert ('bpr_own_kernel' in d['roofline']['kernel']) == (own == '1') and d['roofline']['owners'] == (128 if own == '1' else 0), d['roofline']
     assert 'all-reduce every 128 steps' in d['config']['sharding']                  # (65536 // 256) // 2: two exchanges inside the timed region
     assert abs(d['value'] - 2 * 256 * 256 / (d['ms_per_step'] * 256 * 1e-3)) / d['value'] < 1e-6
     assert d['timed_region']['exchanges_inside'] == 2                               # at batches 128 and 256 of the run (32 warm-up + 96, + 128)

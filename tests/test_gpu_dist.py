@@ -53,12 +53,18 @@ U = init[0] + sum(x['U'] - init[0] for x in st)
 np.testing.assert_allclose(m.fie, st[0]['V'], rtol=2e-4, atol=1e-5)
 np.testing.assert_allclose(m.fib.ravel(), st[0]['b'], rtol=2e-4, atol=1e-5)
 np.testing.assert_allclose(m.fue, U, rtol=2e-4, atol=1e-5)
+# the step kernel that ran: K2o on HALF the CUs per rank (two ranks share this GPU: dist.ranks_sharing_device), or K2f with TKR_OWN=0
+eng = m._eng
+assert eng.layout == 'flow' and eng.ranks_on_device == world
+want = 0 if os.environ.get('TKR_OWN') == '0' else torch.cuda.get_device_properties(0).multi_processor_count // world
+assert eng.plan.owners == want and eng._plan_owners(B) == want, (eng.plan.owners, want)
 dist.barrier(); dist.destroy_process_group()
 print('ok', rank)
 '''
 
 
-def test_two_rank_sharded_training_matches_oracle(tmp_path):
+@pytest.mark.parametrize('own', ['1', '0'])
+def test_two_rank_sharded_training_matches_oracle(tmp_path, own):
     sys.path.insert(0, os.path.join(ROOT, 'top-k-rec_amd'))
     import synth
     r = synth.make_ratings(120, 60, 0, seed=13, mu=2.6, sigma=0.4, min_r=4, max_r=25)
@@ -68,7 +74,7 @@ def test_two_rank_sharded_training_matches_oracle(tmp_path):
     script.write_text(_WORKER % dict(root=ROOT, pkg=os.path.join(ROOT, 'top-k-rec_amd'), data=data))
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
                           '--master-addr', '127.0.0.1', '--master-port', '29641', str(script)],
-                         capture_output=True, text=True, timeout=280)
+                         capture_output=True, text=True, timeout=280, env=dict(os.environ, TKR_OWN=own))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert out.stdout.count('ok') == 2
 

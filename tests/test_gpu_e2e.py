@@ -104,3 +104,46 @@ def test_reference_defaults_and_float_limit(tmp_path):
     assert ub.dtype == np.int64 and ib.dtype == np.int32 and jb.dtype == np.int32 and len(ub) == 32
     for u, i, j in zip(ub, ib, jb):
         assert i in m.tr_data[u] and j not in m.tr_data[u]
+
+
+def test_train_restarts_one_kernel_down_when_a_step_gives_up(tmp_path, monkeypatch):
+    """a launch of a persistent step is not transactional: when a bounded spin runs out (injected through the status word after
+    the first epoch) BPR.train puts back the state it started from and runs again on the next kernel down -- K2o -> K2f -> K2 --
+    instead of raising with half-updated tables.  Same start, same counter-based stream: the result is bit for
+    bit what a run that never had the upper kernels produces."""
+    import tkr_hip
+    from single import BPR, _engine
+    data = _dataset(tmp_path, seed=6)
+
+    def model():
+        m = BPR(k=16, lambda_b=1e-3, lr=0.02)
+        m.load_training_data(os.path.join(data, 'uid'), os.path.join(data, 'vid'), os.path.join(data, 'f0tr.txt'))
+        return m
+
+    orig = _engine.BprEngine.run_batches
+    for failures, env, layout, owners in ((1, dict(TKR_OWN='0'), 'flow', 0), (2, dict(TKR_FLOW='0'), 'bulk', None)):
+        calls = {'n': 0}
+
+        def flaky(self, *a, **kw):
+            out = orig(self, *a, **kw)
+            if calls['n'] < failures and self.layout == 'flow':          # as if a spin of this epoch's launch had run out
+                self.ctl[tkr_hip.FLOW_CTL_STATUS] = 1
+                calls['n'] += 1
+            return out
+        monkeypatch.setattr(_engine.BprEngine, 'run_batches', flaky)
+        m = model()
+        with pytest.warns(UserWarning, match='restarts from its initial state'):
+            m.train(epochs=2, batch_size=64, epoch_sample_limit=64 * 30, seed=9, verbose=False)
+        assert calls['n'] == failures and m._eng.layout == layout and (owners is None or m._eng.plan.owners == owners)
+        assert m._eng.triplets_drawn == 2 * 30 * 64
+        monkeypatch.setattr(_engine.BprEngine, 'run_batches', orig)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        clean = model()
+        clean.train(epochs=2, batch_size=64, epoch_sample_limit=64 * 30, seed=9, verbose=False)
+        for key in env:
+            monkeypatch.delenv(key)
+        assert clean._eng.layout == layout
+        for a, b in ((m.fue, clean.fue), (m.fie, clean.fie), (m.fib, clean.fib)):
+            assert np.array_equal(a, b)
+        assert m.last_epoch_loss == clean.last_epoch_loss

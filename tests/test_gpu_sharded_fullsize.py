@@ -49,6 +49,8 @@ m.fue, m.fie, m.fib = (a.copy() for a in init)
 m.train(epochs=1, batch_size=B, epoch_sample_limit=limit, seed=seed, verbose=False)
 eng = m._eng
 assert eng.layout == 'flow' and eng.n_users == len(m._owned) == len(tdist.shard_users(m.tr_users, rank, world))
+want = 0 if os.environ.get('TKR_OWN') == '0' else torch.cuda.get_device_properties(0).multi_processor_count // world
+assert eng.ranks_on_device == world and eng.plan.owners == want, (eng.plan.owners, want)      # the step that ran: K2o on half the CUs, or K2f
 # (1) replicas bit-identical after the exchange
 tdist.assert_replicated(eng)
 # (2) the owned-row gather covers every training user exactly once
@@ -186,19 +188,21 @@ print('ok', rank)
 '''
 
 
-def _launch(script_text, tmp_path, port, world=2, timeout=900, **fmt):
+def _launch(script_text, tmp_path, port, world=2, timeout=900, env=None, **fmt):
     script = tmp_path / 'worker.py'
     script.write_text(script_text % dict(root=ROOT, pkg=PKG, **fmt))
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
                           '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
-                         capture_output=True, text=True, timeout=timeout)
+                         capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-4000:]
     assert out.stdout.count('ok') == world
 
 
-def test_netflix_shape_sharded_epoch_two_ranks(tmp_path):
-    """BASELINE.json configs[3], sharded: BPR.train over two user shards, one reference epoch (10^6 // 256 = 3906 batches, 1953 per rank)"""
-    _launch(_TRAIN_NF, tmp_path, 29681)
+@pytest.mark.parametrize('own', ['1', '0'])
+def test_netflix_shape_sharded_epoch_two_ranks(tmp_path, own):
+    """BASELINE.json configs[3], sharded: BPR.train over two user shards, one reference epoch (10^6 // 256 = 3906 batches, 1953 per rank);
+    through K2o with the CUs split between the two ranks of this one GPU (128 owners each, 139 rows of 1 KB + slots per owner), and through K2f"""
+    _launch(_TRAIN_NF, tmp_path, 29681, env=dict(TKR_OWN=own))
 
 
 def test_netflix_shape_sharded_scoring_two_ranks(tmp_path):

@@ -753,16 +753,20 @@ static size_t own_lds_bytes(int np, int nb, int n_items, int n_owner) {
 
 }  // namespace tkr
 
-// workgroups (= owners) a device runs at once for factor width k, or 0 when the item rows do not fit their owners' LDS
-extern "C" int32_t tkr_bpr_own_owners(int32_t n_items, int32_t k) {
-    if (n_items <= 0 || k <= 0 || k > 256) return 0;
+// workgroups (= owners) a process runs at once for factor width k when `share` processes split the device's CUs between them
+// (share = 1: one workgroup per CU), or 0 when the item rows do not fit their owners' LDS
+extern "C" int32_t tkr_bpr_own_owners_shared(int32_t n_items, int32_t k, int32_t share) {
+    if (n_items <= 0 || k <= 0 || k > 256 || share <= 0) return 0;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
+    const int owners = cus / share;
+    if (owners <= 0) return 0;
     const int np = (k + 127) / 128;
-    if (tkr::own_lds_bytes(np, 512, n_items, cus) > 160 * 1024) return 0;
-    return cus;
+    if (tkr::own_lds_bytes(np, 512, n_items, owners) > 160 * 1024) return 0;
+    return owners;
 }
+extern "C" int32_t tkr_bpr_own_owners(int32_t n_items, int32_t k) { return tkr_bpr_own_owners_shared(n_items, k, 1); }
 
 extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, const int32_t* occt, const int32_t* ohdr,
                                int32_t ohdr_stride, int32_t n_owner, int32_t batch_size, int32_t first_batch, int32_t n_batches,

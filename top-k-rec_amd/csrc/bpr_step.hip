@@ -215,8 +215,8 @@ __device__ __forceinline__ void run_group(const tkr_bpr_state& st, int lane, int
 
 template <int NE, bool VEC, int kTeam, bool SGD>
 __global__ __launch_bounds__((kTeam * TKR_WAVE)) void bpr_step_kernel(
-    tkr_bpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
-    const int4* __restrict__ hdr, float* __restrict__ loss_out, int reverse) {
+    tkr_bpr_state st, int32_t* rec_all /*word 15 of a user task's record receives its loss sum: not const, not restrict*/,
+    const int2* __restrict__ occ, const int4* __restrict__ hdr, float* __restrict__ loss_out, int reverse) {
     __shared__ float red[kTeam][NE * TKR_WAVE + 1];
     const int lane = threadIdx.x & (TKR_WAVE - 1);
     const int wave = threadIdx.x >> 6;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__((kTeam * TKR_WAVE)) void bpr_step_kernel(
             // record of its own whose last word K1 leaves zero: its sum goes THERE (a plain store), and step_loss_kernel adds a
             // call's records up afterwards.
             const float tot = wave_sum(acc.loss_lane) + acc.loss_x;
-            if (lane == 0) const_cast<int32_t*>(rec_all)[((size_t)blk * kTeam + wave) * 16 + 15] = __float_as_int(tot);
+            if (lane == 0) rec_all[((size_t)blk * kTeam + wave) * 16 + 15] = __float_as_int(tot);
         }
 
         if (heavy) {                               // combine the team's partial gradients in wave order
@@ -337,7 +337,7 @@ static int step_grid(int B, int team) {
 }
 
 template <int NE, bool VEC, int TEAM>
-static int launch_step_t(const tkr_bpr_state& st, const int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
+static int launch_step_t(const tkr_bpr_state& st, int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
                        float* loss_out, hipStream_t stream) {
     static const int reverse = (getenv("TKR_K2_ORDER") && getenv("TKR_K2_ORDER")[0] == '0') ? 0 : 1;
     if (st.opt == 1)
@@ -350,13 +350,13 @@ static int launch_step_t(const tkr_bpr_state& st, const int32_t* rec, const int3
 }
 
 template <int NE, bool VEC>
-static int launch_step(const tkr_bpr_state& st, const int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
+static int launch_step(const tkr_bpr_state& st, int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
                        float* loss_out, hipStream_t stream) {
     return tkr_plan_team(B) == 4 ? launch_step_t<NE, VEC, 4>(st, rec, occ, hdr, B, loss_out, stream)
                                  : launch_step_t<NE, VEC, 16>(st, rec, occ, hdr, B, loss_out, stream);
 }
 
-static int dispatch_step(const tkr_bpr_state& st, const int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
+static int dispatch_step(const tkr_bpr_state& st, int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
                          float* loss_out, hipStream_t stream) {
     const int ne = (st.k + TKR_WAVE - 1) / TKR_WAVE;
     const bool full = (st.k == ne * TKR_WAVE) && ne != 3;           // k = 64, 128, 256: unpredicated vector rows
@@ -415,7 +415,7 @@ static int check_state(const tkr_bpr_state* st) {
 // ---- launch path -------------------------------------------------------------------------------------
 // One direct launch per batch, in plan order on the caller's stream (the kernel boundary is what makes batch
 // t+1 see batch t, single/bpr.py:141).  No hidden state: nothing is captured, cached or allocated here.
-extern "C" int tkr_bpr_run(const tkr_bpr_state* st, const int32_t* rec, const int32_t* occ, const int32_t* hdr,
+extern "C" int tkr_bpr_run(const tkr_bpr_state* st, int32_t* rec, const int32_t* occ, const int32_t* hdr,
                            int32_t batch_size, int32_t n_batches, float* loss_out, void* stream) {
     const int rc = check_state(st);
     if (rc != TKR_OK) return rc;

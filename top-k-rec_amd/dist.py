@@ -20,6 +20,27 @@ def world():
     return 0, 1
 
 
+def ranks_sharing_device(device) -> int:
+    """how many ranks of the process group run on the SAME physical GPU as this one (1 without a process group).  Decided from
+    the device's identity -- host name + PCI bus id / uuid, all-gathered -- not from device_count(): a launcher that shows every
+    rank one GPU (HIP_VISIBLE_DEVICES, SLURM gpus-per-task) and a multi-node job both make world_size > device_count() with one
+    rank per GPU.  A collective: every rank calls it at the same point (BPR.train / bench.py do, before the first step)."""
+    rank, w = world()
+    if w == 1:
+        return 1
+    import socket
+    ident = 'cpu'
+    if device is not None and getattr(device, 'type', 'cpu') == 'cuda':
+        prop = torch.cuda.get_device_properties(device)
+        ident = str(getattr(prop, 'uuid', '')) or ''
+        if not ident or set(ident) <= set('0-'):          # no uuid reported: the PCI address is as good
+            ident = '%s:%s:%s' % (getattr(prop, 'pci_domain_id', 0), getattr(prop, 'pci_bus_id', device.index), getattr(prop, 'pci_device_id', 0))
+    mine = (socket.gethostname(), ident)
+    everyone = [None] * w
+    dist.all_gather_object(everyone, mine)
+    return sum(1 for x in everyone if x == mine)
+
+
 def shared_seed(seed):
     """the seed every rank uses for the model init and as the key of the sample stream: rank 0's (drawn there when the
     caller gave none, like the single-process default) broadcast to all.  Ranks that initialised differently would
@@ -108,7 +129,7 @@ class ItemSync:
             self.flow = flow
             total = flow[5] * (flow[6] + 1)                     # n_items * k factors + n_items biases
             self.start_flat = torch.empty(total, dtype=torch.float32, device=flow[0].device)
-            self.flat = torch.empty(2 * total, dtype=torch.float32, device=flow[0].device)
+            self.flat = torch.zeros(2 * total + 1, dtype=torch.float32, device=flow[0].device)     # + the gave-up flag (any_gave_up)
             return
         tables = getattr(self.eng, 'replicated_tables', None)
         if tables is not None:
@@ -119,7 +140,7 @@ class ItemSync:
                 total = sum(self.sizes)
                 dev = tabs[0][1].device
                 self.start_flat = torch.empty(total, dtype=torch.float32, device=dev)
-                self.flat = torch.empty(2 * total, dtype=torch.float32, device=dev)
+                self.flat = torch.zeros(2 * total + 1, dtype=torch.float32, device=dev)
 
     @staticmethod
     def _shape(P, cnt):
@@ -174,6 +195,24 @@ class ItemSync:
             if len(marks) == 4:
                 self.timing.append(tuple(marks))
 
+    def _flag_status(self, total):
+        """the last word of the exchanged vector: did a persistent step of THIS rank give up during the epoch (the engine's device
+        status word)?  Summed by the same all-reduce, so that every rank learns it without a collective of its own."""
+        ctl = getattr(self.eng, 'ctl', None)
+        if ctl is not None and getattr(self.eng, 'layout', None) == 'flow':
+            import tkr_hip
+            self.flat[2 * total:] = (ctl[tkr_hip.FLOW_CTL_STATUS:tkr_hip.FLOW_CTL_STATUS + 1] != 0).float()
+        else:
+            self.flat[2 * total:].zero_()
+        self._flagged = True
+
+    def any_gave_up(self, mine=False):
+        """after end(): True on EVERY rank if a persistent step gave up on ANY rank during the epoch just exchanged (host wait)"""
+        if getattr(self, '_flagged', False):
+            self._flagged = False
+            return bool(mine) or float(self.flat[-1]) > 0.0
+        return bool(mine)
+
     def end(self):
         _, w = world()
         if w == 1:
@@ -192,10 +231,11 @@ class ItemSync:
             total = n * (k + 1)
             self._mark(marks)
             tkr_hip.sync_flow_pack(V, msV, tail, icnt, self.start_flat, self.flat[:total], self.flat[total:], n, k, 1.0 / w, bufs)
+            self._flag_status(total)
             self._mark(marks)
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self._mark(marks)
-            tkr_hip.sync_flow_unpack(V, msV, tail, rd, icnt, self.start_flat, self.flat[:total], self.flat[total:], n, k, bufs)
+            tkr_hip.sync_flow_unpack(V, msV, tail, rd, icnt, self.start_flat, self.flat[:total], self.flat[total:2 * total], n, k, bufs)
             self._start_valid = (self._bound, getattr(self.eng, 'item_mutations', 0))
             self._mark(marks)
             after = getattr(self.eng, 'after_exchange', None)
@@ -227,6 +267,7 @@ class ItemSync:
             tkr_hip.sync_pack(P, ms, cnt, self.start_flat[off:off + size], self.flat[off:off + size],
                               self.flat[total + off:total + off + size], n, wd, 1.0 / w)
             off += size
+        self._flag_status(total)
         self._mark(marks)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self._mark(marks)

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 import tkr_hip
+from ._config import Tuning
 
 RHO, EPS = 0.9, 1e-10          # tf.train.RMSPropOptimizer defaults (decay, epsilon)
 MAX_PLAN_BATCHES = tkr_hip.PLAN_MAX_BATCHES   # batches planned per K1 call
@@ -178,9 +179,8 @@ class PlanPipeline:
             self._side_dirty = False
 
 
-FUSE_SHORT_CALLS = __import__('os').environ.get('TKR_FUSE_SHORT', '1') != '0'     # K1 + step of a short call in ONE C call (tkr_bpr_own_plan_run)
-OVERLAP_MIN_BATCH = int(__import__('os').environ.get('TKR_OVERLAP_MIN_BATCH', 2048))     # below this the planner is < 5 % of the time and a second active queue slows
-                             # the dependent launch cadence of the step kernels (measured: 5.8 -> 6.8 us at B=256)
+# Tuning switches (TKR_* variables): single/_config.py, parsed once per engine into `self.cfg`.  overlap_min_batch: below it the planner is
+# < 5 % of the time and a second active queue slows the dependent launch cadence of the step kernels (measured: 5.8 -> 6.8 us at B=256)
 
 
 def _chunk_cap(B):
@@ -260,7 +260,7 @@ class PlanMixin:
 
     def _plan_overlap(self, B):
         """plan the chunk after the running one on the side stream?"""
-        return B >= OVERLAP_MIN_BATCH or self._plan_flow()
+        return B >= self.cfg.overlap_min_batch or self._plan_flow()
 
     def _plan_cols(self, B):
         """(d, row_cap) when the step of this engine wants the column plan of its batches beside K1's (VBPR), else None"""
@@ -269,7 +269,8 @@ class PlanMixin:
     def _plan_extra(self, buf, nb, B):
         """more planner-side work for the nb batches K1 just wrote into buf (same stream, right behind K1)"""
 
-    def _init_plans(self):
+    def _init_plans(self, tuning=None):
+        self.cfg = tuning if tuning is not None else Tuning.from_env()
         self._cnt = UpdateCounters(self.n_users, self.n_items, self.device)
         self._drawn = 0                 # position in the counter-based sample stream = triplets that RAN
         self._cur = None                # chunk being consumed
@@ -373,7 +374,7 @@ class PlanMixin:
         """may the first chunk of the epoch AFTER an exchange be planned before it?  Only where the exchange leaves the tables in
         a state K1 can name in advance without touching them (the granule layout: every item at version 0, dist.ItemSync's
         fused unpack) and takes no snapshot at the next begin()."""
-        return self._plan_flow() and __import__('os').environ.get('TKR_EPOCH_AHEAD', '1') != '0'
+        return self._plan_flow() and self.cfg.epoch_ahead
 
     def _next_chunk(self, csr, B, want, then_exchange=0):
         """the chunk that holds the batch at the current stream position; `want` = batches the running call still has to run;
@@ -399,7 +400,7 @@ class PlanMixin:
             nxt, self._ahead = self._ahead, None
         else:
             # a short call (this chunk holds all that is left of it, nothing is planned beside it): K1 goes out in the step's call
-            fuse = (FUSE_SHORT_CALLS and then_exchange == 0 and want <= self._cap(B) and
+            fuse = (self.cfg.fuse_short and then_exchange == 0 and want <= self._cap(B) and
                     getattr(getattr(self, '_step', None), 'plan_and_run', None) is not None and self._plan_owners(B) > 0)
             nxt = self._plan_chunk(0 if cur is None else cur.idx ^ 1, csr, B, self._drawn, False, want, fuse=fuse)
         if overlap and want > nxt.nb:                 # the chunk after it, behind the steps of this one
@@ -529,16 +530,6 @@ def _generators(device, seed, user_seed):
     return gen, gen_u
 
 
-FLOW_MAX_BATCH = int(__import__('os').environ.get('TKR_FLOW_MAX_BATCH', 512))     # batch sizes up to this take the persistent dataflow step (K2f);
-                                   # measured per batch, K2f vs K2: 64: 1.3 vs 3.9 us, 128: 1.8 vs 4.1, 256: 2.6 vs 4.5, 512: 5.1 vs 5.2, 1024: 8.8 vs 6.8
-FLOW_WAVES_PER_CU = int(__import__('os').environ.get('TKR_FLOW_WAVES_PER_CU', 0))    # 0 = the library default
-OWN_MAX_BATCH = int(__import__('os').environ.get('TKR_OWN_MAX_BATCH', 256))    # batch sizes up to this take K2o (item rows owned by one workgroup each, resident
-                                   # in its LDS) where the item table fits the CUs' LDS; TKR_OWN=0: always K2f.  Measured per batch, K2o vs K2f (ML-10M
-                                   # shape, same box): 64: 0.90 vs 1.47 us, 128: 1.32 vs 2.03, 256: 2.18 vs 2.75, 384: 3.79 vs 3.33, 512: 5.95 vs 3.98 (whatever the wave split)
-OWN_WAVES = int(__import__('os').environ.get('TKR_OWN_WAVES', 0))               # owner waves per workgroup, 0 = the library default
-FLOW_ITEM_BUFS = int(__import__('os').environ.get('TKR_FLOW_ITEM_BUFS', 4))     # buffers per item row of the granule tables (2 or 4; include/tkr.h)
-
-
 def _tags(t):
     """the version tags of a granule tensor [..., 2] (float32 storage; [..., 0] value bits, [..., 1] tag bits)"""
     return t.view(torch.int32)[..., 1]
@@ -601,10 +592,10 @@ class BprEngine(PlanMixin):
 
     Two layouts of the same model.  ``bulk``: plain double-buffered tables, one launch of K2 per batch (large batches:
     bandwidth-bound).  ``flow``: granule tables with in-band versions, ONE persistent launch of K2f per chunk (batch sizes
-    up to FLOW_MAX_BATCH, where a launch per batch is latency-bound).  run_batches picks by batch size and converts the
+    up to cfg.flow_max_batch, where a launch per batch is latency-bound).  run_batches picks by batch size and converts the
     tables when it changes; get / set work on either."""
 
-    def __init__(self, n_users, n_items, k, hp, device=None, seed=None, user_seed=None):
+    def __init__(self, n_users, n_items, k, hp, device=None, seed=None, user_seed=None, tuning=None):
         """``user_seed``: this engine holds ONE SHARD of the users (multi-GPU: n_users = rows owned by the rank): the user
         rows are drawn from their own generator (a different one per rank), the replicated item tables from ``seed`` alone
         (identical on every rank)."""
@@ -623,7 +614,7 @@ class BprEngine(PlanMixin):
         self._item_mutations = 0        # writes to the item tables from outside the step kernels (dist.ItemSync: is its snapshot still the truth?)
         self._flow_ran = False          # a persistent launch ran since the status word was last looked at
         self._status_host = self._status_event = None
-        self._init_plans()
+        self._init_plans(tuning)
 
     @property
     def item_mutations(self):
@@ -640,25 +631,27 @@ class BprEngine(PlanMixin):
         return self.layout == 'flow'
 
     def _plan_owners(self, B):
-        if self.layout != 'flow' or B > min(OWN_MAX_BATCH, 1024) or __import__('os').environ.get('TKR_OWN', '1') == '0':
+        """workgroups that own item rows when batch size B steps with K2o, else 0.  K2o wants its workgroups -- 12 waves each, one
+        per CU -- all resident at once; ranks that share a GPU (the multi-rank tests of a one-GPU box, a launcher that packs ranks)
+        split the CUs: `ranks_on_device` (dist.ranks_sharing_device, set by whoever initialises the process group) ranks run
+        CUs // ranks owners each, as long as the rows of an owner still fit its LDS."""
+        if self.layout != 'flow' or B > min(self.cfg.own_max_batch, 1024) or self.cfg.own == '0' or getattr(self, '_own_failed', False):
             return 0
-        n = getattr(self, '_owners', None)
-        if n is None:                                  # once per engine: a property of the device and the table shape
-            n = tkr_hip.bpr_own_owners(self.n_items, self.k, self.device)
-            # K2o wants one workgroup of 12 waves on EVERY CU: two processes on one GPU (the multi-rank tests of a one-GPU box, a
-            # launcher that packs ranks) cannot both have that -- K2f (4 waves per CU) shares.  TKR_OWN=2 overrides.
-            import torch.distributed as tdist
-            if (n and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > torch.cuda.device_count()
-                    and __import__('os').environ.get('TKR_OWN', '1') != '2'):
-                n = 0
-            self._owners = n
-        return n
+        share = max(1, int(getattr(self, 'ranks_on_device', 1)))
+        cache = self.__dict__.setdefault('_owners_by_share', {})
+        if share not in cache:                         # a property of the device, the table shape and the ranks beside us
+            cache[share] = tkr_hip.bpr_own_owners(self.n_items, self.k, self.device, share)
+            if cache[share] == 0 and share > 1:
+                import warnings
+                warnings.warn('K2o is off: %d ranks share this GPU and %d item rows of width %d do not fit %d owners\' LDS; the persistent '
+                              'step without owned rows (K2f) runs instead' % (share, self.n_items, self.k, cache[share]))
+        return cache[share]
 
     def wants_flow(self, B):
         """the granule layout + persistent step for this batch size?  Not when the granule tables would not fit: a granule row
         is k rounded up to 128 elements of 8 bytes, in two buffers, parameter + slot = 4 KB per row WHATEVER k is (k = 16: 16x
         the plain layout), and prepare() holds a copy of the old tables while it builds the new ones."""
-        if B > FLOW_MAX_BATCH or __import__('os').environ.get('TKR_FLOW', '1') == '0' or self.k > tkr_hip.FLOW_MAX_K:
+        if B > self.cfg.flow_max_batch or not self.cfg.flow or self.k > tkr_hip.FLOW_MAX_K:
             return False
         if getattr(self, '_flow_disabled', False):     # a bounded spin of the persistent kernel ran out in this process: K2 from here on
             return False
@@ -669,7 +662,7 @@ class BprEngine(PlanMixin):
         fits = getattr(self, '_flow_fits', None)
         if fits is None:
             rows = self.n_users + self.n_items
-            need = (rows + (FLOW_ITEM_BUFS // 2 - 1) * self.n_items) * (tkr_hip.flow_row_granules(self.k) * 32 + 96 + 8 * self.k)
+            need = (rows + (self.cfg.flow_item_bufs // 2 - 1) * self.n_items) * (tkr_hip.flow_row_granules(self.k) * 32 + 96 + 8 * self.k)
             free = torch.cuda.mem_get_info(self.device)[0] if self.device.type == 'cuda' else need
             fits = self._flow_fits = need <= 0.7 * free
         return fits
@@ -683,8 +676,8 @@ class BprEngine(PlanMixin):
         (pu, mu), (pv, mv), (pb, mb) = (tuple(t.clone() for t in self.get(n)) for n in ('U', 'V', 'b'))
         self.U = self.V = self.b = self.tailU = self.tailV = None
         if layout == 'flow':
-            self.U, self.V = FlowTable(self.n_users, self.k, self.device), FlowTable(self.n_items, self.k, self.device, FLOW_ITEM_BUFS)
-            self.tailU, self.tailV = FlowTail(self.n_users, self.device), FlowTail(self.n_items, self.device, FLOW_ITEM_BUFS)
+            self.U, self.V = FlowTable(self.n_users, self.k, self.device), FlowTable(self.n_items, self.k, self.device, self.cfg.flow_item_bufs)
+            self.tailU, self.tailV = FlowTail(self.n_users, self.device), FlowTail(self.n_items, self.device, self.cfg.flow_item_bufs)
             if self.ctl is None:
                 self.ctl = torch.zeros(tkr_hip.flow_ctl_words(), dtype=torch.int32, device=self.device)
         else:
@@ -711,16 +704,19 @@ class BprEngine(PlanMixin):
         # never ends) every later launch would time out the same way.  The tables of THIS run are lost -- a launch is not
         # transactional -- but the engine stays usable: from here on it steps with K2 (one launch per batch, no co-residency
         # assumption), e.g. after the caller re-imports a checkpoint.
-        # K2o asks for more than K2f -- a 12-wave workgroup resident on EVERY CU: where that is what failed (the GPU is shared), the
-        # next thing to try is K2f (4 waves per CU), and only if that gives up as well the per-batch step.
-        if getattr(self, '_owners', 0):
-            self._owners = 0
+        # K2o asks for more than K2f -- a 12-wave workgroup resident on EVERY CU: where THAT is what failed (the GPU is shared), the
+        # next thing to try is K2f (4 waves per CU); a K2f launch that gives up goes straight to the per-batch step (the
+        # step-down used to follow whether K2o was configured, not which kernel had run: a K2f failure at batch 512 of an engine
+        # that had run K2o at batch 256 "stepped down" to K2f again).
+        if getattr(self, '_last_step_kind', None) == 'own':
+            self._own_failed = True
             nxt = 'the persistent step without owned rows (K2f)'
         else:
             self._flow_disabled = True
             nxt = 'the per-batch step (K2)'
+        self.tables_invalid = True       # until somebody puts tables back (set_users + set_items: BPR.train's retry does)
         self._step_key = None
-        raise tkr_hip.TkrError('persistent BPR step gave up waiting for a row version (status %d): tables are invalid; this engine uses %s '
+        raise tkr_hip.StepGaveUp('persistent BPR step gave up waiting for a row version (status %d): tables are invalid; this engine uses %s '
                                'from now on; post-mortem words (csrc/bpr_flow.hip kCtlDebug) %r' % (code, nxt, post))
 
     def _raise_pending(self):
@@ -821,6 +817,21 @@ class BprEngine(PlanMixin):
             return None
         return self.V.p, self.V.ms, self.tailV.t, self.tailV.rd, self._cnt.icnt, self.n_items, self.k, self.V.bufs
 
+    def snapshot(self):
+        """parameters, slots and the sample stream position as they are now (device copies): what restore() puts back.  A launch of a
+        persistent step is not transactional -- a bounded spin that runs out leaves the tables half-updated -- so BPR.train keeps the
+        state it started from and re-runs from there on the next kernel down (VERDICT r4 #4)."""
+        snap = {n: tuple(t.clone() for t in self.get(n)) for n in ('U', 'V', 'b')}
+        snap['drawn'] = self._drawn
+        return snap
+
+    def restore(self, snap):
+        self.settle(check=False)
+        self.set_users(U=snap['U'][0], msU=snap['U'][1])
+        self.set_items(V=snap['V'][0], b=snap['b'][0], msV=snap['V'][1], msb=snap['b'][1])
+        self._drawn = int(snap['drawn'])
+        self.tables_invalid = False
+
     def copy_model_from(self, other):
         """start from another engine's current parameters and slots (shards of one model)"""
         p, ms = other.get('U')
@@ -845,18 +856,20 @@ class BprEngine(PlanMixin):
             raise ValueError('BPR on the HIP path: k <= 512, and k <= 256 for batch sizes above 1024 (got k = %d, batch_size = %d): a wave '
                              'holds a row in k / 64 registers per array (csrc/bpr_step.hip)' % (self.k, B))
         self.prepare(B)
-        key = (self.layout_epoch, B, FLOW_WAVES_PER_CU, self._plan_owners(B), OWN_WAVES)
+        key = (self.layout_epoch, B, self.cfg.flow_waves_per_cu, self._plan_owners(B), self.cfg.own_waves)
         if getattr(self, '_step_key', None) != key:       # the C struct and the closure are built once per layout, not per call
             self._step_key, self._step = key, self.step_fn(B)
         self._flow_ran = self._flow_ran or self.layout == 'flow'
+        if self.layout == 'flow':
+            self._last_step_kind = 'own' if self._plan_owners(B) else 'flow'
         return self._run(csr, n_batches, B, want_loss, self._step, then_exchange)
 
     def step_fn(self, B):
         state = self.state()
         if self.layout == 'flow':
             if self._plan_owners(B):
-                return tkr_hip.own_stepper(state, B, self.ctl, OWN_WAVES)
-            return tkr_hip.flow_stepper(state, B, self.ctl, FLOW_WAVES_PER_CU)
+                return tkr_hip.own_stepper(state, B, self.ctl, self.cfg.own_waves)
+            return tkr_hip.flow_stepper(state, B, self.ctl, self.cfg.flow_waves_per_cu)
         return lambda plan, lo, nb, loss: tkr_hip.bpr_run(state, plan, B, nb, loss, first=lo)
 
 
@@ -871,7 +884,7 @@ class VbprEngine(PlanMixin):
     COLS_MAX_BATCH = 1024      # the column-plan step (three launches per batch): pair sums are O(B^2) work of B waves
     PLAN_BYTES = 768 << 20     # column plans held per plan buffer (two buffers): bounds the batches planned per K1 call
 
-    def __init__(self, n_users, n_items, k, d, feat, hp, device=None, seed=None, sparse=None, user_seed=None):
+    def __init__(self, n_users, n_items, k, d, feat, hp, device=None, seed=None, sparse=None, user_seed=None, tuning=None):
         self.device = device or default_device()
         self.n_users, self.n_items, self.k, self.kh, self.d = n_users, n_items, k, k // 2, d
         self.hp = hp
@@ -889,7 +902,7 @@ class VbprEngine(PlanMixin):
         self.feat = feat if isinstance(feat, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(feat, dtype=np.float32))
         self.feat = self.feat.to(self.device).contiguous()
         assert self.feat.shape == (n_items, d)
-        self._init_plans()
+        self._init_plans(tuning)
         self.ws = None
         self.sparse = None
         nnz = int(torch.count_nonzero(self.feat))
@@ -919,7 +932,7 @@ class VbprEngine(PlanMixin):
 
     # ---- column-plan step (csrc/vbpr_step.hip, "column-plan path") --------------------------------
     def wants_cols(self, B):
-        if self.sparse is None or __import__('os').environ.get('TKR_VBPR_COLS', '1') == '0':
+        if self.sparse is None or not self.cfg.vbpr_cols:
             return False
         return (self.kh % 4 == 0 and self.kh <= 128 and B <= self.COLS_MAX_BATCH and 0 < self.max_row_nnz <= 1024 and
                 tkr_hip.vbpr_colplan_lds_bytes(B, self.d) <= 160 * 1024)
@@ -936,7 +949,7 @@ class VbprEngine(PlanMixin):
 
     def _plan_overlap(self, B):
         # the column plan costs ~1.5 us per batch: behind the steps of the chunk before, not in front of its own
-        return B >= OVERLAP_MIN_BATCH or (self.wants_cols(B) and __import__('os').environ.get('TKR_VBPR_OVERLAP', '1') != '0')
+        return B >= self.cfg.overlap_min_batch or (self.wants_cols(B) and self.cfg.vbpr_overlap)
 
     def _plan_extra(self, buf, nb, B):
         if buf.cols is not None:

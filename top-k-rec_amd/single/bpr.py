@@ -29,6 +29,7 @@ import numpy as np
 import torch
 
 import textio
+import tkr_hip
 from utils import get_data_from_file, get_id_dict_from_file, tprint
 from .rec import REC
 from . import _engine
@@ -223,6 +224,8 @@ class BPR(REC):
         tprint('Learning rate is %.6f, regularization mode is %s' % (self.lr, self.mode))
         tprint('Training for %d epochs of %d batches using %s sampler' % (epochs, batch_limit, sampling))
         self._warm_start()
+        if world > 1:                                      # ranks packed on one GPU split its CUs between their K2o launches
+            self._eng.ranks_on_device = tdist.ranks_sharing_device(self._eng.device)
         self._eng.prepare(batch_size, 'bulk' if streams > 1 else None)     # table layout of this batch size (see _engine.BprEngine)
         # one process per GPU (torch.distributed initialised by the launcher): users sharded, item-side
         # tables replicated and reconciled once per epoch (dist.py; the reference is single-process)
@@ -242,17 +245,43 @@ class BPR(REC):
             n_batches = tdist.batches_per_rank(n_batches, world)
             self._eng.triplets_drawn = rank * epochs * n_batches * batch_size      # disjoint stream positions
             tdist.assert_replicated(self._eng)             # same seed, same warm start: the replicas must start equal
-            sync = tdist.ItemSync(self._eng)
+        # A persistent step (K2f / K2o) that cannot get its workgroups resident -- a GPU shared with something that never ends --
+        # gives up after a bounded spin and leaves half-updated tables; the engine then steps down one kernel (K2o -> K2f -> K2).
+        # The run starts again from the state kept here, on the same counter-based sample stream: it degrades instead of raising.
+        for attempt in range(3):
+            start = self._eng.snapshot() if self._eng.layout == 'flow' else None
+            if self._train_epochs(epochs, n_batches, batch_size, world, verbose):
+                break
+            if start is None or attempt == 2:
+                raise tkr_hip.StepGaveUp('BPR.train: the step gave up on every kernel form')
+            self._eng.restore(start)
+            self._eng.prepare(batch_size)                  # (the table layout of the kernel the engine stepped down to)
+        self._collect()
+
+    def _train_epochs(self, epochs, n_batches, batch_size, world, verbose):
+        """the epoch loop of bpr.py:136-150; False = a persistent step gave up on some rank (every rank returns False then)"""
+        import dist as tdist
+        sync = tdist.ItemSync(self._eng) if world > 1 else None
         for eid in range(epochs):
             t0 = time.time()
-            if world > 1:
+            if sync is not None:
                 sync.begin()
             # sharded: the exchange follows this call, then an epoch of n_batches more -- its first chunk is planned behind this
             # epoch's last steps (PlanMixin), and the host looks at the loss only after the exchange is queued
-            loss = self._run_epoch(n_batches, batch_size, n_batches if (world > 1 and eid + 1 < epochs) else 0, defer=world > 1)
-            if world > 1:
-                sync.end()
-                loss = self._epoch_loss(loss)
+            gave_up = False
+            try:
+                loss = self._run_epoch(n_batches, batch_size, n_batches if (sync is not None and eid + 1 < epochs) else 0, defer=sync is not None)
+                if sync is not None:
+                    sync.end()
+                    loss = self._epoch_loss(loss)
+            except tkr_hip.StepGaveUp as e:
+                import warnings
+                warnings.warn('BPR.train restarts from its initial state: %s' % e)
+                gave_up = True
+            if sync is not None:
+                gave_up = sync.any_gave_up(gave_up)          # the flag rode in the exchange: every rank agrees, no extra collective
+            if gave_up:
+                return False
             torch.cuda.synchronize(self._eng.device)
             spent = time.time() - t0
             self.last_epoch_loss = loss
@@ -261,7 +290,7 @@ class BPR(REC):
                 sys.stderr.write(' ... total time collapse %8.4fs' % spent)
                 sys.stderr.flush()
                 print()
-        self._collect()
+        return True
 
     def _train_streams(self, epochs, n_batches, batch_size, S, verbose):
         import dist as tdist

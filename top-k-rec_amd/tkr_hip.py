@@ -15,11 +15,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TKR_HIP_LIB') or os.path.join(_HERE, 'libtkr_hip.so')      # the override is for A/B builds of the kernels (scripts/)
 
 _lib = None
-VERSION = 114          # TKR_VERSION of include/tkr.h this binding was written against
+VERSION = 115          # TKR_VERSION of include/tkr.h this binding was written against
 
 
 class TkrError(RuntimeError):
     pass
+
+
+class StepGaveUp(TkrError):
+    """a bounded spin of a persistent step kernel ran out: the tables of the run are invalid, the engine has stepped down to the
+    next kernel (K2o -> K2f -> K2) and works again once valid tables are put back (BPR.train does: single/bpr.py _run_epoch)"""
 
 
 class BprState(C.Structure):
@@ -72,7 +77,7 @@ class VbprState(C.Structure):
                [(n, C.c_void_p) for n in ('f_ptr', 'f_col', 'f_val', 'c_ptr', 'c_item', 'c_val', 'item_tag')]
 
 
-EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_sample_plan_owned', 'tkr_plan_rollback', 'tkr_bpr_run', 'tkr_bpr_flow_run', 'tkr_bpr_own_run', 'tkr_bpr_own_run_between', 'tkr_bpr_own_plan_run', 'tkr_bpr_own_owners', 'tkr_flow_row_granules', 'tkr_flow_ctl_words',
+EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_plan', 'tkr_sample_plan_owned', 'tkr_plan_rollback', 'tkr_bpr_run', 'tkr_bpr_flow_run', 'tkr_bpr_own_run', 'tkr_bpr_own_run_between', 'tkr_bpr_own_plan_run', 'tkr_bpr_own_owners', 'tkr_bpr_own_owners_shared', 'tkr_flow_row_granules', 'tkr_flow_ctl_words',
            'tkr_vbpr_run', 'tkr_vbpr_colplan', 'tkr_vbpr_run_cols', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy',
            'tkr_idmap_create', 'tkr_idmap_destroy', 'tkr_ratings_parse', 'tkr_ratings_sizes', 'tkr_ratings_copy',
            'tkr_ratings_destroy', 'tkr_matrix_read', 'tkr_matrix_sizes', 'tkr_matrix_copy', 'tkr_matrix_destroy',
@@ -308,12 +313,13 @@ def flow_stepper(state, B, ctl, waves_per_cu=0):
     return step
 
 
-def bpr_own_owners(n_items, k, device=None):
-    """workgroups (= owners of item rows) of the persistent step K2o on the current device, 0 = the rows do not fit its LDS"""
+def bpr_own_owners(n_items, k, device=None, share=1):
+    """workgroups (= owners of item rows) of the persistent step K2o on the current device when `share` processes split its CUs,
+    0 = the rows do not fit the owners' LDS"""
     if device is not None and torch.cuda.current_device() != device.index:
         with torch.cuda.device(device):
-            return int(lib().tkr_bpr_own_owners(C.c_int32(n_items), C.c_int32(k)))
-    return int(lib().tkr_bpr_own_owners(C.c_int32(n_items), C.c_int32(k)))
+            return int(lib().tkr_bpr_own_owners_shared(C.c_int32(n_items), C.c_int32(k), C.c_int32(share)))
+    return int(lib().tkr_bpr_own_owners_shared(C.c_int32(n_items), C.c_int32(k), C.c_int32(share)))
 
 
 def bpr_own_run(state, plan, B, n_batches, ctl, loss_out=None, first=0, owner_waves=0):
