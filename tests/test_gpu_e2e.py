@@ -146,4 +146,5 @@ def test_train_restarts_one_kernel_down_when_a_step_gives_up(tmp_path, monkeypat
         assert clean._eng.layout == layout
         for a, b in ((m.fue, clean.fue), (m.fie, clean.fie), (m.fib, clean.fib)):
             assert np.array_equal(a, b)
-        assert m.last_epoch_loss == clean.last_epoch_loss
+        # (K2f adds a batch's loss up with LDS atomics, K2 with a sliced sum: the tables are bitwise, the reported loss to its last bits)
+        assert abs(m.last_epoch_loss - clean.last_epoch_loss) <= 1e-5 * abs(clean.last_epoch_loss)

@@ -23,195 +23,14 @@
 #include <stdlib.h>
 
 #include "tkr_common.h"
-#include "sampler_draw.h"
-
-namespace tkr {
 
 #ifdef TKR_K1_PROF            // scripts/probe_short.py: s_memtime at the phase boundaries of workgroup 0 (100 MHz ticks)
-__device__ unsigned long long k1_prof[32];
-#define K1_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) k1_prof[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define K1_STAMP(i) do { } while (0)
+namespace tkr { __device__ unsigned long long k1_prof[32]; }
+#define K1_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) tkr::k1_prof[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #endif
+#include "plan_parts.h"      // the sorts, task heads, versions and record assembly: shared with the prologue of csrc/bpr_own.hip
 
-constexpr int kPlanThreads = 256;      // resolve/commit kernels, and sample_plan for B <= 1024
-constexpr int kPlanThreadsBig = 1024;  // sample_plan for larger batches (the LDS sort dominates there)
-constexpr int kLightMax = 4;     // oracle/plan_np.py LIGHT_MAX: occurrences one wave handles, B <= 4096
-constexpr int kLightMaxBig = 16; // ... LIGHT_MAX_BIG for larger batches
-__host__ __device__ inline int light_max(int B) { return B <= 4096 ? kLightMax : kLightMaxBig; }
-constexpr int kTeamBig = 16;     // oracle/plan_np.py TEAM: waves per workgroup / heavy task, B > 1024
-constexpr int kTeamSmall = 4;    // ... TEAM_SMALL for B <= 1024 (spreads a small batch over many CUs)
-__host__ __device__ inline int team_for(int B) { return B <= 1024 ? kTeamSmall : kTeamBig; }
-// light tasks per workgroup (oracle light_per_block): every wave slot (half-filled groups measured slower)
-__host__ __device__ inline int light_per_block(int B) { return team_for(B); }
-constexpr int kTouchWords = 16;  // bitmap words per row -> at most 512 batches per call
-
-// In-LDS bitonic sort of n (power of two) 64-bit keys, ascending.
-template <int T>
-__device__ __forceinline__ void bitonic_sort(uint64_t* keys, int n) {
-    for (int size = 2; size <= n; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int p = threadIdx.x; p < (n >> 1); p += T) {
-                const int lo = ((p & ~(stride - 1)) << 1) | (p & (stride - 1));
-                const int hi = lo | stride;
-                const bool asc = ((lo & size) == 0);
-                const uint64_t a = keys[lo], b = keys[hi];
-                if ((a > b) == asc) { keys[lo] = b; keys[hi] = a; }
-            }
-        }
-    }
-    __syncthreads();
-}
-
-// ---- the same sort in registers ------------------------------------------------------------------------------------------------
-// The LDS sort above pays one barrier + one LDS round trip per compare-exchange step (45 steps for 512 keys: 8.3 us of a 24 us
-// kernel that sits in front of every short call).  Here thread t holds keys R*t .. R*t + R - 1 (32-bit: row << OB | occurrence):
-// strides below R exchange registers of one thread, strides below 64 R lanes of one wave -- DPP moves and v_permlane{16,32}_swap,
-// vector-ALU instructions, no LDS, no barrier -- and only the strides from 64 R on (3 steps of 45 at 512 keys over 4 waves) go
-// through LDS.  Same network, same result.
-typedef uint32_t lane_pair __attribute__((ext_vector_type(2)));
-template <int M>
-__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int lane) {
-    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "xor mask inside a wave");
-    if constexpr (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);          // quad_perm [1,0,3,2]
-    else if constexpr (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
-    else if constexpr (M == 4) {                                                                                     // i -> 7 - i -> its quad reversed = i ^ 4
-        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);                               // row_half_mirror
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, t, 0x1b, 0xf, 0xf, false);                                  // quad_perm [3,2,1,0]
-    } else if constexpr (M == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);  // row_ror:8
-    else if constexpr (M == 16) {
-        const lane_pair r = __builtin_amdgcn_permlane16_swap(v, v, false, false);     // x = rows [0,0,2,2] of v, y = rows [1,1,3,3]
-        return (lane & 16) ? r.x : r.y;
-    } else {
-        const lane_pair r = __builtin_amdgcn_permlane32_swap(v, v, false, false);     // x = [lower half, lower half], y = [upper, upper]
-        return (lane & 32) ? r.x : r.y;
-    }
-}
-template <int R, int M>
-__device__ __forceinline__ void lane_step(uint32_t (&k)[R], int lane, bool keep_min) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t o = lane_xor<M>(k[r], lane);
-        k[r] = keep_min ? min(k[r], o) : max(k[r], o);
-    }
-}
-// n = R * T keys, ascending over e = R * thread + r; `xbuf`: n words of LDS, free on entry (barrier inside before its first use)
-template <int T, int R>
-__device__ __forceinline__ void register_sort(uint32_t (&k)[R], uint32_t* xbuf) {
-    const int tid = threadIdx.x, lane = tid & (TKR_WAVE - 1);
-    constexpr int n = R * T;
-    constexpr int LOGN = __builtin_ctz(n);
-    static_assert((n & (n - 1)) == 0, "power of two");
-    // fully unrolled: sizes, strides and register indices are compile-time constants (a register array indexed by a run-time
-    // stride would live in scratch memory)
-#pragma unroll
-    for (int ls = 1; ls <= LOGN; ++ls) {
-#pragma unroll
-        for (int lj = ls - 1; lj >= 0; --lj) {
-            const int size = 1 << ls, stride = 1 << lj;
-            if (stride < R) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int q = r ^ stride;
-                    if (q > r) {
-                        const bool asc = (((tid * R + r) & size) == 0);
-                        const uint32_t a = k[r], b = k[q];
-                        const bool sw = (a > b) == asc;
-                        k[r] = sw ? b : a;
-                        k[q] = sw ? a : b;
-                    }
-                }
-            } else {
-                const int m = stride / R;                            // lane / thread distance
-                const bool asc = (((tid * R) & size) == 0);
-                const bool lower = (tid & m) == 0;
-                const bool keep_min = lower == asc;
-                if (m == 1) lane_step<R, 1>(k, lane, keep_min);
-                else if (m == 2) lane_step<R, 2>(k, lane, keep_min);
-                else if (m == 4) lane_step<R, 4>(k, lane, keep_min);
-                else if (m == 8) lane_step<R, 8>(k, lane, keep_min);
-                else if (m == 16) lane_step<R, 16>(k, lane, keep_min);
-                else if (m == 32) lane_step<R, 32>(k, lane, keep_min);
-                else {                                               // across waves: through LDS
-                    __syncthreads();
-#pragma unroll
-                    for (int r = 0; r < R; ++r) xbuf[tid * R + r] = k[r];
-                    __syncthreads();
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const uint32_t o = xbuf[(tid ^ m) * R + r];
-                        k[r] = keep_min ? min(k[r], o) : max(k[r], o);
-                    }
-                }
-            }
-        }
-    }
-}
-// a whole sort of this kernel through registers: keys of element e from `make(e)` (row << ob | occurrence, ~0 = padding), result
-// into keys[] in the 64-bit form the rest of the kernel reads (row << 32 | occurrence)
-template <int T, int R, class Make>
-__device__ __forceinline__ void sort_via_registers(uint64_t* keys, int ob, Make make) {
-    uint32_t k[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) k[r] = make((int)threadIdx.x * R + r);
-    // the exchange buffer: the upper half of keys[] (n 64-bit slots = 2n words; the lower n words stay clear of the 64-bit result
-    // only after the barrier below)
-    register_sort<T, R>(k, reinterpret_cast<uint32_t*>(keys));
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint32_t v = k[r];
-        keys[(int)threadIdx.x * R + r] = v == 0xffffffffu ? ~0ull : (((uint64_t)(v >> ob) << 32) | (uint64_t)(v & ((1u << ob) - 1u)));
-    }
-    __syncthreads();
-}
-
-// Turn sorted keys[0..n) (row<<32 | occurrence) into task heads + counts.  Returns the
-// number of groups (uniform across the block).  `slot0` = first task slot to fill,
-// `occ0` = occ offset of sorted position 0, `kind` = 0 users / 1 items.
-template <int T>
-__device__ __forceinline__ int emit_tasks(const uint64_t* keys, int n, int4* task, int slot0, int occ0,
-                                          int kind, int* scan /*LDS [T+1]*/,
-                                          uint32_t* __restrict__ touch, int batch) {
-    const int per = (n + T - 1) / T;
-    const int beg = min((int)threadIdx.x * per, n), end = min(beg + per, n);
-    int cnt = 0;
-    for (int p = beg; p < end; ++p)
-        cnt += (p == 0) || ((uint32_t)(keys[p] >> 32) != (uint32_t)(keys[p - 1] >> 32));
-    // exclusive scan of the per-thread head counts: inside a wave by DPP-free shuffles, the <= 16 wave totals by every thread
-    // (thread 0 used to walk all T entries of the LDS array: 256 dependent read-modify-writes, ~7 us of a 35 us kernel, twice)
-    const int lane = threadIdx.x & (TKR_WAVE - 1), wave = threadIdx.x / TKR_WAVE;
-    int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < TKR_WAVE; d <<= 1) {
-        const int up = __shfl_up(incl, d);
-        if (lane >= d) incl += up;
-    }
-    __syncthreads();                                  // `scan` may still be read from the call before
-    if (lane == TKR_WAVE - 1) scan[wave] = incl;
-    __syncthreads();
-    int s = incl - cnt, total = 0;
-#pragma unroll
-    for (int w = 0; w < T / TKR_WAVE; ++w) {
-        const int t = scan[w];
-        if (w < wave) s += t;
-        total += t;
-    }
-    for (int p = beg; p < end; ++p) {
-        const uint32_t row = (uint32_t)(keys[p] >> 32);
-        if ((p == 0) || (row != (uint32_t)(keys[p - 1] >> 32))) {
-            // length of this group: scan forward to the next head (groups are short on
-            // average; long ones cost O(len) once)
-            int q = p + 1;
-            while (q < n && (uint32_t)(keys[q] >> 32) == row) ++q;
-            task[slot0 + s] = make_int4((int)(row | ((uint32_t)kind << 31)), occ0 + p, q - p, 0);
-            atomicOr(&touch[(size_t)row * kTouchWords + (batch >> 5)], 1u << (batch & 31));
-            ++s;
-        }
-    }
-    return total;
-}
+namespace tkr {
 
 template <int T>
 __global__ __launch_bounds__(T) void sample_plan_kernel(
@@ -222,110 +41,15 @@ __global__ __launch_bounds__(T) void sample_plan_kernel(
     int4* __restrict__ task_all, int2* __restrict__ occ_all, int32_t* __restrict__ occt_all,
     uint32_t* __restrict__ touch_u, uint32_t* __restrict__ touch_i, bool reg_sort_ok /*row ids leave room for the occurrence bits in 32-bit keys*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);                       // [npad_items]
-    int* scan = reinterpret_cast<int*>(smem + (size_t)npad_items * 8);        // [T+1]
-
     const int b = blockIdx.x;
     const uint64_t batch0 = ctl ? (uint64_t)ctl[0] : 0ull;                    // device-side chunk base
     const uint64_t g0 = first_triplet + (batch0 + (uint64_t)b) * (uint64_t)B;
-    int32_t* bu = out_u + (size_t)b * B;
-    int32_t* bi = out_i + (size_t)b * B;
-    int32_t* bj = out_j + (size_t)b * B;
-    int4* task = task_all + (size_t)b * 3 * B;
-    int2* occ = occ_all + (size_t)b * 3 * B;
-    int32_t* occt = occt_all + (size_t)b * 3 * B;
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    K1_STAMP(0);
-
-    // ---- draw; item keys go to LDS, triplets to HBM ---------------------------------
-    for (int t = threadIdx.x; t < B; t += T) {
-        int u, i, j;
-        draw_triplet(tr_users, n_tr, row_ptr, pos_cols, cols_sorted, n_items, k0, k1, g0 + t, u, i, j);
-        bu[t] = u; bi[t] = i; bj[t] = j;
-    }
-    __threadfence_block();
-    __syncthreads();
-    K1_STAMP(1);
-
-    // ---- users: sort (u<<32 | t) ----------------------------------------------------------
-    int npad_u = 1;
-    while (npad_u < B) npad_u <<= 1;
-    // registers when the sizes allow (npad_u = T or 2T or 4T keys, 32-bit keys: row ids and occurrence numbers fit one word)
-    int ob = 1;
-    while ((1 << ob) < npad_items) ++ob;
-    const bool in_regs = reg_sort_ok && npad_items == 2 * npad_u && (npad_u == T || npad_u == 2 * T || npad_u == 4 * T || npad_u == 8 * T);
-    if (in_regs) {
-        auto make = [&](int t) { return t < B ? (((uint32_t)bu[t] << ob) | (uint32_t)t) : 0xffffffffu; };
-        if (npad_u == T) sort_via_registers<T, 1>(keys, ob, make);
-        else if (npad_u == 2 * T) sort_via_registers<T, 2>(keys, ob, make);
-        else if (npad_u == 4 * T) sort_via_registers<T, 4>(keys, ob, make);
-        else sort_via_registers<T, 8>(keys, ob, make);
-    } else {
-        for (int t = threadIdx.x; t < npad_u; t += T)
-            keys[t] = (t < B) ? (((uint64_t)(uint32_t)bu[t] << 32) | (uint32_t)t) : ~0ull;
-        bitonic_sort<T>(keys, npad_u);
-    }
-    K1_STAMP(2);
-    const int n_uq = emit_tasks<T>(keys, B, task, 0, 0, 0, scan, touch_u, b);
-    K1_STAMP(3);
-    for (int p = threadIdx.x; p < B; p += T) {
-        const int t = (int)(uint32_t)keys[p];
-        occ[p] = make_int2(bi[t], bj[t]);
-        occt[p] = t;
-    }
-    __syncthreads();
-    K1_STAMP(4);
-
-    // ---- items: sort (item<<32 | o), o<B: i-role of triplet o, else j-role of o-B ---------
-    if (in_regs) {
-        auto make = [&](int o) {
-            return o < B ? (((uint32_t)bi[o] << ob) | (uint32_t)o) : o < 2 * B ? (((uint32_t)bj[o - B] << ob) | (uint32_t)o) : 0xffffffffu;
-        };
-        if (npad_u == T) sort_via_registers<T, 2>(keys, ob, make);
-        else if (npad_u == 2 * T) sort_via_registers<T, 4>(keys, ob, make);
-        else if (npad_u == 4 * T) sort_via_registers<T, 8>(keys, ob, make);
-        else sort_via_registers<T, 16>(keys, ob, make);
-    } else {
-        for (int o = threadIdx.x; o < npad_items; o += T) {
-            uint64_t key = ~0ull;
-            if (o < B) key = ((uint64_t)(uint32_t)bi[o] << 32) | (uint32_t)o;
-            else if (o < 2 * B) key = ((uint64_t)(uint32_t)bj[o - B] << 32) | (uint32_t)o;
-            keys[o] = key;
-        }
-        bitonic_sort<T>(keys, npad_items);
-    }
-    K1_STAMP(5);
-    const int n_iq = emit_tasks<T>(keys, 2 * B, task, n_uq, B, 1, scan, touch_i, b);
-    K1_STAMP(6);
-    for (int p = threadIdx.x; p < 2 * B; p += T) {
-        const int o = (int)(uint32_t)keys[p];
-        const bool role = o >= B;
-        const int t = role ? o - B : o;
-        const uint32_t other = (uint32_t)(role ? bi[t] : bj[t]);
-        occ[B + p] = make_int2(bu[t], (int)(other | ((uint32_t)role << 31)));
-        occt[B + p] = t;
-    }
-    for (int s = n_uq + n_iq + threadIdx.x; s < 3 * B; s += T) task[s] = make_int4(-1, 0, 0, 0);
-    __syncthreads();
-    K1_STAMP(7);
+    plan_phase_a<T, T>(smem, b, tr_users, n_tr, row_ptr, pos_cols, cols_sorted, n_items, seed, g0, B, npad_items, out_u + (size_t)b * B,
+                       out_i + (size_t)b * B, out_j + (size_t)b * B, task_all + (size_t)b * 3 * B, occ_all + (size_t)b * 3 * B,
+                       occt_all + (size_t)b * 3 * B, touch_u, touch_i, reg_sort_ok);
 }
 
 // ---- K1b: parities + per-wave launch records ------------------------------------------------
-// number of updates of `row` before batch `batch` of this call = the VERSION of the row that batch reads
-__device__ __forceinline__ int version_of(const int32_t* __restrict__ cnt, const uint32_t* __restrict__ touch,
-                                          int row, int batch) {
-    const uint32_t* w = touch + (size_t)row * kTouchWords;
-    int c = cnt[row];
-    const int full = batch >> 5;
-    for (int q = 0; q < full; ++q) c += __popc(w[q]);
-    c += __popc(w[full] & ((1u << (batch & 31)) - 1u));
-    return c;
-}
-__device__ __forceinline__ int parity_of(const int32_t* __restrict__ cnt, const uint32_t* __restrict__ touch,
-                                         int row, int batch) {
-    return version_of(cnt, touch, row, batch) & 1;
-}
-
 __device__ __forceinline__ int block_exclusive_scan2(int a, int b, int* scan /*LDS [2*(T+1)]*/, int& tot_a,
                                                       int& tot_b, int& ex_b) {
     // wave scans + the four wave totals (thread 0 used to walk all 256 entries)
@@ -465,28 +189,6 @@ __global__ __launch_bounds__(kPlanThreads) void resolve_kernel(
 // ITEM tasks are laid out in (owner, row) order instead of row order -- still the slots [users, users + items) of the batch, the
 // order of tasks inside a batch means nothing to the step -- and ohdr[owner * ohdr_stride + batch] = first slot | tasks << 16
 // names every owner's run.
-// version of `row` at `batch` (as version_of) and the last batch < `batch` of this call that touched it (-1: none), from ONE
-// round trip: the row's 16 bitmap words as four 16-byte loads (a walk down the words was up to 16 DEPENDENT loads per task: the
-// planner of a 512-batch chunk took 1.08 ms beside the persistent step instead of 0.07)
-__device__ __forceinline__ void row_history(const int32_t* __restrict__ cnt, const uint32_t* __restrict__ touch, int row, int batch, int& ver,
-                                            int& prev) {
-    const uint4* w4 = reinterpret_cast<const uint4*>(touch + (size_t)row * kTouchWords);
-    const uint4 a = w4[0], b = w4[1], c = w4[2], d = w4[3];
-    const uint32_t w[kTouchWords] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-    static_assert(kTouchWords == 16, "four uint4 per row");
-    const int full = batch >> 5;
-    const uint32_t below = (1u << (batch & 31)) - 1u;
-    int v = cnt[row], p = -1;
-#pragma unroll
-    for (int q = 0; q < kTouchWords; ++q) {
-        const uint32_t bits = q < full ? w[q] : q == full ? (w[q] & below) : 0u;
-        v += __popc(bits);
-        if (bits) p = q * 32 + 31 - __clz(bits);
-    }
-    ver = v;
-    prev = p;
-}
-
 template <int T>
 __global__ __launch_bounds__(T) void resolve_flow_kernel(
     int B, const int4* __restrict__ task_all, const int2* __restrict__ occ_all, const int32_t* __restrict__ ucnt,
@@ -604,110 +306,17 @@ __global__ __launch_bounds__(T) void resolve_flow_kernel(
 // In front of a short call nothing runs beside the planner and those ~14 us are all exposed.  Here every thread takes ONE slot:
 // the occurrence and the task of its slot are loaded together, their version words together, the occurrences of a task come from
 // LDS -- two trips through memory instead of five.  Same output, bit for bit.
-constexpr int kWideThreads = 768;
 __global__ __launch_bounds__(kWideThreads) void resolve_flow_wide_kernel(
     int B, const int4* __restrict__ task_all, const int2* __restrict__ occ_all, const int32_t* __restrict__ ucnt,
     const int32_t* __restrict__ icnt, const uint32_t* __restrict__ touch_u, const uint32_t* __restrict__ touch_i,
     int4* __restrict__ pocc_all, int4* __restrict__ prec_all, int n_owner, int32_t* __restrict__ ohdr, int ohdr_stride,
     const int32_t* __restrict__ occt_all, int own_words) {
-    constexpr int T = kWideThreads;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_first_item, s_wave[T / TKR_WAVE];
-    const int b = blockIdx.x, n = 3 * B, s = threadIdx.x;
-    int4* lp = reinterpret_cast<int4*>(smem);                                          // [3B] the batch's pocc
-    int32_t* lt = reinterpret_cast<int32_t*>(lp + n);                                  // [3B] its occt
-    uint32_t* own_mask = reinterpret_cast<uint32_t*>(lt + n);                          // [n_owner][own_words]
-    uint32_t* own_start = own_mask + (size_t)n_owner * own_words;                      // [n_owner]
-    int4* pocc = pocc_all + (size_t)b * n;
-    int4* prec = prec_all + (size_t)b * n * 8;
-    K1_STAMP(8);
-    if (s == 0) s_first_item = n;
-    for (int w = s; w < n_owner * own_words; w += T) own_mask[w] = 0u;
-    int4 t = make_int4(-1, 0, 0, 0);
-    int ver = 0, prev = -1;
-    if (s < n) {
-        t = task_all[(size_t)b * n + s];
-        const int2 o = occ_all[(size_t)b * n + s];
-        const int tt = occt_all[(size_t)b * n + s];
-        const bool user_occ = s < B;                                                   // user occurrences: (i, j); item occurrences: (u, other | role << 31)
-        const int va = user_occ ? version_of(icnt, touch_i, o.x, b) : version_of(ucnt, touch_u, o.x, b);
-        const int vb = version_of(icnt, touch_i, o.y & 0x3fffffff, b);
-        if (t.x != -1) {
-            if (t.x < 0) row_history(icnt, touch_i, t.x & 0x7fffffff, b, ver, prev);
-            else row_history(ucnt, touch_u, t.x, b, ver, prev);
-        }
-        const int4 po = make_int4(o.x, va, o.y, vb);
-        pocc[s] = po;
-        lp[s] = po;
-        lt[s] = tt;
-    }
-    __syncthreads();
-    K1_STAMP(9);
-    const bool item_task = t.x < 0 && t.x != -1;
-    int first_item = 0;
-    if (n_owner > 0) {
-        if (item_task) {
-            atomicMin(&s_first_item, s);
-            const int row = t.x & 0x7fffffff, bit = row / n_owner;
-            atomicOr(&own_mask[(size_t)(row % n_owner) * own_words + (bit >> 5)], 1u << (bit & 31));
-        }
-        __syncthreads();
-        first_item = s_first_item;
-        const int per = (n_owner + T - 1) / T;
-        const int w0 = min(s * per, n_owner), w1 = min(w0 + per, n_owner);
-        int mine = 0;
-        for (int w = w0; w < w1; ++w)
-            for (int j = 0; j < own_words; ++j) mine += __popc(own_mask[(size_t)w * own_words + j]);
-        const int lane = s & (TKR_WAVE - 1), wave = s / TKR_WAVE;
-        int incl = mine;
-#pragma unroll
-        for (int d = 1; d < TKR_WAVE; d <<= 1) {
-            const int up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-        }
-        if (lane == TKR_WAVE - 1) s_wave[wave] = incl;
-        __syncthreads();
-        int run = incl - mine;
-        for (int w = 0; w < wave; ++w) run += s_wave[w];
-        for (int w = w0; w < w1; ++w) {
-            int c = 0;
-            for (int j = 0; j < own_words; ++j) c += __popc(own_mask[(size_t)w * own_words + j]);
-            ohdr[(size_t)w * ohdr_stride + b] = (first_item + run) | (c << 16);
-            own_start[w] = (uint32_t)run;
-            run += c;
-        }
-        __syncthreads();
-    }
-    K1_STAMP(10);
-    if (s < n) {
-        int dst = s;
-        if (n_owner > 0 && item_task) {
-            const int row = t.x & 0x7fffffff, w = row % n_owner, bit = row / n_owner;
-            const uint32_t* m = own_mask + (size_t)w * own_words;
-            int before = __popc(m[bit >> 5] & ((1u << (bit & 31)) - 1u));
-            for (int j = 0; j < (bit >> 5); ++j) before += __popc(m[j]);
-            dst = first_item + (int)own_start[w] + before;
-        }
-        int4* r = prec + (size_t)dst * 8;
-        if (t.x == -1) {
-            r[0] = make_int4(-1, 0, 0, 0);
-#pragma unroll
-            for (int q = 1; q < 8; ++q) r[q] = make_int4(0, 0, 0, 0);
-        } else {
-            r[0] = make_int4(t.x, ver, t.z, b * n + t.y);
-            r[1] = make_int4(b, prev, 0, 0);
-            int tq[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int at = t.y + min(q, t.z - 1);                                  // (always inside the batch: no branch around the load)
-                const int4 v = lp[at];
-                r[2 + q] = (q < t.z) ? v : make_int4(0, 0, 0, 0);
-                tq[q] = (q < t.z) ? lt[at] : 0;
-            }
-            r[6] = make_int4(tq[0], tq[1], tq[2], tq[3]);
-            r[7] = make_int4(0, 0, 0, 0);
-        }
-    }
+    const int b = blockIdx.x, n = 3 * B;
+    int4 t;
+    int prev, total;
+    plan_phase_b_wide<false>(smem, b, B, task_all + (size_t)b * n, occ_all + (size_t)b * n, occt_all + (size_t)b * n, ucnt, icnt, touch_u, touch_i,
+                             pocc_all + (size_t)b * n, prec_all + (size_t)b * n * 8, n_owner, ohdr, ohdr_stride, own_words, t, prev, total);
 #ifdef TKR_K1_PROF
     __syncthreads();
     K1_STAMP(11);
@@ -834,8 +443,9 @@ static int sample_plan_impl(const int32_t* tr_users, int32_t n_tr, const int32_t
         // a short call (its plan sits in front of its step, nothing runs beside it): one thread per task instead of three tasks per thread
         static const int wide_upto = [] { const char* e = getenv("TKR_PLAN_WIDE_UPTO"); return e ? atoi(e) : 64; }();
         const size_t lds_r = n_owner > 0 ? (size_t)4 * n_owner * (own_words + 1) : 0;
-        if (n_batches <= wide_upto && 3 * batch_size <= tkr::kWideThreads && lds_r + (size_t)3 * batch_size * 20 <= 64 * 1024)
-            hipLaunchKernelGGL(tkr::resolve_flow_wide_kernel, dim3(n_batches), dim3(tkr::kWideThreads), lds_r + (size_t)3 * batch_size * 20, s,
+        const size_t lds_w = tkr::plan_phase_b_wide_lds(batch_size, n_owner, own_words);
+        if (n_batches <= wide_upto && 3 * batch_size <= tkr::kWideThreads && lds_w <= 64 * 1024)
+            hipLaunchKernelGGL(tkr::resolve_flow_wide_kernel, dim3(n_batches), dim3(tkr::kWideThreads), lds_w, s,
                                batch_size, reinterpret_cast<const int4*>(task), reinterpret_cast<const int2*>(occ), ucnt, icnt, touch_u,
                                touch_i, reinterpret_cast<int4*>(pocc), reinterpret_cast<int4*>(prec), n_owner, ohdr, ohdr_stride, occt, own_words);
         else
