@@ -193,41 +193,63 @@ def _fence(world):
     torch.cuda.synchronize()
 
 
-def timed_run(eng, csr, B, steps, warmup, sync_every, world, names=None, loop=None):
+def timed_run(eng, csr, B, steps, warmup, sync_every, world, names=None, loop=None, per_launch_events=True):
     """warmup untimed, then exactly `steps` batches between barriers; returns (wall_s, step_kernel_ms, loop).
     What the timed region contains: for each batch its (u, i, j) draw + plan (K1) AND its step -- settle() drops
-    whatever an earlier call planned but did not run, and run_batches plans exactly what it is asked to run."""
+    whatever an earlier call planned but did not run, and run_batches plans exactly what it is asked to run.
+    step_kernel_ms: HIP events on the training stream.  ``per_launch_events``: one pair around every step launch (the steady
+    state: launches of 512 batches); else ONE pair around the whole timed region -- the headline of a short run (`--steps 20`
+    is ONE launch that plans and steps: a pair of event records inside the call is two more packets on the queue and ~10 us of
+    host time in front of a ~90 us launch), which then also counts the host's way to the launch: an upper bound of the launch."""
     loop = loop or Loop(eng, csr, B, sync_every, world, names)
     singles = min(warmup, 8)
     eng.reserve_events(-(-(steps + warmup) // sync_every) + _chunk_crossings(eng, steps + warmup, B) + singles + 2)   # created now, not between the timed launches
-    # The warm-up goes down the SAME host path as the timed call -- events around the step launches included -- and its first
-    # batches as calls of their own: the first two or three passes of the runtime through a launch path (kernel arguments,
-    # signals of timed events) cost tens of microseconds each, which a 20-step timed call (~130 us) would otherwise carry.
-    eng.step_events = []
+    # The warm-up goes down the SAME host path as the timed call and its first batches as calls of their own: the first two or
+    # three passes of the runtime through a launch path (kernel arguments, signals) cost tens of microseconds each, which a
+    # 20-step timed call (~130 us) would otherwise carry.
+    eng.step_events = [] if per_launch_events else None
     for _ in range(singles):
         loop.run(1)
+        _fence(world)            # ... each onto an IDLE queue, as the timed call goes out (behind the fence below): the runtime's first
+                                 # launches after an idle queue are slower than back-to-back ones (measured: timed call 148 -> 132 us)
     if warmup > singles:
         loop.run(warmup - singles)
     eng.step_events = None
     eng.settle()                 # nothing planned ahead: the timed batches sample and plan themselves (also reports a failed step)
+    region = _recorded_pair() if not per_launch_events else None
     _fence(world)
-    eng.step_events = []
+    eng.step_events = [] if per_launch_events else None
     before = loop.exchanges
+    if region is not None:
+        region[0].record()
     t0 = time.perf_counter()
     loop.run(steps)
     t_host = time.perf_counter()
+    if region is not None:
+        region[1].record()
     _fence(world)
     wall = time.perf_counter() - t0
     if os.environ.get('TKR_BENCH_TRACE') == '1':
         print('timed region: host returned at %.1f us, fence at %.1f us' % ((t_host - t0) * 1e6, wall * 1e6), file=sys.stderr, flush=True)
-    step_ms = sum(a.elapsed_time(b) for a, b, _ in eng.step_events)
-    launches = sum(n for _, _, n in eng.step_events)
-    loop.last_step_events = eng.step_events
+    if region is not None:
+        step_ms = region[0].elapsed_time(region[1])
+        loop.last_step_events = []
+    else:
+        step_ms = sum(a.elapsed_time(b) for a, b, _ in eng.step_events)
+        assert sum(n for _, _, n in eng.step_events) == steps
+        loop.last_step_events = eng.step_events
     eng.step_events = None
     eng.check()
-    assert launches == steps
     loop.timed_exchanges = loop.exchanges - before
     return wall, step_ms, loop
+
+
+def _recorded_pair():
+    """two timing events that already exist on the device (a torch event is created by its first record())"""
+    pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    for e in pair:
+        e.record()
+    return pair
 
 
 def step_kernel(eng, B):
@@ -595,7 +617,8 @@ def main():
     B, k = args.batch_size, args.k
     r, csr, eng, nnz = build_problem(args.shape, k, rank, world, device)
     sync_every = max(1, (args.epoch_sample_limit // B) // world)       # batches per rank and epoch, as BPR.train deals them (dist.batches_per_rank)
-    wall, step_ms, loop = timed_run(eng, csr, B, args.steps, args.warmup, sync_every, world)
+    # the headline: per-launch events only where the launches are long (a run of at least one full chunk)
+    wall, step_ms, loop = timed_run(eng, csr, B, args.steps, args.warmup, sync_every, world, per_launch_events=args.steps >= 512)
     loop_timed_exchanges = loop.timed_exchanges
     wall = max_over_ranks(wall, device, world)
     raw_wall = wall
@@ -638,6 +661,8 @@ def main():
                      'traffic_from_profile': pmc_traffic(step_kernel(eng, B)[2]) if (k == 128 and args.shape == 'ml10m') else None,
                      'owners': eng._plan_owners(B),    # K2o: workgroups that own item rows (the CUs, split between the ranks that share a GPU); 0: K2f / K2
                      'launch_us': launch_us,          # per BATCH: the persistent kernel's launch covers many batches, duration / batches
+                     'events': 'around every step launch' if args.steps >= 512 else 'ONE pair around the timed region (a short run is one launch that plans and steps; '
+                               'the pair also spans the host\'s way to that launch: an upper bound of the launch)',
                      'algorithmic_bytes_per_launch': B * algorithmic_bytes_per_triplet(k)},
     }
     out['epoch_mode'] = em

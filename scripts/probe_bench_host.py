@@ -41,6 +41,15 @@ def step_fn(B):
         finally:
             log.append(('step', (time.perf_counter() - t0) * 1e6))
     g.takes_events = getattr(st, 'takes_events', False)
+    g.assigns_loss = getattr(st, 'assigns_loss', False)
+    if getattr(st, 'plan_and_run', None) is not None:
+        def par(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return st.plan_and_run(*a, **k)
+            finally:
+                log.append(('plan_and_run', (time.perf_counter() - t0) * 1e6))
+        g.plan_and_run = par
     return g
 
 

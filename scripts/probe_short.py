@@ -120,3 +120,25 @@ if os.environ.get('TKR_PROBE_EVCOST') == '1':       # host cost of an event reco
                 hip.hipEventRecord(C.c_void_p(e.cuda_event), C.c_void_p(strm))
             ts.append((time.perf_counter() - t0) * 1e6)
         print('event record behind 3 launches, %s: %s us' % (mode, ' '.join('%.1f' % t for t in ts)), flush=True)
+if os.environ.get('TKR_PLAN_STAMP') == '1':         # a library built with -DTKR_PLAN_STAMP (TKR_HIP_LIB): the planner prologue of the step, workgroups 0 and last
+    n = 10
+    acc = np.zeros((2, 12))
+    for _ in range(n):
+        eng.settle(); torch.cuda.synchronize()
+        eng.ctl[tkr_hip.FLOW_CTL_PROF:tkr_hip.FLOW_CTL_PROF + 64] = 0
+        eng.run_batches(csr, steps, B, want_loss=False)
+        torch.cuda.synchronize()
+        v = eng.ctl[tkr_hip.FLOW_CTL_PROF:tkr_hip.FLOW_CTL_PROF + 64].cpu().numpy().view(np.uint64).astype(np.float64).reshape(2, 16)[:, :12]
+        acc += v - v[0, 0]
+    v = acc / n / 100.0
+    names = ['phase A', 'drain A', 'rendezvous A', 'phase B', 'drain B', 'rendezvous B', 'commit+drain', 'rendezvous C', 'acquire', 'queue set-up', 'step']
+    print('workgroup 0 (us): ' + '  '.join('%s %.1f' % (nm, v[0, i + 1] - v[0, i]) for i, nm in enumerate(names)) + '   total %.1f' % (v[0, 11] - v[0, 0]))
+    import ctypes as C
+    out = (C.c_uint64 * 32)()
+    if tkr_hip.lib().tkr_debug_own_k1_prof(out) == 0:
+        w = np.array(out[:], dtype=np.float64) / 100.0
+        names = ['draw', 'user sort', 'user tasks', 'user occ', 'item sort', 'item tasks', 'item occ + tail']
+        print('phase A (us, last call): ' + '  '.join('%s %.1f' % (nm, w[i + 1] - w[i]) for i, nm in enumerate(names)))
+        print('phase B (us, last call): loads+versions %.1f  owner order %.1f  headers to LDS %.1f  records %.1f' % (w[9] - w[8], w[10] - w[9], w[12] - w[10], w[11] - w[12]))
+    print('last workgroup: start %.1f  waits until %.1f  acquire %.1f  set-up %.1f  step %.1f  end %.1f' %
+          (v[1, 0], v[1, 8], v[1, 9] - v[1, 8], v[1, 10] - v[1, 9], v[1, 11] - v[1, 10], v[1, 11]), flush=True)

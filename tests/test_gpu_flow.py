@@ -86,6 +86,58 @@ def test_flow_plan_bit_exact(hip, n_users, n_items, B, nb, chunks, owners):
     assert int(cnt.touch_u.abs().sum()) == 0 and int(cnt.touch_i.abs().sum()) == 0
 
 
+@pytest.mark.parametrize('owners', ['dev', 7, 64])
+@pytest.mark.parametrize('n_users,n_items,B,nb,k', [(300, 150, 256, 7, 64), (2000, 600, 256, 20, 128), (300, 150, 100, 3, 32), (40, 30, 1, 4, 16),
+                                                    (700, 300, 129, 64, 128), (5000, 4000, 200, 33, 100), (60, 40, 32, 5, 16)])
+def test_planner_prologue_of_the_step_is_bit_exact(hip, n_users, n_items, B, nb, k, owners):
+    """K1 INSIDE the step's launch (csrc/bpr_own.hip PLAN = true, reached through tkr_bpr_own_plan_run for a short call): the same plan
+    words as the planner kernels and the oracle -- triplets, tasks, occurrences, records, owner runs, update counters, a clean touch
+    bitmap -- for two calls in a row (the second one's versions start from the first one's counters), and the tables the step
+    leaves are the oracle's"""
+    from single import _engine
+    owners = hip.bpr_own_owners(n_items, k) if owners == 'dev' else owners
+    if nb > owners:
+        pytest.skip('one planner workgroup per batch: a call of more batches than owners plans with the kernels of csrc/sampler.hip')
+    tr, tr_users = _toy(n_users, n_items, seed=n_users + B)
+    dev = torch.device('cuda')
+    row_ptr, pos, srt = P.build_csr(tr, n_users)
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
+    cnt = _engine.UpdateCounters(n_users, n_items, dev)
+    plan = _engine.PlanBuffers(nb, B, dev, flow=True, owners=owners)
+    rng = np.random.Generator(np.random.PCG64(k))
+    ref = R.init_bpr_state(n_users, n_items, k, rng)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.02, mode='l2')
+    F = _Flow(hip, ref, n_users, n_items, k, hp, bufs=4)
+    step = hip.own_stepper(F.st, B, F.ctl)
+    call = hip.plan_call(csr, n_users, n_items, 0xABCDEF12345, B, cnt, plan)
+    ucnt, icnt = np.zeros(n_users, np.int32), np.zeros(n_items, np.int32)
+    tot_u, tot_i = np.zeros(n_users, np.int32), np.zeros(n_items, np.int32)
+    uocc, iocc = np.zeros(n_users, np.int64), np.zeros(n_items, np.int64)
+    first = (1 << 33) + 5
+    for c in range(2):
+        call.first_triplet, call.n_batches = first + c * nb * B, nb
+        loss = torch.zeros(nb, device=dev)
+        step.plan_and_run(plan, call, 0, nb, loss)
+        exp = P.sample_and_plan(tr_users, row_ptr, pos, srt, n_items, 0xABCDEF12345, first + c * nb * B, nb, B, ucnt, icnt, n_owner=owners)
+        flow = P.sample_and_plan.last_flow
+        torch.cuda.synchronize()
+        assert int(F.ctl[hip.FLOW_CTL_STATUS]) == 0
+        for name, got, want in (('u', plan.u, exp[0]), ('i', plan.i, exp[1]), ('j', plan.j, exp[2])):
+            np.testing.assert_array_equal(got.cpu().numpy()[:nb * B], want, err_msg=name)
+        np.testing.assert_array_equal(plan.pocc.cpu().numpy().reshape(nb, 3 * B, 4), flow['pocc'], err_msg='pocc')
+        np.testing.assert_array_equal(plan.prec.cpu().numpy().reshape(nb, 3 * B, 32), flow['prec'], err_msg='prec')
+        np.testing.assert_array_equal(plan.ohdr.cpu().numpy().reshape(owners, plan.cap)[:, :nb], flow['ohdr'], err_msg='ohdr')
+        np.testing.assert_array_equal(plan.task.cpu().numpy().reshape(nb, 3 * B, 4)[:, :, :3], flow['task'][:, :, :3], err_msg='task')
+        np.testing.assert_array_equal(cnt.ucnt.cpu().numpy(), ucnt)
+        np.testing.assert_array_equal(cnt.icnt.cpu().numpy(), icnt)
+        assert int(cnt.touch_u.abs().sum()) == 0 and int(cnt.touch_i.abs().sum()) == 0
+        a, b, uo, io, ref_loss = _oracle(ref, exp, n_users, n_items, nb, B, hp)
+        tot_u += a; tot_i += b; uocc += uo; iocc += io
+        np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, rtol=1e-4)
+    F.item_readers = 2
+    _check(F, ref, tot_u, tot_i, uocc, iocc)
+
+
 class _Flow:
     """granule tables of one model, initialised from an oracle state dict"""
 
@@ -193,7 +245,9 @@ def test_bpr_flow_parity(hip, k, B, nb, mode, lr, kernel):
     loss = torch.zeros(nb, device='cuda')
     F.run(plan, B, nb, loss, kernel=kernel)
     ucnt, icnt, uocc, iocc, ref_loss = _oracle(ref, exp, n_users, n_items, nb, B, hp)
-    _check(F, ref, ucnt, icnt, uocc, iocc)
+    # (the scalar-exchange forms round <u, v_i> + b_i and <u, v_j> + b_j separately before they subtract: a few of 30,000 elements land
+    # 1.6e-5 from the oracle at lr = 0.05, where RMSProp's first steps are +-lr whatever the gradient's size)
+    _check(F, ref, ucnt, icnt, uocc, iocc, **(dict(tol=dict(rtol=2e-4, atol=3e-5)) if kernel[0] in 'sw' else {}))
     np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, rtol=1e-4)
     heavy = (P.sample_and_plan.last_flow['prec'][:, :, 2] > 4).sum()
     assert B < 256 or heavy > 0               # the walk over more than 4 occurrences is exercised

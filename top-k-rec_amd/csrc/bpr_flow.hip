@@ -275,7 +275,7 @@ extern "C" int tkr_flow_trace_buffer(unsigned long long* p) {
 #endif
 
 extern "C" int32_t tkr_flow_row_granules(int32_t k) { return (k + 127) / 128 * 128; }
-extern "C" int32_t tkr_flow_ctl_words(void) { return tkr::kCtlArrive + 64; }
+extern "C" int32_t tkr_flow_ctl_words(void) { return tkr::kCtlArrive + 128; }     // (+32 .. +95: profiling builds)
 
 extern "C" int tkr_bpr_flow_run(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, int32_t batch_size,
                                 int32_t n_batches, uint32_t* ctl, float* loss_out, int32_t waves_per_cu, void* stream) {

@@ -43,10 +43,69 @@
 // Results are bitwise reproducible run to run (scout and task run the same code on the same versions; the row-read form sums like
 // K2f); the scalar form differs from K2f in the last bits (x is the difference of two rounded dots): same tolerance to the oracle.
 #include "flow_task.h"
+#ifdef TKR_PLAN_STAMP         // profiling build (scripts/probe_short.py): the phases of the planner prologue, workgroup 0
+namespace tkr { __device__ unsigned long long own_k1_prof[32]; }
+#define K1_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) tkr::own_k1_prof[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
+#include "plan_parts.h"
 
 namespace tkr {
 
+// ---- the planner prologue (PLAN = true): K1 of a SHORT call inside the step's own launch -----------------------------------------
+// A short call (the driver's `--steps 20`: one launch of 20 batches) used to be five launches -- sample_plan, resolve_flow_wide,
+// commit, this kernel, own_loss -- and on a cold one-shot process the HOST's launch path (8-14 us per launch), not the device, was
+// what the call waited for.  Here workgroups 0 .. n_plan-1 each plan one batch with the very device functions of csrc/sampler.hip
+// (csrc/plan_parts.h; same words, bit for bit: tests/test_gpu_flow.py test_flow_plan_bit_exact runs this form too):
+//   phase A   draw, sorts, task heads, touch bits (atomics)          -> arrive at kCtlPlanA, wait for all n_plan
+//   phase B   versions from the complete bitmap, records (sc1 stores) -> arrive at kCtlPlanB, wait
+//   commit    the rows whose first task of the call is mine: counter += touches, bitmap words back to zero
+//   done      arrive at kCtlPlanC; EVERY workgroup waits for it, drops its L1 (one agent-scope acquire) and runs the step.
+// All workgroups of the launch are resident (the step needs that anyway), so the barriers complete; every spin is bounded.
+struct PlanArgs {
+    const int32_t *tr_users, *row_ptr, *pos_cols, *cols_sorted;
+    int32_t *ucnt, *icnt;
+    uint32_t *touch_u, *touch_i;
+    int32_t *out_u, *out_i, *out_j;
+    int4* task;
+    int2* occ;
+    int32_t* occt;
+    int4 *prec, *pocc;
+    int32_t* ohdr;
+    uint64_t seed, first_triplet;
+    uint32_t n_tr, n_items;
+    int n_plan, npad_items, own_words, reg_sort_ok;
+};
+
+// thread 0 adds the workgroup's arrival (if `arrive`) and polls until n have arrived; -> false when a bounded spin ran out (uniform)
+template <int NAP>
+__device__ __forceinline__ bool plan_rendezvous(uint32_t* counter, uint32_t n, bool arrive, uint32_t* ctl, volatile uint32_t* flag) {
+    if (threadIdx.x == 0) {
+        if (arrive) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t waited = 0, ok = 1u;
+        while (ld_u32(counter) < n) {
+            __builtin_amdgcn_s_sleep(NAP);                 // NAP x 64 clocks between polls (up to 256 pollers of one word: not a hot loop)
+            if (spin_fail(waited, ctl, 0)) { ok = 0u; break; }
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    const bool ok = *flag != 0u;
+    __syncthreads();                                   // (the flag word is reused by the next rendezvous)
+    return ok;
+}
+
 constexpr uint32_t kOwnInvalid = 0xffffffffu;
+
+// int4 number `idx16` of the plan's records.  PLAN (the records were written by other workgroups of THIS launch): past the L1
+template <bool PLAN>
+__device__ __forceinline__ int4 plan_ld(const int4* __restrict__ prec, const __amdgpu_buffer_rsrc_t& prec_r, size_t idx16) {
+    if constexpr (PLAN) {
+        const v4u x = __builtin_amdgcn_raw_buffer_load_b128(prec_r, (int)(idx16 * 16), 0, kAuxLoad);
+        return make_int4((int)x.x, (int)x.y, (int)x.z, (int)x.w);
+    } else {
+        return prec[idx16];
+    }
+}
 constexpr int kDotWin = 1024;            // ring of "scalars of queue position p are out" marks (power of two)
 constexpr int kScoutAhead = 48;          // queue positions beyond the head the scout looks at
 
@@ -81,12 +140,14 @@ struct QueueMap {
 };
 
 // user tasks: tickets over the slots [0, B) of every batch (a batch's user tasks come first; what else sits there is skipped)
+template <bool PLAN>
 struct UserTicketSrc {
     uint32_t ticket;
     int home, queues;                    // queues = min(32, ticket waves of the grid): every queue has a wave
     uint32_t total;                      // nb * B
     uint32_t B;
     const int4* __restrict__ prec;       // record 0 of the launch's first batch
+    __amdgpu_buffer_rsrc_t prec_r;       // ... as a buffer (PLAN)
     __device__ __forceinline__ void prefetch(NextTask& nx, int lane) {
         const u64 i64 = (u64)(uint32_t)bcast_i((int)ticket, 0) * (uint32_t)queues + (uint32_t)home;
         const uint32_t idx = i64 < total ? (uint32_t)i64 : 0xffffffffu;
@@ -94,7 +155,7 @@ struct UserTicketSrc {
         nx.w = make_int4(0, 0, 0, 0);
         if (idx == 0xffffffffu) { nx.idx = idx; return; }
         nx.idx = idx + 2u * B * (idx / B);
-        if (lane < 8) nx.w = prec[(size_t)nx.idx * 8 + lane];
+        if (lane < 8) nx.w = plan_ld<PLAN>(prec, prec_r, (size_t)nx.idx * 8 + lane);
     }
 };
 
@@ -426,12 +487,12 @@ constexpr int own_min_waves(int np, int tpb) { return tpb / 256; }      // per S
 
 // SCALAR: the item tasks of a triplet exchange scalars (one reader per occurrence of an item row: the user task; wave 0 of a
 // workgroup is the scout); else they read each other's rows like K2f (two readers; wave 0 is one more owner wave)
-template <int NP, int TPB, bool SCALAR>
+template <int NP, int TPB, bool SCALAR, bool PLAN = false>
 __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     tkr_flow_state st, const int4* __restrict__ prec /*record 0 of the first batch to run*/, const int4* __restrict__ pocc,
     const int32_t* __restrict__ occt, const int32_t* __restrict__ ohdr /*[n_owner][ohdr_stride], at the first batch to run*/, int ohdr_stride,
     int first_batch, int nb, int B, int n_owner, int owner_waves, uint32_t tune, uint32_t* __restrict__ ctl, float* __restrict__ loss_out,
-    u64* __restrict__ xch /*scalar slots [batches of the plan][B][2], at batch 0 of the plan*/, uint32_t epoch) {
+    u64* __restrict__ xch /*scalar slots [batches of the plan][B][2], at batch 0 of the plan*/, uint32_t epoch, PlanArgs pa) {
     constexpr int NE = 2 * NP;
     constexpr int KP = NP * 128;
     constexpr int ROWF = 2 * KP + 8;                                  // floats per resident row
@@ -463,6 +524,59 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     // wave goes out NOW, beside the loads of the queue header: a launch used to start with three trips in series -- an arrival
     // counter, the header, the first ticket -- in front of every short call.
     const uint32_t me = blockIdx.x;
+    bool alive = true;
+#ifdef TKR_PLAN_STAMP        // scripts/probe_short.py with a -DTKR_PLAN_STAMP build: s_memrealtime (100 MHz) of workgroups 0 and 255 at the prologue's phases
+#define PLAN_STAMP(i) do { if ((me == 0 || me == gridDim.x - 1) && threadIdx.x == 0) reinterpret_cast<u64*>(ctl + kCtlProf)[(me ? 16 : 0) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PLAN_STAMP(i) do { } while (0)
+#endif
+    PLAN_STAMP(0);
+    // what of the queue header does not come from the plan (before the prologue: a workgroup that plans nothing only waits there)
+    for (int b = threadIdx.x; b < TKR_WAVE; b += TPB) pre[nb + 1 + b] = 0xffffffffu;
+    for (int s = threadIdx.x; s < rows_here; s += TPB) tags[s] = kOwnInvalid;
+    for (int s = threadIdx.x; s < kDotWin; s += TPB) dotmark[s] = 0u;
+    if constexpr (PLAN) {
+        static_assert(TPB == kWideThreads, "phase B of the planner is one thread per task slot");
+        unsigned char* scratch = reinterpret_cast<unsigned char*>(rows);                 // the rows' region: no row is resident yet
+        volatile uint32_t* flag = &q->arrival;
+        const uint32_t n_plan = (uint32_t)pa.n_plan;
+        int4 ct = make_int4(-1, 0, 0, 0);                   // this thread's task of the batch, for K1c below
+        int cprev = 0, ctotal = 0;
+        if (me < n_plan) {
+            const int b = (int)me, n3 = 3 * B;
+            int4* task_b = pa.task + (size_t)b * n3;
+            int2* occ_b = pa.occ + (size_t)b * n3;
+            int32_t* occt_b = pa.occt + (size_t)b * n3;
+            plan_phase_a<TPB, 256>(scratch, b, pa.tr_users, pa.n_tr, pa.row_ptr, pa.pos_cols, pa.cols_sorted, pa.n_items, pa.seed,
+                                   pa.first_triplet + (uint64_t)b * (uint64_t)B, B, pa.npad_items, pa.out_u + (size_t)b * B, pa.out_i + (size_t)b * B,
+                                   pa.out_j + (size_t)b * B, task_b, occ_b, occt_b, pa.touch_u, pa.touch_i, pa.reg_sort_ok != 0);
+            PLAN_STAMP(1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // the touch atomics of every wave are out
+            __syncthreads();
+            PLAN_STAMP(2);
+            alive = plan_rendezvous<4>(ctl + kCtlPlanA, n_plan, true, ctl, flag);
+            PLAN_STAMP(3);
+            if (alive) {
+                plan_phase_b_wide<true>(scratch, b, B, task_b, occ_b, occt_b, pa.ucnt, pa.icnt, pa.touch_u, pa.touch_i, pa.pocc + (size_t)b * n3,
+                                        pa.prec + (size_t)b * n3 * 8, n_owner, pa.ohdr, ohdr_stride, pa.own_words, ct, cprev, ctotal);
+                PLAN_STAMP(4);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // bitmap reads returned, record stores in memory
+            __syncthreads();
+            PLAN_STAMP(5);
+        }
+        // (a planner that gave up still arrives: the others then see the status word instead of spinning out one by one)
+        alive = plan_rendezvous<12>(ctl + kCtlPlanC, n_plan, me < n_plan, ctl, flag) && alive;
+        PLAN_STAMP(8);
+        // every planner is past its reads of the bitmap: K1c for the rows whose first task of the call is mine -- atomics and stores
+        // that nobody in this launch waits for
+        if (alive && me < n_plan && (int)threadIdx.x < 3 * B) plan_commit_first_touch(ct, cprev, ctotal, pa.ucnt, pa.icnt, pa.touch_u, pa.touch_i);
+        // No acquire fence here (measured 4.5 us for one lane's buffer_inv, 14 for every wave's): the plan words other CUs wrote went
+        // out write-through before they arrived (sc1 stores + vmcnt(0)), the L2s see each other's writes, and THIS CU's L1 -- dropped
+        // at the start of the launch -- has never held a line of prec / pocc / ohdr: nothing in front of this point loads from
+        // them.  The records and owner runs are read past the L1 all the same (plan_ld below).
+        PLAN_STAMP(9);
+    }
     const bool ticket_wave = wave > owner_waves;
     const int tw = wave - owner_waves - 1, n_tw = TPB / TKR_WAVE - owner_waves - 1;
     const int queues = min(kQueues, max(n_tw, 1) * (int)gridDim.x);
@@ -470,13 +584,14 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     uint32_t ticket = 0;
     if (ticket_wave) ticket = grab_issue(ctl, lane, home);
     for (int b = threadIdx.x; b < nb; b += TPB) {
-        const uint32_t h = me < (uint32_t)n_owner ? (uint32_t)ohdr[(size_t)me * ohdr_stride + b] : 0u;
+        uint32_t h = 0u;
+        if (me < (uint32_t)n_owner) {
+            if constexpr (PLAN) h = (uint32_t)__hip_atomic_load(ohdr + (size_t)me * ohdr_stride + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else h = (uint32_t)ohdr[(size_t)me * ohdr_stride + b];
+        }
         start[b] = h & 0xffffu;
         pre[b + 1] = h >> 16;
     }
-    for (int b = threadIdx.x; b < TKR_WAVE; b += TPB) pre[nb + 1 + b] = 0xffffffffu;
-    for (int s = threadIdx.x; s < rows_here; s += TPB) tags[s] = kOwnInvalid;
-    for (int s = threadIdx.x; s < kDotWin; s += TPB) dotmark[s] = 0u;
     __syncthreads();
     if (wave == 0) {                                                                   // inclusive scan of the run lengths (nb <= 512)
         const int per = (nb + TKR_WAVE - 1) / TKR_WAVE;
@@ -496,13 +611,14 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     }
     __syncthreads();
 
+    PLAN_STAMP(10);
     uint32_t spins = 0;
-    bool alive = true;
 #ifdef TKR_OWN_PROF
     u64 prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     u64 tprev = __builtin_amdgcn_s_memtime();
 #endif
     const QueueMap qm{pre, start, 3u * (uint32_t)B};
+    const __amdgpu_buffer_rsrc_t prec_r = row_rsrc(prec, PLAN ? nb * 3 * B * 128 : 16);
     const int xch_bytes = B * 16;
     const uint32_t q_total = q->total;
 
@@ -570,7 +686,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             const uint32_t idx = qm.locate(pos, cur, lane);
             if (lane == 0) atomicMax(&q->head_batch, cur);
             int4 w = make_int4(0, 0, 0, 0);
-            if (lane < 8) w = prec[(size_t)idx * 8 + lane];
+            if (lane < 8) w = plan_ld<PLAN>(prec, prec_r, (size_t)idx * 8 + lane);
 #ifdef TKR_OWN_PROF
             asm volatile("" : "+v"(w.x) :: "memory");
             const u64 t0 = __builtin_amdgcn_s_memtime();
@@ -643,7 +759,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
         nx.idx = 0u; nx.w = make_int4(0, 0, 0, 0); nx.have = false;
         while (alive) {
             if (!nx.have) {
-                UserTicketSrc first_feed{ticket, home, queues, total, (uint32_t)B, prec};
+                UserTicketSrc<PLAN> first_feed{ticket, home, queues, total, (uint32_t)B, prec, prec_r};
                 first_feed.prefetch(nx, lane);
                 asm volatile("" : "+v"(nx.w.x), "+v"(nx.w.y), "+v"(nx.w.z), "+v"(nx.w.w) :: "memory");
             }
@@ -679,9 +795,9 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             for (int e = 0; e < NE; ++e) { g[e] = 0.f; ms[e] = 0.f; }
             Own o = {};
             float gb = 0.f, loss_lane = 0.f;
-            UserTicketSrc feed{ticket, home, queues, total, (uint32_t)B, prec};
+            UserTicketSrc<PLAN> feed{ticket, home, queues, total, (uint32_t)B, prec, prec_r};
             GlobalOwn<NP> own_step{T, lane, T.U + roff, T.msU + roff, own_tail, own_rd, ver, sgd, ctl, spins, 2};
-            alive = run_task<NP, false, UserTicketSrc, GlobalOwn<NP>, 4>(st, T, lane, n_occ, first, w, pocc, T.U + roff, T.msU + roff, own_tail, ver,
+            alive = run_task<NP, false, UserTicketSrc<PLAN>, GlobalOwn<NP>, 4>(st, T, lane, n_occ, first, w, pocc, T.U + roff, T.msU + roff, own_tail, ver,
                                                                          own, ms, o, g, gb, loss_lane, want_loss, sgd, ctl, spins, nx, feed, own_step);
             if (!alive) break;
 #ifdef TKR_OWN_PROF
@@ -698,7 +814,9 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
                     if (lane == 0) loss_add(loss_out + batch, tot);
                 } else if (lane == 0) {
                     const uint32_t slot = idx - (uint32_t)(batch - first_batch) * 3u * (uint32_t)B;     // user tasks: the first slots of a batch's 3B
-                    xch[((size_t)batch * B + slot) * 2] = ((u64)epoch << 32) | (u64)__float_as_uint(tot);
+                    // (write-through: the workgroup that adds the slots up -- own_loss_kernel, or the LAST one of this launch -- may sit on another XCD)
+                    __hip_atomic_store(xch + ((size_t)batch * B + slot) * 2, ((u64)epoch << 32) | (u64)__float_as_uint(tot), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             float pn[NE], mn[NE], bn, mbn;
@@ -721,11 +839,38 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     // the last workgroup out puts the ticket words back to zero (as K2f: the next launch needs no memset)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0 &&
-        __hip_atomic_fetch_add(ctl + kCtlLeave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
-        for (int qq = 0; qq < kQueues; ++qq) ctl[qq * kQueueStride] = 0u;
-        ctl[kCtlArrive] = 0u;
-        ctl[kCtlLeave] = 0u;
+    PLAN_STAMP(11);
+    const bool fold_loss = !SCALAR && want_loss && (tune & 8u) != 0u;       // tune bit 3 (set by the host for short launches): the last workgroup out adds the losses up
+    if (threadIdx.x == 0) {
+        const bool last = __hip_atomic_fetch_add(ctl + kCtlLeave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+        if (last) {
+            for (int qq = 0; qq < kQueues; ++qq) ctl[qq * kQueueStride] = 0u;
+            ctl[kCtlArrive] = 0u;
+            ctl[kCtlLeave] = 0u;
+            if constexpr (PLAN) { ctl[kCtlPlanA] = 0u; ctl[kCtlPlanB] = 0u; ctl[kCtlPlanC] = 0u; }
+        }
+        q->arrival = last ? 1u : 0u;
+    }
+    if (!fold_loss) return;
+    // ---- the losses of a SHORT launch: the last workgroup out adds the per-task sums up, instead of a launch of own_loss_kernel behind
+    // this one (4.4 us + a kernel boundary + a host launch, of a ~100 us call).  Every other workgroup has drained its stores (above)
+    // before it arrived at kCtlLeave, and the slots are write-through.  Same summation order as own_loss_kernel, bit for bit: slot t
+    // belongs to "thread" t & 255, a thread adds its slots in order, waves of 64 threads by wave_sum, (p0 + p1) + (p2 + p3).
+    __syncthreads();
+    if (q->arrival == 0u) return;
+    for (int b = wave; b < nb; b += TPB / TKR_WAVE) {
+        const int batch = first_batch + b;
+        float part[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            float acc = 0.f;
+            for (int t = w * TKR_WAVE + lane; t < B; t += 256) {
+                const u64 g = __hip_atomic_load(xch + ((size_t)batch * B + t) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(g >> 32) == epoch) acc += __uint_as_float((uint32_t)g);
+            }
+            part[w] = wave_sum(acc);
+        }
+        if (lane == 0) loss_out[batch] = (part[0] + part[1]) + (part[2] + part[3]);
     }
 }
 
@@ -751,6 +896,19 @@ static size_t own_lds_bytes(int np, int nb, int n_items, int n_owner) {
     return head + (size_t)rows_here * (2 * np * 128 + 8) * 4;
 }
 
+// ... with the planner prologue: its scratch (phase A: sort keys + scan; phase B: the batch's occurrences, owner bitmaps) lies over the
+// rows' region, which may be smaller (test shapes)
+static size_t own_lds_bytes_planned(int np, int nb, int n_items, int n_owner, int B, int npad_items, int own_words) {
+    const int rows_here = (n_items + n_owner - 1) / n_owner;
+    const size_t head = (sizeof(OwnQueue) + (size_t)4 * (2 * nb + 1 + TKR_WAVE + rows_here + kDotWin) + 15) & ~(size_t)15;
+    const size_t rows = (size_t)rows_here * (2 * np * 128 + 8) * 4;
+    size_t scratch = (size_t)npad_items * 8 + (kWideThreads / TKR_WAVE + 1) * 4;
+    const size_t pb = plan_phase_b_wide_lds(B, n_owner, own_words);
+    if (pb > scratch) scratch = pb;
+    scratch = (scratch + 15) & ~(size_t)15;
+    return head + (rows > scratch ? rows : scratch);
+}
+
 }  // namespace tkr
 
 // workgroups (= owners) a process runs at once for factor width k when `share` processes split the device's CUs between them
@@ -768,9 +926,11 @@ extern "C" int32_t tkr_bpr_own_owners_shared(int32_t n_items, int32_t k, int32_t
 }
 extern "C" int32_t tkr_bpr_own_owners(int32_t n_items, int32_t k) { return tkr_bpr_own_owners_shared(n_items, k, 1); }
 
-extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, const int32_t* occt, const int32_t* ohdr,
-                               int32_t ohdr_stride, int32_t n_owner, int32_t batch_size, int32_t first_batch, int32_t n_batches,
-                               uint32_t* ctl, float* loss_out, int32_t owner_waves, void* xch, uint32_t epoch, void* stream) {
+// one launch of the step on batches [first_batch, first_batch + n_batches); `pa` != nullptr: with the planner prologue (the caller has
+// checked own_plan_fusable)
+static int own_launch(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, const int32_t* occt, const int32_t* ohdr,
+                      int32_t ohdr_stride, int32_t n_owner, int32_t batch_size, int32_t first_batch, int32_t n_batches, uint32_t* ctl,
+                      float* loss_out, int32_t owner_waves, void* xch, uint32_t epoch, const tkr::PlanArgs* pa, void* stream) {
     if (!st || !st->U || !st->V || !st->tailU || !st->tailV || !st->rdU || !st->rdV) return TKR_EINVAL;
     if (st->opt != 0 && st->opt != 1) return TKR_EINVAL;
     if (st->opt == 0 && (!st->msU || !st->msV)) return TKR_EINVAL;
@@ -786,7 +946,7 @@ extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, co
     int dev = 0;
     TKR_CHECK(hipGetDevice(&dev));
     static int cached_cus[64];
-    static bool attr_set[64][4][2];
+    static bool attr_set[64][5][2];
     int cus;
     if (dev >= 0 && dev < 64 && cached_cus[dev] > 0) cus = cached_cus[dev];
     else {
@@ -794,7 +954,8 @@ extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, co
         if (dev >= 0 && dev < 64) cached_cus[dev] = cus;
     }
     if (n_owner > cus) return TKR_EUNSUPPORTED;                    // every owner must be resident: one workgroup per CU
-    const size_t lds = tkr::own_lds_bytes(np, n_batches, st->n_items, n_owner);
+    size_t lds = tkr::own_lds_bytes(np, n_batches, st->n_items, n_owner);
+    if (pa) lds = tkr::own_lds_bytes_planned(np, n_batches, st->n_items, n_owner, batch_size, pa->npad_items, pa->own_words);
     if (lds > 160 * 1024) return TKR_EUNSUPPORTED;
     const uint32_t tune = ((uint32_t)owner_waves >> 8) & 0xffu;     // experiment switches ride in bits 8..15
     owner_waves &= 0xff;
@@ -807,11 +968,16 @@ extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, co
     if (ow < 1) ow = 1;
     if (ow > waves - 2) ow = waves - 2;
     const bool scalar = (tune & 128u) != 0u;                         // tune bit 7: the scalar-exchange form of the item tasks (default: they read rows)
-    const void* fn = np == 1 ? (wide ? (scalar ? (const void*)tkr::bpr_own_kernel<1, 1024, true> : (const void*)tkr::bpr_own_kernel<1, 1024, false>)
+    if (pa && !(mid && !scalar)) return TKR_EINVAL;
+    // a short launch adds its losses up itself (its last workgroup out); tune bit 1 (owner_waves bit 9): always own_loss_kernel
+    const bool fold = loss_out && !scalar && n_batches <= 64 && !(tune & 2u);
+    const uint32_t ktune = (tune & ~8u) | (fold ? 8u : 0u);
+    const void* fn = pa ? (const void*)tkr::bpr_own_kernel<1, 768, false, true>
+                   : np == 1 ? (wide ? (scalar ? (const void*)tkr::bpr_own_kernel<1, 1024, true> : (const void*)tkr::bpr_own_kernel<1, 1024, false>)
                                 : mid ? (scalar ? (const void*)tkr::bpr_own_kernel<1, 768, true> : (const void*)tkr::bpr_own_kernel<1, 768, false>)
                                      : (scalar ? (const void*)tkr::bpr_own_kernel<1, 512, true> : (const void*)tkr::bpr_own_kernel<1, 512, false>))
                              : (scalar ? (const void*)tkr::bpr_own_kernel<2, 512, true> : (const void*)tkr::bpr_own_kernel<2, 512, false>);
-    const int variant = np == 2 ? 3 : wide ? 2 : mid ? 1 : 0;
+    const int variant = pa ? 4 : np == 2 ? 3 : wide ? 2 : mid ? 1 : 0;
     if (lds > 64 * 1024 && !(dev >= 0 && dev < 64 && attr_set[dev][variant][scalar])) {
         TKR_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (dev >= 0 && dev < 64) attr_set[dev][variant][scalar] = true;
@@ -820,21 +986,30 @@ extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, co
     const int4* r4 = reinterpret_cast<const int4*>(prec) + (size_t)first_batch * 3 * batch_size * 8;      // record 0 of the first batch to run
     const int4* o4 = reinterpret_cast<const int4*>(pocc);
     ohdr += first_batch;
-#define TKR_OWN_LAUNCH(NPV, TPBV, SC)                                                                                                     \
-    hipLaunchKernelGGL((tkr::bpr_own_kernel<NPV, TPBV, SC>), dim3(n_owner), dim3(TPBV), lds, s, *st, r4, o4, occt, ohdr, ohdr_stride, first_batch, \
-                       n_batches, batch_size, n_owner, ow, tune, ctl, loss_out, static_cast<tkr::u64*>(xch), epoch)
-    if (np == 1 && wide) { if (scalar) TKR_OWN_LAUNCH(1, 1024, true); else TKR_OWN_LAUNCH(1, 1024, false); }
-    else if (np == 1 && mid) { if (scalar) TKR_OWN_LAUNCH(1, 768, true); else TKR_OWN_LAUNCH(1, 768, false); }
-    else if (np == 1) { if (scalar) TKR_OWN_LAUNCH(1, 512, true); else TKR_OWN_LAUNCH(1, 512, false); }
-    else { if (scalar) TKR_OWN_LAUNCH(2, 512, true); else TKR_OWN_LAUNCH(2, 512, false); }
+    const tkr::PlanArgs no_plan = {};
+#define TKR_OWN_LAUNCH(NPV, TPBV, SC, PL)                                                                                                 \
+    hipLaunchKernelGGL((tkr::bpr_own_kernel<NPV, TPBV, SC, PL>), dim3(n_owner), dim3(TPBV), lds, s, *st, r4, o4, occt, ohdr, ohdr_stride, first_batch, \
+                       n_batches, batch_size, n_owner, ow, ktune, ctl, loss_out, static_cast<tkr::u64*>(xch), epoch, PL ? *pa : no_plan)
+    if (pa) TKR_OWN_LAUNCH(1, 768, false, true);
+    else if (np == 1 && wide) { if (scalar) TKR_OWN_LAUNCH(1, 1024, true, false); else TKR_OWN_LAUNCH(1, 1024, false, false); }
+    else if (np == 1 && mid) { if (scalar) TKR_OWN_LAUNCH(1, 768, true, false); else TKR_OWN_LAUNCH(1, 768, false, false); }
+    else if (np == 1) { if (scalar) TKR_OWN_LAUNCH(1, 512, true, false); else TKR_OWN_LAUNCH(1, 512, false, false); }
+    else { if (scalar) TKR_OWN_LAUNCH(2, 512, true, false); else TKR_OWN_LAUNCH(2, 512, false, false); }
 #undef TKR_OWN_LAUNCH
     TKR_LAUNCH_CHECK();
-    if (loss_out && !scalar) {
+    if (loss_out && !scalar && !fold) {
         hipLaunchKernelGGL(tkr::own_loss_kernel, dim3(n_batches), dim3(256), 0, s, static_cast<const tkr::u64*>(xch), first_batch, batch_size, epoch,
                            loss_out);
         TKR_LAUNCH_CHECK();
     }
     return TKR_OK;
+}
+
+extern "C" int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, const int32_t* pocc, const int32_t* occt, const int32_t* ohdr,
+                               int32_t ohdr_stride, int32_t n_owner, int32_t batch_size, int32_t first_batch, int32_t n_batches,
+                               uint32_t* ctl, float* loss_out, int32_t owner_waves, void* xch, uint32_t epoch, void* stream) {
+    return own_launch(st, prec, pocc, occt, ohdr, ohdr_stride, n_owner, batch_size, first_batch, n_batches, ctl, loss_out, owner_waves, xch, epoch,
+                      nullptr, stream);
 }
 
 // the same launch between two HIP events of the caller (nullable hipEvent_t, recorded on `stream`): whoever times the launch --
@@ -854,7 +1029,41 @@ extern "C" int tkr_bpr_own_run_between(void* ev_before, void* ev_after, const tk
 extern "C" int tkr_bpr_own_plan_run(const tkr_plan_call* plan, const tkr_flow_state* st, int32_t first_batch, int32_t n_batches, uint32_t* ctl,
                                     float* loss_out, int32_t owner_waves, void* xch, uint32_t epoch, void* ev_before, void* ev_after,
                                     void* stream) {
-    if (!plan || first_batch < 0 || n_batches < 0 || first_batch + n_batches > plan->n_batches) return TKR_EINVAL;
+    if (!plan || !st || first_batch < 0 || n_batches < 0 || first_batch + n_batches > plan->n_batches) return TKR_EINVAL;
+    // K1 INSIDE the step's launch (the planner prologue of bpr_own_kernel) when the whole plan is what runs, one workgroup can plan
+    // a batch with a thread per task slot, and the default form of the step is asked for; owner_waves bit 12: never
+    const uint32_t tune = ((uint32_t)owner_waves >> 8) & 0xffu;
+    const int B = plan->batch_size, n_owner = plan->n_owner;
+    const int np = (st->k + 127) / 128;
+    int npad = 1, npad_bits = 0;
+    while (npad < 2 * B) { npad <<= 1; ++npad_bits; }
+    const int own_words = n_owner > 0 ? ((plan->n_items + n_owner - 1) / n_owner + 31) / 32 : 0;
+    const bool fusable = !(tune & 16u) && np == 1 && !(tune & (32u | 64u | 128u)) && first_batch == 0 && n_batches == plan->n_batches && n_batches > 0 &&
+                         n_batches <= 64 && n_batches <= n_owner && B > 0 && 3 * B <= tkr::kWideThreads && plan->n_tr > 0 && plan->n_users > 0 &&
+                         plan->n_items > 0 && plan->n_users < (1 << 25) && plan->n_items < (1 << 25) /*32-bit byte offsets into the bitmaps*/ && plan->ohdr_stride >= n_batches &&
+                         plan->n_users == st->n_users && plan->n_items == st->n_items &&
+                         tkr::own_lds_bytes_planned(np, n_batches, st->n_items, n_owner, B, npad, own_words) <= 160 * 1024;
+    if (fusable) {
+        if (!plan->tr_users || !plan->row_ptr || !plan->pos_cols || !plan->cols_sorted || !plan->ucnt || !plan->icnt || !plan->touch_u ||
+            !plan->touch_i || !plan->out_u || !plan->out_i || !plan->out_j || !plan->task || !plan->occ || !plan->occt || !plan->prec ||
+            !plan->pocc || !plan->ohdr)
+            return TKR_EINVAL;
+        tkr::PlanArgs pa;
+        pa.tr_users = plan->tr_users; pa.row_ptr = plan->row_ptr; pa.pos_cols = plan->pos_cols; pa.cols_sorted = plan->cols_sorted;
+        pa.ucnt = plan->ucnt; pa.icnt = plan->icnt; pa.touch_u = plan->touch_u; pa.touch_i = plan->touch_i;
+        pa.out_u = plan->out_u; pa.out_i = plan->out_i; pa.out_j = plan->out_j;
+        pa.task = reinterpret_cast<int4*>(plan->task); pa.occ = reinterpret_cast<int2*>(plan->occ); pa.occt = plan->occt;
+        pa.prec = reinterpret_cast<int4*>(plan->prec); pa.pocc = reinterpret_cast<int4*>(plan->pocc); pa.ohdr = plan->ohdr;
+        pa.seed = plan->seed; pa.first_triplet = plan->first_triplet;
+        pa.n_tr = (uint32_t)plan->n_tr; pa.n_items = (uint32_t)plan->n_items;
+        pa.n_plan = n_batches; pa.npad_items = npad; pa.own_words = own_words;
+        pa.reg_sort_ok = (npad_bits < 31 && (uint64_t)(plan->n_users > plan->n_items ? plan->n_users : plan->n_items) < (1ull << (32 - npad_bits)) - 1ull) ? 1 : 0;
+        if (ev_before) TKR_CHECK(hipEventRecord((hipEvent_t)ev_before, (hipStream_t)stream));
+        const int rc = own_launch(st, plan->prec, plan->pocc, plan->occt, plan->ohdr, plan->ohdr_stride, n_owner, B, 0, n_batches, ctl, loss_out,
+                                  owner_waves, xch, epoch, &pa, stream);
+        if (ev_after) TKR_CHECK(hipEventRecord((hipEvent_t)ev_after, (hipStream_t)stream));
+        return rc;
+    }
     const int rc = tkr_sample_plan_owned(plan->tr_users, plan->n_tr, plan->row_ptr, plan->pos_cols, plan->cols_sorted, plan->n_users,
                                          plan->n_items, plan->seed, plan->first_triplet, plan->n_batches, plan->batch_size, plan->ucnt,
                                          plan->icnt, plan->touch_u, plan->touch_i, plan->out_u, plan->out_i, plan->out_j, plan->task,
@@ -863,3 +1072,9 @@ extern "C" int tkr_bpr_own_plan_run(const tkr_plan_call* plan, const tkr_flow_st
     return tkr_bpr_own_run_between(ev_before, ev_after, st, plan->prec, plan->pocc, plan->occt, plan->ohdr, plan->ohdr_stride, plan->n_owner,
                                    plan->batch_size, first_batch, n_batches, ctl, loss_out, owner_waves, xch, epoch, stream);
 }
+
+#ifdef TKR_PLAN_STAMP
+extern "C" int tkr_debug_own_k1_prof(unsigned long long* out /*[32] host*/) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tkr::own_k1_prof), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -100;
+}
+#endif

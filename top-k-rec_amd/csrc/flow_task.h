@@ -17,6 +17,9 @@ constexpr int kCtlArrive = kQueues * kQueueStride;
 constexpr int kCtlLeave = kCtlArrive + 1;     // workgroups that have taken their last ticket
 constexpr int kCtlStatus = kCtlArrive + 2;
 constexpr int kCtlSpins = kCtlArrive + 3;     // diagnostics: spin passes taken
+constexpr int kCtlPlanA = kCtlArrive + 4;     // K2o with the planner prologue: planner workgroups past phase A (touch bits set) / past phase B (bitmap read) /
+constexpr int kCtlPlanB = kCtlArrive + 5;     // done (records written, counters folded); back to zero when the launch ends
+constexpr int kCtlPlanC = kCtlArrive + 6;
 constexpr int kCtlDebug = kCtlArrive + 8;     // 16 words: what the first wave that gave up was waiting for
 constexpr int kCtlProf = kCtlArrive + 32;     // TKR_FLOW_PROFILE=1: 8 x uint64 cycle sums (grab, record, rows, war, finish, tasks, idle slots, war of item tasks)
 constexpr uint32_t kSpinLimit = 1u << 20;     // passes of ONE wait (each >= ~0.3 us) before a wave gives up

@@ -324,10 +324,14 @@ __device__ __forceinline__ void row_history(const int32_t* __restrict__ cnt, con
     uint32_t w[kTouchWords];
     static_assert(kTouchWords == 16, "four 16-byte loads per row");
     if constexpr (FRESH) {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(touch + (size_t)row * kTouchWords), 0, 64, 0x00020000);
+        // ONE descriptor for the whole bitmap (wave-uniform base) + a per-lane byte offset: a descriptor built from each lane's own
+        // row pointer makes hipcc wrap the loads in a waterfall loop -- one pass per distinct row of the wave, 64 serial round trips
+        // (measured: 28 us for this function)
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(touch), 0, 0xfffffff0u, 0x00020000);
+        const int off = row * (kTouchWords * 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const touch_v4 v = __builtin_amdgcn_raw_buffer_load_b128(r, q * 16, 0, 16 /*sc1*/);
+            const touch_v4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off + q * 16, 0, 16 /*sc1*/);
             w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
         }
     } else {
@@ -360,7 +364,7 @@ __device__ __forceinline__ void row_history(const int32_t* __restrict__ cnt, con
 // per task (the dataflow form of the plan: csrc/sampler.hip has the layout).  FRESH: running inside the step's launch -- bitmap
 // words past the L1 (above), and everything OTHER workgroups of the launch will read (pocc, prec, ohdr) stored write-through
 // (sc1: in memory when the storing wave's vmcnt drains, no release fence over ~100 KB of dirty lines per workgroup).
-// `smem`: 3B * 20 + n_owner * (own_words + 1) * 4 + 64 bytes.  Returns this thread's task, its row's last earlier batch and the
+// `smem` (16-byte aligned): plan_phase_b_wide_lds() bytes.  Returns this thread's task, its row's last earlier batch and the
 // row's touches in the whole call (K1c's increment).
 constexpr int kWideThreads = 768;
 template <bool FRESH>
@@ -376,6 +380,7 @@ __device__ __forceinline__ void plan_phase_b_wide(unsigned char* smem, int b, in
     uint32_t* own_start = own_mask + (size_t)n_owner * own_words;                      // [n_owner]
     int* s_wave = reinterpret_cast<int*>(own_start + n_owner);                         // [T / 64]
     int* s_first_item = s_wave + T / TKR_WAVE;
+    int4* hdr = reinterpret_cast<int4*>((reinterpret_cast<uintptr_t>(s_first_item + 1) + 15) & ~(uintptr_t)15);     // [3B][2] words 0..7 of every record, by destination slot
     const __amdgpu_buffer_rsrc_t pocc_r = __builtin_amdgcn_make_buffer_rsrc(pocc, 0, n * 16, 0x00020000);
     const __amdgpu_buffer_rsrc_t prec_r = __builtin_amdgcn_make_buffer_rsrc(prec, 0, n * 128, 0x00020000);
     auto put = [&](const __amdgpu_buffer_rsrc_t& r, int4* base, int idx16, const int4 v) {      // int4 number idx16 of a batch's array
@@ -448,6 +453,10 @@ __device__ __forceinline__ void plan_phase_b_wide(unsigned char* smem, int b, in
         __syncthreads();
     }
     K1_STAMP(10);
+    // the 128-byte records, written as WHOLE cache lines: a task's two header words go to LDS at its destination slot, then eight
+    // lanes assemble one record each pass (a wave: eight consecutive records = 1 KB contiguous).  A thread that writes its own record
+    // piece by piece puts eight 16-byte stores on eight different lines per instruction: 6,144 partial-line writes per batch, and as
+    // write-through stores (FRESH) each is a fabric transaction of its own -- 34 us of a 16 us phase.
     if (s < n) {
         int dst = s;
         if (n_owner > 0 && item_task) {
@@ -457,31 +466,33 @@ __device__ __forceinline__ void plan_phase_b_wide(unsigned char* smem, int b, in
             for (int j = 0; j < (bit >> 5); ++j) before += __popc(m[j]);
             dst = first_item + (int)own_start[w] + before;
         }
-        if (t.x == -1) {
-            put(prec_r, prec, dst * 8, make_int4(-1, 0, 0, 0));
-#pragma unroll
-            for (int q = 1; q < 8; ++q) put(prec_r, prec, dst * 8 + q, make_int4(0, 0, 0, 0));
-        } else {
-            put(prec_r, prec, dst * 8, make_int4(t.x, ver, t.z, b * n + t.y));
-            put(prec_r, prec, dst * 8 + 1, make_int4(b, prev, 0, 0));
-            int tq[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int at = t.y + min(q, t.z - 1);                                  // (always inside the batch: no branch around the load)
-                const int4 v = lp[at];
-                put(prec_r, prec, dst * 8 + 2 + q, (q < t.z) ? v : make_int4(0, 0, 0, 0));
-                tq[q] = (q < t.z) ? lt[at] : 0;
+        hdr[2 * dst] = t.x == -1 ? make_int4(-1, 0, 0, 0) : make_int4(t.x, ver, t.z, b * n + t.y);
+        hdr[2 * dst + 1] = t.x == -1 ? make_int4(0, 0, 0, 0) : make_int4(b, prev, 0, 0);
+    }
+    __syncthreads();
+    K1_STAMP(12);
+    for (int base = 0; base < n; base += T / 8) {
+        const int rec = base + (s >> 3), q = s & 7;
+        if (rec < n) {
+            const int4 h0 = hdr[2 * rec];
+            int4 v = make_int4(0, 0, 0, 0);
+            if (q == 0) v = h0;
+            else if (q == 1) v = hdr[2 * rec + 1];
+            else if (h0.x != -1 && q < 7) {
+                const int occ0 = h0.w - b * n, cnt_occ = h0.z;                         // first occurrence inside the batch, occurrences
+                if (q < 6) { if (q - 2 < cnt_occ) v = lp[occ0 + q - 2]; }
+                else v = make_int4(lt[occ0], cnt_occ > 1 ? lt[occ0 + 1] : 0, cnt_occ > 2 ? lt[occ0 + 2] : 0, cnt_occ > 3 ? lt[occ0 + 3] : 0);
             }
-            put(prec_r, prec, dst * 8 + 6, make_int4(tq[0], tq[1], tq[2], tq[3]));
-            put(prec_r, prec, dst * 8 + 7, make_int4(0, 0, 0, 0));
+            put(prec_r, prec, rec * 8 + q, v);
         }
     }
+    K1_STAMP(11);
     t_out = t;
     prev_out = prev;
     total_out = total;
 }
 static inline size_t plan_phase_b_wide_lds(int B, int n_owner, int own_words) {
-    return (size_t)3 * B * 20 + (size_t)4 * n_owner * (own_words + 1) + (kWideThreads / TKR_WAVE + 1) * 4 + 12;
+    return (size_t)3 * B * 20 + (size_t)4 * n_owner * (own_words + 1) + (kWideThreads / TKR_WAVE + 1) * 4 + 16 + (size_t)3 * B * 32;
 }
 
 // ---- K1c for the rows whose FIRST task of the call is this thread's: the row's touches of the whole call go into its update counter,
@@ -494,7 +505,7 @@ __device__ __forceinline__ void plan_commit_first_touch(const int4 t, int prev, 
     const bool item = t.x < 0;
     const int row = t.x & 0x7fffffff;
     int32_t* cnt = item ? icnt + row : ucnt + row;
-    *cnt += total;
+    atomicAdd(cnt, total);               // (no return value: nothing waits for the round trip)
     uint4* w = reinterpret_cast<uint4*>((item ? touch_i : touch_u) + (size_t)row * kTouchWords);
 #pragma unroll
     for (int q = 0; q < kTouchWords / 4; ++q) w[q] = make_uint4(0u, 0u, 0u, 0u);

@@ -46,7 +46,8 @@ class Tuning:
     own_max_batch: int = 256         # TKR_OWN_MAX_BATCH: batch sizes up to this take K2o (K2o vs K2f per batch at the ML-10M shape:
                                      #   64: 0.90 vs 1.47 us, 256: 2.18 vs 2.75, 384: 3.79 vs 3.33, 512: 5.95 vs 3.98)
     own_waves: int = 0               # TKR_OWN_WAVES: owner waves per workgroup | experiment bits 8..15, 0 = the library default
-    fuse_short: bool = True          # TKR_FUSE_SHORT: K1 of a short call rides in the step's launch (tkr_bpr_own_plan_run)
+    fuse_short: bool = True          # TKR_FUSE_SHORT: K1 and the step of a short call leave in ONE C call (tkr_bpr_own_plan_run)
+    fuse_plan: bool = True           # TKR_FUSE_PLAN: ... and K1 runs INSIDE the step's launch (the planner prologue of csrc/bpr_own.hip); 0: its own launches
     overlap_min_batch: int = 2048    # TKR_OVERLAP_MIN_BATCH: from this batch size on K1 of the next chunk runs on the side stream
     epoch_ahead: bool = True         # TKR_EPOCH_AHEAD: plan the first chunk after an exchange ahead of it
     vbpr_cols: bool = True           # TKR_VBPR_COLS: the column-plan form of the VBPR step
@@ -60,7 +61,7 @@ class Tuning:
         parsers = {
             'flow': _flag, 'flow_max_batch': _int_in(0, 1 << 20), 'flow_waves_per_cu': _int_in(0, 32),
             'flow_item_bufs': lambda n, r: int(_choice('2', '4')(n, r)), 'own': _choice('0', '1', '2'),
-            'own_max_batch': _int_in(0, 1024), 'own_waves': _int_in(0, 0xffff), 'fuse_short': _flag,
+            'own_max_batch': _int_in(0, 1024), 'own_waves': _int_in(0, 0xffff), 'fuse_short': _flag, 'fuse_plan': _flag,
             'overlap_min_batch': _int_in(1, 1 << 30), 'epoch_ahead': _flag, 'vbpr_cols': _flag, 'vbpr_overlap': _flag,
         }
         out = cls()

@@ -856,7 +856,7 @@ class BprEngine(PlanMixin):
             raise ValueError('BPR on the HIP path: k <= 512, and k <= 256 for batch sizes above 1024 (got k = %d, batch_size = %d): a wave '
                              'holds a row in k / 64 registers per array (csrc/bpr_step.hip)' % (self.k, B))
         self.prepare(B)
-        key = (self.layout_epoch, B, self.cfg.flow_waves_per_cu, self._plan_owners(B), self.cfg.own_waves)
+        key = (self.layout_epoch, B, self.cfg.flow_waves_per_cu, self._plan_owners(B), self.cfg.own_waves, self.cfg.fuse_plan)
         if getattr(self, '_step_key', None) != key:       # the C struct and the closure are built once per layout, not per call
             self._step_key, self._step = key, self.step_fn(B)
         self._flow_ran = self._flow_ran or self.layout == 'flow'
@@ -868,7 +868,7 @@ class BprEngine(PlanMixin):
         state = self.state()
         if self.layout == 'flow':
             if self._plan_owners(B):
-                return tkr_hip.own_stepper(state, B, self.ctl, self.cfg.own_waves)
+                return tkr_hip.own_stepper(state, B, self.ctl, self.cfg.own_waves | (0 if self.cfg.fuse_plan else 0x1000))
             return tkr_hip.flow_stepper(state, B, self.ctl, self.cfg.flow_waves_per_cu)
         return lambda plan, lo, nb, loss: tkr_hip.bpr_run(state, plan, B, nb, loss, first=lo)
 
