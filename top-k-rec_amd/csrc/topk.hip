@@ -677,6 +677,156 @@ __device__ __forceinline__ void write_rows_refine(const TopkSmem<IdT>& sm, const
     write_rows<IdT>(sm, ws, n_rows, K, -INFINITY, out_ids, out_scores, part);
 }
 
+// ---- bound-and-refine, final stage in a kernel of its own (round 5) ------------------------------------------------------------
+// write_rows_refine rescored inside the tile kernel: 8 waves per CU of 256 registers each, every wave waiting out ~17 passes of
+// dependent row gathers per piece of a block, and a block cut into two pieces rescored ~33 candidates per user TWICE -- 17 % of the
+// Netflix pass, 36 % of the ML-10M pass, at an occupancy chosen for the MFMA loop.  Now a piece only DUMPS its lists (approximate
+// scores, scaled units of the user; every list a superset of the exact best K of its tiles) with its final threshold, and
+// topk_finish_kernel -- one wave per row, small, 12+ waves per CU -- takes the union of a row's pieces, drops what lies below the
+// largest threshold any piece reached (each is a lower bound of the K-th best exact score minus the margin: valid for every piece),
+// rescores the survivors ONCE with the fp32 kernel's own fma chain and sorts.  Same ids, same score bits.
+constexpr int kDumpCap = kCap;           // entries per (row, slot)
+template <typename IdT>
+__device__ __forceinline__ void dump_rows(const TopkSmem<IdT>& sm, const TopkSlot& ws, int n_rows, int K, float thr, float m2,
+                                          uint64_t* __restrict__ dump, float2* __restrict__ dhdr, int dstride) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int me = lane & 31, half = lane >> 5;
+    if (__ballot(sm.cnt[wave * 32 + me] > 32) != 0) {
+        thr = trim_all_users<IdT, true>(sm, wave * 32 + me, half, K, thr, m2);
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int r_me = ws.block * sm.users + wave * 32 + me;
+    if (half == 0 && r_me < n_rows)
+        dhdr[(size_t)r_me * dstride + ws.slot] = make_float2(__int_as_float(min(sm.cnt[wave * 32 + me], kCap)), thr);
+    for (int u = 0; u < 32; ++u) {
+        const int uq = wave * 32 + u, r = ws.block * sm.users + uq;
+        if (r >= n_rows) break;                                  // wave-uniform
+        const int n = min(sm.cnt[uq], kCap);
+        if (lane < n)
+            dump[((size_t)r * dstride + ws.slot) * kDumpCap + lane] =
+                ((uint64_t)__float_as_uint(sm.cs[lane * sm.users + uq]) << 32) | (uint32_t)sm.ci[lane * sm.users + uq];
+    }
+}
+
+// one wave per row.  KS > 0: k == 16 * KS (every trip count a constant, all the loads of a candidate's item row in flight at once);
+// KS == 0: any k through exact_score.
+template <int KS>
+__global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __restrict__ dump, const float2* __restrict__ dhdr, int n_rows,
+                                                         int stride, const int32_t* __restrict__ nslots, int users_per_block,
+                                                         const uint32_t* __restrict__ flagged, const float* __restrict__ U,
+                                                         const int32_t* __restrict__ uidx, const float* __restrict__ Vt,
+                                                         const float* __restrict__ bias, int k, int K, int32_t* __restrict__ out_ids,
+                                                         float* __restrict__ out_scores) {
+    __shared__ __attribute__((aligned(16))) float s_urow[4][128];
+    __shared__ uint32_t s_q[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= n_rows) return;
+    const int block = r / users_per_block;
+    if (flagged && flagged[block]) return;                       // a list of this block overflowed: the fp32 kernel redoes it
+    const int S = nslots ? nslots[block] : stride;
+    float B = -INFINITY;                                         // the largest threshold any piece reached
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        float t = -INFINITY;
+        if (s0 + lane < S) t = dhdr[(size_t)r * stride + s0 + lane].y;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t = fmaxf(t, __shfl_xor(t, o, 64));
+        B = fmaxf(B, t);
+    }
+    const int urow_i = uidx ? uidx[r] : r;
+    const float* up = U + (size_t)urow_i * k;
+    if constexpr (KS > 0) {
+        if (lane < 4 * KS) reinterpret_cast<float4*>(s_urow[wave])[lane] = reinterpret_cast<const float4*>(up)[lane];
+    }
+    uint32_t* q = s_q[wave];
+    int queued = 0;
+    uint64_t best = 0ull;                                        // lanes 0..31: the best so far, descending (0 = none)
+    bool first = true;
+    auto flush = [&](int m) {                                    // rescore the first m <= 64 queued columns, merge them into `best`
+        const bool live = lane < m;
+        const int col = live ? (int)q[lane] : 0;
+        float sc;
+        if constexpr (KS > 0) {
+            constexpr int q4 = 2 * KS;
+            const float4* vrow = reinterpret_cast<const float4*>(Vt + (size_t)col * (16 * KS));
+            float4 va[q4], vb[q4];
+#pragma unroll
+            for (int j = 0; j < q4; ++j) { va[j] = vrow[j]; vb[j] = vrow[q4 + j]; }
+            const float4* urow = reinterpret_cast<const float4*>(s_urow[wave]);
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < q4; ++j) {
+                const float4 b0 = urow[j], b1 = urow[q4 + j];
+                acc = fmaf(va[j].x, b0.x, acc); acc = fmaf(vb[j].x, b1.x, acc);
+                acc = fmaf(va[j].y, b0.y, acc); acc = fmaf(vb[j].y, b1.y, acc);
+                acc = fmaf(va[j].z, b0.z, acc); acc = fmaf(vb[j].z, b1.z, acc);
+                acc = fmaf(va[j].w, b0.w, acc); acc = fmaf(vb[j].w, b1.w, acc);
+            }
+            acc = acc + (bias ? bias[col] : 0.f);
+            sc = acc + 0.0f;
+        } else {
+            sc = live ? exact_score(up, Vt + (size_t)col * k, k, bias, col) : 0.f;
+        }
+        const uint64_t key = live ? (((uint64_t)ordered_bits(sc) << 32) | ((uint32_t)col + 1u)) : 0ull;
+        if (first) {                                             // nothing to merge with: one sort of the 64
+            best = wave_sort_desc(key, lane);
+            first = false;
+        } else {                                                 // best 32 so far in lanes 0..31 + 32 new ones, twice
+#pragma unroll 1
+            for (int hx = 0; hx < 2; ++hx) {
+                const uint64_t in = (uint64_t)__shfl((unsigned long long)key, (lane & 31) + 32 * hx, 64);
+                best = wave_sort_desc(lane < 32 ? best : in, lane);
+            }
+        }
+        if (lane >= 32) best = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t rest = (lane + m < queued) ? q[lane + m] : 0u;       // what stays queued moves to the front
+        const uint32_t rest2 = (lane + 64 + m < queued) ? q[lane + 64 + m] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        q[lane] = rest;
+        q[lane + 64] = rest2;
+        queued -= m;
+        __builtin_amdgcn_wave_barrier();
+    };
+    __builtin_amdgcn_wave_barrier();
+    for (int s = 0; s < S; ++s) {
+        const size_t at = (size_t)r * stride + s;
+        const int n = __float_as_int(dhdr[at].x);
+        uint64_t e = 0ull;
+        if (lane < n) e = dump[at * kDumpCap + lane];
+        const bool keep = lane < n && __uint_as_float((uint32_t)(e >> 32)) >= B;
+        const uint64_t m = __ballot(keep);
+        if (keep) q[queued + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)e;
+        queued += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (queued >= 64) flush(64);
+    }
+    while (queued > 0) flush(min(queued, 64));
+    if (lane < K) {
+        const bool have = best != 0ull;
+        const uint32_t ob = (uint32_t)(best >> 32);
+        const uint32_t f = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+        out_ids[(size_t)r * K + lane] = have ? (int32_t)((uint32_t)best - 1u) : -1;
+        if (out_scores) out_scores[(size_t)r * K + lane] = have ? __uint_as_float(f) : -INFINITY;
+    }
+}
+
+// A compiler hole, ROCm 7.2 / gfx950 (found in round 5; tests/test_gpu_topk.py test_exact_arithmetic_lists caught it): the wait states
+// between a 16-pass MFMA and the first VALU read of its result (19 on this chip; the hardware does NOT interlock them) are counted by
+// hipcc along the LAYOUT of the code, not along the control flow.  On a workgroup's LAST tile the staging code between the chain and
+// the filter is skipped by two scalar branches, the `s_nop 2` hipcc had placed in front of `v_accvgpr_read a15` is all that is left,
+// and the lane reads register 15 -- the last the matrix pipe writes -- one MFMA early: scores of tile rows 27 and 31 came out short
+// of their last two products, depending on how the rest of the file happened to be laid out.  The wait goes in by hand, right behind
+// the chain: 20 states of ~6,400 per tile.
+// (`acc` is an operand of the statement: it cannot move above the chain or below the first read; where the accumulators live in
+// AGPRs hipcc copies them out in front of it -- in line with the chain, where its own count is right)
+__device__ __forceinline__ void mfma_result_guard(f32x16& acc) {            // behind a chain of 16-pass MFMAs (v_mfma_f32_32x32x2_f32)
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));
+}
+__device__ __forceinline__ void mfma_result_guard_8pass(f32x16& acc) {      // behind 8-pass MFMAs (v_mfma_f32_32x32x16_f16 / _bf16): 11 states
+    asm volatile("s_nop 10" : "+v"(acc));
+}
+
 // waves per workgroup of an instantiation: 8 (two per SIMD: one wave's filter overlaps the other's MFMA
 // chain); 6 when candidate ids need 32 bits (LDS); 4 for wide factor rows (100+ operand registers)
 template <int KHP, typename IdT>
@@ -811,6 +961,7 @@ __global__ __launch_bounds__((WAVES * TKR_WAVE)) void score_topk_kernel(
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, breg[kk + 2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, breg[kk + 3], acc, 0, 0, 0);
         }
+        mfma_result_guard(acc);
         // tile t+1: registers -> the other LDS buffer (free since the barrier of tile t-1); tile t+2 -> registers
         if (t + 1 < n_tiles) stage_store(t + 1, buf ^ 1);
         if (t + 2 < n_tiles) stage_load(t + 2);
@@ -947,6 +1098,7 @@ __global__ __launch_bounds__(256) void score_topk_slab_kernel(
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, breg[sl * KHP + kk + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, breg[sl * KHP + kk + 3], acc, 0, 0, 0);
             }
+            if (sl + 1 == SLABS) mfma_result_guard(acc);
             // the next unit: registers -> the other buffer (free since the barrier before this unit); the one after it -> registers
             int t1 = t, s1 = sl;
             next_unit(t1, s1);
@@ -1051,7 +1203,8 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT, REFINE>() * TKR_WAVE), 2)
     const float* __restrict__ bias, int n_cols, int k, const uint32_t* __restrict__ mask, int mask_pitch, int K,
     int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int tiles_per_split, uint64_t* __restrict__ part,
     uint32_t* __restrict__ thr_shared, const int4* __restrict__ items /*(block, t_begin, t_end, slot | stride << 16) or null*/,
-    uint32_t* __restrict__ extra, const unsigned char* __restrict__ vimg) {
+    uint32_t* __restrict__ extra, const unsigned char* __restrict__ vimg, uint64_t* __restrict__ dump /*or null: rescore here*/,
+    float2* __restrict__ dhdr, int dump_stride /*list slots per row in the dump*/) {
     static_assert(!IMG || REFINE, "the tile image is the scaled fp16 operand of the bound-and-refine arithmetic");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 #if TKR_ABL & 256
@@ -1304,6 +1457,7 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT, REFINE>() * TKR_WAVE), 2)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[s][0], acc, 0, 0, 0);
             }
         }
+        mfma_result_guard_8pass(acc);
         // Where the one barrier of the tile sits.  k <= 64: EARLY, right after the staging -- tile t+1 is in LDS, every wave
         // is done reading tile t, and the filter touches only the wave's own lists, so a wave whose filter is short starts
         // the next MFMA chain while its neighbours still append or trim (Netflix shape, k = 64: 11.2 -> 10.2 ms).  The bias
@@ -1372,6 +1526,10 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT, REFINE>() * TKR_WAVE), 2)
     if constexpr (REFINE) {
         if (__ballot(lost) != 0 && lane == 0) extra[4 + ws.block] = 1u;       // the exact kernel redoes this block
 #if !(TKR_ABL & 64)
+        if (dump) {                                               // the final stage runs in topk_finish_kernel
+            dump_rows<IdT>(sm, ws, n_rows, K, thr, m2, dump, dhdr, dump_stride);
+            return;
+        }
         // (the kernel that stages its tiles through registers has fewer to spare: 4 instead of 8 loads per half in flight, no scratch)
         write_rows_refine<IdT, KS, IMG ? kRescoreInFlight : 4>(sm, ws, n_rows, K, thr, m2, U, uidx, Vt, bias, k, out_ids, out_scores, part,
                                                                tile, 2 * TILEB);                                // the tile buffers are free now
@@ -1440,10 +1598,11 @@ __global__ __launch_bounds__(256) void topk_bounds_kernel(const float* __restric
 __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t* __restrict__ part, int n_rows, int S, int K,
                                                         int32_t* __restrict__ out_ids, float* __restrict__ out_scores,
                                                         const int32_t* __restrict__ nslots /*per user block, or null: S everywhere*/,
-                                                        int users_per_block) {
+                                                        int users_per_block, const uint32_t* __restrict__ only_flagged /*or null: every block*/) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
+    if (only_flagged && !only_flagged[r / users_per_block]) return;      // topk_finish_kernel wrote this block's rows
     const uint64_t* p = part + (size_t)r * S * K;                // S slots per row; the block's first nslots are used
     if (nslots) {
         S = nslots[r / users_per_block];
@@ -1671,10 +1830,11 @@ static int plan_topk(int users, int n_rows, int n_cols, int K, void* workspace, 
     return TKR_OK;
 }
 
-static int merge_planned(const TopkPlan& p, int users, int n_rows, int K, int32_t* out_ids, float* out_scores, hipStream_t stream) {
+static int merge_planned(const TopkPlan& p, int users, int n_rows, int K, int32_t* out_ids, float* out_scores, hipStream_t stream,
+                         const uint32_t* only_flagged = nullptr) {
     if (p.merge_lists > 1)
         hipLaunchKernelGGL(merge_topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, reinterpret_cast<const uint64_t*>(p.part),
-                           n_rows, p.merge_lists, K, out_ids, out_scores, p.nslots, users);
+                           n_rows, p.merge_lists, K, out_ids, out_scores, p.nslots, users, only_flagged);
     return (int)hipGetLastError();
 }
 
@@ -1762,6 +1922,21 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
     TopkPlan p;
     int rc = plan_topk(users, n_rows, n_cols, K, workspace, workspace_bytes, REFINE ? (size_t)(4 + n_blocks) : 0, stream, p);
     if (rc != TKR_OK) return rc;
+    // the dump of the pieces' lists for topk_finish_kernel: behind what the plan uses, when the workspace has the room
+    uint64_t* dump = nullptr;
+    float2* dhdr = nullptr;
+    const int slots = p.merge_lists > 1 ? p.merge_lists : 1;
+    if constexpr (REFINE) {
+        static const bool no_finish = getenv("TKR_TOPK_FINISH") && getenv("TKR_TOPK_FINISH")[0] == '0';
+        if (p.extra && !no_finish) {
+            const size_t used = ((size_t)((unsigned char*)(p.extra + 4 + n_blocks) - (unsigned char*)workspace) + 255) & ~(size_t)255;
+            const size_t need = (size_t)n_rows * slots * (kDumpCap * sizeof(uint64_t) + sizeof(float2));
+            if (used + need <= workspace_bytes) {
+                dump = reinterpret_cast<uint64_t*>(static_cast<unsigned char*>(workspace) + used);
+                dhdr = reinterpret_cast<float2*>(dump + (size_t)n_rows * slots * kDumpCap);
+            }
+        }
+    }
     if constexpr (REFINE) {
         if (!p.extra) return TKR_EAGAIN_EXACT;                    // no room for the block flags: the caller runs the fp32 kernel
         hipLaunchKernelGGL(topk_bounds_kernel, dim3(std::min(256, (n_cols + 3) / 4)), dim3(256), 0, stream, Vt, bias, n_cols, k, p.extra);
@@ -1770,15 +1945,27 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
                                n_cols, k, p.extra, vimg);
     }
     hipLaunchKernelGGL(use_img ? kern_img : kern, p.grid, dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,
-                       out_ids, out_scores, p.tps, p.part, p.thr_shared, p.items, p.extra, (const unsigned char*)vimg);
+                       out_ids, out_scores, p.tps, p.part, p.thr_shared, p.items, p.extra, (const unsigned char*)vimg, dump, dhdr, slots);
     rc = (int)hipGetLastError();
     if (rc != TKR_OK) return rc;
-    if constexpr (REFINE) {                                       // blocks with an overflowed list: the fp32 kernel, same work items
+    if constexpr (REFINE) {
+        if (dump) {
+            const dim3 fg((n_rows + 3) / 4);
+            if (k == 16 * KS)
+                hipLaunchKernelGGL(topk_finish_kernel<KS>, fg, dim3(256), 0, stream, dump, dhdr, n_rows, slots, p.merge_lists > 1 ? p.nslots : nullptr,
+                                   users, p.extra + 4, U, uidx, Vt, bias, k, K, out_ids, out_scores);
+            else
+                hipLaunchKernelGGL(topk_finish_kernel<0>, fg, dim3(256), 0, stream, dump, dhdr, n_rows, slots, p.merge_lists > 1 ? p.nslots : nullptr,
+                                   users, p.extra + 4, U, uidx, Vt, bias, k, K, out_ids, out_scores);
+            rc = (int)hipGetLastError();
+            if (rc != TKR_OK) return rc;
+        }
+        // blocks with an overflowed list: the fp32 kernel, same work items
         rc = launch_fp32_planned<IdT, topk_waves_bf16<KS, IdT, true>()>(p, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores,
                                                                         p.extra + 4, stream);
         if (rc != TKR_OK) return rc;
     }
-    return merge_planned(p, users, n_rows, K, out_ids, out_scores, stream);
+    return merge_planned(p, users, n_rows, K, out_ids, out_scores, stream, (REFINE && dump) ? p.extra + 4 : nullptr);
 }
 
 template <int SLABS, typename IdT>
@@ -1899,7 +2086,9 @@ extern "C" int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K) {
     const int64_t pieces = (1024 + blocks - 1) / blocks + 1;     // 256 x (spans per CU <= 4)
     const int64_t lists = splits > pieces ? splits : pieces;
     const int64_t refine_words = 4 + ((int64_t)n_rows + 127) / 128;      // bounds + one flag per user block (>= 128 users each)
-    return lists * n_rows * K * (int64_t)sizeof(uint64_t) + (int64_t)n_rows * (int64_t)sizeof(uint32_t) + refine_words * 4;
+    // + the pieces' list dumps for topk_finish_kernel (bound-and-refine): kDumpCap entries + a header per (row, piece)
+    const int64_t dump = lists * n_rows * (tkr::kDumpCap * (int64_t)sizeof(uint64_t) + 8) + 512;
+    return lists * n_rows * K * (int64_t)sizeof(uint64_t) + (int64_t)n_rows * (int64_t)sizeof(uint32_t) + refine_words * 4 + dump;
 }
 
 extern "C" int64_t tkr_topk_workspace_bytes_for(int32_t n_rows, int32_t n_cols, int32_t k, int32_t K) {

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(W * 64) void vbpr_tproject_kernel(tkr_vbpr_state st
                 loss_lane += (fabsf(ure[e]) + fabsf(uce[e])) * st.lu + fabsf(vi[e]) * st.li + fabsf(vj[e]) * st.lj;
         }
         const float tot = wave_sum(loss_lane) + loss;
-        if (lane == 0) loss_add_spread(loss_out, tot);
+        if (lane == 0) loss_out[t] = tot;                            // this triplet's word (vbpr_loss_sum_kernel adds a batch's words up)
     }
 }
 
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void vbpr_pairsum_kernel(const float* __restri
     if (lane == 0) { sS[t] = s_row; sT[t] = s_col; }
     if (loss_out) {
         loss = wave_sum(loss);
-        if (lane == 0) loss_add_spread(loss_out, loss);
+        if (lane == 0) loss_out[B + t] = loss;
     }
 }
 
@@ -491,9 +491,12 @@ __device__ __forceinline__ void col_block(const tkr_vbpr_state& st, const PairSu
         st.msicb[c] = ms;
         st.icb[c] = v - st.lr * gg / sqrtf(ms + st.eps);
     }
-    if (loss_out) {
+    if (loss_out) {                                              // the block's word: its four waves in wave order
         lpart = wave_sum(lpart);
-        if (lane == 0 && lpart != 0.f) loss_add_spread(loss_out, lpart);
+        __syncthreads();                                         // (shm: the long runs are done with it)
+        if (lane == 0) shm[tid >> 6] = lpart;
+        __syncthreads();
+        if (tid == 0) loss_out[cb] = (shm[0] + shm[1]) + (shm[2] + shm[3]);
     }
 }
 
@@ -502,7 +505,8 @@ __global__ __launch_bounds__(256) void vbpr_update_kernel(
     tkr_vbpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ, const int32_t* __restrict__ occt,
     const int4* __restrict__ hdr, const float* __restrict__ s_in, const float* __restrict__ t_in, const float* __restrict__ P,
     const float* __restrict__ Wraw /*[B][kh]: uce_u(t)*/, const int4* __restrict__ colh, const int2* __restrict__ cent,
-    int n_row_blocks, int cpb, float* __restrict__ loss_out, int tune) {
+    int n_row_blocks, int cpb, float* __restrict__ loss_out /*the batch's loss words: [B] projection | [B] pair sums | [column blocks]*/,
+    int ps_B /*batch size*/, int tune) {
     constexpr int G = 256 / LPC;
     constexpr int ROWS_LDS = 2 * 4 * (NE * TKR_WAVE + 1);
     constexpr int COLS_LDS = G * (4 * LPC + 1) + 2 * G;
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(256) void vbpr_update_kernel(
                               reinterpret_cast<red_t>(shm + 4 * (NE * TKR_WAVE + 1)), blockIdx.x, n_row_blocks);
         return;
     }
-    col_block<LPC>(st, ps, Wraw, colh, cent, (int)blockIdx.x - n_row_blocks, cpb, loss_out, tune, shm);
+    col_block<LPC>(st, ps, Wraw, colh, cent, (int)blockIdx.x - n_row_blocks, cpb, loss_out ? loss_out + 2 * ps_B : nullptr, tune, shm);
 }
 
 template <int NE, int LPC>
@@ -527,17 +531,26 @@ static void launch_update(const tkr_vbpr_state& st, const int32_t* rec, const in
     const int n_row_blocks = vbpr_grid(B, 4);
     const int n_col_blocks = (st.d + cpb - 1) / cpb;
     hipLaunchKernelGGL((vbpr_update_kernel<NE, LPC>), dim3(n_row_blocks + n_col_blocks), dim3(256), 0, stream, st, rec, occ2, occt, hdr4,
-                       s_buf, t_buf, P, Wm, colh, cent, n_row_blocks, cpb, loss, tune);
+                       s_buf, t_buf, P, Wm, colh, cent, n_row_blocks, cpb, loss, B, tune);
 }
 
 }  // namespace tkr
 
 namespace tkr {
-// loss_out[b] += the 64 slots of batch b (as vbpr_step.hip's loss_slots_kernel)
-__global__ __launch_bounds__(64) void loss_slots_sum_kernel(const float* __restrict__ slots, float* __restrict__ loss_out) {
+// loss_out[b] += the `count` loss words of batch b: one per triplet from the projection, one per triplet from the pair sums, one per
+// column block of the update -- plain stores of their tasks (64 spread atomic slots cost the step 2.9 of 25.7 us: ~5,500 atomics per
+// batch, each a memory operation its wave's next load waits behind).  Fixed order: thread t adds words t, t + 256, ..., then the
+// wave tree, then the four waves -- the loss of a batch is bitwise reproducible.
+__global__ __launch_bounds__(256) void vbpr_loss_sum_kernel(const float* __restrict__ words, size_t stride, int count, float* __restrict__ loss_out) {
+    __shared__ float part[4];
     const int b = blockIdx.x;
-    const float v = wave_sum(slots[(size_t)b * kLossSlots * kLossSlotStride + threadIdx.x * kLossSlotStride]);
-    if (threadIdx.x == 0) loss_out[b] += v;
+    const float* w = words + (size_t)b * stride;
+    float acc = 0.f;
+    for (int q = threadIdx.x; q < count; q += 256) acc += w[q];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_out[b] += (part[0] + part[1]) + (part[2] + part[3]);
 }
 }  // namespace tkr
 
@@ -607,12 +620,14 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
     int pw = pw_env ? pw_env : (row_cap <= 64 ? 4 : (row_cap <= 128 || B > 256 ? 8 : 16));
     if (NH == 2 && pw > 8) pw = 8;          // kh > 64: two registers per gathered row and wave -- the 16-wave team is not instantiated there:
                                             // two rounds of gathers per wave instead of one (was a silent fall-through)
-    // the loss slots of the call's batches: behind the step's own scratch (tkr_common.h loss_add_spread; LossSlots is vbpr_step.hip's)
+    // the loss words of the call's batches: behind the step's own scratch, every word written by its task (nothing to zero)
+    const int lpc_ = kh <= 16 ? 4 : (kh <= 32 ? 8 : (kh <= 64 ? 16 : 32));
+    const int cpb_ = (cols_per_block <= 0 || cols_per_block > 256 / lpc_) ? 256 / lpc_ : cols_per_block;
+    const int n_col_blocks = (st->d + cpb_ - 1) / cpb_;
+    const size_t loss_stride = (size_t)2 * B + n_col_blocks;
     float* slots = loss_out ? workspace + tkr_vbpr_workspace_core_floats(B, kh, st->d) : nullptr;
-    if (slots) {
-        if (n_batches > 512) return TKR_EUNSUPPORTED;
-        TKR_CHECK(hipMemsetAsync(slots, 0, (size_t)n_batches * tkr::kLossSlots * tkr::kLossSlotStride * sizeof(float), s));
-    }
+    if (slots && (n_batches > 512 || (int64_t)n_batches * (int64_t)loss_stride > tkr_vbpr_workspace_floats(B, kh, st->d) - tkr_vbpr_workspace_core_floats(B, kh, st->d)))
+        return TKR_EUNSUPPORTED;
     for (int b = 0; b < n_batches; ++b) {
         const int32_t* ti = tri_i + (size_t)b * B;
         const int32_t* tj = tri_j + (size_t)b * B;
@@ -626,7 +641,7 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
         const int2* ce = reinterpret_cast<const int2*>(cent) + (size_t)b * B * tcap;
         const int32_t* tc = tcnt + (size_t)b * B;
         const int2* te = reinterpret_cast<const int2*>(tent) + (size_t)b * B * tcap;
-        float* l = slots ? slots + (size_t)b * tkr::kLossSlots * tkr::kLossSlotStride : nullptr;
+        float* l = slots ? slots + (size_t)b * loss_stride : nullptr;
         if (tune & 64) {
         } else if (NH == 1 && pw == 4) hipLaunchKernelGGL((tkr::vbpr_tproject_kernel<1, 4>), dim3(B), dim3(256), 0, s, *st, ti, tj, tu, tp, tc, te, tcap, B, P, ab2, Wm, l, tune);
         else if (NH == 1 && pw == 8) hipLaunchKernelGGL((tkr::vbpr_tproject_kernel<1, 8>), dim3(B), dim3(512), 0, s, *st, ti, tj, tu, tp, tc, te, tcap, B, P, ab2, Wm, l, tune);
@@ -647,7 +662,7 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
         TKR_LAUNCH_CHECK();
     }
     if (slots && n_batches > 0) {
-        hipLaunchKernelGGL(tkr::loss_slots_sum_kernel, dim3(n_batches), dim3(64), 0, s, slots, loss_out);
+        hipLaunchKernelGGL(tkr::vbpr_loss_sum_kernel, dim3(n_batches), dim3(256), 0, s, slots, loss_stride, (int)loss_stride, loss_out);
         TKR_LAUNCH_CHECK();
     }
     return TKR_OK;

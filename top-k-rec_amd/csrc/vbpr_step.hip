@@ -689,9 +689,11 @@ extern "C" int64_t tkr_vbpr_workspace_core_floats(int32_t batch_size, int32_t kh
     const int64_t slots = (int64_t)tkr_plan_max_blocks(batch_size) * tkr_plan_team(batch_size);     // sparse view: A, a per item task
     return S * batch_size * (kh + 1) + 2ll * batch_size + 2ll * batch_size * kh + slots * (kh + 1) + 5ll * batch_size;
 }
-// ... and behind it the loss slots of up to 512 batches of a call (tkr_common.h loss_add_spread)
+// ... and behind it the loss words of up to 512 batches of a call: 64 spread slots per batch for this file's kernels (tkr_common.h
+// loss_add_spread), one word per triplet (twice) and per column block for the column-plan step (csrc/vbpr_cols.hip: no atomics)
 extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d) {
-    return tkr_vbpr_workspace_core_floats(batch_size, kh, d) + 512ll * tkr::kLossSlots * tkr::kLossSlotStride;
+    const int64_t spread = (int64_t)tkr::kLossSlots * tkr::kLossSlotStride, per_task = 2ll * batch_size + d;
+    return tkr_vbpr_workspace_core_floats(batch_size, kh, d) + 512ll * (spread > per_task ? spread : per_task);
 }
 
 namespace tkr {
