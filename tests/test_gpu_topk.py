@@ -20,15 +20,18 @@ pytestmark = pytest.mark.gpu
 from oracle import ref_np as R
 
 
-@pytest.fixture(scope='module', params=['bf16x3', 'fp32', 'refine'])
+@pytest.fixture(scope='module', params=['bf16x3', 'fp32', 'refine', 'refine+finish'])
 def hip(request):
-    """every test runs under all score arithmetics of K4 (include/tkr.h, tkr_topk_set_math)"""
+    """every test runs under all score arithmetics of K4 (include/tkr.h, tkr_topk_set_math), bound-and-refine also with its final
+    stage in a kernel of its own (tkr_topk_set_finish)"""
     import tkr_hip
     assert torch.cuda.is_available()
     tkr_hip.lib()
-    tkr_hip.set_topk_math(request.param)
+    tkr_hip.set_topk_math(request.param.split('+')[0])
+    tkr_hip.set_topk_finish(request.param.endswith('+finish'))
     yield tkr_hip
     tkr_hip.set_topk_math(tkr_hip.TOPK_MATH_DEFAULT)
+    tkr_hip.set_topk_finish(False)
 
 
 def _dev(a):

@@ -710,64 +710,109 @@ __device__ __forceinline__ void dump_rows(const TopkSmem<IdT>& sm, const TopkSlo
 
 // one wave per row.  KS > 0: k == 16 * KS (every trip count a constant, all the loads of a candidate's item row in flight at once);
 // KS == 0: any k through exact_score.
+// value of quad lane Q (lane & ~3 | Q) in every lane of the quad: a VALU move, no LDS
+template <int Q>
+__device__ __forceinline__ float quad_bcast(uint32_t v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, (int)v, Q * 0x55, 0xf, 0xf, false));
+}
+
 template <int KS>
-__global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __restrict__ dump, const float2* __restrict__ dhdr, int n_rows,
-                                                         int stride, const int32_t* __restrict__ nslots, int users_per_block,
-                                                         const uint32_t* __restrict__ flagged, const float* __restrict__ U,
-                                                         const int32_t* __restrict__ uidx, const float* __restrict__ Vt,
-                                                         const float* __restrict__ bias, int k, int K, int32_t* __restrict__ out_ids,
-                                                         float* __restrict__ out_scores) {
-    __shared__ __attribute__((aligned(16))) float s_urow[4][128];
+__global__ __launch_bounds__(256, 3) void topk_finish_kernel(const uint64_t* __restrict__ dump, const float2* __restrict__ dhdr, int n_rows,
+                                                            int stride, const int32_t* __restrict__ nslots, int users_per_block,
+                                                            const uint32_t* __restrict__ flagged, const float* __restrict__ U,
+                                                            const int32_t* __restrict__ uidx, const float* __restrict__ Vt,
+                                                            const float* __restrict__ bias, int k, int K, int32_t* __restrict__ out_ids,
+                                                            float* __restrict__ out_scores) {
     __shared__ uint32_t s_q[4][128];
+    __shared__ uint64_t s_key[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + wave;
+    const int r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);       // (provably wave-uniform: the user's row comes through the scalar cache)
     if (r >= n_rows) return;
     const int block = r / users_per_block;
     if (flagged && flagged[block]) return;                       // a list of this block overflowed: the fp32 kernel redoes it
+    // ONE round trip for everything that does not depend on anything else: the block's piece count, the headers of up to 64 pieces
+    // (lane s: piece s), the entries of the first four pieces (lane e: entry e of each; lanes past a list's length read what an
+    // earlier call left there and are masked below).  (First version: count -> headers -> per piece its length -> its entries,
+    // one after the other: 8 dependent trips per row.)
     const int S = nslots ? nslots[block] : stride;
-    float B = -INFINITY;                                         // the largest threshold any piece reached
-    for (int s0 = 0; s0 < S; s0 += 64) {
-        float t = -INFINITY;
-        if (s0 + lane < S) t = dhdr[(size_t)r * stride + s0 + lane].y;
+    float2 hme = make_float2(0.f, -INFINITY);
+    if (lane < stride) hme = dhdr[(size_t)r * stride + lane];
+    uint64_t e4[4];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) t = fmaxf(t, __shfl_xor(t, o, 64));
-        B = fmaxf(B, t);
-    }
-    const int urow_i = uidx ? uidx[r] : r;
+    for (int j = 0; j < 4; ++j) e4[j] = dump[((size_t)r * stride + min(j, stride - 1)) * kDumpCap + lane];
+    const int urow_i = __builtin_amdgcn_readfirstlane(uidx ? uidx[r] : r);
     const float* up = U + (size_t)urow_i * k;
-    if constexpr (KS > 0) {
-        if (lane < 4 * KS) reinterpret_cast<float4*>(s_urow[wave])[lane] = reinterpret_cast<const float4*>(up)[lane];
-    }
+    float B = lane < S ? hme.y : -INFINITY;                      // the largest threshold any piece reached
+    for (int s0 = 64; s0 < S; s0 += 64)                          // (more than 64 pieces of one block: a one-block problem cut 256 ways)
+        if (s0 + lane < S) B = fmaxf(B, dhdr[(size_t)r * stride + s0 + lane].y);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) B = fmaxf(B, __shfl_xor(B, o, 64));
     uint32_t* q = s_q[wave];
+    uint64_t* keys = s_key[wave];
     int queued = 0;
     uint64_t best = 0ull;                                        // lanes 0..31: the best so far, descending (0 = none)
     bool first = true;
     auto flush = [&](int m) {                                    // rescore the first m <= 64 queued columns, merge them into `best`
-        const bool live = lane < m;
-        const int col = live ? (int)q[lane] : 0;
-        float sc;
         if constexpr (KS > 0) {
-            constexpr int q4 = 2 * KS;
-            const float4* vrow = reinterpret_cast<const float4*>(Vt + (size_t)col * (16 * KS));
-            float4 va[q4], vb[q4];
+            // FOUR lanes per candidate: quad lane c reads the 16-byte chunks 4i + c of the candidate's item row -- a quad reads 64
+            // contiguous bytes per instruction, a wave 16 rows x 64 B instead of 64 rows x 16 B (one lane per candidate: every
+            // instruction touched 64 different cache lines for 16 bytes each; the kernel ran at the rate of the texture addresser,
+            // 9 B / clock / CU, 268 us at the ML-10M shape).  The exact chain -- element for element the fp32-MFMA kernel's:
+            // k-halves interleaved, k ascending -- runs in all four lanes of the quad on values handed round by DPP (VALU moves);
+            // the user's row sits in scalar registers.
+            constexpr int q4 = 2 * KS;                           // 16-byte chunks per k-half
+            constexpr int NI = (2 * q4 + 3) / 4;                 // loads per lane: chunks 4i + c, i < NI
+            const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vt), 0, 0xfffffff0u, 0x00020000);
+            const float4* urow = reinterpret_cast<const float4*>(up);      // wave-uniform addresses: scalar loads
+            typedef uint32_t ld4 __attribute__((ext_vector_type(4)));
+            const int c4 = lane & 3;
+#pragma unroll 1
+            for (int p0 = 0; p0 < m; p0 += 16) {
+                const int ci = p0 + (lane >> 2);
+                const bool live = ci < m;
+                const int col = live ? (int)q[ci] : 0;
+                const int voff = col * (64 * KS) + c4 * 16;
+                ld4 v[NI];
 #pragma unroll
-            for (int j = 0; j < q4; ++j) { va[j] = vrow[j]; vb[j] = vrow[q4 + j]; }
-            const float4* urow = reinterpret_cast<const float4*>(s_urow[wave]);
-            float acc = 0.f;
+                for (int i = 0; i < NI; ++i) v[i] = (4 * i + c4 < 2 * q4) ? __builtin_amdgcn_raw_buffer_load_b128(vr, voff + i * 64, 0, 0) : ld4{0u, 0u, 0u, 0u};
+                float acc = 0.f;
 #pragma unroll
-            for (int j = 0; j < q4; ++j) {
-                const float4 b0 = urow[j], b1 = urow[q4 + j];
-                acc = fmaf(va[j].x, b0.x, acc); acc = fmaf(vb[j].x, b1.x, acc);
-                acc = fmaf(va[j].y, b0.y, acc); acc = fmaf(vb[j].y, b1.y, acc);
-                acc = fmaf(va[j].z, b0.z, acc); acc = fmaf(vb[j].z, b1.z, acc);
-                acc = fmaf(va[j].w, b0.w, acc); acc = fmaf(vb[j].w, b1.w, acc);
+                for (int j = 0; j < q4; ++j) {                   // chunk j of half 0 and chunk q4 + j of half 1
+                    const float4 b0 = urow[j], b1 = urow[q4 + j];
+                    const int i0 = j >> 2, i1 = (q4 + j) >> 2;
+                    float a0x, a0y, a0z, a0w, a1x, a1y, a1z, a1w;
+                    switch (j & 3) {                             // (compile-time in the unrolled loop; q4 is a multiple of 4 for KS >= 2, so both chunks sit in the same quad lane)
+                        case 0: a0x = quad_bcast<0>(v[i0].x); a0y = quad_bcast<0>(v[i0].y); a0z = quad_bcast<0>(v[i0].z); a0w = quad_bcast<0>(v[i0].w); break;
+                        case 1: a0x = quad_bcast<1>(v[i0].x); a0y = quad_bcast<1>(v[i0].y); a0z = quad_bcast<1>(v[i0].z); a0w = quad_bcast<1>(v[i0].w); break;
+                        case 2: a0x = quad_bcast<2>(v[i0].x); a0y = quad_bcast<2>(v[i0].y); a0z = quad_bcast<2>(v[i0].z); a0w = quad_bcast<2>(v[i0].w); break;
+                        default: a0x = quad_bcast<3>(v[i0].x); a0y = quad_bcast<3>(v[i0].y); a0z = quad_bcast<3>(v[i0].z); a0w = quad_bcast<3>(v[i0].w); break;
+                    }
+                    switch ((q4 + j) & 3) {
+                        case 0: a1x = quad_bcast<0>(v[i1].x); a1y = quad_bcast<0>(v[i1].y); a1z = quad_bcast<0>(v[i1].z); a1w = quad_bcast<0>(v[i1].w); break;
+                        case 1: a1x = quad_bcast<1>(v[i1].x); a1y = quad_bcast<1>(v[i1].y); a1z = quad_bcast<1>(v[i1].z); a1w = quad_bcast<1>(v[i1].w); break;
+                        case 2: a1x = quad_bcast<2>(v[i1].x); a1y = quad_bcast<2>(v[i1].y); a1z = quad_bcast<2>(v[i1].z); a1w = quad_bcast<2>(v[i1].w); break;
+                        default: a1x = quad_bcast<3>(v[i1].x); a1y = quad_bcast<3>(v[i1].y); a1z = quad_bcast<3>(v[i1].z); a1w = quad_bcast<3>(v[i1].w); break;
+                    }
+                    acc = fmaf(a0x, b0.x, acc); acc = fmaf(a1x, b1.x, acc);
+                    acc = fmaf(a0y, b0.y, acc); acc = fmaf(a1y, b1.y, acc);
+                    acc = fmaf(a0z, b0.z, acc); acc = fmaf(a1z, b1.z, acc);
+                    acc = fmaf(a0w, b0.w, acc); acc = fmaf(a1w, b1.w, acc);
+                    __builtin_amdgcn_sched_barrier(0);           // (or every DPP move of the row is hoisted in front of the chain: 128 temporaries)
+                }
+                acc = acc + (bias ? bias[col] : 0.f);
+                const float sc = acc + 0.0f;
+                if (c4 == 0) keys[ci & 63] = live ? (((uint64_t)ordered_bits(sc) << 32) | ((uint32_t)col + 1u)) : 0ull;
             }
-            acc = acc + (bias ? bias[col] : 0.f);
-            sc = acc + 0.0f;
+            for (int ci = ((m + 15) & ~15) + lane; ci < 64; ci += 64) keys[ci] = 0ull;       // the slots no pass wrote
+            __builtin_amdgcn_wave_barrier();
         } else {
-            sc = live ? exact_score(up, Vt + (size_t)col * k, k, bias, col) : 0.f;
+            const bool live = lane < m;
+            const int col = live ? (int)q[lane] : 0;
+            const float sc = live ? exact_score(up, Vt + (size_t)col * k, k, bias, col) : 0.f;
+            keys[lane] = live ? (((uint64_t)ordered_bits(sc) << 32) | ((uint32_t)col + 1u)) : 0ull;
+            __builtin_amdgcn_wave_barrier();
         }
-        const uint64_t key = live ? (((uint64_t)ordered_bits(sc) << 32) | ((uint32_t)col + 1u)) : 0ull;
+        const uint64_t key = keys[lane];
         if (first) {                                             // nothing to merge with: one sort of the 64
             best = wave_sort_desc(key, lane);
             first = false;
@@ -789,19 +834,22 @@ __global__ __launch_bounds__(256) void topk_finish_kernel(const uint64_t* __rest
         __builtin_amdgcn_wave_barrier();
     };
     __builtin_amdgcn_wave_barrier();
-    for (int s = 0; s < S; ++s) {
-        const size_t at = (size_t)r * stride + s;
-        const int n = __float_as_int(dhdr[at].x);
-        uint64_t e = 0ull;
-        if (lane < n) e = dump[at * kDumpCap + lane];
-        const bool keep = lane < n && __uint_as_float((uint32_t)(e >> 32)) >= B;
-        const uint64_t m = __ballot(keep);
-        if (keep) q[queued + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)e;
-        queued += __popcll(m);
-        __builtin_amdgcn_wave_barrier();
-        if (queued >= 64) flush(64);
+    int s = 0;
+    while (s < S || queued > 0) {                                // (one call site of the rescoring)
+        while (s < S && queued < 64) {
+            const size_t at = (size_t)r * stride + s;
+            const int n = s < 64 ? __shfl(__float_as_int(hme.x), s, 64) : __float_as_int(dhdr[at].x);
+            uint64_t e = s == 0 ? e4[0] : s == 1 ? e4[1] : s == 2 ? e4[2] : e4[3];
+            if (s >= 4) e = dump[at * kDumpCap + lane];
+            const bool keep = lane < n && __uint_as_float((uint32_t)(e >> 32)) >= B;
+            const uint64_t m = __ballot(keep);
+            if (keep) q[queued + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)e;
+            queued += __popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            ++s;
+        }
+        if (queued > 0) flush(min(queued, 64));
     }
-    while (queued > 0) flush(min(queued, 64));
     if (lane < K) {
         const bool have = best != 0ull;
         const uint32_t ob = (uint32_t)(best >> 32);
@@ -1891,6 +1939,8 @@ static size_t topk_image_bytes(int n_cols, int k) {               // the fp16 ti
     return (size_t)((n_cols + 31) / 32) * 32 * KS * 32;
 }
 
+static int g_topk_finish = -1;     // the final stage of bound-and-refine in topk_finish_kernel: tkr_topk_set_finish / TKR_TOPK_FINISH=1
+
 template <int KS, typename IdT, bool REFINE>
 static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias, int n_cols,
                             int k, const uint32_t* mask, int pitch, int K, int32_t* out_ids, float* out_scores,
@@ -1927,8 +1977,14 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
     float2* dhdr = nullptr;
     const int slots = p.merge_lists > 1 ? p.merge_lists : 1;
     if constexpr (REFINE) {
-        static const bool no_finish = getenv("TKR_TOPK_FINISH") && getenv("TKR_TOPK_FINISH")[0] == '0';
-        if (p.extra && !no_finish) {
+        // OFF unless TKR_TOPK_FINISH=1 (round 5, measured; tests/test_gpu_topk.py runs both): the main kernel drops to 0.81 ms at the
+        // ML-10M shape without its final stage (1.06 with), but topk_finish_kernel takes 0.27-0.29 ms whatever its gather looks like
+        // (a lane per candidate, 16 loads in flight; four lanes per candidate on 64-byte runs) -- ~12 us of dependent latency per
+        // row (headers + entries, the row gathers, a 128-deep fma chain, a 21-stage sort) over the 12 waves per CU its 157-168
+        // registers allow; in the tile kernel the same stage hides behind the second workgroup of the CU.  ML-10M 1.13 vs 1.12 ms,
+        // Netflix shape 8.9-9.1 vs 8.45 ms: kept selectable, not the default.
+        if (g_topk_finish < 0) g_topk_finish = (getenv("TKR_TOPK_FINISH") && getenv("TKR_TOPK_FINISH")[0] == '1') ? 1 : 0;
+        if (p.extra && g_topk_finish == 1) {
             const size_t used = ((size_t)((unsigned char*)(p.extra + 4 + n_blocks) - (unsigned char*)workspace) + 255) & ~(size_t)255;
             const size_t need = (size_t)n_rows * slots * (kDumpCap * sizeof(uint64_t) + sizeof(float2));
             if (used + need <= workspace_bytes) {
@@ -2068,6 +2124,12 @@ extern "C" int tkr_k4_prof_read(unsigned long long* out8) {      // timing build
     return (int)e;
 }
 #endif
+
+extern "C" int tkr_topk_set_finish(int32_t on) {
+    if (on != 0 && on != 1) return TKR_EINVAL;
+    tkr::g_topk_finish = on;
+    return TKR_OK;
+}
 
 extern "C" int tkr_topk_set_math(int32_t mode) {
     if (mode < 0 || mode > 2) return TKR_EINVAL;

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TKR_HIP_LIB') or os.path.join(_HERE, 'libtkr_hip.so')      # the override is for A/B builds of the kernels (scripts/)
 
 _lib = None
-VERSION = 115          # TKR_VERSION of include/tkr.h this binding was written against
+VERSION = 116          # TKR_VERSION of include/tkr.h this binding was written against
 
 
 class TkrError(RuntimeError):
@@ -81,7 +81,7 @@ EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_pl
            'tkr_vbpr_run', 'tkr_vbpr_colplan', 'tkr_vbpr_run_cols', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy',
            'tkr_idmap_create', 'tkr_idmap_destroy', 'tkr_ratings_parse', 'tkr_ratings_sizes', 'tkr_ratings_copy',
            'tkr_ratings_destroy', 'tkr_matrix_read', 'tkr_matrix_sizes', 'tkr_matrix_copy', 'tkr_matrix_destroy',
-           'tkr_matrix_write', 'tkr_raw_ranks', 'tkr_count_hits_rr', 'tkr_topk_set_math',
+           'tkr_matrix_write', 'tkr_raw_ranks', 'tkr_count_hits_rr', 'tkr_topk_set_math', 'tkr_topk_set_finish',
            'tkr_sync_snapshot', 'tkr_sync_pack', 'tkr_sync_unpack', 'tkr_sync_flow_snapshot', 'tkr_sync_flow_pack',
            'tkr_sync_flow_unpack')
 EXPORTS_I64 = ('tkr_vbpr_workspace_floats', 'tkr_vbpr_colplan_lds_bytes', 'tkr_topk_workspace_bytes_for', 'tkr_topk_workspace_bytes', 'tkr_plan_workspace_bytes')
@@ -450,6 +450,11 @@ def set_topk_math(mode):
     them -- same lists and score bits as 'fp32'; k <= 128), 'bf16x3' (split products on the dense matrix pipe, k <= 128) or
     'fp32' (fp32 MFMA) -- see include/tkr.h"""
     _check(lib().tkr_topk_set_math(C.c_int32({'bf16x3': 0, 'fp32': 1, 'refine': 2}[mode])), 'tkr_topk_set_math')
+
+
+def set_topk_finish(on):
+    """bound-and-refine: the final stage (exact rescoring + sort) in a kernel of its own, once per row -- see include/tkr.h"""
+    _check(lib().tkr_topk_set_finish(C.c_int32(1 if on else 0)), 'tkr_topk_set_finish')
 
 
 def score_topk(U, Vt, K, bias=None, user_idx=None, mask=None, mask_pitch=0, want_scores=False, split=True):
