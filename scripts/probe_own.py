@@ -33,6 +33,11 @@ for v in variants:
     print('%s B %d %-3s owners %d: %.3f us/batch (events %.3f), %.1f M triplets/s, %.2f spin passes per task' %
           (shape, B, v, eng._plan_owners(B), wall / steps * 1e6, e0.elapsed_time(e1) * 1e3 / steps, steps * B / wall / 1e6,
            spins / (steps * 3.0 * B)), flush=True)
+    ld = eng.ctl[tkr_hip.FLOW_CTL_PROF + 64:tkr_hip.FLOW_CTL_PROF + 68].cpu().numpy().astype(np.float64)
+    if ld[0] > 0:
+        print('   loader form: %d item tasks through the ring; per task: %.2f spins waiting for its slot, %.2f loader spins blocked; %.1f %% of the tasks waited for a row (own chain or a stale / unfinished partner)'
+              % (ld[0], ld[1] / ld[0], ld[2] / ld[0], 100 * ld[3] / ld[0]), flush=True)
+    eng.ctl[tkr_hip.FLOW_CTL_PROF + 64:tkr_hip.FLOW_CTL_PROF + 68] = 0
     if os.environ.get('TKR_OWN_PROF') == '1' and v != 'f':          # a library built with -DTKR_OWN_PROF (TKR_HIP_LIB)
         pr = eng.ctl[tkr_hip.FLOW_CTL_PROF:tkr_hip.FLOW_CTL_PROF + 32].cpu().numpy().view(np.uint64).astype(np.float64)
         n, m = max(pr[6], 1), max(pr[13], 1)

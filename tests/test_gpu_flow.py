@@ -34,7 +34,7 @@ def _toy(n_users, n_items, seed, max_deg=12):
     return tr, list(tr.keys())
 
 
-KERNEL_TUNE = {'f': 0, 'o': 0, 's': 0x8000, 'w': 0xc000}      # K2f | K2o, item tasks read rows (default) | ... exchange scalars | ... on 16 waves
+KERNEL_TUNE = {'f': 0, 'o': 0, 's': 0x8000, 'w': 0xc000, 'l': 0x0100}      # K2f | K2o, item tasks read rows (default) | ... exchange scalars | ... on 16 waves | K2o with a loader wave (partner rows staged in LDS)
 
 
 def _owners(hip, which, n_items, k):
@@ -232,7 +232,7 @@ def _check(F, ref, ucnt, icnt, uocc, iocc, tol=dict(rtol=2e-4, atol=1e-5), slots
 @pytest.mark.parametrize('k,B,nb,mode,lr', [(16, 64, 12, 'l2', 0.05), (128, 256, 10, 'l2', 0.05), (50, 256, 6, 'l1', 0.05),
                                            (200, 128, 4, 'l2', 1e-4), (64, 1024, 5, 'l2', 0.05), (128, 256, 40, 'l1', 0.02),
                                            (256, 64, 6, 'l2', 0.05)])
-@pytest.mark.parametrize('kernel', ['f', 'o', 'o8', 's', 's8', 'w'])
+@pytest.mark.parametrize('kernel', ['f', 'o', 'o8', 's', 's8', 'w', 'l', 'l8'])
 def test_bpr_flow_parity(hip, k, B, nb, mode, lr, kernel):
     n_users, n_items = 400, 120               # small tables: every item is updated in (almost) every batch, many rows have > 4 occurrences
     tr, tr_users = _toy(n_users, n_items, seed=k + B)
@@ -254,7 +254,7 @@ def test_bpr_flow_parity(hip, k, B, nb, mode, lr, kernel):
 
 
 @pytest.mark.parametrize('bufs', [2, 4])
-@pytest.mark.parametrize('kernel', ['f', 'o', 'o3', 's', 's3', 'w'])
+@pytest.mark.parametrize('kernel', ['f', 'o', 'o3', 's', 's3', 'w', 'l', 'l3'])
 def test_flow_is_deterministic_and_launch_split_invariant(hip, kernel, bufs):
     """bitwise: two runs of one launch, and the same chunk cut into launches of 1 + 3 + the rest and 2 + 1 + 4 + the rest (K2o: the
     rows an owner holds in LDS do not outlive a launch; the first task of a row in the next launch takes it from the tables again)"""
@@ -278,7 +278,7 @@ def test_flow_is_deterministic_and_launch_split_invariant(hip, kernel, bufs):
 
 @pytest.mark.parametrize('bufs', [2, 4])
 @pytest.mark.parametrize('kernel,waves_per_cu', [('f', 4), ('f', 8), ('f', 12), ('o', 0), ('o', 1), ('o', 6), ('o3', 2), ('s', 0), ('s', 1), ('s3', 2),
-                                                 ('w', 0), ('w', 13)])
+                                                 ('w', 0), ('w', 13), ('l', 0), ('l', 1), ('l3', 2)])
 def test_flow_few_waves_and_hot_rows(hip, kernel, waves_per_cu, bufs):
     """12 items: every item row is rewritten in every batch (a hand-off chain through all 64 batches), all of them with dozens of
     occurrences; and the result must not depend on how many waves run"""
@@ -296,7 +296,7 @@ def test_flow_few_waves_and_hot_rows(hip, kernel, waves_per_cu, bufs):
     _check(F, ref, ucnt, icnt, uocc, iocc, tol=dict(rtol=5e-4, atol=2e-5))
 
 
-@pytest.mark.parametrize('kernel', ['f', 'o', 's'])
+@pytest.mark.parametrize('kernel', ['f', 'o', 's', 'l'])
 def test_flow_sgd(hip, kernel):
     n_users, n_items, k, B, nb = 400, 120, 128, 256, 8
     tr, tr_users = _toy(n_users, n_items, seed=5)

@@ -188,6 +188,8 @@ struct ItemRow {                         // where the own row of an item task is
     const volatile uint32_t* tag;        // the row's version word in LDS
     const float* row;                    // the row's slot in LDS
     int halves;                          // 16-byte halves of a tail in the tables
+    bool rd_staged;                      // LOADER: the acknowledge word was copied beside the partner rows ...
+    uint32_t rd_val;                     // ... this is it (a lower bound of the word now: acknowledgements only grow)
 };
 
 // the task's way: wait for the row (LDS: the task before it in the chain; tables: only at a launch's first touch), then the acknowledge word
@@ -208,6 +210,10 @@ __device__ __forceinline__ bool item_own_wait(const FlowTables& T, int lane, con
         asm volatile("" ::: "memory");                  // the row is read AFTER its tag
         lds_row_read<NP>(r.row, lane, sgd, own, ms, o);
         o.ok = true;
+        if (r.rd_staged) {                              // no trip to memory for the acknowledge word either: own_publish polls it if this copy falls short
+            o.rd = r.rd_val;
+            return true;
+        }
     }
     return flow_own<NP>(T, lane, r.own_p, r.own_ms, r.own_tail, r.own_rd, r.ver, own, ms, o, sgd, ctl, spins, r.halves);   // o.ok: only rd is loaded
 }
@@ -483,11 +489,50 @@ __device__ __forceinline__ bool own_publish(int lane, bool is_item, uint32_t bma
     return true;
 }
 
+// ---- the loader / consumer form (LOADER = true, round 5) -----------------------------------------------------------------------------
+// One wave of the workgroup -- the loader -- walks the owner queue ahead of the waves that run its tasks and copies every task's
+// record and PARTNER rows (an occurrence's user row, the other item's row and bias granule) into a ring of LDS slots by direct-to-LDS
+// loads (global_load_lds: no registers, a dozen in flight); the task's wave validates the tags it finds there (flow_task.h LdsStage)
+// and only goes to memory itself for what was not final yet when the loader asked.  The loader stays at most kLoadAhead batches in
+// front of the queue's head: further ahead, more of what it stages is stale by the time it is read.
+constexpr int kLoadSlotRows = 8;                                  // 4 occurrences x (user row, other item's row)
+constexpr int kLoadAhead = 2;
+constexpr int kLoaders = 3;                                       // loader waves per workgroup
+template <int NP>
+constexpr int load_slot_bytes() { return 128 + 64 + kLoadSlotRows * NP * 1024; }        // record | bias granules | rows (KB-aligned behind the first 192 bytes + pad)
+template <int NP>
+constexpr int load_slot_stride() { return (load_slot_bytes<NP>() + 1023) & ~1023; }
+
+__device__ __forceinline__ void wait_vmcnt_at_most(int n) {       // s_waitcnt takes an immediate: the loads of a slot are counted at run time
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;       // (a slot is at most 2 + 3 * 4 = 14 loads at k <= 128)
+    }
+}
+// 16 bytes per lane of the first `lanes` lanes, global -> LDS at dst + 16 * lane, past the L1 (sc1: the tags must be memory's)
+__device__ __forceinline__ void dma16(const void* src_lane, unsigned char* dst_wave, int lane, int lanes) {
+    if (lane < lanes)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (__attribute__((address_space(3))) void*)dst_wave, 16, 0, 16);
+}
+
 constexpr int own_min_waves(int np, int tpb) { return tpb / 256; }      // per SIMD: 16 waves per CU at <= 128 registers (k <= 128), 8 at <= 256
 
 // SCALAR: the item tasks of a triplet exchange scalars (one reader per occurrence of an item row: the user task; wave 0 of a
 // workgroup is the scout); else they read each other's rows like K2f (two readers; wave 0 is one more owner wave)
-template <int NP, int TPB, bool SCALAR, bool PLAN = false>
+template <int NP, int TPB, bool SCALAR, bool PLAN = false, bool LOADER = false>
 __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     tkr_flow_state st, const int4* __restrict__ prec /*record 0 of the first batch to run*/, const int4* __restrict__ pocc,
     const int32_t* __restrict__ occt, const int32_t* __restrict__ ohdr /*[n_owner][ohdr_stride], at the first batch to run*/, int ohdr_stride,
@@ -519,6 +564,13 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     uint32_t* tags = start + nb;                                                       // [rows_here]
     uint32_t* dotmark = tags + rows_here;                                              // [kDotWin]: position + 1 of the task whose scalars are out
     float* rows = reinterpret_cast<float*>(smem + ((sizeof(OwnQueue) + (size_t)4 * (2 * nb + 1 + TKR_WAVE + rows_here + kDotWin) + 15) & ~(size_t)15));
+    // LOADER: ring_slots slots of partner rows behind the resident rows (KB-aligned), their ready / freed words behind the ring
+    unsigned char* ring = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(rows + (size_t)rows_here * ROWF) + 1023) & ~(uintptr_t)1023);
+    const int ring_slots = LOADER ? (int)((tune >> 8) & 0xffu) : 0;                     // (the host sizes the LDS: own_lds_bytes_loader)
+    const uint32_t load_ahead = LOADER ? (tune >> 16) : 0u;                             // batches the loaders may run in front of the queue's head
+    const int n_loaders = LOADER ? min(kLoaders, owner_waves) : 0;                      // of the owner_waves + 1 waves on the owner queue: at least one runs tasks
+    volatile uint32_t* ring_ready = reinterpret_cast<volatile uint32_t*>(ring + (size_t)ring_slots * load_slot_stride<NP>());   // position + 1 staged in the slot
+    volatile uint32_t* ring_freed = ring_ready + ring_slots;                            // position + 1 whose task has taken the slot's contents
 
     // owner number = workgroup number (every workgroup is resident: which CU it sits on means nothing).  The first ticket of a user-task
     // wave goes out NOW, beside the loads of the queue header: a launch used to start with three trips in series -- an arrival
@@ -535,6 +587,9 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     for (int b = threadIdx.x; b < TKR_WAVE; b += TPB) pre[nb + 1 + b] = 0xffffffffu;
     for (int s = threadIdx.x; s < rows_here; s += TPB) tags[s] = kOwnInvalid;
     for (int s = threadIdx.x; s < kDotWin; s += TPB) dotmark[s] = 0u;
+    if constexpr (LOADER) {
+        for (int s = threadIdx.x; s < 2 * ring_slots; s += TPB) ring_ready[s] = 0u;
+    }
     if constexpr (PLAN) {
         static_assert(TPB == kWideThreads, "phase B of the planner is one thread per task slot");
         unsigned char* scratch = reinterpret_cast<unsigned char*>(rows);                 // the rows' region: no row is resident yet
@@ -613,6 +668,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
 
     PLAN_STAMP(10);
     uint32_t spins = 0;
+    uint32_t ld_ready_spins = 0, ld_tasks = 0, ld_block_spins = 0, ld_fallback = 0;      // LOADER: diagnostics (scripts/probe_own.py)
 #ifdef TKR_OWN_PROF
     u64 prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     u64 tprev = __builtin_amdgcn_s_memtime();
@@ -638,6 +694,8 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
         r.tag = tags + slot;
         r.row = rows + (size_t)slot * ROWF;
         r.halves = item_halves;
+        r.rd_staged = false;
+        r.rd_val = 0u;
     };
 
     constexpr uint32_t kItemReaders = SCALAR ? 1u : 2u;
@@ -675,7 +733,90 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
                 idle = 0;
             }
         }
-    } else if (wave <= owner_waves) {                                                  // (SCALAR: waves 1 .. owner_waves; else 0 .. owner_waves)
+    } else if (LOADER && wave > owner_waves - n_loaders && wave <= owner_waves) {
+        // ================= the loaders: partner rows of the queue's next tasks -> LDS =================
+        // (kLoaders waves, positions dealt round robin: one wave's turn is a record through the scalar cache -- a trip of its own --
+        // before it can address the rows; a single loader staged 0.4 tasks per us where the queue wants 0.8)
+        constexpr int SLOTB = load_slot_stride<NP>();
+        uint32_t lcur = 0;
+        int prev_slot = -1;
+        uint32_t prev_pos = 0;
+        uint32_t waited = 0;
+        for (uint32_t pos = (uint32_t)(owner_waves - wave); pos < q_total; pos += (uint32_t)n_loaders) {
+            const int slot = (int)(pos % (uint32_t)ring_slots);
+            const uint32_t idx = qm.locate(pos, lcur, lane);
+            // the slot is free (the task ring_slots positions back took its contents), and the head is not more than kLoadAhead batches behind
+            bool gave_up = false;
+            // (... unless a wave already waits for this very position: an owner whose tasks are batches apart must not wait for a head
+            // that waits for it)
+            auto blocked = [&]() {
+                return (pos >= (uint32_t)ring_slots && ring_freed[slot] != pos - (uint32_t)ring_slots + 1u) ||
+                       (lcur > *reinterpret_cast<volatile uint32_t*>(&q->head_batch) + load_ahead &&
+                        pos >= *reinterpret_cast<volatile uint32_t*>(&q->head));
+            };
+            if (blocked()) {
+                // before this wave waits for the queue, the slot it filled last goes out: the task that waits for THAT slot may be the
+                // one the queue is waiting for (first version: published only behind the next slot's loads -- with three task waves the
+                // workgroup locked up, with seven it merely stalled)
+                if (prev_slot >= 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) ring_ready[prev_slot] = prev_pos + 1u;
+                    prev_slot = -1;
+                }
+                while (blocked()) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (spin_fail(waited, ctl, 0)) { gave_up = true; break; }
+                }
+            }
+            if (gave_up) break;
+            unsigned char* sl = ring + (size_t)slot * SLOTB;
+            // the record: to the slot for the task's wave, and through the scalar cache for this wave's own addressing
+            const int4* rp = prec + (size_t)__builtin_amdgcn_readfirstlane((int)idx) * 8;
+            const int4 h0 = rp[0];
+            int loads = 1;
+            dma16(reinterpret_cast<const unsigned char*>(rp) + lane * 16, sl, lane, 8);
+            const int n_occ = h0.z;
+            {   // the acknowledge word of the task's own row (the buffer version ver + 1 will take): 4 bytes, lane 0
+                const int row_o = h0.x & 0x7fffffff;
+                const uint32_t ver_o = (uint32_t)h0.y;
+                const uint32_t* rdw = T.rdV + (T.imask + 1u) * (size_t)row_o + ((ver_o + 1u) & T.imask);
+                if (lane == 0)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)rdw, (__attribute__((address_space(3))) void*)(sl + 192), 4, 0, 16);
+                loads += 1;
+            }
+            if (n_occ >= 1 && n_occ <= 4) {
+                const int4 oc[4] = {rp[2], rp[3], rp[4], rp[5]};
+#pragma unroll
+                for (int qo = 0; qo < 4; ++qo) {
+                    if (qo < n_occ) {                              // (a, version of a, b | role << 31, version of b): a = user, b = the other item
+                        const int a = oc[qo].x, b = oc[qo].z & 0x3fffffff;
+                        const uint32_t va = (uint32_t)oc[qo].y, vb = (uint32_t)oc[qo].w;
+                        const u64* ua = T.U + (va & 1u) * T.ustride + (size_t)a * T.kp;
+                        const u64* vbp = T.V + (vb & T.imask) * T.istride + (size_t)b * T.kp;
+                        const u64* tb = T.tailV + ((size_t)(vb & T.imask) * st.n_items + b) * (2 * (size_t)tail_halves(T.imask));
+#pragma unroll
+                        for (int c = 0; c < NP; ++c) {
+                            dma16(reinterpret_cast<const unsigned char*>(ua) + c * 1024 + lane * 16, sl + 1024 + ((2 * qo) * NP + c) * 1024, lane, 64);
+                            dma16(reinterpret_cast<const unsigned char*>(vbp) + c * 1024 + lane * 16, sl + 1024 + ((2 * qo + 1) * NP + c) * 1024, lane, 64);
+                        }
+                        dma16(reinterpret_cast<const unsigned char*>(tb), sl + 128 + 16 * qo, lane, 1);     // {bias, tag, its slot, tag}: the first granule is what a task reads
+                        loads += 2 * NP + 1;
+                    }
+                }
+            }
+            // the slot BEFORE this one is complete once at most this slot's loads are outstanding (loads return in order)
+            if (prev_slot >= 0) {
+                wait_vmcnt_at_most(loads);
+                if (lane == 0) ring_ready[prev_slot] = prev_pos + 1u;
+            }
+            prev_slot = slot;
+            prev_pos = pos;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (prev_slot >= 0 && lane == 0) ring_ready[prev_slot] = prev_pos + 1u;
+        spins += waited;
+        ld_block_spins += waited;
+    } else if (wave <= owner_waves) {                                                  // (SCALAR: waves 1 .. owner_waves; else 0 .. owner_waves; LOADER: 0 .. owner_waves - kLoaders)
         // ================= item tasks of the rows this workgroup owns =================
         uint32_t cur = 0;
         while (alive) {
@@ -686,7 +827,33 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             const uint32_t idx = qm.locate(pos, cur, lane);
             if (lane == 0) atomicMax(&q->head_batch, cur);
             int4 w = make_int4(0, 0, 0, 0);
-            if (lane < 8) w = plan_ld<PLAN>(prec, prec_r, (size_t)idx * 8 + lane);
+            LdsStage stg = {nullptr, nullptr, nullptr, 0u};
+            uint32_t staged_rd = 0u;
+            if constexpr (LOADER) {
+                // the loader has (or will have) this position's record and partner rows in slot pos % ring_slots
+                const int rslot = (int)(pos % (uint32_t)ring_slots);
+                unsigned char* sl = ring + (size_t)rslot * load_slot_stride<NP>();
+                uint32_t waited = 0;
+                while (ring_ready[rslot] != pos + 1u) {
+                    if (spin_fail(waited, ctl, 0)) { alive = false; break; }
+                }
+                if (!alive) break;
+                spins += waited;
+                ld_ready_spins += waited;
+                ld_tasks += 1u;
+                asm volatile("" ::: "memory");
+                if (lane < 8) w = *reinterpret_cast<const int4*>(sl + lane * 16);
+                staged_rd = *reinterpret_cast<const volatile uint32_t*>(sl + 192);
+                const int n_st = bcast_i(w.z, 0);
+                if (n_st >= 1 && n_st <= 4) {
+                    stg = LdsStage{sl + 1024, sl + 128, ring_freed + rslot, pos + 1u};
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) ring_freed[rslot] = pos + 1u;   // nothing staged beyond the record
+                }
+            } else {
+                if (lane < 8) w = plan_ld<PLAN>(prec, prec_r, (size_t)idx * 8 + lane);
+            }
 #ifdef TKR_OWN_PROF
             asm volatile("" : "+v"(w.x) :: "memory");
             const u64 t0 = __builtin_amdgcn_s_memtime();
@@ -695,6 +862,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             ItemRow r;
             int row, slot;
             item_row(w, r, row, slot);
+            if constexpr (LOADER) { r.rd_staged = true; r.rd_val = staged_rd; }
             const int rowk = bcast_i(w.x, 0);
             const uint32_t ver = r.ver;
             const int n_occ = bcast_i(w.z, 0), first = bcast_i(w.w, 0), batch = bcast_i(w.x, 1);
@@ -706,6 +874,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             for (int e = 0; e < NE; ++e) { g[e] = 0.f; ms[e] = 0.f; }
             Own o = {};
             float gb = 0.f;
+            const uint32_t spins_before = spins;
             if constexpr (SCALAR) {
                 alive = item_task<NP, false>(st, T, lane, n_occ, first, w, pocc, occt, r, sgd, xch + (size_t)batch * B * 2, xch_bytes, epoch, own, ms, o,
                                              g, gb, ctl, spins, tune);
@@ -716,10 +885,15 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
                 NoFeed feed;
                 LdsOwnStep<NP> own_step{T, lane, r, sgd, ctl, spins};
                 float loss_lane = 0.f;
-                alive = run_task<NP, true, NoFeed, LdsOwnStep<NP>, 4>(st, T, lane, n_occ, first, w, pocc, r.own_p, r.own_ms, r.own_tail, ver, own, ms, o,
-                                                                      g, gb, loss_lane, false, sgd, ctl, spins, nx, feed, own_step);
+                if constexpr (LOADER)
+                    alive = run_task<NP, true, NoFeed, LdsOwnStep<NP>, 4, LdsStage>(st, T, lane, n_occ, first, w, pocc, r.own_p, r.own_ms, r.own_tail, ver,
+                                                                                    own, ms, o, g, gb, loss_lane, false, sgd, ctl, spins, nx, feed, own_step, stg);
+                else
+                    alive = run_task<NP, true, NoFeed, LdsOwnStep<NP>, 4>(st, T, lane, n_occ, first, w, pocc, r.own_p, r.own_ms, r.own_tail, ver, own, ms, o,
+                                                                          g, gb, loss_lane, false, sgd, ctl, spins, nx, feed, own_step);
             }
             if (!alive) break;
+            if constexpr (LOADER && !SCALAR) { if (spins != spins_before) ld_fallback += 1u; }
             if (lane == 0) dotmark[pos & (kDotWin - 1)] = pos + 1u;
 #ifdef TKR_OWN_PROF
             const u64 t1 = __builtin_amdgcn_s_memtime();
@@ -832,6 +1006,12 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     }
 
     if (lane == 0 && spins) atomicAdd(ctl + kCtlSpins, spins);
+    if constexpr (LOADER) {
+        if (lane == 0) {
+            atomicAdd(ctl + kCtlProf + 64, ld_tasks); atomicAdd(ctl + kCtlProf + 65, ld_ready_spins);
+            atomicAdd(ctl + kCtlProf + 66, ld_block_spins); atomicAdd(ctl + kCtlProf + 67, ld_fallback);
+        }
+    }
 #ifdef TKR_OWN_PROF
     if (lane == 0)
         for (int qq = 0; qq < 16; ++qq) atomicAdd(reinterpret_cast<u64*>(ctl + kCtlProf) + qq, prof[qq]);
@@ -896,6 +1076,18 @@ static size_t own_lds_bytes(int np, int nb, int n_items, int n_owner) {
     return head + (size_t)rows_here * (2 * np * 128 + 8) * 4;
 }
 
+// ... with the loader's ring of `slots` slots behind the rows (KB-aligned) and the slots' ready / freed words
+static size_t own_lds_bytes_loader(int np, int nb, int n_items, int n_owner, int slots) {
+    const size_t base = (own_lds_bytes(np, nb, n_items, n_owner) + 1023) & ~(size_t)1023;
+    const size_t stride = np == 1 ? load_slot_stride<1>() : load_slot_stride<2>();
+    return base + (size_t)slots * stride + (size_t)slots * 8 + 16;
+}
+static int own_loader_slots(int np, int nb, int n_items, int n_owner) {            // as many as fit, at most 16; fewer than 4: no loader form
+    int slots = 16;
+    while (slots >= 4 && own_lds_bytes_loader(np, nb, n_items, n_owner, slots) > 160 * 1024) --slots;
+    return slots >= 4 ? slots : 0;
+}
+
 // ... with the planner prologue: its scratch (phase A: sort keys + scan; phase B: the batch's occurrences, owner bitmaps) lies over the
 // rows' region, which may be smaller (test shapes)
 static size_t own_lds_bytes_planned(int np, int nb, int n_items, int n_owner, int B, int npad_items, int own_words) {
@@ -946,7 +1138,7 @@ static int own_launch(const tkr_flow_state* st, const int32_t* prec, const int32
     int dev = 0;
     TKR_CHECK(hipGetDevice(&dev));
     static int cached_cus[64];
-    static bool attr_set[64][5][2];
+    static bool attr_set[64][6][2];
     int cus;
     if (dev >= 0 && dev < 64 && cached_cus[dev] > 0) cus = cached_cus[dev];
     else {
@@ -971,13 +1163,19 @@ static int own_launch(const tkr_flow_state* st, const int32_t* prec, const int32
     if (pa && !(mid && !scalar)) return TKR_EINVAL;
     // a short launch adds its losses up itself (its last workgroup out); tune bit 1 (owner_waves bit 9): always own_loss_kernel
     const bool fold = loss_out && !scalar && n_batches <= 64 && !(tune & 2u);
-    const uint32_t ktune = (tune & ~8u) | (fold ? 8u : 0u);
+    // tune bit 0 (owner_waves bit 8): the loader / consumer form (k <= 128, 12 waves, row-read item tasks, no planner prologue) where
+    // at least four slots of partner rows fit behind the owner's rows
+    const int ring_slots = ((tune & 1u) && mid && !scalar && !pa) ? tkr::own_loader_slots(np, n_batches, st->n_items, n_owner) : 0;
+    if (ring_slots) lds = tkr::own_lds_bytes_loader(np, n_batches, st->n_items, n_owner, ring_slots);
+    static const int ahead_env = getenv("TKR_OWN_AHEAD") ? atoi(getenv("TKR_OWN_AHEAD")) : 0;       // tuning aid
+    const uint32_t ktune = (tune & ~8u & 0xffu) | (fold ? 8u : 0u) | ((uint32_t)ring_slots << 8) | ((uint32_t)(ahead_env > 0 ? ahead_env : tkr::kLoadAhead) << 16);
     const void* fn = pa ? (const void*)tkr::bpr_own_kernel<1, 768, false, true>
+                   : ring_slots ? (const void*)tkr::bpr_own_kernel<1, 768, false, false, true>
                    : np == 1 ? (wide ? (scalar ? (const void*)tkr::bpr_own_kernel<1, 1024, true> : (const void*)tkr::bpr_own_kernel<1, 1024, false>)
                                 : mid ? (scalar ? (const void*)tkr::bpr_own_kernel<1, 768, true> : (const void*)tkr::bpr_own_kernel<1, 768, false>)
                                      : (scalar ? (const void*)tkr::bpr_own_kernel<1, 512, true> : (const void*)tkr::bpr_own_kernel<1, 512, false>))
                              : (scalar ? (const void*)tkr::bpr_own_kernel<2, 512, true> : (const void*)tkr::bpr_own_kernel<2, 512, false>);
-    const int variant = pa ? 4 : np == 2 ? 3 : wide ? 2 : mid ? 1 : 0;
+    const int variant = pa ? 4 : ring_slots ? 5 : np == 2 ? 3 : wide ? 2 : mid ? 1 : 0;
     if (lds > 64 * 1024 && !(dev >= 0 && dev < 64 && attr_set[dev][variant][scalar])) {
         TKR_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (dev >= 0 && dev < 64) attr_set[dev][variant][scalar] = true;
@@ -991,6 +1189,9 @@ static int own_launch(const tkr_flow_state* st, const int32_t* prec, const int32
     hipLaunchKernelGGL((tkr::bpr_own_kernel<NPV, TPBV, SC, PL>), dim3(n_owner), dim3(TPBV), lds, s, *st, r4, o4, occt, ohdr, ohdr_stride, first_batch, \
                        n_batches, batch_size, n_owner, ow, ktune, ctl, loss_out, static_cast<tkr::u64*>(xch), epoch, PL ? *pa : no_plan)
     if (pa) TKR_OWN_LAUNCH(1, 768, false, true);
+    else if (ring_slots)
+        hipLaunchKernelGGL((tkr::bpr_own_kernel<1, 768, false, false, true>), dim3(n_owner), dim3(768), lds, s, *st, r4, o4, occt, ohdr, ohdr_stride,
+                           first_batch, n_batches, batch_size, n_owner, ow, ktune, ctl, loss_out, static_cast<tkr::u64*>(xch), epoch, no_plan);
     else if (np == 1 && wide) { if (scalar) TKR_OWN_LAUNCH(1, 1024, true, false); else TKR_OWN_LAUNCH(1, 1024, false, false); }
     else if (np == 1 && mid) { if (scalar) TKR_OWN_LAUNCH(1, 768, true, false); else TKR_OWN_LAUNCH(1, 768, false, false); }
     else if (np == 1) { if (scalar) TKR_OWN_LAUNCH(1, 512, true, false); else TKR_OWN_LAUNCH(1, 512, false, false); }

@@ -256,6 +256,29 @@ struct TicketSrc {
 template <int G>
 constexpr int group_shift() { return G <= 4 ? 4 : 3; }      // lane L speaks for occurrence L >> shift in the reductions
 
+// Where the FIRST pass of a fetch finds the partner rows.  NoStage: in the granule tables (every pass asks memory).  LdsStage (K2o's
+// loader / consumer form, csrc/bpr_own.hip): a loader wave of the workgroup has copied them into an LDS slot ahead of time --
+// occurrence q: granule row `a` at base + 2q rows, row `b` at base + (2q + 1) rows, b's bias granule at bias + 16q -- and the pass
+// validates the tags it finds THERE: a row that was fresh when the loader asked for it costs no trip through memory at all, a stale
+// one is caught like any other (wait_pair, then a pass on the tables).  The slot is given back once the pass holds it in registers.
+struct NoStage {
+    static constexpr bool on = false;
+    __device__ __forceinline__ bool have() const { return false; }
+};
+struct LdsStage {
+    static constexpr bool on = true;
+    const unsigned char* base;          // the slot's rows (KB-aligned); nullptr: nothing staged for this task
+    const unsigned char* bias;          // the slot's bias granules
+    volatile uint32_t* rel;             // word that frees the slot ...
+    uint32_t relv;                      // ... when it holds this value
+    __device__ __forceinline__ bool have() const { return base != nullptr; }
+};
+template <int NP>
+__device__ __forceinline__ void lds_granule_row(const unsigned char* row, int lane, v4u (&x)[NP]) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) x[q] = *reinterpret_cast<const v4u*>(row + q * 1024 + lane * 16);
+}
+
 template <int NP, int G>
 struct Packed {
     float pa[G][2 * NP];     // item row: the user rows u_q;  user row: v_i - v_j of occurrence q  (0 for q >= n)
@@ -268,11 +291,11 @@ struct Packed {
     int n;
 };
 
-template <int NP, int G, bool ITEM, class Src>
+template <int NP, int G, bool ITEM, class Src, class Stg = NoStage>
 __device__ __forceinline__ bool flow_fetch(const tkr_flow_state& st, const FlowTables& T, int lane, int n, const int4 d,
                                            const u64* own_p, const u64* own_ms, const u64* own_tail, uint32_t own_ver,
                                            float (&own)[2 * NP], float (&ms)[2 * NP], Own& o, bool want_loss, bool sgd,
-                                           uint32_t* ctl, uint32_t& spins, NextTask& nx, Src& feed, Packed<NP, G>& pk) {
+                                           uint32_t* ctl, uint32_t& spins, NextTask& nx, Src& feed, Packed<NP, G>& pk, Stg stg = Stg()) {
     constexpr int NE = 2 * NP;
     static_assert(G <= 4 || G == 8, "group width");
     v4u xo[NP], xm[NP], xt = {0u, 0u, 0u, 0u};
@@ -281,6 +304,7 @@ __device__ __forceinline__ bool flow_fetch(const tkr_flow_state& st, const FlowT
     uint32_t waited = 0;
     const int own_halves = tail_halves(ITEM ? T.imask : 1u);
     const size_t itg = 2 * (size_t)tail_halves(T.imask);           // granules of an item row's tail
+    bool staged_pass = Stg::on && stg.have();                      // the first pass reads what the loader staged
     for (;;) {
         // a pass first ISSUES every load it still needs and only then looks at tags: one round trip per pass, not per row
         if (!o.ok) {
@@ -288,8 +312,23 @@ __device__ __forceinline__ bool flow_fetch(const tkr_flow_state& st, const FlowT
             if (!sgd) issue_row<NP>(own_ms, lane, xm);
             xt = issue_tail(own_tail, lane & (own_halves - 1), own_halves);
         }
+        if constexpr (Stg::on && ITEM) {
+            if (staged_pass) {
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    const int src = (q < n) ? q : 0;
+                    lds_granule_row<NP>(stg.base + (2 * src) * (NP * 1024), lane, xa[q]);
+                    lds_granule_row<NP>(stg.base + (2 * src + 1) * (NP * 1024), lane, xb[q]);
+                    xta[q] = v2u{0u, (uint32_t)bcast_i(d.y, src)};
+                    xtb[q] = *reinterpret_cast<const v2u*>(stg.bias + 16 * src);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the slot's contents are in registers: the loader may have it back
+                if (lane == 0) *stg.rel = stg.relv;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < G; ++q) {
+            if (Stg::on && staged_pass) break;
             const int src = (q < n) ? q : 0;
             const int a = bcast_i(d.x, src), b = bcast_i(d.z, src) & 0x3fffffff;
             const uint32_t va = (uint32_t)bcast_i(d.y, src), vb = (uint32_t)bcast_i(d.w, src);
@@ -329,6 +368,7 @@ __device__ __forceinline__ bool flow_fetch(const tkr_flow_state& st, const FlowT
         // ticket behind the previous task's write-through stores (0.4 us) and then the round trip of its record (0.55 us),
         // a quarter of a wave's time per task.
         if (!nx.have) feed.prefetch(nx, lane);
+        staged_pass = false;
         if (part_ok) break;
         // How far away is what we wait for?  The buffer of version v holds v, v-2, v-4, ... (two buffers per row; v-4, v-8 with
         // four): the tag of the version before means the producer is one or two updates away (poll), an older one at least three
@@ -594,18 +634,20 @@ struct GlobalOwn {
     }
 };
 
-template <int NP, bool ITEM, class Src, class OwnStep, int KBIG = 8>
+template <int NP, bool ITEM, class Src, class OwnStep, int KBIG = 8, class Stg = NoStage>
 __device__ __forceinline__ bool run_task(const tkr_flow_state& st, const FlowTables& T, int lane, int n_occ, int first, const int4 w,
                                          const int4* __restrict__ pocc, const u64* own_p, const u64* own_ms, const u64* own_tail,
                                          uint32_t ver, float (&own)[2 * NP], float (&ms)[2 * NP], Own& o,
                                          float (&g)[2 * NP], float& gb, float& loss_lane, bool want_loss, bool sgd, uint32_t* ctl,
-                                         uint32_t& spins, NextTask& nx, Src& feed, OwnStep& own_step) {
+                                         uint32_t& spins, NextTask& nx, Src& feed, OwnStep& own_step, Stg stg = Stg()) {
 #define TKR_FETCH(GG, nn, dd, PK)                                                                                                  \
     flow_fetch<NP, GG, ITEM>(st, T, lane, nn, dd, own_p, own_ms, own_tail, ver, own, ms, o, want_loss, sgd, ctl, spins, nx, feed, PK)
 #define TKR_ONE(GG, nn, dd)                                                                                    \
     {                                                                                                          \
         Packed<NP, GG> pk;                                                                                     \
-        if (!TKR_FETCH(GG, nn, dd, pk)) return false;                                                          \
+        if (!flow_fetch<NP, GG, ITEM, Src, Stg>(st, T, lane, nn, dd, own_p, own_ms, own_tail, ver, own, ms, o, want_loss, sgd, ctl, spins, nx, \
+                                                feed, pk, stg))                                                \
+            return false;                                                                                      \
         if (!own_step(own, ms, o)) return false;                                                               \
         flow_apply<NP, GG, ITEM>(st, T, lane, pk, own, o, g, gb, loss_lane, want_loss);                          \
         return true;                                                                                           \
