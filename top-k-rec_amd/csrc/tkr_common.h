@@ -105,6 +105,12 @@ __device__ __forceinline__ float softplus_neg(float x) { return fmaxf(-x, 0.f) +
 // stable form of the oracle; the tolerance of the step tests is 3e-4.
 __device__ __forceinline__ float pair_exp(float x) { return __expf(fminf(fmaxf(x, -80.f), 80.f)); }
 __device__ __forceinline__ float pair_sigmoid(float ea, float eb) { return __builtin_amdgcn_rcpf(fmaf(ea, eb, 1.f)); }
+// ... and the pair's term of the loss, log(1 + e^-(a + b)) = log(1 + e^a e^b) - (a + b): one hardware log on the denominator the
+// sigmoid needs anyway (the stable libm form -- an exp and a log1p per pair, B^2 pairs -- was 2.9 of the 25.7 us of a 256-batch).
+// Beyond x = 30 the term is below 1e-13 (and the difference of two 30s has no bits left for it): 0.
+__device__ __forceinline__ float pair_softplus_neg(float ea, float eb, float x) {
+    return x > 30.f ? 0.f : __logf(fmaf(ea, eb, 1.f)) - x;
+}
 
 __device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
 

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void vbpr_pairsum_kernel(const float* __restri
         if (64 * r < B) {                                            // uniform
             const bool in = lane + 64 * r < B;
             s_row += in ? pair_sigmoid(ea_t, be[r]) : 0.f;
-            if (loss_out) loss += in ? softplus_neg(a_t + beta[min(lane + 64 * r, B - 1)]) : 0.f;
+            if (loss_out) loss += in ? pair_softplus_neg(ea_t, be[r], a_t + beta[min(lane + 64 * r, B - 1)]) : 0.f;
             s_col += in ? pair_sigmoid(al[r], eb_t) : 0.f;
         }
     }

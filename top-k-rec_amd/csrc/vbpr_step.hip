@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void vbpr_pair_kernel(const float* __restrict_
     float s_row = 0.f, s_col = 0.f, loss = 0.f;
     for (int o = lane; o < B; o += 64) {
         s_row += pair_sigmoid(ea_t, ebeta[o]);
-        if (loss_out) loss += softplus_neg(a_t + beta[o]);
+        if (loss_out) loss += pair_softplus_neg(ea_t, ebeta[o], a_t + beta[o]);
         s_col += pair_sigmoid(ealpha[o], eb_t);
     }
     s_row = wave_sum(s_row);
