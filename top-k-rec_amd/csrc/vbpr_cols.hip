@@ -346,8 +346,8 @@ __global__ __launch_bounds__(256) void vbpr_pairsum_kernel(const float* __restri
 // run-to-run identical).
 constexpr int kLightRun = 32;
 
-template <int LPC>
-__device__ __forceinline__ void col_accumulate(const int2* __restrict__ cent, int first, int last, const PairSumArrays& ps,
+template <int LPC, class PS>
+__device__ __forceinline__ void col_accumulate(const int2* __restrict__ cent, int first, int last, const PS& ps,
                                                const float* __restrict__ Wraw, int kh, int gl, bool live, float4& g, float& gi) {
     for (int p = first; p < last; p += 4) {
         int2 e[4];
@@ -370,8 +370,8 @@ __device__ __forceinline__ void col_accumulate(const int2* __restrict__ cent, in
     }
 }
 
-template <int LPC>
-__device__ __forceinline__ void col_block(const tkr_vbpr_state& st, const PairSumArrays& ps, const float* __restrict__ Wraw,
+template <int LPC, class PS>
+__device__ __forceinline__ void col_block(const tkr_vbpr_state& st, const PS& ps, const float* __restrict__ Wraw,
                                           const int4* __restrict__ colh, const int2* __restrict__ cent, int cb, int cpb,
                                           float* __restrict__ loss_out, int tune, float* shm) {
     constexpr int G = 256 / LPC;
@@ -439,7 +439,7 @@ __device__ __forceinline__ void col_block(const tkr_vbpr_state& st, const PairSu
                 g.x = fmaf(a, w4[q].x, g.x); g.y = fmaf(a, w4[q].y, g.y); g.z = fmaf(a, w4[q].z, g.z); g.w = fmaf(a, w4[q].w, g.w);
                 gi = fmaf(-sv, s4[q], gi);
             }
-            if (n > 7) col_accumulate<LPC>(cent, beg + 7, beg + n, ps, Wraw, kh, gl, live, g, gi);
+            if (n > 7) col_accumulate<LPC, PS>(cent, beg + 7, beg + n, ps, Wraw, kh, gl, live, g, gi);
         }
     }
     // ---- long runs: all G groups of the block on one column at a time
@@ -453,7 +453,7 @@ __device__ __forceinline__ void col_block(const tkr_vbpr_state& st, const PairSu
         const int lo = min(nq, grp * chunk), hi = min(nq, lo + chunk);
         float4 pg = make_float4(0.f, 0.f, 0.f, 0.f);
         float pgi = 0.f;
-        col_accumulate<LPC>(cent, bq + lo, bq + hi, ps, Wraw, kh, gl, live, pg, pgi);
+        col_accumulate<LPC, PS>(cent, bq + lo, bq + hi, ps, Wraw, kh, gl, live, pg, pgi);
         float* mp = part + grp * (4 * LPC + 1);
         mp[4 * gl + 0] = pg.x; mp[4 * gl + 1] = pg.y; mp[4 * gl + 2] = pg.z; mp[4 * gl + 3] = pg.w;
         if (gl == 0) mp[4 * LPC] = pgi;
@@ -500,38 +500,70 @@ __device__ __forceinline__ void col_block(const tkr_vbpr_state& st, const PairSu
     }
 }
 
-template <int NE, int LPC>
+// INLINE: no pair-sum launch in front of this one -- rows and columns work S_t / T_t out where they need them (PairSumInline; s_in
+// then points at the batch's [alpha | beta | e^alpha | e^beta]), and B / 4 more blocks at the end of the grid add up the pair terms
+// of the loss, one wave per triplet (what vbpr_pairsum_kernel did beside its sums).
+template <int NE, int LPC, bool INLINE>
 __global__ __launch_bounds__(256) void vbpr_update_kernel(
     tkr_vbpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ, const int32_t* __restrict__ occt,
     const int4* __restrict__ hdr, const float* __restrict__ s_in, const float* __restrict__ t_in, const float* __restrict__ P,
     const float* __restrict__ Wraw /*[B][kh]: uce_u(t)*/, const int4* __restrict__ colh, const int2* __restrict__ cent,
-    int n_row_blocks, int cpb, float* __restrict__ loss_out /*the batch's loss words: [B] projection | [B] pair sums | [column blocks]*/,
+    int n_row_blocks, int n_col_blocks, int cpb, float* __restrict__ loss_out /*the batch's loss words: [B] projection | [B] pair sums | [column blocks]*/,
     int ps_B /*batch size*/, int tune) {
     constexpr int G = 256 / LPC;
     constexpr int ROWS_LDS = 2 * 4 * (NE * TKR_WAVE + 1);
     constexpr int COLS_LDS = G * (4 * LPC + 1) + 2 * G;
     __shared__ float shm[ROWS_LDS > COLS_LDS ? ROWS_LDS : COLS_LDS];
-    const PairSumArrays ps{s_in, t_in};
-    if ((int)blockIdx.x < n_row_blocks) {
-        if (tune & 8) return;
-        typedef float (*red_t)[NE * TKR_WAVE + 1];
-        vbpr_rows_body<NE, 4>(st, rec_all, occ, occt, hdr, ps, P, nullptr, nullptr, nullptr, reinterpret_cast<red_t>(shm),
-                              reinterpret_cast<red_t>(shm + 4 * (NE * TKR_WAVE + 1)), blockIdx.x, n_row_blocks);
-        return;
+    typedef float (*red_t)[NE * TKR_WAVE + 1];
+    if constexpr (INLINE) {
+        const float* ab = s_in;
+        if ((int)blockIdx.x >= n_row_blocks + n_col_blocks) {        // the pair terms of the loss: wave per triplet
+            const int lane = threadIdx.x & 63, t = ((int)blockIdx.x - n_row_blocks - n_col_blocks) * 4 + (threadIdx.x >> 6);
+            if (t >= ps_B || !loss_out) return;
+            const float a_t = ab[t], ea_t = ab[2 * ps_B + t];
+            float loss = 0.f;
+            for (int b = lane; b < ps_B; b += 64) loss += pair_softplus_neg(ea_t, ab[3 * ps_B + b], a_t + ab[ps_B + b]);
+            loss = wave_sum(loss);
+            if (lane == 0) loss_out[ps_B + t] = loss;
+            return;
+        }
+        if ((int)blockIdx.x < n_row_blocks) {
+            if (tune & 8) return;
+            PairSumInline<64> ps;
+            ps.load(ab + 2 * ps_B, ab + 3 * ps_B, ps_B);
+            vbpr_rows_body<NE, 4>(st, rec_all, occ, occt, hdr, ps, P, nullptr, nullptr, nullptr, reinterpret_cast<red_t>(shm),
+                                  reinterpret_cast<red_t>(shm + 4 * (NE * TKR_WAVE + 1)), blockIdx.x, n_row_blocks);
+            return;
+        }
+        PairSumInline<LPC> ps;
+        ps.load(ab + 2 * ps_B, ab + 3 * ps_B, ps_B);
+        col_block<LPC>(st, ps, Wraw, colh, cent, (int)blockIdx.x - n_row_blocks, cpb, loss_out ? loss_out + 2 * ps_B : nullptr, tune, shm);
+    } else {
+        const PairSumArrays ps{s_in, t_in};
+        if ((int)blockIdx.x < n_row_blocks) {
+            if (tune & 8) return;
+            vbpr_rows_body<NE, 4>(st, rec_all, occ, occt, hdr, ps, P, nullptr, nullptr, nullptr, reinterpret_cast<red_t>(shm),
+                                  reinterpret_cast<red_t>(shm + 4 * (NE * TKR_WAVE + 1)), blockIdx.x, n_row_blocks);
+            return;
+        }
+        col_block<LPC>(st, ps, Wraw, colh, cent, (int)blockIdx.x - n_row_blocks, cpb, loss_out ? loss_out + 2 * ps_B : nullptr, tune, shm);
     }
-    col_block<LPC>(st, ps, Wraw, colh, cent, (int)blockIdx.x - n_row_blocks, cpb, loss_out ? loss_out + 2 * ps_B : nullptr, tune, shm);
 }
 
 template <int NE, int LPC>
 static void launch_update(const tkr_vbpr_state& st, const int32_t* rec, const int2* occ2, const int32_t* occt, const int4* hdr4,
                           const float* s_buf, const float* t_buf, const float* P, const float* Wm, const int4* colh, const int2* cent,
-                          int B, int cpb, float* loss, hipStream_t stream, int tune) {
+                          int B, int cpb, float* loss, hipStream_t stream, int tune, const float* ab_inline /*or null: S / T from s_buf / t_buf*/) {
     constexpr int G = 256 / LPC;
     if (cpb <= 0 || cpb > G) cpb = G;
     const int n_row_blocks = vbpr_grid(B, 4);
     const int n_col_blocks = (st.d + cpb - 1) / cpb;
-    hipLaunchKernelGGL((vbpr_update_kernel<NE, LPC>), dim3(n_row_blocks + n_col_blocks), dim3(256), 0, stream, st, rec, occ2, occt, hdr4,
-                       s_buf, t_buf, P, Wm, colh, cent, n_row_blocks, cpb, loss, B, tune);
+    if (ab_inline)
+        hipLaunchKernelGGL((vbpr_update_kernel<NE, LPC, true>), dim3(n_row_blocks + n_col_blocks + (loss ? (B + 3) / 4 : 0)), dim3(256), 0, stream, st, rec,
+                           occ2, occt, hdr4, ab_inline, nullptr, P, Wm, colh, cent, n_row_blocks, n_col_blocks, cpb, loss, B, tune);
+    else
+        hipLaunchKernelGGL((vbpr_update_kernel<NE, LPC, false>), dim3(n_row_blocks + n_col_blocks), dim3(256), 0, stream, st, rec, occ2, occt, hdr4,
+                           s_buf, t_buf, P, Wm, colh, cent, n_row_blocks, n_col_blocks, cpb, loss, B, tune);
 }
 
 }  // namespace tkr
@@ -628,6 +660,12 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
     float* slots = loss_out ? workspace + tkr_vbpr_workspace_core_floats(B, kh, st->d) : nullptr;
     if (slots && (n_batches > 512 || (int64_t)n_batches * (int64_t)loss_stride > tkr_vbpr_workspace_floats(B, kh, st->d) - tkr_vbpr_workspace_core_floats(B, kh, st->d)))
         return TKR_EUNSUPPORTED;
+    // The pair sums INSIDE the update launch (two launches per batch: TKR_VBPR_PAIRS=1): rows and column groups work S_t / T_t out for
+    // their own entries from e^alpha / e^beta (PairSumInline).  Measured (round 5, B = 256, d = 20,000): 31.6 us per batch against
+    // 23.1 with the pair-sum launch -- the 4.5 us launch and its boundary go, but every one of the update's ~1,400 blocks now does
+    // 100-250 reciprocals per lane in front of its stores.  Parity-green, not the default.
+    static const int pairs_env = getenv("TKR_VBPR_PAIRS") ? atoi(getenv("TKR_VBPR_PAIRS")) : -1;
+    const bool inline_pairs = pairs_env == 1 && B <= 256;
     for (int b = 0; b < n_batches; ++b) {
         const int32_t* ti = tri_i + (size_t)b * B;
         const int32_t* tj = tri_j + (size_t)b * B;
@@ -648,10 +686,10 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
         else if (NH == 1) hipLaunchKernelGGL((tkr::vbpr_tproject_kernel<1, 16>), dim3(B), dim3(1024), 0, s, *st, ti, tj, tu, tp, tc, te, tcap, B, P, ab2, Wm, l, tune);
         else if (pw == 4) hipLaunchKernelGGL((tkr::vbpr_tproject_kernel<2, 4>), dim3(B), dim3(256), 0, s, *st, ti, tj, tu, tp, tc, te, tcap, B, P, ab2, Wm, l, tune);
         else hipLaunchKernelGGL((tkr::vbpr_tproject_kernel<2, 8>), dim3(B), dim3(512), 0, s, *st, ti, tj, tu, tp, tc, te, tcap, B, P, ab2, Wm, l, tune);
-        if (!(tune & 32)) hipLaunchKernelGGL(tkr::vbpr_pairsum_kernel, dim3((B + 3) / 4), dim3(256), 0, s, ab2, B, s_buf, t_buf, l);
+        if (!(tune & 32) && !inline_pairs) hipLaunchKernelGGL(tkr::vbpr_pairsum_kernel, dim3((B + 3) / 4), dim3(256), 0, s, ab2, B, s_buf, t_buf, l);
         if (tune & 128) continue;
         const int lpc = kh <= 16 ? 4 : (kh <= 32 ? 8 : (kh <= 64 ? 16 : 32));
-#define TKR_UPD(NE_, LPC_) tkr::launch_update<NE_, LPC_>(*st, r, o2, ot, h4, s_buf, t_buf, P, Wm, ch, ce, B, cols_per_block, l, s, tune)
+#define TKR_UPD(NE_, LPC_) tkr::launch_update<NE_, LPC_>(*st, r, o2, ot, h4, s_buf, t_buf, P, Wm, ch, ce, B, cols_per_block, l, s, tune, inline_pairs ? ab2 : nullptr)
         switch (lpc) {
             case 4: TKR_UPD(1, 4); break;
             case 8: TKR_UPD(1, 8); break;

@@ -86,6 +86,55 @@ struct PairSumArrays {
     }
 };
 
+// ... or nowhere: the TEAM lanes that ask (a wave for a row task, the lanes of one column group) work S_t and T_t out themselves from
+// e^alpha, e^beta of the batch ([B] each, 2 KB, cache-hot): 2B / TEAM reciprocals per lane and entry.  What this buys is the launch
+// of the pair-sum kernel between the projection and the update and the boundary in front of it (4.5 + 1.7 of the 25 us of a
+// 256-batch): csrc/vbpr_cols.hip runs the column-plan step in TWO launches with it.  Fixed order per asker.
+template <int TEAM>
+struct PairSumInline {
+    static constexpr int NB = 256 / TEAM;       // a lane's share of the batch (B <= 256): b = lane-in-team + TEAM * r
+    const float* __restrict__ ea;
+    const float* __restrict__ eb;
+    float la[NB], lb[NB];                       // e^alpha_b, e^beta_b of the lane's share, loaded ONCE (load(): one round trip; a loop
+                                                // that fetched them per entry was 16 dependent cache trips per entry: 47 us per batch)
+    __device__ __forceinline__ void load(const float* ea_, const float* eb_, int B) {
+        ea = ea_; eb = eb_;
+        const int l = threadIdx.x & (TEAM - 1);
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            const int b = l + TEAM * r;
+            la[r] = b < B ? ea_[b] : INFINITY;  // (past the batch: 1 / (1 + x * inf) = 0)
+            lb[r] = b < B ? eb_[b] : INFINITY;
+        }
+    }
+    template <int N>
+    __device__ __forceinline__ void get(const int (&tri)[N], int n, float (&S)[N], float (&T)[N]) const {
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            const int x = tri[q < n ? q : 0];
+            const float ea_t = ea[x], eb_t = eb[x];
+            float s = 0.f, t = 0.f;
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                s += pair_sigmoid(ea_t, lb[r]);
+                t += pair_sigmoid(la[r], eb_t);
+            }
+            if constexpr (TEAM == 64) {
+                s = wave_sum(s);
+                t = wave_sum(t);
+            } else {
+#pragma unroll
+                for (int o = TEAM / 2; o > 0; o >>= 1) {
+                    s += __shfl_xor(s, o, 64);
+                    t += __shfl_xor(t, o, 64);
+                }
+            }
+            S[q] = s;
+            T[q] = t;
+        }
+    }
+};
+
 template <int NE, int kVTeam, typename PairSums>
 __device__ __forceinline__ void vbpr_rows_body(
     const tkr_vbpr_state& st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ,
