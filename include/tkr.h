@@ -211,8 +211,14 @@ int tkr_bpr_own_run(const tkr_flow_state* st, const int32_t* prec, const int32_t
 /* One call for a SHORT training call -- K1 of a chunk and the persistent step on it, back to back: tkr_sample_plan_owned with the
  * arguments of `plan` (a struct: a caller fills it once per plan buffer and changes first_triplet / n_batches per call), then
  * tkr_bpr_own_run on batches [first_batch, first_batch + n_batches) of that plan, with the caller's two events (hipEvent_t or NULL)
- * recorded around the step launch.  Four launches without a trip back through the host language between them: a 20-batch call
- * is ~105 us of device work, and an interpreter between the launches leaves the device waiting for the host. */
+ * recorded around the step launch.  No trip back through the host language between them: a 20-batch call is ~90 us of device
+ * work, and an interpreter between the launches leaves the device waiting for the host.
+ * From 0.1.16 the whole plan is what most short calls run, and then K1 runs INSIDE the step's launch (ONE launch: workgroups
+ * 0 .. n_batches-1 plan a batch each in front of the step, csrc/bpr_own.hip PLAN; the last workgroup out adds the losses up): when
+ * first_batch == 0, n_batches == plan->n_batches <= min(64, n_owner), batch_size <= 256, k <= 128, the default step form, n_users and
+ * n_items below 2^25; otherwise tkr_sample_plan_owned's launches + the step's, as before.  Same words in every plan array and the same
+ * tables either way.  owner_waves bit 12: never the one-launch form; bit 9: the losses always by their own launch; bit 8: the loader /
+ * consumer form of the step (long launches only; measured slower). */
 typedef struct tkr_plan_call {
     const int32_t *tr_users, *row_ptr, *pos_cols, *cols_sorted;
     int32_t *ucnt, *icnt;
