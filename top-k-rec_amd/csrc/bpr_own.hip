@@ -602,9 +602,14 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             int4* task_b = pa.task + (size_t)b * n3;
             int2* occ_b = pa.occ + (size_t)b * n3;
             int32_t* occt_b = pa.occt + (size_t)b * n3;
-            plan_phase_a<TPB, 256>(scratch, b, pa.tr_users, pa.n_tr, pa.row_ptr, pa.pos_cols, pa.cols_sorted, pa.n_items, pa.seed,
-                                   pa.first_triplet + (uint64_t)b * (uint64_t)B, B, pa.npad_items, pa.out_u + (size_t)b * B, pa.out_i + (size_t)b * B,
-                                   pa.out_j + (size_t)b * B, task_b, occ_b, occt_b, pa.touch_u, pa.touch_i, pa.reg_sort_ok != 0);
+            if (pa.reg_sort_ok != 0 && pa.npad_items == 512 && B > 128)      // the common short call (batch 129 .. 256): users and items side by side
+                plan_phase_a_split<TPB>(scratch, b, pa.tr_users, pa.n_tr, pa.row_ptr, pa.pos_cols, pa.cols_sorted, pa.n_items, pa.seed,
+                                        pa.first_triplet + (uint64_t)b * (uint64_t)B, B, pa.out_u + (size_t)b * B, pa.out_i + (size_t)b * B,
+                                        pa.out_j + (size_t)b * B, task_b, occ_b, occt_b, pa.touch_u, pa.touch_i);
+            else
+                plan_phase_a<TPB, 256>(scratch, b, pa.tr_users, pa.n_tr, pa.row_ptr, pa.pos_cols, pa.cols_sorted, pa.n_items, pa.seed,
+                                       pa.first_triplet + (uint64_t)b * (uint64_t)B, B, pa.npad_items, pa.out_u + (size_t)b * B, pa.out_i + (size_t)b * B,
+                                       pa.out_j + (size_t)b * B, task_b, occ_b, occt_b, pa.touch_u, pa.touch_i, pa.reg_sort_ok != 0);
             PLAN_STAMP(1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // the touch atomics of every wave are out
             __syncthreads();

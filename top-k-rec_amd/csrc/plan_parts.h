@@ -77,10 +77,10 @@ __device__ __forceinline__ void lane_step(uint32_t (&k)[R], int lane, bool keep_
 }
 // n = R * T keys, ascending over e = R * thread + r; `xbuf`: n words of LDS, free on entry (barrier inside before its first use)
 template <int T, int R>
-__device__ __forceinline__ void register_sort(uint32_t (&k)[R], uint32_t* xbuf, bool active = true) {
+__device__ __forceinline__ void register_sort(uint32_t (&k)[R], uint32_t* xbuf, bool active = true, int tid_role = -1) {
     // `active` (wave-uniform): false for the waves of a LARGER workgroup than the T sorting threads (the planner prologue of
     // csrc/bpr_own.hip runs on 768): they only meet the others at the barriers
-    const int tid = threadIdx.x, lane = tid & (TKR_WAVE - 1);
+    const int tid = tid_role >= 0 ? tid_role : (int)threadIdx.x, lane = tid & (TKR_WAVE - 1);      // (tid_role: the thread's number inside a GROUP of T threads of a larger workgroup)
     constexpr int n = R * T;
     constexpr int LOGN = __builtin_ctz(n);
     static_assert((n & (n - 1)) == 0, "power of two");
@@ -286,6 +286,122 @@ __device__ __forceinline__ void plan_phase_a(unsigned char* smem, int b, const i
         occt[B + p] = t;
     }
     for (int s = n_uq + n_iq + threadIdx.x; s < 3 * B; s += T) task[s] = make_int4(-1, 0, 0, 0);
+    __syncthreads();
+    K1_STAMP(7);
+}
+
+// ---- phase A with the user side and the item side of a batch on TWO wave groups at once (the planner prologue of csrc/bpr_own.hip,
+// 129 <= B <= 256): threads 0..255 sort the users and emit their task heads and occurrence lists while threads 256..511 do the same
+// for the items (one after the other the two sides are 4.3 + 5.1 us of a 17 us phase); further threads only meet the barriers.  Both
+// sides pass the same barriers in the same order: a register sort of R x 256 keys crosses waves in 3 steps whatever R is, the head
+// count of either side is one scan.  Same words as plan_phase_a.  `smem`: (256 + 512) * 8 + 64 bytes.
+template <int T>
+__device__ __forceinline__ void plan_phase_a_split(unsigned char* smem, int b, const int32_t* __restrict__ tr_users, uint32_t n_tr,
+                                                   const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ pos_cols,
+                                                   const int32_t* __restrict__ cols_sorted, uint32_t n_items, uint64_t seed, uint64_t g0, int B,
+                                                   int32_t* __restrict__ bu, int32_t* __restrict__ bi, int32_t* __restrict__ bj,
+                                                   int4* __restrict__ task, int2* __restrict__ occ, int32_t* __restrict__ occt,
+                                                   uint32_t* __restrict__ touch_u, uint32_t* __restrict__ touch_i) {
+    static_assert(T >= 512 && T % 64 == 0, "two groups of 256 threads");
+    constexpr int TS = 256;
+    uint64_t* keys_u = reinterpret_cast<uint64_t*>(smem);                     // [256]
+    uint64_t* keys_i = keys_u + 256;                                          // [512]
+    int* scan = reinterpret_cast<int*>(keys_i + 512);                         // [2][4] head counts of the waves of either side
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const int tid = threadIdx.x, role = tid >> 8, rt = tid & 255, lane = tid & 63, rw = rt >> 6;
+    K1_STAMP(0);
+    for (int t = tid; t < B; t += T) {
+        int u, i, j;
+        draw_triplet(tr_users, n_tr, row_ptr, pos_cols, cols_sorted, n_items, k0, k1, g0 + t, u, i, j);
+        bu[t] = u; bi[t] = i; bj[t] = j;
+    }
+    __threadfence_block();
+    __syncthreads();
+    K1_STAMP(1);
+    constexpr int ob = 9;                                                     // occurrence bits of the 32-bit keys: 512 item occurrences
+    const bool active = role < 2;
+    uint64_t* keys = role == 0 ? keys_u : keys_i;
+    // ---- the sorts (eight barriers either way)
+    if (role == 1) {
+        uint32_t k[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int o = rt * 2 + r;
+            k[r] = o < B ? (((uint32_t)bi[o] << ob) | (uint32_t)o) : o < 2 * B ? (((uint32_t)bj[o - B] << ob) | (uint32_t)o) : 0xffffffffu;
+        }
+        register_sort<TS, 2>(k, reinterpret_cast<uint32_t*>(keys_i), true, rt);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t v = k[r];
+            keys_i[rt * 2 + r] = v == 0xffffffffu ? ~0ull : (((uint64_t)(v >> ob) << 32) | (uint64_t)(v & ((1u << ob) - 1u)));
+        }
+        __syncthreads();
+    } else {
+        uint32_t k[1];
+        k[0] = (role == 0 && rt < B) ? (((uint32_t)bu[rt] << ob) | (uint32_t)rt) : 0xffffffffu;
+        register_sort<TS, 1>(k, reinterpret_cast<uint32_t*>(keys_u), role == 0, rt);
+        __syncthreads();
+        if (role == 0) {
+            const uint32_t v = k[0];
+            keys_u[rt] = v == 0xffffffffu ? ~0ull : (((uint64_t)(v >> ob) << 32) | (uint64_t)(v & ((1u << ob) - 1u)));
+        }
+        __syncthreads();
+    }
+    K1_STAMP(2);
+    // ---- task heads: a thread's share of the sorted keys, the head counts scanned per side
+    const int n = role == 0 ? B : 2 * B;
+    const int per = role == 0 ? 1 : 2;
+    const int beg = active ? min(rt * per, n) : 0, end = active ? min(beg + per, n) : 0;
+    int cnt = 0;
+    for (int p = beg; p < end; ++p) cnt += (p == 0) || ((uint32_t)(keys[p] >> 32) != (uint32_t)(keys[p - 1] >> 32));
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < TKR_WAVE; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (active && lane == TKR_WAVE - 1) scan[role * 4 + rw] = incl;
+    __syncthreads();
+    int tot_u = 0, tot_i = 0, s = incl - cnt;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int cu = scan[w], ci = scan[4 + w];
+        tot_u += cu; tot_i += ci;
+        if (w < rw) s += role == 0 ? cu : ci;
+    }
+    if (active) {
+        const int slot0 = role == 0 ? 0 : tot_u, occ0 = role == 0 ? 0 : B;
+        uint32_t* touch = role == 0 ? touch_u : touch_i;
+        for (int p = beg; p < end; ++p) {
+            const uint32_t row = (uint32_t)(keys[p] >> 32);
+            if ((p == 0) || (row != (uint32_t)(keys[p - 1] >> 32))) {
+                int q = p + 1;
+                while (q < n && (uint32_t)(keys[q] >> 32) == row) ++q;
+                task[slot0 + s] = make_int4((int)(row | ((uint32_t)role << 31)), occ0 + p, q - p, 0);
+                atomicOr(&touch[(size_t)row * kTouchWords + (b >> 5)], 1u << (b & 31));
+                ++s;
+            }
+        }
+        // ---- occurrence lists
+        if (role == 0) {
+            if (rt < B) {
+                const int t = (int)(uint32_t)keys_u[rt];
+                occ[rt] = make_int2(bi[t], bj[t]);
+                occt[rt] = t;
+            }
+        } else {
+            for (int p = rt; p < 2 * B; p += 256) {
+                const int o = (int)(uint32_t)keys_i[p];
+                const bool rj = o >= B;
+                const int t = rj ? o - B : o;
+                const uint32_t other = (uint32_t)(rj ? bi[t] : bj[t]);
+                occ[B + p] = make_int2(bu[t], (int)(other | ((uint32_t)rj << 31)));
+                occt[B + p] = t;
+            }
+        }
+    }
+    for (int q = tot_u + tot_i + tid; q < 3 * B; q += T) task[q] = make_int4(-1, 0, 0, 0);
     __syncthreads();
     K1_STAMP(7);
 }
