@@ -256,12 +256,20 @@ __global__ __launch_bounds__((kTeam * TKR_WAVE)) void bpr_step_kernel(
         if constexpr (!SGD) msb_raw = st.msb[boff];
         const float br = is_item ? br_raw : 0.f, msb = is_item ? msb_raw : 0.f;
 
+        // occurrences 4 .. 67 of the task (the first four ride in the record): asked for NOW, in one load beside the first group's rows.
+        // Fetched group by group they were a trip of their own in front of every further group's row loads: a 16-occurrence light
+        // task (batch 8192) was 7 dependent trips, the tail of the launch.
+        int2 omore = make_int2(0, 0);
+        if (n_occ > 4 && lane < n_occ - 4) omore = occ[first + (4 + lane) * team];
         for (int done = 0; done < n_occ; done += 4) {
             const int n = min(4, n_occ - done);
             int oa[4], ob[4];
             if (done == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { oa[q] = bcast_i(word, 4 + 2 * q); ob[q] = bcast_i(word, 5 + 2 * q); }
+            } else if (done + 4 <= 68) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { oa[q] = bcast_i(omore.x, (done - 4 + q) & 63); ob[q] = bcast_i(omore.y, (done - 4 + q) & 63); }
             } else {                              // very heavy rows: fetch the next 4 occurrences
                 int2 o = make_int2(0, 0);
                 if (lane < n) o = occ[first + (done + lane) * team];
@@ -332,7 +340,8 @@ static int step_grid(int B, int team) {
     const int lpb = team;                            // oracle/plan_np.py light_per_block
     const int light = (3 * B + lpb - 1) / lpb;
     int grid = light + 16;
-    if (grid > 2048) grid = 2048;
+    static const int cap = getenv("TKR_K2_GRID") ? atoi(getenv("TKR_K2_GRID")) : 2048;      // tuning aid
+    if (grid > cap) grid = cap;
     return grid;
 }
 
