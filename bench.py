@@ -63,7 +63,7 @@ def topk_roofline(tf, k):
             'bf16x3': 'bf16x3 split, 6 x v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulate: executed bf16 rate %.0f TFLOP/s of %.0f '
                       'dense' % (6 * tf, MFMA_BF16_PEAK_TF),
             'fp32': 'v_mfma_f32_32x32x2_f32'}[math]
-    return {'kernel': 'tkr::score_topk_kernel' if math == 'fp32' else 'tkr::score_topk_bf16_kernel', 'bound': 'mfma', 'achieved': tf,
+    return {'kernel': ('tkr::score_topk_slab_kernel' if k > 256 else 'tkr::score_topk_kernel') if math == 'fp32' else 'tkr::score_topk_bf16_kernel', 'bound': 'mfma', 'achieved': tf,
             'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak, 'arithmetic': what, 'vs_fp32_mfma_peak': tf / MFMA_F32_PEAK_TF}
 
 
@@ -576,6 +576,7 @@ def summary(out):
          'B8192_frac': leg('throughput_mode', 'roofline', 'frac'), 'B65536_frac': leg('throughput_mode_B65536', 'roofline', 'frac'),
          'topk_ms': leg('topk', 'ms_per_pass'), 'topk_frac': leg('topk', 'roofline', 'frac'),
          'topk_nf_ms': leg('topk_netflix_shape', 'ms_per_pass'), 'topk_nf_frac': leg('topk_netflix_shape', 'roofline', 'frac'),
+         'topk_k512_ms': leg('topk_wide', 'k512', 'ms_per_pass'), 'topk_k768_ms': leg('topk_wide', 'k768', 'ms_per_pass'),
          'vbpr_ms': leg('vbpr', 'ms_per_step'), 'vbpr_frac': leg('vbpr', 'roofline', 'frac'),
          'vbpr_dc128_ms': leg('vbpr', 'dense_dc128', 'ms_per_step'),
          'cpu_Mtps': (leg('cpu_baseline', 'value') or 0) / 1e6 or None}
@@ -717,6 +718,14 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             topk['cpu_baseline'] = topk_cpu_baseline(r, k)
         out['topk'] = topk
+        if rank == 0 and world == 1:
+            # the widths above the matrix-pipe arithmetics: k = 512 (what the trainer goes to) and 768 (K4's limit) through the slab
+            # kernels on fp32 MFMA (csrc/topk.hip score_topk_slab_kernel<2 / 3>; the 3-slab form spills 168 registers)
+            out['topk_wide'] = {}
+            for kw in (512, 768):
+                tw = topk_bench(r, kw, device, rank, world, reps=2)
+                out['topk_wide']['k%d' % kw] = {'value': tw['value'], 'unit': 'users/s', 'ms_per_pass': tw['ms_per_pass'],
+                                                'roofline': {q: tw['roofline'][q] for q in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac')}}
         if rank == 0 and world == 1:
             out['topk_netflix_shape'] = topk_bench_netflix(k, device)
             out['vbpr'] = vbpr_bench(r, csr, k, device)
