@@ -346,22 +346,24 @@ __global__ __launch_bounds__(256) void vbpr_pairsum_kernel(const float* __restri
 // run-to-run identical).
 constexpr int kLightRun = 32;
 
-template <int LPC, class PS>
+// UN entries of a run in flight at a time: 4 behind a light run's header; 16 on the long runs of a narrow dense feat (a column meets
+// all 2B triplet rows: 32 entries per group -- at 4 per round that was eight dependent trips, 8 of the update's 11 us at d_c = 128)
+template <int LPC, class PS, int UN = 4>
 __device__ __forceinline__ void col_accumulate(const int2* __restrict__ cent, int first, int last, const PS& ps,
                                                const float* __restrict__ Wraw, int kh, int gl, bool live, float4& g, float& gi) {
-    for (int p = first; p < last; p += 4) {
-        int2 e[4];
-        int et[4];
-        float tt[4], ss[4];
-        float4 wr[4];
+    for (int p = first; p < last; p += UN) {
+        int2 e[UN];
+        int et[UN];
+        float tt[UN], ss[UN];
+        float4 wr[UN];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { e[q] = cent[min(p + q, last - 1)]; et[q] = e[q].x; }
+        for (int q = 0; q < UN; ++q) { e[q] = cent[min(p + q, last - 1)]; et[q] = e[q].x; }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < UN; ++q)
             wr[q] = live ? *reinterpret_cast<const float4*>(Wraw + (size_t)e[q].x * kh + 4 * gl) : make_float4(0.f, 0.f, 0.f, 0.f);
-        ps.get(et, 4, ss, tt);
+        ps.get(et, UN, ss, tt);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < UN; ++q) {
             const float sv = (p + q < last) ? __int_as_float(e[q].y) : 0.f;
             const float a = -sv * tt[q];
             g.x = fmaf(a, wr[q].x, g.x); g.y = fmaf(a, wr[q].y, g.y); g.z = fmaf(a, wr[q].z, g.z); g.w = fmaf(a, wr[q].w, g.w);
@@ -370,7 +372,7 @@ __device__ __forceinline__ void col_accumulate(const int2* __restrict__ cent, in
     }
 }
 
-template <int LPC, class PS>
+template <int LPC, class PS, int UNL = 4>
 __device__ __forceinline__ void col_block(const tkr_vbpr_state& st, const PS& ps, const float* __restrict__ Wraw,
                                           const int4* __restrict__ colh, const int2* __restrict__ cent, int cb, int cpb,
                                           float* __restrict__ loss_out, int tune, float* shm) {
@@ -453,7 +455,7 @@ __device__ __forceinline__ void col_block(const tkr_vbpr_state& st, const PS& ps
         const int lo = min(nq, grp * chunk), hi = min(nq, lo + chunk);
         float4 pg = make_float4(0.f, 0.f, 0.f, 0.f);
         float pgi = 0.f;
-        col_accumulate<LPC, PS>(cent, bq + lo, bq + hi, ps, Wraw, kh, gl, live, pg, pgi);
+        col_accumulate<LPC, PS, UNL>(cent, bq + lo, bq + hi, ps, Wraw, kh, gl, live, pg, pgi);
         float* mp = part + grp * (4 * LPC + 1);
         mp[4 * gl + 0] = pg.x; mp[4 * gl + 1] = pg.y; mp[4 * gl + 2] = pg.z; mp[4 * gl + 3] = pg.w;
         if (gl == 0) mp[4 * LPC] = pgi;
@@ -503,7 +505,7 @@ __device__ __forceinline__ void col_block(const tkr_vbpr_state& st, const PS& ps
 // INLINE: no pair-sum launch in front of this one -- rows and columns work S_t / T_t out where they need them (PairSumInline; s_in
 // then points at the batch's [alpha | beta | e^alpha | e^beta]), and B / 4 more blocks at the end of the grid add up the pair terms
 // of the loss, one wave per triplet (what vbpr_pairsum_kernel did beside its sums).
-template <int NE, int LPC, bool INLINE>
+template <int NE, int LPC, bool INLINE, int UNL = 4>
 __global__ __launch_bounds__(256) void vbpr_update_kernel(
     tkr_vbpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ, const int32_t* __restrict__ occt,
     const int4* __restrict__ hdr, const float* __restrict__ s_in, const float* __restrict__ t_in, const float* __restrict__ P,
@@ -546,14 +548,15 @@ __global__ __launch_bounds__(256) void vbpr_update_kernel(
                                   reinterpret_cast<red_t>(shm + 4 * (NE * TKR_WAVE + 1)), blockIdx.x, n_row_blocks);
             return;
         }
-        col_block<LPC>(st, ps, Wraw, colh, cent, (int)blockIdx.x - n_row_blocks, cpb, loss_out ? loss_out + 2 * ps_B : nullptr, tune, shm);
+        col_block<LPC, PairSumArrays, UNL>(st, ps, Wraw, colh, cent, (int)blockIdx.x - n_row_blocks, cpb, loss_out ? loss_out + 2 * ps_B : nullptr, tune, shm);
     }
 }
 
 template <int NE, int LPC>
 static void launch_update(const tkr_vbpr_state& st, const int32_t* rec, const int2* occ2, const int32_t* occt, const int4* hdr4,
                           const float* s_buf, const float* t_buf, const float* P, const float* Wm, const int4* colh, const int2* cent,
-                          int B, int cpb, float* loss, hipStream_t stream, int tune, const float* ab_inline /*or null: S / T from s_buf / t_buf*/) {
+                          int B, int cpb, float* loss, hipStream_t stream, int tune, const float* ab_inline /*or null: S / T from s_buf / t_buf*/,
+                          bool long_runs) {
     constexpr int G = 256 / LPC;
     if (cpb <= 0 || cpb > G) cpb = G;
     const int n_row_blocks = vbpr_grid(B, 4);
@@ -561,6 +564,9 @@ static void launch_update(const tkr_vbpr_state& st, const int32_t* rec, const in
     if (ab_inline)
         hipLaunchKernelGGL((vbpr_update_kernel<NE, LPC, true>), dim3(n_row_blocks + n_col_blocks + (loss ? (B + 3) / 4 : 0)), dim3(256), 0, stream, st, rec,
                            occ2, occt, hdr4, ab_inline, nullptr, P, Wm, colh, cent, n_row_blocks, n_col_blocks, cpb, loss, B, tune);
+    else if (long_runs)           // a narrow dense feat: every column's run is split over the block's groups, 16 entries in flight (168 registers; 32: slower, 21.5 vs 19.7 us)
+        hipLaunchKernelGGL((vbpr_update_kernel<NE, LPC, false, 16>), dim3(n_row_blocks + n_col_blocks), dim3(256), 0, stream, st, rec, occ2, occt, hdr4,
+                           s_buf, t_buf, P, Wm, colh, cent, n_row_blocks, n_col_blocks, cpb, loss, B, tune);
     else
         hipLaunchKernelGGL((vbpr_update_kernel<NE, LPC, false>), dim3(n_row_blocks + n_col_blocks), dim3(256), 0, stream, st, rec, occ2, occt, hdr4,
                            s_buf, t_buf, P, Wm, colh, cent, n_row_blocks, n_col_blocks, cpb, loss, B, tune);
@@ -666,6 +672,7 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
     // 100-250 reciprocals per lane in front of its stores.  Parity-green, not the default.
     static const int pairs_env = getenv("TKR_VBPR_PAIRS") ? atoi(getenv("TKR_VBPR_PAIRS")) : -1;
     const bool inline_pairs = pairs_env == 1 && B <= 256;
+    const bool long_runs = 2.0 * B * (double)row_cap / st->d > (double)tkr::kLightRun;      // (row_cap: the longest row of feat)
     for (int b = 0; b < n_batches; ++b) {
         const int32_t* ti = tri_i + (size_t)b * B;
         const int32_t* tj = tri_j + (size_t)b * B;
@@ -689,7 +696,7 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
         if (!(tune & 32) && !inline_pairs) hipLaunchKernelGGL(tkr::vbpr_pairsum_kernel, dim3((B + 3) / 4), dim3(256), 0, s, ab2, B, s_buf, t_buf, l);
         if (tune & 128) continue;
         const int lpc = kh <= 16 ? 4 : (kh <= 32 ? 8 : (kh <= 64 ? 16 : 32));
-#define TKR_UPD(NE_, LPC_) tkr::launch_update<NE_, LPC_>(*st, r, o2, ot, h4, s_buf, t_buf, P, Wm, ch, ce, B, cols_per_block, l, s, tune, inline_pairs ? ab2 : nullptr)
+#define TKR_UPD(NE_, LPC_) tkr::launch_update<NE_, LPC_>(*st, r, o2, ot, h4, s_buf, t_buf, P, Wm, ch, ce, B, cols_per_block, l, s, tune, inline_pairs ? ab2 : nullptr, long_runs)
         switch (lpc) {
             case 4: TKR_UPD(1, 4); break;
             case 8: TKR_UPD(1, 8); break;
