@@ -85,6 +85,32 @@ def test_sample_plan_bit_exact(hip, n_users, n_items, B, nb, chunks):
             np.testing.assert_array_equal(g, e, err_msg=name)
 
 
+def test_negative_draw_membership_at_every_search_width(hip):
+    """the membership search of the negative draw (csrc/sampler_draw.h is_member, a k-ary search) on rows of every length around
+    powers of two and of four, and on rows with few free items so that most candidates ARE members: (u, i, j) equal the oracle's"""
+    from single import _engine
+    n_items = 9000
+    rng = np.random.Generator(np.random.PCG64(7))
+    degs = [1, 2, 3, 15, 16, 17, 31, 32, 33, 34, 63, 64, 65, 511, 512, 513, 528, 529, 1000, 4095, 4096, 4097, 8191, 8192, 8193, 8990, 8999]
+    tr = {u: [int(x) for x in rng.permutation(n_items)[:d]] for u, d in enumerate(degs)}
+    # ... and rows that are dense runs with single gaps (candidates hit the pivots themselves)
+    tr[len(degs)] = [x for x in range(n_items) if x % 16 != 0]
+    tr[len(degs) + 1] = [x for x in range(n_items) if x % 563 != 1]
+    tr_users = list(tr.keys())
+    n_users = len(tr_users)
+    row_ptr, pos, srt = P.build_csr(tr, n_users)
+    dev = torch.device('cuda')
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
+    B, nb = 512, 8
+    plan = _engine.PlanBuffers(nb, B, dev)
+    hip.sample_plan(csr, n_users, n_items, 99, 12345, nb, B, _engine.UpdateCounters(n_users, n_items, dev), plan)
+    u, i, j = P.sample_triplets(tr_users, row_ptr, pos, srt, n_items, 99, 12345, nb * B)
+    np.testing.assert_array_equal(plan.u.cpu().numpy().reshape(-1), u)
+    np.testing.assert_array_equal(plan.i.cpu().numpy().reshape(-1), i)
+    np.testing.assert_array_equal(plan.j.cpu().numpy().reshape(-1), j)
+    assert len(set(u.tolist())) == n_users            # every row length was drawn from
+
+
 def test_sample_plan_ctl_offset(hip):
     """the device-side batch base (ctl) walks the same stream as first_triplet does"""
     from single import _engine

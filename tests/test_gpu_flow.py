@@ -396,6 +396,56 @@ def test_short_calls_in_one_c_call_equal_two(monkeypatch):
     assert torch.equal(out[True][2], out[False][2]) and torch.equal(out[True][3], out[False][3])
 
 
+def test_the_same_short_call_again_skips_planning_decisions_not_work(monkeypatch):
+    """BprEngine._run_again: a short call repeated (same data, batch size and count) goes straight to the C call of the other plan
+    buffer.  Tables, losses, counters and stream position equal those of an engine that plans and steps in separate calls, also
+    with a settle(), another batch count, other training data and a changed switch in between (each must take the long way once)."""
+    from single import _engine
+    n_users, n_items, k = 900, 200, 64
+    tr, tr_users = _toy(n_users, n_items, seed=3)
+    row_ptr, pos, srt = P.build_csr(tr, n_users)
+    dev = torch.device('cuda')
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
+    csr2 = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.02, mode='l2')
+    out = {}
+    for fuse in (True, False):
+        monkeypatch.setenv('TKR_FUSE_SHORT', '1' if fuse else '0')
+        e = _engine.BprEngine(n_users, n_items, k, hp, dev, seed=21)
+        real, taken = e._run_again, []
+
+        def spy(*a, _real=real, _taken=taken):
+            r = _real(*a)
+            _taken.append(r is not False)
+            return r
+        e._run_again = spy
+        losses = []
+        script = ([(csr, 20)] * 4 + [('settle', 0)] + [(csr, 20)] * 2 + [(csr, 7)] * 3 + [(csr2, 7)] * 2 + [('waves', 0)] + [(csr2, 7)] * 2 +
+                  [(csr2, 600), (csr2, 5)])
+        for what, m in script:
+            if what == 'settle':
+                e.settle()
+            elif what == 'waves':
+                e.cfg.own_waves = 7
+            else:
+                losses.append(e.run_batches(what, m, 256, want_loss=True).clone())
+        e.check()
+        if fuse:
+            # asked (what the last call left behind fits) and answered: 4x20: -, no (the other buffer's call is not there yet), yes, yes |
+            # settle | yes, yes | 3x7: yes, yes, yes | other data: -, no (the other buffer's call names the first data), | switch: -, yes |
+            # more than a chunk: no | -
+            assert taken == [False, True, True, True, True, True, True, True, False, True, False], taken
+        else:
+            assert not any(taken)
+        out[fuse] = ([t.clone() for n in ('U', 'V', 'b') for t in e.get(n)], torch.cat(losses), e.cnt.ucnt.clone(), e.cnt.icnt.clone(),
+                     e.triplets_drawn)
+    for x, y in zip(out[True][0], out[False][0]):
+        assert torch.equal(x, y)
+    assert torch.equal(out[True][1], out[False][1])
+    assert torch.equal(out[True][2], out[False][2]) and torch.equal(out[True][3], out[False][3])
+    assert out[True][4] == out[False][4] == (6 * 20 + 7 * 7 + 605) * 256
+
+
 @pytest.mark.parametrize('bufs', [2, 4])
 def test_fused_exchange_of_the_granule_tables(monkeypatch, bufs):
     """dist.ItemSync on the dataflow layout (tkr_sync_flow_snapshot / pack / unpack) against the same exchange through get /

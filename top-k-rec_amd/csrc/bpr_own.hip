@@ -96,6 +96,14 @@ __device__ __forceinline__ bool plan_rendezvous(uint32_t* counter, uint32_t n, b
 
 constexpr uint32_t kOwnInvalid = 0xffffffffu;
 
+// LDS of the planner prologue's two phases (they follow each other in the same bytes); the mirror of csrc/plan_parts.h lies behind
+__host__ __device__ inline size_t plan_scratch_bytes(int B, int npad_items, int n_owner, int own_words) {
+    size_t a = (size_t)npad_items * 8 + (kWideThreads / TKR_WAVE + 1) * 4;
+    if (a < (size_t)(256 + 512) * 8 + 64) a = (size_t)(256 + 512) * 8 + 64;                  // plan_phase_a_split
+    const size_t pb = (size_t)3 * B * 20 + (size_t)4 * n_owner * (own_words + 1) + (kWideThreads / TKR_WAVE + 1) * 4 + 16 + (size_t)3 * B * 32;    // plan_phase_b_wide_lds
+    return ((a > pb ? a : pb) + 15) & ~(size_t)15;
+}
+
 // int4 number `idx16` of the plan's records.  PLAN (the records were written by other workgroups of THIS launch): past the L1
 template <bool PLAN>
 __device__ __forceinline__ int4 plan_ld(const int4* __restrict__ prec, const __amdgpu_buffer_rsrc_t& prec_r, size_t idx16) {
@@ -602,10 +610,12 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             int4* task_b = pa.task + (size_t)b * n3;
             int2* occ_b = pa.occ + (size_t)b * n3;
             int32_t* occt_b = pa.occt + (size_t)b * n3;
-            if (pa.reg_sort_ok != 0 && pa.npad_items == 512 && B > 128)      // the common short call (batch 129 .. 256): users and items side by side
+            const bool split = pa.reg_sort_ok != 0 && pa.npad_items == 512 && B > 128;
+            const PlanMirror mir = plan_mirror(scratch + plan_scratch_bytes(B, pa.npad_items, n_owner, pa.own_words), B);      // behind both phases' own scratch
+            if (split)                                       // the common short call (batch 129 .. 256): users and items side by side
                 plan_phase_a_split<TPB>(scratch, b, pa.tr_users, pa.n_tr, pa.row_ptr, pa.pos_cols, pa.cols_sorted, pa.n_items, pa.seed,
                                         pa.first_triplet + (uint64_t)b * (uint64_t)B, B, pa.out_u + (size_t)b * B, pa.out_i + (size_t)b * B,
-                                        pa.out_j + (size_t)b * B, task_b, occ_b, occt_b, pa.touch_u, pa.touch_i);
+                                        pa.out_j + (size_t)b * B, task_b, occ_b, occt_b, pa.touch_u, pa.touch_i, mir);
             else
                 plan_phase_a<TPB, 256>(scratch, b, pa.tr_users, pa.n_tr, pa.row_ptr, pa.pos_cols, pa.cols_sorted, pa.n_items, pa.seed,
                                        pa.first_triplet + (uint64_t)b * (uint64_t)B, B, pa.npad_items, pa.out_u + (size_t)b * B, pa.out_i + (size_t)b * B,
@@ -618,7 +628,8 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             PLAN_STAMP(3);
             if (alive) {
                 plan_phase_b_wide<true>(scratch, b, B, task_b, occ_b, occt_b, pa.ucnt, pa.icnt, pa.touch_u, pa.touch_i, pa.pocc + (size_t)b * n3,
-                                        pa.prec + (size_t)b * n3 * 8, n_owner, pa.ohdr, ohdr_stride, pa.own_words, ct, cprev, ctotal);
+                                        pa.prec + (size_t)b * n3 * 8, n_owner, pa.ohdr, ohdr_stride, pa.own_words, ct, cprev, ctotal,
+                                        split, mir);
                 PLAN_STAMP(4);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // bitmap reads returned, record stores in memory
@@ -1099,10 +1110,7 @@ static size_t own_lds_bytes_planned(int np, int nb, int n_items, int n_owner, in
     const int rows_here = (n_items + n_owner - 1) / n_owner;
     const size_t head = (sizeof(OwnQueue) + (size_t)4 * (2 * nb + 1 + TKR_WAVE + rows_here + kDotWin) + 15) & ~(size_t)15;
     const size_t rows = (size_t)rows_here * (2 * np * 128 + 8) * 4;
-    size_t scratch = (size_t)npad_items * 8 + (kWideThreads / TKR_WAVE + 1) * 4;
-    const size_t pb = plan_phase_b_wide_lds(B, n_owner, own_words);
-    if (pb > scratch) scratch = pb;
-    scratch = (scratch + 15) & ~(size_t)15;
+    const size_t scratch = plan_scratch_bytes(B, npad_items, n_owner, own_words) + plan_mirror_lds(B);
     return head + (rows > scratch ? rows : scratch);
 }
 

@@ -290,6 +290,31 @@ __device__ __forceinline__ void plan_phase_a(unsigned char* smem, int b, const i
     K1_STAMP(7);
 }
 
+// ---- what phase A of a batch leaves in LDS for phase B of the SAME workgroup (the planner prologue of csrc/bpr_own.hip): the draw, the
+// task heads and the occurrence lists.  Phase B then starts from LDS instead of a round trip to the words this CU has just stored,
+// and phase A itself builds its sort keys and occurrence lists from the LDS copy of the draw (two more round trips).
+struct PlanMirror {
+    int4* task;        // [3B]
+    int2* occ;         // [3B]
+    int32_t* occt;     // [3B]
+    int32_t *u, *i, *j;        // [B] each
+};
+__device__ __forceinline__ PlanMirror plan_mirror(unsigned char* p /*16-byte aligned*/, int B) {
+    PlanMirror m;
+    m.task = reinterpret_cast<int4*>(p);
+    m.occ = reinterpret_cast<int2*>(m.task + 3 * B);
+    m.occt = reinterpret_cast<int32_t*>(m.occ + 3 * B);
+    m.u = m.occt + 3 * B;
+    m.i = m.u + B;
+    m.j = m.i + B;
+    return m;
+}
+static inline size_t plan_mirror_lds(int B) { return (size_t)3 * B * (16 + 8 + 4) + (size_t)3 * B * 4; }
+
+// the LDS side of a workgroup barrier only: LDS traffic drained (lgkmcnt), global loads of the wave stay in flight across it
+// (__syncthreads waits for them too)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- phase A with the user side and the item side of a batch on TWO wave groups at once (the planner prologue of csrc/bpr_own.hip,
 // 129 <= B <= 256): threads 0..255 sort the users and emit their task heads and occurrence lists while threads 256..511 do the same
 // for the items (one after the other the two sides are 4.3 + 5.1 us of a 17 us phase); further threads only meet the barriers.  Both
@@ -301,7 +326,7 @@ __device__ __forceinline__ void plan_phase_a_split(unsigned char* smem, int b, c
                                                    const int32_t* __restrict__ cols_sorted, uint32_t n_items, uint64_t seed, uint64_t g0, int B,
                                                    int32_t* __restrict__ bu, int32_t* __restrict__ bi, int32_t* __restrict__ bj,
                                                    int4* __restrict__ task, int2* __restrict__ occ, int32_t* __restrict__ occt,
-                                                   uint32_t* __restrict__ touch_u, uint32_t* __restrict__ touch_i) {
+                                                   uint32_t* __restrict__ touch_u, uint32_t* __restrict__ touch_i, const PlanMirror mir) {
     static_assert(T >= 512 && T % 64 == 0, "two groups of 256 threads");
     constexpr int TS = 256;
     uint64_t* keys_u = reinterpret_cast<uint64_t*>(smem);                     // [256]
@@ -314,9 +339,10 @@ __device__ __forceinline__ void plan_phase_a_split(unsigned char* smem, int b, c
         int u, i, j;
         draw_triplet(tr_users, n_tr, row_ptr, pos_cols, cols_sorted, n_items, k0, k1, g0 + t, u, i, j);
         bu[t] = u; bi[t] = i; bj[t] = j;
+        mir.u[t] = u; mir.i[t] = i; mir.j[t] = j;
     }
-    __threadfence_block();
     __syncthreads();
+    bu = mir.u; bi = mir.i; bj = mir.j;                                       // from here on the draw is read from LDS
     K1_STAMP(1);
     constexpr int ob = 9;                                                     // occurrence bits of the 32-bit keys: 512 item occurrences
     const bool active = role < 2;
@@ -378,7 +404,9 @@ __device__ __forceinline__ void plan_phase_a_split(unsigned char* smem, int b, c
             if ((p == 0) || (row != (uint32_t)(keys[p - 1] >> 32))) {
                 int q = p + 1;
                 while (q < n && (uint32_t)(keys[q] >> 32) == row) ++q;
-                task[slot0 + s] = make_int4((int)(row | ((uint32_t)role << 31)), occ0 + p, q - p, 0);
+                const int4 head = make_int4((int)(row | ((uint32_t)role << 31)), occ0 + p, q - p, 0);
+                task[slot0 + s] = head;
+                mir.task[slot0 + s] = head;
                 atomicOr(&touch[(size_t)row * kTouchWords + (b >> 5)], 1u << (b & 31));
                 ++s;
             }
@@ -387,8 +415,9 @@ __device__ __forceinline__ void plan_phase_a_split(unsigned char* smem, int b, c
         if (role == 0) {
             if (rt < B) {
                 const int t = (int)(uint32_t)keys_u[rt];
-                occ[rt] = make_int2(bi[t], bj[t]);
-                occt[rt] = t;
+                const int2 o2 = make_int2(bi[t], bj[t]);
+                occ[rt] = o2; occt[rt] = t;
+                mir.occ[rt] = o2; mir.occt[rt] = t;
             }
         } else {
             for (int p = rt; p < 2 * B; p += 256) {
@@ -396,12 +425,13 @@ __device__ __forceinline__ void plan_phase_a_split(unsigned char* smem, int b, c
                 const bool rj = o >= B;
                 const int t = rj ? o - B : o;
                 const uint32_t other = (uint32_t)(rj ? bi[t] : bj[t]);
-                occ[B + p] = make_int2(bu[t], (int)(other | ((uint32_t)rj << 31)));
-                occt[B + p] = t;
+                const int2 o2 = make_int2(bu[t], (int)(other | ((uint32_t)rj << 31)));
+                occ[B + p] = o2; occt[B + p] = t;
+                mir.occ[B + p] = o2; mir.occt[B + p] = t;
             }
         }
     }
-    for (int q = tot_u + tot_i + tid; q < 3 * B; q += T) task[q] = make_int4(-1, 0, 0, 0);
+    for (int q = tot_u + tot_i + tid; q < 3 * B; q += T) { task[q] = make_int4(-1, 0, 0, 0); mir.task[q] = make_int4(-1, 0, 0, 0); }
     __syncthreads();
     K1_STAMP(7);
 }
@@ -476,6 +506,23 @@ __device__ __forceinline__ void row_history(const int32_t* __restrict__ cnt, con
     row_history<FRESH>(cnt, touch, row, batch, ver, prev, total);
 }
 
+// a row's counter and the first 64 batches of its bitmap, as loads that are only ISSUED here (FRESH form of phase B: a call of at
+// most 64 batches inside the step's launch; the words were set by other workgroups of the launch: past the L1)
+struct RowBits { int cnt; unsigned long long bits; };
+__device__ __forceinline__ RowBits row_bits(const int32_t* __restrict__ cnt, const uint32_t* touch, int row) {
+    RowBits h;
+    h.cnt = cnt[row];
+    h.bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(touch + (size_t)row * kTouchWords), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return h;
+}
+// ... the version of the row at `batch` (< 64); prev = its last batch before that (-1: none), total = its batches in the call
+__device__ __forceinline__ int row_bits_version(const RowBits& h, int batch, int& prev, int& total) {
+    const unsigned long long below = h.bits & ((1ull << batch) - 1ull);
+    prev = below ? 63 - __clzll((long long)below) : -1;
+    total = __popcll(h.bits);
+    return h.cnt + __popcll(below);
+}
+
 // ---- phase B of a batch, one thread per task slot and per occurrence (3B <= 768 threads): full versions + one 128-byte record
 // per task (the dataflow form of the plan: csrc/sampler.hip has the layout).  FRESH: running inside the step's launch -- bitmap
 // words past the L1 (above), and everything OTHER workgroups of the launch will read (pocc, prec, ohdr) stored write-through
@@ -487,7 +534,8 @@ template <bool FRESH>
 __device__ __forceinline__ void plan_phase_b_wide(unsigned char* smem, int b, int B, const int4* task_b, const int2* occ_b, const int32_t* occt_b,
                                                   const int32_t* __restrict__ ucnt, const int32_t* __restrict__ icnt, const uint32_t* touch_u,
                                                   const uint32_t* touch_i, int4* pocc /*of batch b*/, int4* prec /*of batch b*/, int n_owner,
-                                                  int32_t* ohdr, int ohdr_stride, int own_words, int4& t_out, int& prev_out, int& total_out) {
+                                                  int32_t* ohdr, int ohdr_stride, int own_words, int4& t_out, int& prev_out, int& total_out,
+                                                  const bool mirrored = false, const PlanMirror mir = PlanMirror{}) {
     constexpr int T = kWideThreads;
     const int n = 3 * B, s = threadIdx.x;
     int4* lp = reinterpret_cast<int4*>(smem);                                          // [3B] the batch's pocc
@@ -513,23 +561,35 @@ __device__ __forceinline__ void plan_phase_b_wide(unsigned char* smem, int b, in
     for (int w = s; w < n_owner * own_words; w += T) own_mask[w] = 0u;
     int4 t = make_int4(-1, 0, 0, 0);
     int ver = 0, prev = -1, total = 0;
+    // FRESH (a call planned inside the step's launch: at most 64 batches, so a row's history is its counter and bitmap words 0..1):
+    // the three histories of a slot are ISSUED here and only looked at behind the owner order below -- LDS work between barriers that
+    // wait for LDS alone (lds_barrier), ~3.6 us that used to follow the loads' round trip instead of hiding it
+    RowBits ha = {0, 0ull}, hb = {0, 0ull}, ht = {0, 0ull};
+    int2 o = make_int2(0, 0);
+    int tt = 0;
+    auto bar = [&]() { if constexpr (FRESH) lds_barrier(); else __syncthreads(); };
     if (s < n) {
-        t = task_b[s];
-        const int2 o = occ_b[s];
-        const int tt = occt_b[s];
+        if (mirrored) { t = mir.task[s]; o = mir.occ[s]; tt = mir.occt[s]; }          // phase A of this workgroup left them in LDS
+        else { t = task_b[s]; o = occ_b[s]; tt = occt_b[s]; }
         const bool user_occ = s < B;                                                   // user occurrences: (i, j); item occurrences: (u, other | role << 31)
-        const int va = user_occ ? version_of<FRESH>(icnt, touch_i, o.x, b) : version_of<FRESH>(ucnt, touch_u, o.x, b);
-        const int vb = version_of<FRESH>(icnt, touch_i, o.y & 0x3fffffff, b);
-        if (t.x != -1) {
-            if (t.x < 0) row_history<FRESH>(icnt, touch_i, t.x & 0x7fffffff, b, ver, prev, total);
-            else row_history<FRESH>(ucnt, touch_u, t.x, b, ver, prev, total);
+        if constexpr (FRESH) {
+            ha = user_occ ? row_bits(icnt, touch_i, o.x) : row_bits(ucnt, touch_u, o.x);
+            hb = row_bits(icnt, touch_i, o.y & 0x3fffffff);
+            if (t.x != -1) ht = t.x < 0 ? row_bits(icnt, touch_i, t.x & 0x7fffffff) : row_bits(ucnt, touch_u, t.x);
+        } else {
+            const int va = user_occ ? version_of<FRESH>(icnt, touch_i, o.x, b) : version_of<FRESH>(ucnt, touch_u, o.x, b);
+            const int vb = version_of<FRESH>(icnt, touch_i, o.y & 0x3fffffff, b);
+            if (t.x != -1) {
+                if (t.x < 0) row_history<FRESH>(icnt, touch_i, t.x & 0x7fffffff, b, ver, prev, total);
+                else row_history<FRESH>(ucnt, touch_u, t.x, b, ver, prev, total);
+            }
+            const int4 po = make_int4(o.x, va, o.y, vb);
+            put(pocc_r, pocc, s, po);
+            lp[s] = po;
+            lt[s] = tt;
         }
-        const int4 po = make_int4(o.x, va, o.y, vb);
-        put(pocc_r, pocc, s, po);
-        lp[s] = po;
-        lt[s] = tt;
     }
-    __syncthreads();
+    bar();
     K1_STAMP(9);
     const bool item_task = t.x < 0 && t.x != -1;
     int first_item = 0;
@@ -539,7 +599,7 @@ __device__ __forceinline__ void plan_phase_b_wide(unsigned char* smem, int b, in
             const int row = t.x & 0x7fffffff, bit = row / n_owner;
             atomicOr(&own_mask[(size_t)(row % n_owner) * own_words + (bit >> 5)], 1u << (bit & 31));
         }
-        __syncthreads();
+        bar();
         first_item = *s_first_item;
         const int per = (n_owner + T - 1) / T;
         const int w0 = min(s * per, n_owner), w1 = min(w0 + per, n_owner);
@@ -554,7 +614,7 @@ __device__ __forceinline__ void plan_phase_b_wide(unsigned char* smem, int b, in
             if (lane >= d) incl += up;
         }
         if (lane == TKR_WAVE - 1) s_wave[wave] = incl;
-        __syncthreads();
+        bar();
         int run = incl - mine;
         for (int w = 0; w < wave; ++w) run += s_wave[w];
         for (int w = w0; w < w1; ++w) {
@@ -566,9 +626,19 @@ __device__ __forceinline__ void plan_phase_b_wide(unsigned char* smem, int b, in
             own_start[w] = (uint32_t)run;
             run += c;
         }
-        __syncthreads();
+        bar();
     }
     K1_STAMP(10);
+    if constexpr (FRESH) {
+        if (s < n) {
+            int pa_, ta_;
+            const int4 po = make_int4(o.x, row_bits_version(ha, b, pa_, ta_), o.y, row_bits_version(hb, b, pa_, ta_));
+            if (t.x != -1) ver = row_bits_version(ht, b, prev, total);
+            put(pocc_r, pocc, s, po);
+            lp[s] = po;
+            lt[s] = tt;
+        }
+    }
     // the 128-byte records, written as WHOLE cache lines: a task's two header words go to LDS at its destination slot, then eight
     // lanes assemble one record each pass (a wave: eight consecutive records = 1 KB contiguous).  A thread that writes its own record
     // piece by piece puts eight 16-byte stores on eight different lines per instruction: 6,144 partial-line writes per batch, and as

@@ -10,6 +10,9 @@ constexpr int kMaxRounds = 64;   // oracle/plan_np.py MAX_ROUNDS
 // is `item` among cols_sorted[lo, hi) (ascending)?  A 4-ary search: three pivots per step, loaded together -- the draw of a triplet is
 // a chain of dependent loads (user -> row bounds -> positive; then this search for every candidate negative), and a binary search is
 // log2(degree) trips where this is log4 (a degree of 36: 3 trips instead of 6; the draw is 4.9 us of the 17 us phase A of a batch).
+// Wider is NOT faster (round 5, measured inside the planner prologue of csrc/bpr_own.hip: sixteen segments per step + a window of 32
+// at the end = 2 trips and 47 loads per candidate took 9.0 us where this takes 5.6): a load whose 64 lanes hit 64 different lines
+// occupies the CU's L1 for ~64 cycles whether or not anybody waits for it, so the cost is trips x ~0.5 us + loads x ~0.14 us.
 __device__ __forceinline__ bool is_member(const int32_t* __restrict__ cols_sorted, int lo, int hi, int item) {
     int a = lo, b = hi;                              // if present, item sits in [a, b)
     while (b - a > 3) {
