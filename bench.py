@@ -203,19 +203,26 @@ def timed_run(eng, csr, B, steps, warmup, sync_every, world, names=None, loop=No
     host time in front of a ~90 us launch), which then also counts the host's way to the launch: an upper bound of the launch."""
     loop = loop or Loop(eng, csr, B, sync_every, world, names)
     singles = min(warmup, 8)
-    eng.reserve_events(-(-(steps + warmup) // sync_every) + _chunk_crossings(eng, steps + warmup, B) + singles + 2)   # created now, not between the timed launches
+    if per_launch_events:
+        eng.reserve_events(-(-(steps + warmup) // sync_every) + _chunk_crossings(eng, steps + warmup, B) + singles + 2)   # created now, not between the timed launches
     # The warm-up goes down the SAME host path as the timed call and its first batches as calls of their own: the first two or
     # three passes of the runtime through a launch path (kernel arguments, signals) cost tens of microseconds each, which a
     # 20-step timed call (~130 us) would otherwise carry.
     eng.step_events = [] if per_launch_events else None
-    for _ in range(singles):
+    for w in range(singles):
+        if w == singles - 1 and warmup == singles:
+            eng.settle()         # the status word of the warm-up so far (a copy to the host) is looked at BEFORE the last warm-up launch:
+                                 # the first launch behind a device-to-host copy costs the host ~4 us more (scripts/probe_short_host.py
+                                 # PROBE_SETTLE: 112 -> 116 us per timed call), and in training no copy sits in front of every call
         loop.run(1)
         _fence(world)            # ... each onto an IDLE queue, as the timed call goes out (behind the fence below): the runtime's first
                                  # launches after an idle queue are slower than back-to-back ones (measured: timed call 148 -> 132 us)
     if warmup > singles:
         loop.run(warmup - singles)
     eng.step_events = None
-    eng.settle()                 # nothing planned ahead: the timed batches sample and plan themselves (also reports a failed step)
+    # nothing planned ahead: the timed batches sample and plan themselves (what a warm-up call planned beyond its own batches is
+    # rolled back; the status check of everything that ran comes behind the timed region: eng.check() below)
+    eng.settle(check=not (0 < singles == warmup))
     region = _recorded_pair() if not per_launch_events else None
     _fence(world)
     eng.step_events = [] if per_launch_events else None

@@ -137,8 +137,8 @@ if os.environ.get('TKR_PLAN_STAMP') == '1':         # a library built with -DTKR
     out = (C.c_uint64 * 32)()
     if tkr_hip.lib().tkr_debug_own_k1_prof(out) == 0:
         w = np.array(out[:], dtype=np.float64) / 100.0
-        names = ['draw', 'user sort', 'user tasks', 'user occ', 'item sort', 'item tasks', 'item occ + tail']
-        print('phase A (us, last call): ' + '  '.join('%s %.1f' % (nm, w[i + 1] - w[i]) for i, nm in enumerate(names)))
+        print('phase A (us, last call): draw %.1f  sorts %.1f  head scan %.1f | users: heads %.1f occ %.1f | items: heads %.1f occ %.1f | tail %.1f' %
+              (w[1] - w[0], w[2] - w[1], w[3] - w[2], w[4] - w[3], w[5] - w[4], w[17] - w[16], w[18] - w[17], w[7] - max(w[5], w[18])))
         print('phase B (us, last call): loads+versions %.1f  owner order %.1f  headers to LDS %.1f  records %.1f' % (w[9] - w[8], w[10] - w[9], w[12] - w[10], w[11] - w[12]))
     print('last workgroup: start %.1f  waits until %.1f  acquire %.1f  set-up %.1f  step %.1f  end %.1f' %
           (v[1, 0], v[1, 8], v[1, 9] - v[1, 8], v[1, 10] - v[1, 9], v[1, 11] - v[1, 10], v[1, 11]), flush=True)

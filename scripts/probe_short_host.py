@@ -8,7 +8,7 @@ import bench
 
 dev = torch.device('cuda', 0)
 r, csr, eng, nnz = bench.build_problem('ml10m', 128, 0, 1, dev)
-steps, warm = 20, 3
+steps, warm = 20, int(os.environ.get('PROBE_WARMUPS', '3'))
 inner = []
 loop = bench.Loop(eng, csr, 256, 10 ** 9, 1)
 for w in range(warm):
@@ -27,6 +27,12 @@ if os.environ.get('PROBE_INNER') == '1':
         real(*a)
         inner.append((time.perf_counter() - t) * 1e6)
     st.plan_and_run = par
+if os.environ.get('PROBE_SETTLE') == '1':         # bench.timed_run settles (and checks the status word: a copy to the host) in front of the timed call
+    eng.settle()
+if os.environ.get('PROBE_SETTLE') == '2':
+    eng.settle(check=False)
+if os.environ.get('PROBE_RESERVE') == '1':
+    eng.reserve_events(12)
 bench._fence(1)
 ev = os.environ.get('PROBE_EVENT') == '1'
 if ev:

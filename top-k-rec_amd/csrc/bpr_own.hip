@@ -46,6 +46,7 @@
 #ifdef TKR_PLAN_STAMP         // profiling build (scripts/probe_short.py): the phases of the planner prologue, workgroup 0
 namespace tkr { __device__ unsigned long long own_k1_prof[32]; }
 #define K1_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) tkr::own_k1_prof[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define K1_STAMP_ITEMS(i) do { if (blockIdx.x == 0 && threadIdx.x == 256) tkr::own_k1_prof[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #endif
 #include "plan_parts.h"
 
@@ -585,6 +586,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     // counter, the header, the first ticket -- in front of every short call.
     const uint32_t me = blockIdx.x;
     bool alive = true;
+    int commit_key = -1, commit_total = 0;       // PLAN: the row this thread commits at the end of the kernel (a task's row word), its touches
 #ifdef TKR_PLAN_STAMP        // scripts/probe_short.py with a -DTKR_PLAN_STAMP build: s_memrealtime (100 MHz) of workgroups 0 and 255 at the prologue's phases
 #define PLAN_STAMP(i) do { if ((me == 0 || me == gridDim.x - 1) && threadIdx.x == 0) reinterpret_cast<u64*>(ctl + kCtlProf)[(me ? 16 : 0) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -639,9 +641,12 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
         // (a planner that gave up still arrives: the others then see the status word instead of spinning out one by one)
         alive = plan_rendezvous<12>(ctl + kCtlPlanC, n_plan, me < n_plan, ctl, flag) && alive;
         PLAN_STAMP(8);
-        // every planner is past its reads of the bitmap: K1c for the rows whose first task of the call is mine -- atomics and stores
-        // that nobody in this launch waits for
-        if (alive && me < n_plan && (int)threadIdx.x < 3 * B) plan_commit_first_touch(ct, cprev, ctotal, pa.ucnt, pa.icnt, pa.touch_u, pa.touch_i);
+        // every planner is past its reads of the bitmap: K1c (the rows whose first task of the call is this thread's get the call's
+        // touches added to their counters, their bitmap words zeroed) may go out -- atomics and stores that nobody in this launch
+        // reads.  They go out at the END of the kernel: issued here they sat in front of the queue set-up's loads in the planners'
+        // memory queues (set-up 3.0 us on a planner against 1.2 elsewhere, and the planners own rows like everybody else).
+        commit_key = (alive && me < n_plan && (int)threadIdx.x < 3 * B && ct.x != -1 && cprev == -1) ? ct.x : -1;
+        commit_total = ctotal;
         // No acquire fence here (measured 4.5 us for one lane's buffer_inv, 14 for every wave's): the plan words other CUs wrote went
         // out write-through before they arrived (sc1 stores + vmcnt(0)), the L2s see each other's writes, and THIS CU's L1 -- dropped
         // at the start of the launch -- has never held a line of prec / pocc / ohdr: nothing in front of this point loads from
@@ -1036,6 +1041,9 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     PLAN_STAMP(11);
+    if constexpr (PLAN) {
+        if (commit_key != -1) plan_commit_first_touch(make_int4(commit_key, 0, 0, 0), -1, commit_total, pa.ucnt, pa.icnt, pa.touch_u, pa.touch_i);
+    }
     const bool fold_loss = !SCALAR && want_loss && (tune & 8u) != 0u;       // tune bit 3 (set by the host for short launches): the last workgroup out adds the losses up
     if (threadIdx.x == 0) {
         const bool last = __hip_atomic_fetch_add(ctl + kCtlLeave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;

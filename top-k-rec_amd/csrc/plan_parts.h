@@ -10,6 +10,9 @@
 #ifndef K1_STAMP
 #define K1_STAMP(i) do { } while (0)
 #endif
+#ifndef K1_STAMP_ITEMS
+#define K1_STAMP_ITEMS(i) do { } while (0)
+#endif
 
 namespace tkr {
 
@@ -389,6 +392,7 @@ __device__ __forceinline__ void plan_phase_a_split(unsigned char* smem, int b, c
     }
     if (active && lane == TKR_WAVE - 1) scan[role * 4 + rw] = incl;
     __syncthreads();
+    K1_STAMP(3); K1_STAMP_ITEMS(16);
     int tot_u = 0, tot_i = 0, s = incl - cnt;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -411,6 +415,7 @@ __device__ __forceinline__ void plan_phase_a_split(unsigned char* smem, int b, c
                 ++s;
             }
         }
+        K1_STAMP(4); K1_STAMP_ITEMS(17);
         // ---- occurrence lists
         if (role == 0) {
             if (rt < B) {
@@ -431,6 +436,7 @@ __device__ __forceinline__ void plan_phase_a_split(unsigned char* smem, int b, c
             }
         }
     }
+    K1_STAMP(5); K1_STAMP_ITEMS(18);
     for (int q = tot_u + tot_i + tid; q < 3 * B; q += T) { task[q] = make_int4(-1, 0, 0, 0); mir.task[q] = make_int4(-1, 0, 0, 0); }
     __syncthreads();
     K1_STAMP(7);

@@ -353,13 +353,17 @@ def own_stepper(state, B, ctl, owner_waves=0):
     fused.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p,
                       C.c_void_p, C.c_void_p]
 
+    raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)          # the stream's handle without a Stream object around it (~1 us)
+    dev_index = device.index
+
     def plan_and_run(plan, call, first, n_batches, loss_out, events=None):
         """K1 of the chunk described by `call` (a PlanCall into `plan`) and the step on its batches [first, first + n_batches): one C call"""
-        assert torch.cuda.current_device() == device.index and 0 < call.n_batches <= min(plan.cap, PLAN_MAX_BATCHES)
+        assert torch.cuda.current_device() == dev_index and 0 < call.n_batches <= min(plan.cap, PLAN_MAX_BATCHES)
         plan.epoch += 1
+        stream = raw_stream(dev_index) if raw_stream is not None else torch.cuda.current_stream(device).cuda_stream
         rc = fused(C.addressof(call), st, first, n_batches, ctl_ptr, None if loss_out is None else loss_out.data_ptr(), owner_waves,
                    plan.xch.data_ptr(), plan.epoch & 0xffffffff or 1, None if events is None else events[0].cuda_event,
-                   None if events is None else events[1].cuda_event, torch.cuda.current_stream(device).cuda_stream)
+                   None if events is None else events[1].cuda_event, stream)
         if rc:
             _check(rc, 'tkr_bpr_own_plan_run')
     step.state = state
