@@ -43,6 +43,13 @@
 // Results are bitwise reproducible run to run (scout and task run the same code on the same versions; the row-read form sums like
 // K2f); the scalar form differs from K2f in the last bits (x is the difference of two rounded dots): same tolerance to the oracle.
 #include "flow_task.h"
+// s_sleep between two polls of an LDS word (a row's tag, a ring slot's mark).  The polls are ds_read now (flow_task.h lds_peek; as
+// flat loads each took a trip down the vector-memory path, which throttled them by accident): a wave that spins on LDS at full rate
+// takes issue cycles from the two working waves of its SIMD.  Measured per batch in steady state / per 20-batch call, ML-10M shape:
+// nap 0: 2.03 us / 112 us, 1: 2.00 / 105, 2: 1.98 / 101, 4: 1.95 / 99, 8: 1.98 / 98, 16: 2.01 / 99, 32: 2.12 / 102 (flat polls: 2.2 / 110).
+#ifndef TKR_TAG_NAP
+#define TKR_TAG_NAP 4
+#endif
 #ifdef TKR_PLAN_STAMP         // profiling build (scripts/probe_short.py): the phases of the planner prologue, workgroup 0
 namespace tkr { __device__ unsigned long long own_k1_prof[32]; }
 #define K1_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) tkr::own_k1_prof[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -87,10 +94,10 @@ __device__ __forceinline__ bool plan_rendezvous(uint32_t* counter, uint32_t n, b
             __builtin_amdgcn_s_sleep(NAP);                 // NAP x 64 clocks between polls (up to 256 pollers of one word: not a hot loop)
             if (spin_fail(waited, ctl, 0)) { ok = 0u; break; }
         }
-        *flag = ok;
+        lds_poke(flag, ok);
     }
     __syncthreads();
-    const bool ok = *flag != 0u;
+    const bool ok = lds_peek(flag) != 0u;
     __syncthreads();                                   // (the flag word is reused by the next rendezvous)
     return ok;
 }
@@ -207,10 +214,13 @@ __device__ __forceinline__ bool item_own_wait(const FlowTables& T, int lane, con
                                               Own& o, uint32_t* ctl, uint32_t& spins) {
     if (r.from_lds) {
         uint32_t waited = 0;
-        while (*r.tag != r.ver) {
+        while (lds_peek(r.tag) != r.ver) {
+#if TKR_TAG_NAP > 0
+            __builtin_amdgcn_s_sleep(TKR_TAG_NAP);
+#endif
             if (spin_fail(waited, ctl, 0)) {
                 if (waited >= kSpinLimit && lane == 0 && atomicCAS(ctl + kCtlDebug, 0u, 4u) == 0u) {
-                    ctl[kCtlDebug + 1] = *r.tag; ctl[kCtlDebug + 3] = r.ver;
+                    ctl[kCtlDebug + 1] = lds_peek(r.tag); ctl[kCtlDebug + 3] = r.ver;
                 }
                 return false;
             }
@@ -231,7 +241,7 @@ __device__ __forceinline__ bool item_own_wait(const FlowTables& T, int lane, con
 template <int NP>
 __device__ __forceinline__ bool item_own_peek(int lane, const ItemRow& r, float (&own)[2 * NP], Own& o) {
     if (r.from_lds) {
-        if (*r.tag != r.ver) return false;
+        if (lds_peek(r.tag) != r.ver) return false;
         asm volatile("" ::: "memory");
         float ms[2 * NP];
         lds_row_read<NP>(r.row, lane, true, own, ms, o);
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
     for (int s = threadIdx.x; s < rows_here; s += TPB) tags[s] = kOwnInvalid;
     for (int s = threadIdx.x; s < kDotWin; s += TPB) dotmark[s] = 0u;
     if constexpr (LOADER) {
-        for (int s = threadIdx.x; s < 2 * ring_slots; s += TPB) ring_ready[s] = 0u;
+        for (int s = threadIdx.x; s < 2 * ring_slots; s += TPB) lds_poke(ring_ready + s, 0u);
     }
     if constexpr (PLAN) {
         static_assert(TPB == kWideThreads, "phase B of the planner is one thread per task slot");
@@ -629,9 +639,12 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             alive = plan_rendezvous<4>(ctl + kCtlPlanA, n_plan, true, ctl, flag);
             PLAN_STAMP(3);
             if (alive) {
-                plan_phase_b_wide<true>(scratch, b, B, task_b, occ_b, occt_b, pa.ucnt, pa.icnt, pa.touch_u, pa.touch_i, pa.pocc + (size_t)b * n3,
-                                        pa.prec + (size_t)b * n3 * 8, n_owner, pa.ohdr, ohdr_stride, pa.own_words, ct, cprev, ctotal,
-                                        split, mir);
+                if (split)
+                    plan_phase_b_wide<true, true>(scratch, b, B, task_b, occ_b, occt_b, pa.ucnt, pa.icnt, pa.touch_u, pa.touch_i, pa.pocc + (size_t)b * n3,
+                                                  pa.prec + (size_t)b * n3 * 8, n_owner, pa.ohdr, ohdr_stride, pa.own_words, ct, cprev, ctotal, mir);
+                else
+                    plan_phase_b_wide<true, false>(scratch, b, B, task_b, occ_b, occt_b, pa.ucnt, pa.icnt, pa.touch_u, pa.touch_i, pa.pocc + (size_t)b * n3,
+                                                   pa.prec + (size_t)b * n3 * 8, n_owner, pa.ohdr, ohdr_stride, pa.own_words, ct, cprev, ctotal);
                 PLAN_STAMP(4);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // bitmap reads returned, record stores in memory
@@ -726,18 +739,18 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
         int idle = 0;
         const uint32_t ahead = (uint32_t)kScoutAhead;
         for (;;) {
-            const uint32_t head = *reinterpret_cast<volatile uint32_t*>(&q->head);
+            const uint32_t head = lds_peek(&q->head);
             if (head >= q_total) break;
             if ((idle & 63) == 63 && ld_u32(ctl + kCtlStatus) != 0u) break;          // somebody gave up
             if (hpos < head || hpos >= q_total || hpos >= head + ahead) {              // (re)start at the head: what was skipped may be final now
                 if (hpos >= head && idle) __builtin_amdgcn_s_sleep(16);               // a whole window without work
                 hpos = head;
-                hcur = *reinterpret_cast<volatile uint32_t*>(&q->head_batch);
+                hcur = lds_peek(&q->head_batch);
                 idle = idle < (1 << 20) ? idle + 1 : idle;
                 if (hpos >= q_total) continue;
             }
             const uint32_t pos = hpos++;
-            if (*reinterpret_cast<volatile uint32_t*>(&dotmark[pos & (kDotWin - 1)]) == pos + 1u) continue;
+            if (lds_peek(&dotmark[pos & (kDotWin - 1)]) == pos + 1u) continue;
             const uint32_t idx = qm.locate(pos, hcur, lane);
             int4 w = make_int4(0, 0, 0, 0);
             if (lane < 8) w = prec[(size_t)idx * 8 + lane];
@@ -771,9 +784,9 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             // (... unless a wave already waits for this very position: an owner whose tasks are batches apart must not wait for a head
             // that waits for it)
             auto blocked = [&]() {
-                return (pos >= (uint32_t)ring_slots && ring_freed[slot] != pos - (uint32_t)ring_slots + 1u) ||
-                       (lcur > *reinterpret_cast<volatile uint32_t*>(&q->head_batch) + load_ahead &&
-                        pos >= *reinterpret_cast<volatile uint32_t*>(&q->head));
+                return (pos >= (uint32_t)ring_slots && lds_peek(ring_freed + slot) != pos - (uint32_t)ring_slots + 1u) ||
+                       (lcur > lds_peek(&q->head_batch) + load_ahead &&
+                        pos >= lds_peek(&q->head));
             };
             if (blocked()) {
                 // before this wave waits for the queue, the slot it filled last goes out: the task that waits for THAT slot may be the
@@ -781,7 +794,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
                 // workgroup locked up, with seven it merely stalled)
                 if (prev_slot >= 0) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) ring_ready[prev_slot] = prev_pos + 1u;
+                    if (lane == 0) lds_poke(ring_ready + prev_slot, prev_pos + 1u);
                     prev_slot = -1;
                 }
                 while (blocked()) {
@@ -828,13 +841,13 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
             // the slot BEFORE this one is complete once at most this slot's loads are outstanding (loads return in order)
             if (prev_slot >= 0) {
                 wait_vmcnt_at_most(loads);
-                if (lane == 0) ring_ready[prev_slot] = prev_pos + 1u;
+                if (lane == 0) lds_poke(ring_ready + prev_slot, prev_pos + 1u);
             }
             prev_slot = slot;
             prev_pos = pos;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (prev_slot >= 0 && lane == 0) ring_ready[prev_slot] = prev_pos + 1u;
+        if (prev_slot >= 0 && lane == 0) lds_poke(ring_ready + prev_slot, prev_pos + 1u);
         spins += waited;
         ld_block_spins += waited;
     } else if (wave <= owner_waves) {                                                  // (SCALAR: waves 1 .. owner_waves; else 0 .. owner_waves; LOADER: 0 .. owner_waves - kLoaders)
@@ -855,7 +868,10 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
                 const int rslot = (int)(pos % (uint32_t)ring_slots);
                 unsigned char* sl = ring + (size_t)rslot * load_slot_stride<NP>();
                 uint32_t waited = 0;
-                while (ring_ready[rslot] != pos + 1u) {
+                while (lds_peek(ring_ready + rslot) != pos + 1u) {
+#if TKR_TAG_NAP > 0
+                    __builtin_amdgcn_s_sleep(TKR_TAG_NAP);
+#endif
                     if (spin_fail(waited, ctl, 0)) { alive = false; break; }
                 }
                 if (!alive) break;
@@ -863,14 +879,14 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
                 ld_ready_spins += waited;
                 ld_tasks += 1u;
                 asm volatile("" ::: "memory");
-                if (lane < 8) w = *reinterpret_cast<const int4*>(sl + lane * 16);
-                staged_rd = *reinterpret_cast<const volatile uint32_t*>(sl + 192);
+                if (lane < 8) { const v4u rw = *(const lds_v4u_t*)(sl + lane * 16); w = make_int4((int)rw.x, (int)rw.y, (int)rw.z, (int)rw.w); }
+                staged_rd = lds_peek(reinterpret_cast<const volatile uint32_t*>(sl + 192));
                 const int n_st = bcast_i(w.z, 0);
                 if (n_st >= 1 && n_st <= 4) {
                     stg = LdsStage{sl + 1024, sl + 128, ring_freed + rslot, pos + 1u};
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) ring_freed[rslot] = pos + 1u;   // nothing staged beyond the record
+                    if (lane == 0) lds_poke(ring_freed + rslot, pos + 1u);   // nothing staged beyond the record
                 }
             } else {
                 if (lane < 8) w = plan_ld<PLAN>(prec, prec_r, (size_t)idx * 8 + lane);
@@ -936,7 +952,7 @@ __global__ __launch_bounds__(TPB, own_min_waves(NP, TPB)) void bpr_own_kernel(
                     make_float2(__uint_as_float(o.exp[2] + (rb == 2u ? add : 0u)), __uint_as_float(o.exp[3] + (rb == 3u ? add : 0u)));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the row is in LDS before its tag says so
-            if (lane == 0) *reinterpret_cast<volatile uint32_t*>(tags + slot) = ver + 1u;
+            if (lane == 0) lds_poke(tags + slot, ver + 1u);
 
             alive = own_publish<NP>(lane, true, T.imask, sgd, T.V, T.msV, T.tailV, woff, (size_t)st.n_items, row, rowk, ver, n_occ, o, r.own_rd, pn,
                                     mn, bn, mbn, ctl, spins, kItemReaders);

@@ -261,6 +261,15 @@ constexpr int group_shift() { return G <= 4 ? 4 : 3; }      // lane L speaks for
 // occurrence q: granule row `a` at base + 2q rows, row `b` at base + (2q + 1) rows, b's bias granule at bias + 16q -- and the pass
 // validates the tags it finds THERE: a row that was fresh when the loader asked for it costs no trip through memory at all, a stale
 // one is caught like any other (wait_pair, then a pass on the tables).  The slot is given back once the pass holds it in registers.
+// Volatile accesses to LDS words (tags, queue heads, ring marks): through a generic pointer hipcc leaves them FLAT instructions --
+// address-space inference skips volatile operations -- i.e. a trip down the vector-memory path to reach LDS, returned under vmcnt
+// (`s_waitcnt vmcnt(0)` in every poll: the wave's outstanding global loads come back first).  Cast to the LDS address space explicitly.
+typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32_t;
+typedef __attribute__((address_space(3))) v4u lds_v4u_t;
+typedef __attribute__((address_space(3))) v2u lds_v2u_t;
+__device__ __forceinline__ uint32_t lds_peek(const volatile uint32_t* p) { return *(const lds_vu32_t*)(p); }
+__device__ __forceinline__ void lds_poke(volatile uint32_t* p, uint32_t v) { *(lds_vu32_t*)(p) = v; }
+
 struct NoStage {
     static constexpr bool on = false;
     __device__ __forceinline__ bool have() const { return false; }
@@ -276,7 +285,7 @@ struct LdsStage {
 template <int NP>
 __device__ __forceinline__ void lds_granule_row(const unsigned char* row, int lane, v4u (&x)[NP]) {
 #pragma unroll
-    for (int q = 0; q < NP; ++q) x[q] = *reinterpret_cast<const v4u*>(row + q * 1024 + lane * 16);
+    for (int q = 0; q < NP; ++q) x[q] = *(const lds_v4u_t*)(row + q * 1024 + lane * 16);          // (ds_read_b128, not a flat load: see lds_peek)
 }
 
 template <int NP, int G>
@@ -320,10 +329,10 @@ __device__ __forceinline__ bool flow_fetch(const tkr_flow_state& st, const FlowT
                     lds_granule_row<NP>(stg.base + (2 * src) * (NP * 1024), lane, xa[q]);
                     lds_granule_row<NP>(stg.base + (2 * src + 1) * (NP * 1024), lane, xb[q]);
                     xta[q] = v2u{0u, (uint32_t)bcast_i(d.y, src)};
-                    xtb[q] = *reinterpret_cast<const v2u*>(stg.bias + 16 * src);
+                    xtb[q] = *(const lds_v2u_t*)(stg.bias + 16 * src);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the slot's contents are in registers: the loader may have it back
-                if (lane == 0) *stg.rel = stg.relv;
+                if (lane == 0) lds_poke(stg.rel, stg.relv);
             }
         }
 #pragma unroll

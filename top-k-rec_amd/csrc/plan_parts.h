@@ -536,12 +536,12 @@ __device__ __forceinline__ int row_bits_version(const RowBits& h, int batch, int
 // `smem` (16-byte aligned): plan_phase_b_wide_lds() bytes.  Returns this thread's task, its row's last earlier batch and the
 // row's touches in the whole call (K1c's increment).
 constexpr int kWideThreads = 768;
-template <bool FRESH>
+template <bool FRESH, bool MIRRORED = false>
 __device__ __forceinline__ void plan_phase_b_wide(unsigned char* smem, int b, int B, const int4* task_b, const int2* occ_b, const int32_t* occt_b,
                                                   const int32_t* __restrict__ ucnt, const int32_t* __restrict__ icnt, const uint32_t* touch_u,
                                                   const uint32_t* touch_i, int4* pocc /*of batch b*/, int4* prec /*of batch b*/, int n_owner,
                                                   int32_t* ohdr, int ohdr_stride, int own_words, int4& t_out, int& prev_out, int& total_out,
-                                                  const bool mirrored = false, const PlanMirror mir = PlanMirror{}) {
+                                                  const PlanMirror mir = PlanMirror{}) {
     constexpr int T = kWideThreads;
     const int n = 3 * B, s = threadIdx.x;
     int4* lp = reinterpret_cast<int4*>(smem);                                          // [3B] the batch's pocc
@@ -550,7 +550,10 @@ __device__ __forceinline__ void plan_phase_b_wide(unsigned char* smem, int b, in
     uint32_t* own_start = own_mask + (size_t)n_owner * own_words;                      // [n_owner]
     int* s_wave = reinterpret_cast<int*>(own_start + n_owner);                         // [T / 64]
     int* s_first_item = s_wave + T / TKR_WAVE;
-    int4* hdr = reinterpret_cast<int4*>((reinterpret_cast<uintptr_t>(s_first_item + 1) + 15) & ~(uintptr_t)15);     // [3B][2] words 0..7 of every record, by destination slot
+    // [3B][2] words 0..7 of every record, by destination slot (the offset is rounded up as an integer, not the pointer: a pointer that
+    // has been through uintptr_t is a GENERIC pointer to hipcc, and every access through it a flat instruction)
+    const size_t hdr_off = ((size_t)n * 20 + (size_t)4 * n_owner * (own_words + 1) + (T / TKR_WAVE + 1) * 4 + 15) & ~(size_t)15;
+    int4* hdr = reinterpret_cast<int4*>(smem + hdr_off);
     const __amdgpu_buffer_rsrc_t pocc_r = __builtin_amdgcn_make_buffer_rsrc(pocc, 0, n * 16, 0x00020000);
     const __amdgpu_buffer_rsrc_t prec_r = __builtin_amdgcn_make_buffer_rsrc(prec, 0, n * 128, 0x00020000);
     auto put = [&](const __amdgpu_buffer_rsrc_t& r, int4* base, int idx16, const int4 v) {      // int4 number idx16 of a batch's array
@@ -575,7 +578,7 @@ __device__ __forceinline__ void plan_phase_b_wide(unsigned char* smem, int b, in
     int tt = 0;
     auto bar = [&]() { if constexpr (FRESH) lds_barrier(); else __syncthreads(); };
     if (s < n) {
-        if (mirrored) { t = mir.task[s]; o = mir.occ[s]; tt = mir.occt[s]; }          // phase A of this workgroup left them in LDS
+        if constexpr (MIRRORED) { t = mir.task[s]; o = mir.occ[s]; tt = mir.occt[s]; }          // phase A of this workgroup left them in LDS
         else { t = task_b[s]; o = occ_b[s]; tt = occt_b[s]; }
         const bool user_occ = s < B;                                                   // user occurrences: (i, j); item occurrences: (u, other | role << 31)
         if constexpr (FRESH) {
@@ -600,8 +603,11 @@ __device__ __forceinline__ void plan_phase_b_wide(unsigned char* smem, int b, in
     const bool item_task = t.x < 0 && t.x != -1;
     int first_item = 0;
     if (n_owner > 0) {
+        {   // the first item task of the batch: one LDS atomic per wave (every item task's own atomicMin queued ~500 deep on one word)
+            const unsigned long long im = __ballot(item_task);
+            if (im != 0ull && (s & (TKR_WAVE - 1)) == 0) atomicMin(s_first_item, (s & ~(TKR_WAVE - 1)) + __ffsll((long long)im) - 1);
+        }
         if (item_task) {
-            atomicMin(s_first_item, s);
             const int row = t.x & 0x7fffffff, bit = row / n_owner;
             atomicOr(&own_mask[(size_t)(row % n_owner) * own_words + (bit >> 5)], 1u << (bit & 31));
         }
