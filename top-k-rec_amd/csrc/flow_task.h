@@ -182,9 +182,15 @@ __device__ __forceinline__ uint32_t pick_exp(const Own& o, uint32_t buf) {
     return buf == 0u ? o.exp[0] : buf == 1u ? o.exp[1] : buf == 2u ? o.exp[2] : o.exp[3];
 }
 
+#ifndef TKR_SPIN_NAP
+#define TKR_SPIN_NAP 4      // x 64 clocks between two passes of a bounded spin
+#endif
+#ifndef TKR_PAIR_NAP
+#define TKR_PAIR_NAP 12     // ... between two 16-byte polls of a row's first pair (wait_pair)
+#endif
 __device__ __forceinline__ bool spin_fail(uint32_t& spins, uint32_t* ctl, int nap = 4) {
     asm volatile("" ::: "memory");                 // the next pass re-loads
-    if (nap) __builtin_amdgcn_s_sleep(4);
+    if (nap) __builtin_amdgcn_s_sleep(TKR_SPIN_NAP);
     ++spins;
     if ((spins & 255u) == 0u && ld_u32(ctl + kCtlStatus) != 0u) return true;      // somebody else gave up
     if (spins >= kSpinLimit) {
@@ -217,7 +223,7 @@ __device__ __forceinline__ bool wait_pair(const u64* row, uint32_t tag, int far,
         const v4u p = __builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, kAuxLoad);
         if (p.y == tag) return true;
         if ((int)(tag - p.y) >= far) __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_sleep(12);             // ~0.3 us between polls (measured 0 / 12 / 28 / 60: 2.184 / 2.160 / 2.184 / 2.244 us per batch under K2o)
+        __builtin_amdgcn_s_sleep(TKR_PAIR_NAP);   // ~0.3 us between polls (measured 0 / 12 / 28 / 60: 2.184 / 2.160 / 2.184 / 2.244 us per batch under K2o)
         if (spin_fail(waited, ctl, 4)) return false;
     }
 }

@@ -43,8 +43,8 @@ class Tuning:
     flow_waves_per_cu: int = 0       # TKR_FLOW_WAVES_PER_CU: K2f waves per CU, 0 = the library default
     flow_item_bufs: int = 4          # TKR_FLOW_ITEM_BUFS: buffers per item row of the granule tables (2 or 4; include/tkr.h)
     own: str = '1'                   # TKR_OWN: 0 = never K2o, 1 = K2o where the item rows fit the owners' LDS, 2 = as 1 (kept for scripts)
-    own_max_batch: int = 256         # TKR_OWN_MAX_BATCH: batch sizes up to this take K2o (K2o vs K2f per batch at the ML-10M shape:
-                                     #   64: 0.90 vs 1.47 us, 256: 2.18 vs 2.75, 384: 3.79 vs 3.33, 512: 5.95 vs 3.98)
+    own_max_batch: int = 256         # TKR_OWN_MAX_BATCH: batch sizes up to this take K2o (K2o vs K2f per batch at the ML-10M shape, round 5:
+                                     #   64: 0.79 vs 1.45 us, 128: 1.16 vs 2.01, 256: 1.95 vs 2.73, 384: 3.44 vs 3.28, 512: 5.47 vs 4.06)
     own_waves: int = 0               # TKR_OWN_WAVES: owner waves per workgroup | experiment bits 8..15, 0 = the library default
     fuse_short: bool = True          # TKR_FUSE_SHORT: K1 and the step of a short call leave in ONE C call (tkr_bpr_own_plan_run)
     fuse_plan: bool = True           # TKR_FUSE_PLAN: ... and K1 runs INSIDE the step's launch (the planner prologue of csrc/bpr_own.hip); 0: its own launches
