@@ -23,6 +23,7 @@ from __future__ import annotations
 import os
 import sys
 import time
+import warnings
 from collections import defaultdict
 
 import numpy as np
@@ -182,6 +183,9 @@ class BPR(REC):
         if old is not None and old[1].shape == base_ms.shape:      # slots of users nobody trains: what the checkpoint / previous train() left
             base_ms = old[1].numpy().copy()                # (a table of another shape -- k or the user list changed between train() calls -- is
                                                            # dropped: ADVICE r3, an assert here lost a whole sharded run at its very end)
+        elif old is not None:
+            warnings.warn('the saved RMSProp slots of the users this run does not train have shape %s, the model now %s: they start from 1.0 again'
+                          % (tuple(old[1].shape), base_ms.shape))
         for ids, rows, slots in tdist.gather_owned_rows(self._owned, p, ms):
             base[ids], base_ms[ids] = rows, slots
         self._global_users = (torch.from_numpy(base.copy()), torch.from_numpy(base_ms))       # what export_model writes
@@ -275,7 +279,6 @@ class BPR(REC):
                     sync.end()
                     loss = self._epoch_loss(loss)
             except tkr_hip.StepGaveUp as e:
-                import warnings
                 warnings.warn('BPR.train restarts from its initial state: %s' % e)
                 gave_up = True
             if sync is not None:
