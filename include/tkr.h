@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TKR_VERSION 116 /* 0.1.16: tkr_topk_set_finish (larger tkr_topk_workspace_bytes), tkr_bpr_own_plan_run plans inside the step's launch. 0.1.15: tkr_bpr_own_owners_shared; tkr_bpr_run takes `rec` non-const. 0.1.14: per-task loss sums instead of atomics on loss_out (larger tkr_vbpr_workspace_floats; K2 writes word 15 of its records). 0.1.13: tkr_bpr_own_plan_run, K4 to k = 768. 0.1.12: tkr_bpr_own_run_between. 0.1.11: K2o (tkr_sample_plan_owned, tkr_bpr_own_run: item rows owned by one workgroup each, resident in its LDS); prec[5] = last batch of the call that updated the row. 0.1.10: tkr_topk_workspace_bytes_for (K4 stages pre-converted fp16 tiles). 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
+#define TKR_VERSION 117 /* 0.1.17: tkr_vbpr_set_pairs (tkr_vbpr_workspace_floats + 64). 0.1.16: tkr_topk_set_finish (larger tkr_topk_workspace_bytes), tkr_bpr_own_plan_run plans inside the step's launch. 0.1.15: tkr_bpr_own_owners_shared; tkr_bpr_run takes `rec` non-const. 0.1.14: per-task loss sums instead of atomics on loss_out (larger tkr_vbpr_workspace_floats; K2 writes word 15 of its records). 0.1.13: tkr_bpr_own_plan_run, K4 to k = 768. 0.1.12: tkr_bpr_own_run_between. 0.1.11: K2o (tkr_sample_plan_owned, tkr_bpr_own_run: item rows owned by one workgroup each, resident in its LDS); prec[5] = last batch of the call that updated the row. 0.1.10: tkr_topk_workspace_bytes_for (K4 stages pre-converted fp16 tiles). 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
 #define TKR_OK 0
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
@@ -277,6 +277,11 @@ typedef struct {
 
 /* floats of scratch tkr_vbpr_run needs (split-K partials, s_t, P_t, W_t) */
 int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d);
+/* tkr_vbpr_run_cols: where the [B, B] pair sums S_t, T_t of a batch (vbpr.py:61) are formed -- 0: a launch of their own between the
+ * projection and the update (three launches per batch); 1: every task of the update works out the sums it needs (batch <= 256);
+ * 2: the first blocks of the update launch form them for everybody (two launches per batch).  Same sums, same order of summation,
+ * bit for bit (1: within fp32 rounding of the others).  Initial value from TKR_VBPR_PAIRS. */
+int tkr_vbpr_set_pairs(int32_t mode);
 /* n_batches consecutive batches planned by tkr_sample_plan (tri_i / tri_j = its out_i / out_j);
  * kh <= 128, batch_size <= 65536 (batches above 8192 are planned grid-wide, see tkr_sample_plan); loss_out as in tkr_bpr_run */
 int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* tri_j, const int32_t* rec,

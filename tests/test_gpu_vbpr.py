@@ -68,6 +68,49 @@ def test_vbpr_step_parity(k, d, B, nb, mode, dense, view):
     np.testing.assert_allclose(loss, np.array(ref_loss), rtol=2e-4)
 
 
+@pytest.mark.parametrize('k,d,B,nb,mode,density', [(128, 700, 256, 5, 'l2', 0.1), (56, 333, 128, 4, 'l1', 0.1), (128, 1030, 1024, 3, 'l2', 0.1),
+                                                     (16, 40, 64, 6, 'l2', 1.0), (128, 128, 256, 4, 'l2', 1.0)])
+def test_vbpr_pair_sum_forms_agree(k, d, B, nb, mode, density):
+    """the column-plan step with its pair sums S_t, T_t from a launch of their own (tkr_vbpr_set_pairs(0)), from the first blocks of the
+    update launch (2: same code, same order -- tables, slots and losses BIT FOR BIT) and worked out by every task for itself (1, batch
+    <= 256: within fp32 rounding); sparse rows and the long runs of a narrow dense feat"""
+    import tkr_hip
+    from single import _engine
+    n_users, n_items = 300, 90
+    tr, tr_users = _toy(n_users, n_items, seed=k + d)
+    rng = np.random.Generator(np.random.PCG64(d))
+    feat = np.abs(rng.standard_normal((n_items, d))).astype(np.float32)
+    if density < 1.0:
+        feat *= rng.random((n_items, d)) < density
+    feat /= np.maximum(np.linalg.norm(feat, axis=1, keepdims=True), 1e-6)
+    feat = feat.astype(np.float32)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, le=1e-3, lr=0.02, mode=mode)
+    dev = torch.device('cuda')
+    row_ptr, pos, srt = P.build_csr(tr, n_users)
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
+    out = {}
+    try:
+        for form in (0, 2, 1):
+            if form == 1 and B > 256:
+                continue
+            tkr_hip.set_vbpr_pairs(form)
+            eng = _engine.VbprEngine(n_users, n_items, k, d, feat, hp, dev, seed=5, sparse=True)
+            assert eng.wants_cols(B)
+            r2 = np.random.Generator(np.random.PCG64(1))
+            eng.set_dense(cem=(r2.standard_normal((d, k // 2)) * 0.05).astype(np.float32), icb=(r2.standard_normal(d) * 0.05).astype(np.float32))
+            losses = [eng.run_batches(csr, nb, B).clone() for _ in range(2)]          # two calls: the counter of form 2 starts over
+            torch.cuda.synchronize()
+            out[form] = [t.clone() for n in ('U', 'I', 'irb') for t in eng.get(n)] + [eng.cem.clone(), eng.mscem.clone(), eng.icb.clone(),
+                                                                                      eng.msicb.clone(), torch.cat(losses)]
+    finally:
+        tkr_hip.set_vbpr_pairs(0)
+    for x, y in zip(out[0], out[2]):
+        assert torch.equal(x, y)
+    if 1 in out:
+        for x, y in zip(out[0], out[1]):
+            torch.testing.assert_close(x, y, rtol=3e-4, atol=2e-5)
+
+
 def test_vbpr_class_end_to_end(tmp_path):
     import synth
     from single import VBPR

@@ -301,9 +301,10 @@ __global__ __launch_bounds__(W * 64) void vbpr_tproject_kernel(tkr_vbpr_state st
 
 // L2: the [B, B] pair sums (csrc/vbpr_step.hip, head).  One wave per triplet t, every alpha / beta the wave needs loaded up front
 // (B <= 1024: 16 per lane and array):  S_t = sum_b sigma(-(alpha_t + beta_b)),  T_t = sum_a sigma(-(alpha_a + beta_t)).
-__global__ __launch_bounds__(256) void vbpr_pairsum_kernel(const float* __restrict__ ab /*[2][B]*/, int B, float* __restrict__ sS,
-                                                          float* __restrict__ sT, float* __restrict__ loss_out) {
-    const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
+// FRESH: the sums are read by other blocks of the SAME launch (the pair blocks of vbpr_update_kernel): stored write-through
+template <bool FRESH>
+__device__ __forceinline__ void pairsum_wave(const float* __restrict__ ab /*[4][B]*/, int B, float* sS, float* sT, float* __restrict__ loss_out,
+                                             int t, int lane) {
     if (t >= B) return;
     const float* beta = ab + B;
     const float* ealpha = ab + 2 * B;                                // e^alpha, e^beta (pair_exp, tkr_common.h)
@@ -331,11 +332,22 @@ __global__ __launch_bounds__(256) void vbpr_pairsum_kernel(const float* __restri
     }
     s_row = wave_sum(s_row);
     s_col = wave_sum(s_col);
-    if (lane == 0) { sS[t] = s_row; sT[t] = s_col; }
+    if (lane == 0) {
+        if constexpr (FRESH) {
+            __hip_atomic_store(sS + t, s_row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sT + t, s_col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            sS[t] = s_row; sT[t] = s_col;
+        }
+    }
     if (loss_out) {
         loss = wave_sum(loss);
         if (lane == 0) loss_out[B + t] = loss;
     }
+}
+__global__ __launch_bounds__(256) void vbpr_pairsum_kernel(const float* __restrict__ ab /*[4][B]*/, int B, float* __restrict__ sS,
+                                                          float* __restrict__ sT, float* __restrict__ loss_out) {
+    pairsum_wave<false>(ab, B, sS, sT, loss_out, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 // L3.  Blocks [0, n_row_blocks) run the row tasks of the batch (vbpr_rows_body: the launch records of K1), the others the
@@ -401,21 +413,26 @@ __device__ __forceinline__ void col_block(const tkr_vbpr_state& st, const PS& ps
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     float gi = 0.f;
     // ---- light runs: the group alone; entries 0..2 came with the header, the others four in flight
-    if (own && n > 0 && n <= kLightRun) {
-        const int et[3] = {h0.z, h1.x, h1.z};
-        const int ev[3] = {h0.w, h1.y, h1.w};
-        int2 more[4];
+    const bool light = own && n > 0 && n <= kLightRun;
+    const int et[3] = {h0.z, h1.x, h1.z};
+    const int ev[3] = {h0.w, h1.y, h1.w};
+    int2 more[4] = {make_int2(0, 0), make_int2(0, 0), make_int2(0, 0), make_int2(0, 0)};
+    float4 wr[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    if (light) {
         if (n > 3) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) more[q] = cent[beg + min(3 + q, n - 1)];
         }
-        float tt[3], ss[3];
-        float4 wr[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int t = q < n ? et[q] : et[0];
             wr[q] = live ? *reinterpret_cast<const float4*>(Wraw + (size_t)t * kh + 4 * gl) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    }
+    // (pair sums formed by the first blocks of THIS launch: every wave of the block comes by here, with the loads above in flight)
+    pair_sums_wait(ps);
+    if (light) {
+        float tt[3], ss[3];
         ps.get(et, n, ss, tt);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -505,19 +522,56 @@ __device__ __forceinline__ void col_block(const tkr_vbpr_state& st, const PS& ps
 // INLINE: no pair-sum launch in front of this one -- rows and columns work S_t / T_t out where they need them (PairSumInline; s_in
 // then points at the batch's [alpha | beta | e^alpha | e^beta]), and B / 4 more blocks at the end of the grid add up the pair terms
 // of the loss, one wave per triplet (what vbpr_pairsum_kernel did beside its sums).
-template <int NE, int LPC, bool INLINE, int UNL = 4>
+// FUSED (round 5): no pair-sum launch either, and nobody recomputes anything -- the first (B + 3) / 4 blocks of the grid ARE the pair-sum
+// kernel (same code, same order of summation: S_t, T_t and the loss words are bit for bit those of the three-launch form), store
+// their sums write-through, drain, and bump `pair_done`; every other block runs its chain (header -> entries -> uce rows; the rows'
+// records and occurrences) and only looks at the counter where it first needs a sum (PairSumFresh) -- by then, ~2.5 us into the
+// launch, the pair blocks (~3 us) are done or nearly so.  s_in = S, t_in = T as in the three-launch form, ab = the batch's
+// [alpha | beta | e^alpha | e^beta].  Two launches per batch.
+// MEASURED (MI355X, ML-10M shape, batch 256, per batch without the loss): sparse d = 20,000: 25.4 us against 22.7 with the pair-sum
+// launch; dense d_c = 128: 23.6 against 18.0 (first version, every wave polling the counter and reading the sums past the L1: 28.6 /
+// 21.8).  The pair blocks are not done at ~3 us but at ~5 (two trips for their inputs, the write-through stores' drain, the
+// counter's atomic), the waiters see it a poll later, and the update's own chain behind the sums (sums -> entries 4..7 -> stores) is
+// still ahead of them: what overlaps is the 2.5 us of header + first gathers, what is added is the hand-off.  The third way of
+// removing the pair launch that lost (after round 4's last-block sums and round 5's inline sums): selectable (tkr_vbpr_set_pairs(2)),
+// bit-identical, not the default.
+template <int NE, int LPC, bool INLINE, int UNL = 4, bool FUSED = false>
 __global__ __launch_bounds__(256) void vbpr_update_kernel(
     tkr_vbpr_state st, const int32_t* __restrict__ rec_all, const int2* __restrict__ occ, const int32_t* __restrict__ occt,
     const int4* __restrict__ hdr, const float* __restrict__ s_in, const float* __restrict__ t_in, const float* __restrict__ P,
     const float* __restrict__ Wraw /*[B][kh]: uce_u(t)*/, const int4* __restrict__ colh, const int2* __restrict__ cent,
     int n_row_blocks, int n_col_blocks, int cpb, float* __restrict__ loss_out /*the batch's loss words: [B] projection | [B] pair sums | [column blocks]*/,
-    int ps_B /*batch size*/, int tune) {
+    int ps_B /*batch size*/, int tune, const float* __restrict__ ab = nullptr, uint32_t* pair_done = nullptr, uint32_t pair_target = 0u) {
     constexpr int G = 256 / LPC;
     constexpr int ROWS_LDS = 2 * 4 * (NE * TKR_WAVE + 1);
     constexpr int COLS_LDS = G * (4 * LPC + 1) + 2 * G;
     __shared__ float shm[ROWS_LDS > COLS_LDS ? ROWS_LDS : COLS_LDS];
     typedef float (*red_t)[NE * TKR_WAVE + 1];
-    if constexpr (INLINE) {
+    if constexpr (FUSED) {
+        static_assert(!INLINE, "one way of getting the pair sums");
+        const int n_pair = (ps_B + 3) / 4;
+        if ((int)blockIdx.x < n_pair) {
+            pairsum_wave<true>(ab, ps_B, const_cast<float*>(s_in), const_cast<float*>(t_in), loss_out, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the write-through stores are in memory
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(pair_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        const int bid = (int)blockIdx.x - n_pair;
+        const bool past_l1 = (ps_B & 31) != 0;
+        if (bid < n_row_blocks) {
+            if (tune & 8) return;
+            const PairSumFresh ps{s_in, t_in, pair_done, pair_target, nullptr, past_l1};
+            vbpr_rows_body<NE, 4>(st, rec_all, occ, occt, hdr, ps, P, nullptr, nullptr, nullptr, reinterpret_cast<red_t>(shm),
+                                  reinterpret_cast<red_t>(shm + 4 * (NE * TKR_WAVE + 1)), bid, n_row_blocks);
+            return;
+        }
+        __shared__ uint32_t pairs_here;                                // wave 0 of the block tells the others (PairSumFresh)
+        if (threadIdx.x == 0) pairs_here = 0u;
+        __syncthreads();
+        const PairSumFresh ps{s_in, t_in, pair_done, pair_target, &pairs_here, past_l1};
+        col_block<LPC, PairSumFresh, UNL>(st, ps, Wraw, colh, cent, bid - n_row_blocks, cpb, loss_out ? loss_out + 2 * ps_B : nullptr, tune, shm);
+    } else if constexpr (INLINE) {
         const float* ab = s_in;
         if ((int)blockIdx.x >= n_row_blocks + n_col_blocks) {        // the pair terms of the loss: wave per triplet
             const int lane = threadIdx.x & 63, t = ((int)blockIdx.x - n_row_blocks - n_col_blocks) * 4 + (threadIdx.x >> 6);
@@ -556,12 +610,21 @@ template <int NE, int LPC>
 static void launch_update(const tkr_vbpr_state& st, const int32_t* rec, const int2* occ2, const int32_t* occt, const int4* hdr4,
                           const float* s_buf, const float* t_buf, const float* P, const float* Wm, const int4* colh, const int2* cent,
                           int B, int cpb, float* loss, hipStream_t stream, int tune, const float* ab_inline /*or null: S / T from s_buf / t_buf*/,
-                          bool long_runs) {
+                          bool long_runs, const float* ab_fused = nullptr /*the pair sums by the first blocks of this launch*/,
+                          uint32_t* pair_done = nullptr, uint32_t pair_target = 0u) {
     constexpr int G = 256 / LPC;
     if (cpb <= 0 || cpb > G) cpb = G;
     const int n_row_blocks = vbpr_grid(B, 4);
     const int n_col_blocks = (st.d + cpb - 1) / cpb;
-    if (ab_inline)
+    if (ab_fused) {
+        const dim3 grid((B + 3) / 4 + n_row_blocks + n_col_blocks);
+        if (long_runs)
+            hipLaunchKernelGGL((vbpr_update_kernel<NE, LPC, false, 16, true>), grid, dim3(256), 0, stream, st, rec, occ2, occt, hdr4, s_buf, t_buf, P, Wm, colh,
+                               cent, n_row_blocks, n_col_blocks, cpb, loss, B, tune, ab_fused, pair_done, pair_target);
+        else
+            hipLaunchKernelGGL((vbpr_update_kernel<NE, LPC, false, 4, true>), grid, dim3(256), 0, stream, st, rec, occ2, occt, hdr4, s_buf, t_buf, P, Wm, colh,
+                               cent, n_row_blocks, n_col_blocks, cpb, loss, B, tune, ab_fused, pair_done, pair_target);
+    } else if (ab_inline)
         hipLaunchKernelGGL((vbpr_update_kernel<NE, LPC, true>), dim3(n_row_blocks + n_col_blocks + (loss ? (B + 3) / 4 : 0)), dim3(256), 0, stream, st, rec,
                            occ2, occt, hdr4, ab_inline, nullptr, P, Wm, colh, cent, n_row_blocks, n_col_blocks, cpb, loss, B, tune);
     else if (long_runs)           // a narrow dense feat: every column's run is split over the block's groups, 16 entries in flight (168 registers; 32: slower, 21.5 vs 19.7 us)
@@ -591,6 +654,27 @@ __global__ __launch_bounds__(256) void vbpr_loss_sum_kernel(const float* __restr
     if (threadIdx.x == 0) loss_out[b] += (part[0] + part[1]) + (part[2] + part[3]);
 }
 }  // namespace tkr
+
+// where the pair sums S_t, T_t of a batch come from: 0 = their own launch between the projection and the update (three launches
+// per batch), 1 = every task works out the ones it needs (PairSumInline, batch <= 256), 2 = the first blocks of the update launch
+// (vbpr_update_kernel FUSED).  Initial value: TKR_VBPR_PAIRS, else kVbprPairsDefault.
+namespace tkr {
+constexpr int kVbprPairsDefault = 0;
+static int g_vbpr_pairs = -1;
+static int vbpr_pairs_mode() {
+    if (g_vbpr_pairs < 0) {
+        const char* e = getenv("TKR_VBPR_PAIRS");
+        const int v = e ? atoi(e) : kVbprPairsDefault;
+        g_vbpr_pairs = (v >= 0 && v <= 2) ? v : kVbprPairsDefault;
+    }
+    return g_vbpr_pairs;
+}
+}  // namespace tkr
+extern "C" int tkr_vbpr_set_pairs(int32_t mode) {
+    if (mode < 0 || mode > 2) return TKR_EINVAL;
+    tkr::g_vbpr_pairs = mode;
+    return TKR_OK;
+}
 
 extern "C" int64_t tkr_vbpr_colplan_lds_bytes(int32_t batch_size, int32_t d) {
     const int64_t RW = (d + tkr::kColWaves - 1) / tkr::kColWaves;
@@ -670,8 +754,13 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
     // their own entries from e^alpha / e^beta (PairSumInline).  Measured (round 5, B = 256, d = 20,000): 31.6 us per batch against
     // 23.1 with the pair-sum launch -- the 4.5 us launch and its boundary go, but every one of the update's ~1,400 blocks now does
     // 100-250 reciprocals per lane in front of its stores.  Parity-green, not the default.
-    static const int pairs_env = getenv("TKR_VBPR_PAIRS") ? atoi(getenv("TKR_VBPR_PAIRS")) : -1;
-    const bool inline_pairs = pairs_env == 1 && B <= 256;
+    // TKR_VBPR_PAIRS=2: the pair sums by the first blocks of the update launch (vbpr_update_kernel FUSED) -- two launches per batch
+    // and nothing recomputed; 0: the three-launch form.
+    const int pairs_mode = tkr::vbpr_pairs_mode();
+    const bool inline_pairs = pairs_mode == 1 && B <= 256;
+    const bool fused_pairs = pairs_mode == 2;
+    uint32_t* pair_done = reinterpret_cast<uint32_t*>(workspace + tkr_vbpr_workspace_floats(B, kh, st->d) - 64);     // the call's counter: last 64 words
+    if (fused_pairs) TKR_CHECK(hipMemsetAsync(pair_done, 0, sizeof(uint32_t), (hipStream_t)stream));
     const bool long_runs = 2.0 * B * (double)row_cap / st->d > (double)tkr::kLightRun;      // (row_cap: the longest row of feat)
     for (int b = 0; b < n_batches; ++b) {
         const int32_t* ti = tri_i + (size_t)b * B;
@@ -693,10 +782,11 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
         else if (NH == 1) hipLaunchKernelGGL((tkr::vbpr_tproject_kernel<1, 16>), dim3(B), dim3(1024), 0, s, *st, ti, tj, tu, tp, tc, te, tcap, B, P, ab2, Wm, l, tune);
         else if (pw == 4) hipLaunchKernelGGL((tkr::vbpr_tproject_kernel<2, 4>), dim3(B), dim3(256), 0, s, *st, ti, tj, tu, tp, tc, te, tcap, B, P, ab2, Wm, l, tune);
         else hipLaunchKernelGGL((tkr::vbpr_tproject_kernel<2, 8>), dim3(B), dim3(512), 0, s, *st, ti, tj, tu, tp, tc, te, tcap, B, P, ab2, Wm, l, tune);
-        if (!(tune & 32) && !inline_pairs) hipLaunchKernelGGL(tkr::vbpr_pairsum_kernel, dim3((B + 3) / 4), dim3(256), 0, s, ab2, B, s_buf, t_buf, l);
+        if (!(tune & 32) && !inline_pairs && !fused_pairs) hipLaunchKernelGGL(tkr::vbpr_pairsum_kernel, dim3((B + 3) / 4), dim3(256), 0, s, ab2, B, s_buf, t_buf, l);
         if (tune & 128) continue;
         const int lpc = kh <= 16 ? 4 : (kh <= 32 ? 8 : (kh <= 64 ? 16 : 32));
-#define TKR_UPD(NE_, LPC_) tkr::launch_update<NE_, LPC_>(*st, r, o2, ot, h4, s_buf, t_buf, P, Wm, ch, ce, B, cols_per_block, l, s, tune, inline_pairs ? ab2 : nullptr, long_runs)
+#define TKR_UPD(NE_, LPC_) tkr::launch_update<NE_, LPC_>(*st, r, o2, ot, h4, s_buf, t_buf, P, Wm, ch, ce, B, cols_per_block, l, s, tune, inline_pairs ? ab2 : nullptr, long_runs, \
+                                                         fused_pairs ? ab2 : nullptr, pair_done, (uint32_t)(b + 1) * (uint32_t)((B + 3) / 4))
         switch (lpc) {
             case 4: TKR_UPD(1, 4); break;
             case 8: TKR_UPD(1, 8); break;

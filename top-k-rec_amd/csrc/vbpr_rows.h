@@ -86,6 +86,59 @@ struct PairSumArrays {
     }
 };
 
+// ... or two arrays that the FIRST blocks of this very launch are writing (csrc/vbpr_cols.hip, the pair blocks of vbpr_update_kernel).
+// A task waits where it first needs a sum until `done` says every pair block has stored its sums (the pair blocks have the lowest
+// block ids: they are resident before any block that waits).  Who polls the word matters: every wave of a ~1,500-block grid polling
+// it through the L2 (6,000 pollers of one channel) cost the update launch 6 us; here ONE wave per block polls (with a nap) and tells
+// the block's other waves through an LDS word (`flag`: set up by the block before anybody waits; null: this wave polls for itself --
+// the row blocks, where a wave without a task never comes by).  The sums are then ordinary cached loads: this CU's L1 was dropped at
+// the start of the launch and nothing of the launch reads the arrays before its wait; `past_l1`: the arrays share a cache line with
+// their neighbours (batch size not a multiple of 32), read them past the L1.  A wait that never ends is a broken launch: trap.
+struct PairSumFresh {
+    const float* s;
+    const float* t;
+    const uint32_t* done;
+    uint32_t target;
+    volatile uint32_t* flag;
+    bool past_l1;
+    mutable bool ready = false;
+    __device__ __forceinline__ void wait() const {
+        if (ready) return;
+        uint32_t spins = 0;
+        if (flag == nullptr || (threadIdx.x >> 6) == 0) {
+            while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1u << 22)) __builtin_trap();
+            }
+            if (flag != nullptr && (threadIdx.x & 63) == 0) *(__attribute__((address_space(3))) volatile uint32_t*)(flag) = 1u;
+        } else {
+            while (*(const __attribute__((address_space(3))) volatile uint32_t*)(flag) == 0u) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1u << 24)) __builtin_trap();
+            }
+        }
+        asm volatile("" ::: "memory");
+        ready = true;
+    }
+    template <int N>
+    __device__ __forceinline__ void get(const int (&tri)[N], int n, float (&S)[N], float (&T)[N]) const {
+        wait();
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            const int x = tri[q < n ? q : 0];
+            if (past_l1) {
+                S[q] = __hip_atomic_load(s + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                T[q] = __hip_atomic_load(t + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                S[q] = s[x];
+                T[q] = t[x];
+            }
+        }
+    }
+};
+template <class PS> __device__ __forceinline__ void pair_sums_wait(const PS&) {}
+__device__ __forceinline__ void pair_sums_wait(const PairSumFresh& ps) { ps.wait(); }
+
 // ... or nowhere: the TEAM lanes that ask (a wave for a row task, the lanes of one column group) work S_t and T_t out themselves from
 // e^alpha, e^beta of the batch ([B] each, 2 KB, cache-hot): 2B / TEAM reciprocals per lane and entry.  What this buys is the launch
 // of the pair-sum kernel between the projection and the update and the boundary in front of it (4.5 + 1.7 of the 25 us of a

@@ -693,7 +693,7 @@ extern "C" int64_t tkr_vbpr_workspace_core_floats(int32_t batch_size, int32_t kh
 // loss_add_spread), one word per triplet (twice) and per column block for the column-plan step (csrc/vbpr_cols.hip: no atomics)
 extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d) {
     const int64_t spread = (int64_t)tkr::kLossSlots * tkr::kLossSlotStride, per_task = 2ll * batch_size + d;
-    return tkr_vbpr_workspace_core_floats(batch_size, kh, d) + 512ll * (spread > per_task ? spread : per_task);
+    return tkr_vbpr_workspace_core_floats(batch_size, kh, d) + 512ll * (spread > per_task ? spread : per_task) + 64;      // (+ the column-plan step's pair counter)
 }
 
 namespace tkr {

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TKR_HIP_LIB') or os.path.join(_HERE, 'libtkr_hip.so')      # the override is for A/B builds of the kernels (scripts/)
 
 _lib = None
-VERSION = 116          # TKR_VERSION of include/tkr.h this binding was written against
+VERSION = 117          # TKR_VERSION of include/tkr.h this binding was written against
 
 
 class TkrError(RuntimeError):
@@ -81,7 +81,7 @@ EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_pl
            'tkr_vbpr_run', 'tkr_vbpr_colplan', 'tkr_vbpr_run_cols', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy',
            'tkr_idmap_create', 'tkr_idmap_destroy', 'tkr_ratings_parse', 'tkr_ratings_sizes', 'tkr_ratings_copy',
            'tkr_ratings_destroy', 'tkr_matrix_read', 'tkr_matrix_sizes', 'tkr_matrix_copy', 'tkr_matrix_destroy',
-           'tkr_matrix_write', 'tkr_raw_ranks', 'tkr_count_hits_rr', 'tkr_topk_set_math', 'tkr_topk_set_finish',
+           'tkr_matrix_write', 'tkr_raw_ranks', 'tkr_count_hits_rr', 'tkr_topk_set_math', 'tkr_topk_set_finish', 'tkr_vbpr_set_pairs',
            'tkr_sync_snapshot', 'tkr_sync_pack', 'tkr_sync_unpack', 'tkr_sync_flow_snapshot', 'tkr_sync_flow_pack',
            'tkr_sync_flow_unpack')
 EXPORTS_I64 = ('tkr_vbpr_workspace_floats', 'tkr_vbpr_colplan_lds_bytes', 'tkr_topk_workspace_bytes_for', 'tkr_topk_workspace_bytes', 'tkr_plan_workspace_bytes')
@@ -371,6 +371,11 @@ def own_stepper(state, B, ctl, owner_waves=0):
     step.plan_and_run = plan_and_run
     step.assigns_loss = not ((owner_waves >> 8) & 0x80)      # the row-read form writes loss_out[b] (csrc/bpr_own.hip own_loss_kernel); the scalar form adds
     return step
+
+
+def set_vbpr_pairs(mode):
+    """where tkr_vbpr_run_cols forms a batch's pair sums: 0 own launch, 1 every task for itself, 2 the first blocks of the update launch (include/tkr.h)"""
+    _check(lib().tkr_vbpr_set_pairs(C.c_int32(int(mode))), 'tkr_vbpr_set_pairs')
 
 
 def vbpr_workspace_floats(B, kh, d):
