@@ -192,29 +192,38 @@ __device__ __forceinline__ void item_group(const tkr_bpr_state& st, int lane, co
     }
 }
 
+#ifndef TKR_K2_WAVES
+#define TKR_K2_WAVES 1
+#endif
+#ifndef TKR_K2_GS
+#define TKR_K2_GS 2
+#endif
+template <int NE> constexpr int kGroupOf = NE >= 2 ? TKR_K2_GS : 4;
+
 template <int NE, bool VEC, bool ITEM>
 __device__ __forceinline__ void run_group(const tkr_bpr_state& st, int lane, int n, const int (&oa)[4],
                                           const int (&ob)[4], const float (&row)[NE], float br, float (&g)[NE],
                                           Acc& acc, bool want_loss) {
+    constexpr int GS = kGroupOf<NE>;
     if constexpr (ITEM) {
-        switch (n) {
-            case 1: item_group<NE, VEC, 1>(st, lane, oa, ob, row, br, g, acc); break;
-            case 2: item_group<NE, VEC, 2>(st, lane, oa, ob, row, br, g, acc); break;
-            case 3: item_group<NE, VEC, 3>(st, lane, oa, ob, row, br, g, acc); break;
-            default: item_group<NE, VEC, 4>(st, lane, oa, ob, row, br, g, acc); break;
+        if (n == 1) item_group<NE, VEC, 1>(st, lane, oa, ob, row, br, g, acc);
+        else if (GS == 2 || n == 2) item_group<NE, VEC, 2>(st, lane, oa, ob, row, br, g, acc);
+        else if constexpr (GS > 2) {
+            if (n == 3) item_group<NE, VEC, 3>(st, lane, oa, ob, row, br, g, acc);
+            else item_group<NE, VEC, 4>(st, lane, oa, ob, row, br, g, acc);
         }
     } else {
-        switch (n) {
-            case 1: user_group<NE, VEC, 1>(st, lane, oa, ob, row, g, acc, want_loss); break;
-            case 2: user_group<NE, VEC, 2>(st, lane, oa, ob, row, g, acc, want_loss); break;
-            case 3: user_group<NE, VEC, 3>(st, lane, oa, ob, row, g, acc, want_loss); break;
-            default: user_group<NE, VEC, 4>(st, lane, oa, ob, row, g, acc, want_loss); break;
+        if (n == 1) user_group<NE, VEC, 1>(st, lane, oa, ob, row, g, acc, want_loss);
+        else if (GS == 2 || n == 2) user_group<NE, VEC, 2>(st, lane, oa, ob, row, g, acc, want_loss);
+        else if constexpr (GS > 2) {
+            if (n == 3) user_group<NE, VEC, 3>(st, lane, oa, ob, row, g, acc, want_loss);
+            else user_group<NE, VEC, 4>(st, lane, oa, ob, row, g, acc, want_loss);
         }
     }
 }
 
 template <int NE, bool VEC, int kTeam, bool SGD>
-__global__ __launch_bounds__((kTeam * TKR_WAVE)) void bpr_step_kernel(
+__global__ __launch_bounds__((kTeam * TKR_WAVE), (TKR_K2_WAVES)) void bpr_step_kernel(
     tkr_bpr_state st, int32_t* rec_all /*word 15 of a user task's record receives its loss sum: not const, not restrict*/,
     const int2* __restrict__ occ, const int4* __restrict__ hdr, float* __restrict__ loss_out, int reverse) {
     __shared__ float red[kTeam][NE * TKR_WAVE + 1];
@@ -261,20 +270,23 @@ __global__ __launch_bounds__((kTeam * TKR_WAVE)) void bpr_step_kernel(
         // task (batch 8192) was 7 dependent trips, the tail of the launch.
         int2 omore = make_int2(0, 0);
         if (n_occ > 4 && lane < n_occ - 4) omore = occ[first + (4 + lane) * team];
-        for (int done = 0; done < n_occ; done += 4) {
-            const int n = min(4, n_occ - done);
-            int oa[4], ob[4];
-            if (done == 0) {
+        // occurrences per round: 4 (k <= 64) or 2 (wider rows: the partner rows of four occurrences are 16 registers + 16 of addresses,
+        // 83 in all, and a 16-wave workgroup then has a CU to itself; TKR_K2_GS)
+        constexpr int GS = kGroupOf<NE>;
+        for (int done = 0; done < n_occ; done += GS) {
+            const int n = min(GS, n_occ - done);
+            int oa[4] = {0, 0, 0, 0}, ob[4] = {0, 0, 0, 0};
+            if (done < 4) {                       // (4 % GS == 0: a round lies inside the record or behind it)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { oa[q] = bcast_i(word, 4 + 2 * q); ob[q] = bcast_i(word, 5 + 2 * q); }
-            } else if (done + 4 <= 68) {
+                for (int q = 0; q < GS; ++q) { oa[q] = bcast_i(word, (4 + 2 * (done + q)) & 15); ob[q] = bcast_i(word, (5 + 2 * (done + q)) & 15); }
+            } else if (done + GS <= 68) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { oa[q] = bcast_i(omore.x, (done - 4 + q) & 63); ob[q] = bcast_i(omore.y, (done - 4 + q) & 63); }
-            } else {                              // very heavy rows: fetch the next 4 occurrences
+                for (int q = 0; q < GS; ++q) { oa[q] = bcast_i(omore.x, (done - 4 + q) & 63); ob[q] = bcast_i(omore.y, (done - 4 + q) & 63); }
+            } else {                              // very heavy rows: fetch the next occurrences
                 int2 o = make_int2(0, 0);
                 if (lane < n) o = occ[first + (done + lane) * team];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { oa[q] = bcast_i(o.x, q); ob[q] = bcast_i(o.y, q); }
+                for (int q = 0; q < GS; ++q) { oa[q] = bcast_i(o.x, q); ob[q] = bcast_i(o.y, q); }
             }
             if (is_item) run_group<NE, VEC, true>(st, lane, n, oa, ob, own, br, g, acc, false);
             else run_group<NE, VEC, false>(st, lane, n, oa, ob, own, 0.f, g, acc, loss_out != nullptr);
