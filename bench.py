@@ -14,8 +14,11 @@ of the item-side state per epoch (every (limit//B)//N steps); weak scaling (K st
 Prints ONE JSON line (rank 0).  Extra objects beside the contract fields:
   roofline        dominant kernel (K2) against the HBM roofline: algorithmic bytes per launch
                   (B x (48k+56) B, SURVEY.md §8d) / average launch duration from HIP events;
-                  `traffic` (PMC bytes measured in THIS run) is null -- counters need rocprofv3 --
-                  `traffic_from_profile` replays the figure of the committed profiles/rNN_pmc_traffic.json
+                  `traffic` = HBM bytes per batch of the headline step measured in THIS run: two rocprofv3 counter
+                  passes (FETCH_SIZE, WRITE_SIZE; kernel trace only) of scripts/pmc_leg.py in child processes
+                  (live_traffic(); ~10 s; --no-live-traffic / --no-extras skip them; null with `traffic_how`
+                  saying why where rocprofv3 cannot run); `traffic_from_profile` replays the committed
+                  profiles/rNN_pmc_traffic.json (the other legs: only that)
   cpu_baseline    the numpy oracle with the reference's cost structure (per-element legacy
                   np.random sampler + numpy step), bounded sample, rank 0, N = 1 only
   throughput_mode the same path at batch_size 8192 (a legal train() argument; NOT the headline)
@@ -120,6 +123,50 @@ def pmc_mfma(match):
     except (OSError, ValueError, KeyError):
         pass
     return None
+
+
+def live_traffic(k, B, shape, batches=4096):
+    """HBM bytes per BATCH of the headline step, measured NOW: two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE: separate passes, kernel
+    trace only, as MI355X_MICROARCH.md prescribes) of scripts/pmc_leg.py in child processes, bytes = KB x 1024 x the factors of the
+    known-byte calibration copy (profiles/rNN_pmc_traffic.json: FETCH x 1.98, WRITE x 1.00 on gfx950).  -> (bytes per batch | None, note)"""
+    import csv, glob, shutil, subprocess, tempfile
+    if shutil.which('rocprofv3') is None:
+        return None, 'rocprofv3 not on PATH'
+    if any(v.startswith(('ROCPROF', 'ROCP_', 'ROCTX')) for v in os.environ):
+        return None, 'this process runs under a profiler already'
+    fr, fw = 1.9842944385544612, 1.0
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    if files:
+        try:
+            cal = json.load(open(files[-1]))['calibration']
+            fr, fw = float(cal['read_factor']), float(cal['write_factor'])
+        except (OSError, ValueError, KeyError):
+            pass
+    got = {}
+    for C in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='tkr_pmc_', dir='/tmp')
+        try:
+            p = subprocess.run(['rocprofv3', '--kernel-trace', '--pmc', C, '--output-format', 'csv', '-d', d, '-o', 'b', '--', sys.executable,
+                                os.path.join(ROOT, 'scripts', 'pmc_leg.py'), str(k), str(B), shape, str(batches)],
+                               cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240)
+            info = json.loads(p.stdout.decode().strip().splitlines()[-1])
+            hits = glob.glob(os.path.join(d, '**', 'b_counter_collection.csv'), recursive=True)
+            name = info['kernel'].split('::')[-1]
+            kb = 0.0
+            for row in csv.DictReader(open(hits[0])):
+                if name in row['Kernel_Name'] and row.get('Counter_Name', C) == C:
+                    kb += float(row['Counter_Value'])
+            got[C] = (kb * 1024.0, info['batches'])
+        except Exception as e:          # a counter pass is evidence, never a reason to lose the bench line
+            return None, '%s pass failed: %s' % (C, type(e).__name__)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    rd, nb = got['FETCH_SIZE']
+    wr, _ = got['WRITE_SIZE']
+    if rd <= 0 or wr <= 0:
+        return None, 'no counter rows for the step kernel'
+    return (rd * fr + wr * fw) / nb, ('rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two child passes of scripts/pmc_leg.py (%d batches each), per BATCH '
+                                    '(a launch of the persistent kernel covers up to 512); read x %.3f, write x %.3f (calibration copy)' % (nb, fr, fw))
 
 
 def algorithmic_bytes_per_triplet(k):
@@ -604,6 +651,7 @@ def main():
     ap.add_argument('--epoch-sample-limit', type=int, default=10 ** 6)   # train.py:6
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true')
+    ap.add_argument('--no-live-traffic', action='store_true')       # skip the two rocprofv3 counter passes behind roofline.traffic (~25 s)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -676,6 +724,12 @@ def main():
     out['epoch_mode'] = em
     if world == 1:
         out['steady_state'] = em
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_live_traffic and eng.layout == 'flow':
+        t_bytes, t_note = live_traffic(k, B, args.shape)
+        out['roofline']['traffic'] = t_bytes
+        out['roofline']['traffic_how'] = t_note
+        if t_bytes:
+            out['roofline']['traffic_over_algorithmic'] = t_bytes / (B * algorithmic_bytes_per_triplet(k))
     if rank == 0 and world == 1 and not args.no_extras:
         # throughput mode: same kernels, batch_size 8192 (fresh tables)
         from single import _engine

@@ -113,3 +113,19 @@ def test_exchange_cadence_survives_short_calls():
     # (the two ranks of this test time-slice ONE GPU: the same build measures 1.03x to 1.27x here depending on how the two processes'
     # launches interleave -- the bound only says that no per-batch cost sits outside the step launches)
     assert em['ms_per_epoch_minus_collective'] < 1.5 * em['batches_x_launch_us_ms'] + 0.15, em
+
+
+def test_live_counter_traffic_of_the_headline_step():
+    """bench.py's `roofline.traffic`: two rocprofv3 counter passes of scripts/pmc_leg.py in child processes.  HBM bytes per batch
+    of the persistent step lie between the algorithmic bytes (every row read and written once) and a few times that (the granule
+    tables move 8 bytes per fp32: DESIGN.md §5); where rocprofv3 is not available the answer is None with a reason, never an error."""
+    import shutil
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'top-k-rec_amd')]
+    import bench
+    got, how = bench.live_traffic(128, 256, 'ml10m', batches=1024)
+    if shutil.which('rocprofv3') is None:
+        assert got is None and 'rocprofv3' in how
+        return
+    assert got is not None, how
+    alg = 256 * bench.algorithmic_bytes_per_triplet(128)
+    assert alg <= got <= 4.0 * alg, (got, alg, how)
