@@ -1217,6 +1217,15 @@ static int own_launch(const tkr_flow_state* st, const int32_t* prec, const int32
         TKR_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         if (dev >= 0 && dev < 64) attr_set[dev][variant][scalar] = true;
     }
+    // every owner must be RESIDENT (the dataflow inside a launch waits for workgroups that have to be running): asked of the runtime
+    // once per kernel form and device, at the largest LDS size a launch may ask for (K2f had the query, K2o did not)
+    static signed char fits[64][6][2];
+    if (dev >= 0 && dev < 64 && fits[dev][variant][scalar] == 0) {
+        int per_cu = 0;
+        TKR_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, tpb, 160 * 1024));
+        fits[dev][variant][scalar] = per_cu >= 1 ? 1 : -1;
+    }
+    if (dev >= 0 && dev < 64 && fits[dev][variant][scalar] < 0) return TKR_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const int4* r4 = reinterpret_cast<const int4*>(prec) + (size_t)first_batch * 3 * batch_size * 8;      // record 0 of the first batch to run
     const int4* o4 = reinterpret_cast<const int4*>(pocc);
