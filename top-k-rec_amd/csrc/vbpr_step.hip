@@ -249,10 +249,25 @@ __global__ __launch_bounds__(256) void vbpr_pair_kernel(const float* __restrict_
     const float* ebeta = ab + 3 * B;
     const float a_t = ab[t], ea_t = ealpha[t], eb_t = ebeta[t];
     float s_row = 0.f, s_col = 0.f, loss = 0.f;
-    for (int o = lane; o < B; o += 64) {
-        s_row += pair_sigmoid(ea_t, ebeta[o]);
-        if (loss_out) loss += pair_softplus_neg(ea_t, ebeta[o], a_t + beta[o]);
-        s_col += pair_sigmoid(ealpha[o], eb_t);
+    // eight partners of the lane in flight (a load, a wait and three transcendentals per trip of the plain loop: 87 us of the 205 of a
+    // batch of 8192, where the arithmetic alone is ~30); the sums still run in index order, one accumulator each: same bits
+    constexpr int UN = 8;                               // (16: no faster)
+    for (int o0 = lane; o0 < B; o0 += 64 * UN) {
+        float eb[UN], ea[UN], be[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int o = min(o0 + 64 * q, B - 1);
+            eb[q] = ebeta[o]; ea[q] = ealpha[o];
+            be[q] = loss_out ? beta[o] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            if (o0 + 64 * q < B) {
+                s_row += pair_sigmoid(ea_t, eb[q]);
+                if (loss_out) loss += pair_softplus_neg(ea_t, eb[q], a_t + be[q]);
+                s_col += pair_sigmoid(ea[q], eb_t);
+            }
+        }
     }
     s_row = wave_sum(s_row);
     s_col = wave_sum(s_col);
