@@ -396,7 +396,10 @@ static int sample_plan_impl(const int32_t* tr_users, int32_t n_tr, const int32_t
     if (batch_size > 8192 || (batch_size >= big_from && !flow && workspace &&
                               workspace_bytes >= tkr_plan_workspace_bytes_for(batch_size, n_batches))) {
         // above 8192 the 2B 64-bit keys no longer fit one workgroup's LDS; from 4096 (TKR_PLAN_BIG_FROM) the grid-wide planner is
-        // simply faster (measured per batch: 4.7 vs 6.3 us at 4096, 7.6 vs 10.5 us at 8192) -- the two produce identical plans
+        // faster alone (per batch: 4.7 vs 6.3 us at 4096, 7.6 vs 10.5 us at 8192).  Beside the steps neither hides (round 5: the
+        // steps slow down by what the planner takes): in ONE long call the per-batch planner's three launches come out ahead (22.9 vs
+        // 24.1 us per batch at 8192, scripts/probe_plan_host.py), in epoch-sized calls (BPR.train, bench.py: 122 batches per call at
+        // 8192) the faster planner does (24.7 vs 28.8) -- that is the default.  The two produce identical plans
         if (flow) return TKR_EUNSUPPORTED;                  // the dataflow step is for small batches
         const int rc = tkr_sample_plan_big(tr_users, n_tr, row_ptr, pos_cols, cols_sorted, n_users, n_items, seed, first_triplet, ctl,
                                            n_batches, batch_size, ucnt, icnt, touch_u, touch_i, out_u, out_i, out_j, task, occ, rec,

@@ -50,6 +50,7 @@ class Tuning:
     fuse_plan: bool = True           # TKR_FUSE_PLAN: ... and K1 runs INSIDE the step's launch (the planner prologue of csrc/bpr_own.hip); 0: its own launches
     overlap_min_batch: int = 2048    # TKR_OVERLAP_MIN_BATCH: from this batch size on K1 of the next chunk runs on the side stream
     epoch_ahead: bool = True         # TKR_EPOCH_AHEAD: plan the first chunk after an exchange ahead of it
+    call_ahead: bool = True          # TKR_CALL_AHEAD: plain layout (batch > 512): plan the NEXT call's first chunk behind the last steps of this one
     vbpr_cols: bool = True           # TKR_VBPR_COLS: the column-plan form of the VBPR step
     vbpr_overlap: bool = True        # TKR_VBPR_OVERLAP: its column plan on the side stream
 
@@ -62,7 +63,7 @@ class Tuning:
             'flow': _flag, 'flow_max_batch': _int_in(0, 1 << 20), 'flow_waves_per_cu': _int_in(0, 32),
             'flow_item_bufs': lambda n, r: int(_choice('2', '4')(n, r)), 'own': _choice('0', '1', '2'),
             'own_max_batch': _int_in(0, 1024), 'own_waves': _int_in(0, 0xffff), 'fuse_short': _flag, 'fuse_plan': _flag,
-            'overlap_min_batch': _int_in(1, 1 << 30), 'epoch_ahead': _flag, 'vbpr_cols': _flag, 'vbpr_overlap': _flag,
+            'overlap_min_batch': _int_in(1, 1 << 30), 'epoch_ahead': _flag, 'call_ahead': _flag, 'vbpr_cols': _flag, 'vbpr_overlap': _flag,
         }
         out = cls()
         for f in fields(cls):

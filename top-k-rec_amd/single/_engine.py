@@ -410,6 +410,12 @@ class PlanMixin:
             nxt = self._plan_chunk(0 if cur is None else cur.idx ^ 1, csr, B, self._drawn, False, want, fuse=fuse)
         if overlap and want > nxt.nb:                 # the chunk after it, behind the steps of this one
             self._ahead = self._plan_chunk(nxt.idx ^ 1, csr, B, nxt.first + nxt.nb * B, True, want - nxt.nb)
+        elif overlap and then_exchange == 0 and not self._plan_flow() and self.cfg.call_ahead and want == nxt.nb and want > 8:
+            # the LAST chunk of a call on the plain layout (batch > 512: a launch per batch, K1 6-10 us per batch beside 19 us of step):
+            # callers come back for more of the same -- BPR.train runs an epoch per call, at batch 8192 an epoch of 122 batches is
+            # less than one chunk and NOTHING was ever planned beside the steps -- so the next call's first chunk is planned now, of
+            # this chunk's size, behind this chunk's steps.  A caller that does something else first finds it rolled back (settle()).
+            self._ahead = self._plan_chunk(nxt.idx ^ 1, csr, B, nxt.first + nxt.nb * B, True, nxt.nb)
         elif then_exchange > 0 and want <= nxt.nb and self._epoch_ahead_ok(B):
             # the LAST chunk of an epoch: after the exchange every item row is at version 0 again and the users go on where this
             # chunk leaves them -- everything K1 needs to plan the first chunk of the next epoch, so it runs now, on the side stream
