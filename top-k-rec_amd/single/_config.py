@@ -50,7 +50,8 @@ class Tuning:
     fuse_plan: bool = True           # TKR_FUSE_PLAN: ... and K1 runs INSIDE the step's launch (the planner prologue of csrc/bpr_own.hip); 0: its own launches
     overlap_min_batch: int = 2048    # TKR_OVERLAP_MIN_BATCH: from this batch size on K1 of the next chunk runs on the side stream
     epoch_ahead: bool = True         # TKR_EPOCH_AHEAD: plan the first chunk after an exchange ahead of it
-    call_ahead: bool = True          # TKR_CALL_AHEAD: plain layout (batch > 512): plan the NEXT call's first chunk behind the last steps of this one
+    call_ahead: bool = False         # TKR_CALL_AHEAD: plain layout (batch > 512): plan the NEXT call's first chunk behind the last steps of this one
+                                     #   (epoch-sized calls at batch 8192: 25.5 -> 24.7 us per batch; a call nobody follows up pays for the plan: 24.1 -> 24.7)
     vbpr_cols: bool = True           # TKR_VBPR_COLS: the column-plan form of the VBPR step
     vbpr_overlap: bool = True        # TKR_VBPR_OVERLAP: its column plan on the side stream
 
