@@ -148,3 +148,37 @@ def test_train_restarts_one_kernel_down_when_a_step_gives_up(tmp_path, monkeypat
             assert np.array_equal(a, b)
         # (K2f adds a batch's loss up with LDS atomics, K2 with a sliced sum: the tables are bitwise, the reported loss to its last bits)
         assert abs(m.last_epoch_loss - clean.last_epoch_loss) <= 1e-5 * abs(clean.last_epoch_loss)
+
+
+def test_call_ahead_plans_the_next_call_behind_this_one():
+    """plain layout (batch > 512), TKR_CALL_AHEAD=1: the last chunk of a call plans the next call's first chunk on the side stream.
+    Same tables, counters and stream position as without, whether the caller comes back for more, for less, or looks at the counters
+    (settle() rolls the unused plan back) in between"""
+    import numpy as np
+    from oracle import plan_np as P
+    from single import _engine
+    from single._config import Tuning
+    rng = np.random.Generator(np.random.PCG64(4))
+    n_users, n_items, k, B = 3000, 700, 64, 2048
+    tr = {int(u): [int(x) for x in rng.integers(0, n_items, int(rng.integers(1, 12)))] for u in range(n_users)}
+    row_ptr, pos, srt = P.build_csr(tr, n_users)
+    dev = torch.device('cuda')
+    csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(list(tr.keys()), np.int32), dev)
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=1e-3, lr=0.02, mode='l2')
+    out = {}
+    for ahead in (False, True):
+        cfg = Tuning.from_env({})
+        cfg.call_ahead = ahead
+        e = _engine.BprEngine(n_users, n_items, k, hp, dev, seed=9, tuning=cfg)
+        e.run_batches(csr, 20, B, want_loss=False)
+        assert (e._ahead is not None) == ahead
+        e.run_batches(csr, 20, B, want_loss=False)          # comes back for the same
+        e.run_batches(csr, 9, B, want_loss=False)           # ... for less than was planned
+        ucnt = e.cnt.ucnt.clone()                           # looks at the counters: settle() drops what was planned and did not run
+        e.run_batches(csr, 20, B, want_loss=False)
+        e.check()
+        out[ahead] = ([t.clone() for n in ('U', 'V', 'b') for t in e.get(n)], ucnt, e.cnt.icnt.clone(), e.triplets_drawn)
+    for x, y in zip(out[False][0], out[True][0]):
+        assert torch.equal(x, y)
+    assert torch.equal(out[False][1], out[True][1]) and torch.equal(out[False][2], out[True][2])
+    assert out[False][3] == out[True][3] == 69 * B
