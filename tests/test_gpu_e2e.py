@@ -110,7 +110,8 @@ def test_train_restarts_one_kernel_down_when_a_step_gives_up(tmp_path, monkeypat
     """a launch of a persistent step is not transactional: when a bounded spin runs out (injected through the status word after
     the first epoch) BPR.train puts back the state it started from and runs again on the next kernel down -- K2o -> K2f -> K2 --
     instead of raising with half-updated tables.  Same start, same counter-based stream: the result is bit for
-    bit what a run that never had the upper kernels produces."""
+    bit what a run that never had the upper kernels produces -- also when the launch gave up inside its planner prologue and left
+    K1's touch bitmaps dirty."""
     import tkr_hip
     from single import BPR, _engine
     data = _dataset(tmp_path, seed=6)
@@ -128,6 +129,10 @@ def test_train_restarts_one_kernel_down_when_a_step_gives_up(tmp_path, monkeypat
             out = orig(self, *a, **kw)
             if calls['n'] < failures and self.layout == 'flow':          # as if a spin of this epoch's launch had run out
                 self.ctl[tkr_hip.FLOW_CTL_STATUS] = 1
+                # ... in the planner prologue of the launch: its commit never ran and K1's touch bits of the call are still set
+                # (restore() has to clear them, or the retry plans against wrong versions and buffer parities)
+                self._cnt.touch_u[::3] = 0x5a5a
+                self._cnt.touch_i[::2] = 0x0f0f
                 calls['n'] += 1
             return out
         monkeypatch.setattr(_engine.BprEngine, 'run_batches', flaky)

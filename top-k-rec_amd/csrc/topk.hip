@@ -1469,9 +1469,12 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT, REFINE>() * TKR_WAVE), 2)
     unsigned long long k4p[8] = {0, 0, 0, 0, 0, 0, 0, 0}, k4t = k4_start;
     K4_MARK(5)
 #endif
+    // the rated-item word of (tile, user) comes from HBM (every workgroup reads its own 512 bytes per tile: never a cache hit): it
+    // is asked for one tile ahead, right behind the barrier, and has the filter of this tile and the chain of the next to arrive
+    uint32_t mask_next = (mask && user_ok && t_begin < n_tiles) ? mask[(size_t)t_begin * mask_pitch + row] : 0u;
     for (int t = t_begin; t < n_tiles; ++t) {
         const int buf = t & 1;
-        uint32_t maskw = (mask && user_ok) ? mask[(size_t)t * mask_pitch + row] : 0u;
+        uint32_t maskw = mask_next;
         // ---- 32 items x 32 users x k: six bf16 partial products per 16-wide k step, fp32 accumulation.
         // A operand: lane (item ul, k-group h) reads elements 16s + 8h .. +7 of each part; small terms first.
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1534,6 +1537,7 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT, REFINE>() * TKR_WAVE), 2)
         K4_MARK(1)
         if constexpr (kEarlyBarrier) __syncthreads();
         K4_MARK(2)
+        if (mask && user_ok && t + 1 < n_tiles) mask_next = mask[(size_t)(t + 1) * mask_pitch + row];
         if (!user_ok) maskw = 0xffffffffu;
         if (t == n_tiles_all - 1) maskw |= tail_mask;
         if (t == next_sched && !(TKR_ABL & 16)) {
@@ -1961,7 +1965,8 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
     const int ROWB = use_img ? KS * 32 : (REFINE ? 1 : 3) * KS * 32 + 16;
     const int W = topk_waves_bf16<KS, IdT, REFINE>();
     const int users = W * 32;
-    const size_t lds = (size_t)2 * 32 * ROWB + 64 * 4 + (size_t)users * 8 + (size_t)users * kCap * (4 + sizeof(IdT));
+    size_t lds = (size_t)2 * 32 * ROWB + 64 * 4 + (size_t)users * 8 + (size_t)users * kCap * (4 + sizeof(IdT));
+    if (const char* e = getenv("TKR_TOPK_LDS_PAD")) lds += (size_t)atoi(e);      // occupancy experiments (scripts/)
     if (lds > 160 * 1024) return TKR_EUNSUPPORTED;
     auto kern = score_topk_bf16_kernel<KS, IdT, REFINE, false>;
     auto kern_img = score_topk_bf16_kernel<KS, IdT, REFINE, REFINE>;

@@ -838,6 +838,10 @@ class BprEngine(PlanMixin):
 
     def restore(self, snap):
         self.settle(check=False)
+        # K1's per-row touch bits of a call are cleared by ITS commit (plan_commit_first_touch / commit_kernel); a launch whose planner
+        # prologue gave up never got there, and stale bits would give the next plan wrong versions and buffer parities
+        self._cnt.touch_u.zero_()
+        self._cnt.touch_i.zero_()
         self.set_users(U=snap['U'][0], msU=snap['U'][1])
         self.set_items(V=snap['V'][0], b=snap['b'][0], msV=snap['V'][1], msb=snap['b'][1])
         self._drawn = int(snap['drawn'])
