@@ -28,6 +28,8 @@
 #include <vector>
 
 #include "tkr_common.h"
+#include "topk_parts.h"
+#include "topk_refine.h"
 #include "../../include/tkr.h"
 
 #ifndef TKR_ABL
@@ -49,108 +51,6 @@ __device__ unsigned long long g_k4_prof[8];
 #endif
 
 namespace tkr {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kTopkMaxWaves = 8;
-constexpr int kCap = 64;                 // candidate slots per user (= wave width: one entry per lane in a trim)
-constexpr int kMaxK = 32;                // K + 32 (largest per-tile inflow) <= kCap
-constexpr int TKR_EAGAIN_EXACT = -100;   // internal: the bound-and-refine launch cannot run here (no workspace for its flags)
-
-__device__ __forceinline__ uint32_t ordered_bits(float s) {      // monotone float -> uint
-    const uint32_t f = __float_as_uint(s);
-    return (f & 0x80000000u) ? ~f : (f | 0x80000000u);
-}
-
-// value of lane (lane ^ STRIDE).  Strides 1..8 stay in the VALU (DPP), 16 uses the LDS crossbar without
-// an address (ds_swizzle), only 32 needs a bpermute.
-__device__ __forceinline__ float unordered_bits(uint32_t ob) {    // inverse of ordered_bits; 0 -> below every float
-    if (ob == 0u) return -INFINITY;
-    return __uint_as_float((ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob);
-}
-
-// Item-range splits of one user block cooperate through thr_shared[row]: the K-th best score inside ANY subset of
-// the catalogue is a lower bound of the K-th best overall, so every range may filter with the largest bound any
-// range has published.  Ranges are dispatched range-major (blockIdx.x fastest), so later ranges start with the
-// thresholds of earlier ones instead of -inf and skip the expensive low-threshold phase.  Results do not depend on
-// the timing: a column of the global top K passes every such bound, and the final order comes from the exact sorts.
-__device__ __forceinline__ float share_threshold(uint32_t* thr_shared, int row, bool publish, float thr) {
-    if (!thr_shared) return thr;
-    uint32_t seen = 0u;
-    if (publish && thr > -INFINITY) seen = atomicMax(&thr_shared[row], ordered_bits(thr));
-    seen = max(seen, (uint32_t)__shfl_xor((int)seen, 32, 64));  // the h = 1 lane of the user gets it too
-    return fmaxf(thr, unordered_bits(seen));
-}
-// Bound-and-refine arithmetic: the filter runs on approximate scores with `thr` = (lower bound of the K-th best EXACT score)
-// - margin; what the item ranges of a block tell each other is the bound itself.
-// thr and margin are in the user's scaled units (scale = a power of two), the shared word is not.
-__device__ __forceinline__ float share_bound(uint32_t* thr_shared, int row, bool publish, float thr, float margin, float scale,
-                                             float inv_scale) {
-    if (!thr_shared) return thr;
-    uint32_t seen = 0u;
-    if (publish && thr > -INFINITY) seen = atomicMax(&thr_shared[row], ordered_bits((thr + margin) * inv_scale));
-    seen = max(seen, (uint32_t)__shfl_xor((int)seen, 32, 64));
-    return fmaxf(thr, unordered_bits(seen) * scale - margin);
-}
-
-// 2^e with amax * 2^e in [2^13, 2^14) (|e| <= 60; 1 for amax = 0): the power-of-two scaling of the fp16 pass
-__device__ __forceinline__ float pow2_scale(float amax) {
-    if (!(amax > 0.f)) return 1.f;
-    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
-    const int sft = max(-60, min(60, 13 - e));
-    return __uint_as_float((uint32_t)(127 + sft) << 23);
-}
-
-template <int STRIDE>
-__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
-    if constexpr (STRIDE == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-    else if constexpr (STRIDE == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // [2,3,0,1]
-    else if constexpr (STRIDE == 4) {   // half_mirror (i ^ 7) then quad reverse (i ^ 3)
-        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);
-        return (uint32_t)__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xf, 0xf, true);
-    } else if constexpr (STRIDE == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);   // row_ror:8
-    else if constexpr (STRIDE == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);   // xor 16 inside each 32 lanes
-    else return (uint32_t)__shfl_xor((int)v, 32, 64);
-}
-
-template <int SIZE, int STRIDE>
-__device__ __forceinline__ void cmpx(uint32_t& hi, uint32_t& lo, int lane) {
-    const uint32_t ohi = lane_xor<STRIDE>(hi), olo = lane_xor<STRIDE>(lo);
-    const bool other_gt = (ohi > hi) || (ohi == hi && olo > lo);
-    const bool upper = (lane & STRIDE) != 0;                 // I am the higher lane of the pair
-    const bool desc = (lane & SIZE) == 0;                    // this block sorts descending
-    const bool take_max = (upper != desc);                   // lower lane of a descending block keeps the max
-    const bool take_other = (take_max == other_gt);
-    hi = take_other ? ohi : hi;
-    lo = take_other ? olo : lo;
-}
-
-// descending bitonic sort of one 64-bit key per lane across the wave (keys are distinct)
-__device__ __forceinline__ uint64_t wave_sort_desc(uint64_t key, int lane) {
-    uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
-    cmpx<2, 1>(hi, lo, lane);
-    cmpx<4, 2>(hi, lo, lane); cmpx<4, 1>(hi, lo, lane);
-    cmpx<8, 4>(hi, lo, lane); cmpx<8, 2>(hi, lo, lane); cmpx<8, 1>(hi, lo, lane);
-    cmpx<16, 8>(hi, lo, lane); cmpx<16, 4>(hi, lo, lane); cmpx<16, 2>(hi, lo, lane); cmpx<16, 1>(hi, lo, lane);
-    cmpx<32, 16>(hi, lo, lane); cmpx<32, 8>(hi, lo, lane); cmpx<32, 4>(hi, lo, lane); cmpx<32, 2>(hi, lo, lane);
-    cmpx<32, 1>(hi, lo, lane);
-    cmpx<64, 32>(hi, lo, lane); cmpx<64, 16>(hi, lo, lane); cmpx<64, 8>(hi, lo, lane); cmpx<64, 4>(hi, lo, lane);
-    cmpx<64, 2>(hi, lo, lane); cmpx<64, 1>(hi, lo, lane);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// the first 15 stages of the network: lanes 0-31 end up sorted descending, lanes 32-63 ASCENDING (two independent
-// 32-key sorts, no exchange across the halves)
-__device__ __forceinline__ uint64_t wave_sort_halves(uint64_t key, int lane) {
-    uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
-    cmpx<2, 1>(hi, lo, lane);
-    cmpx<4, 2>(hi, lo, lane); cmpx<4, 1>(hi, lo, lane);
-    cmpx<8, 4>(hi, lo, lane); cmpx<8, 2>(hi, lo, lane); cmpx<8, 1>(hi, lo, lane);
-    cmpx<16, 8>(hi, lo, lane); cmpx<16, 4>(hi, lo, lane); cmpx<16, 2>(hi, lo, lane); cmpx<16, 1>(hi, lo, lane);
-    cmpx<32, 16>(hi, lo, lane); cmpx<32, 8>(hi, lo, lane); cmpx<32, 4>(hi, lo, lane); cmpx<32, 2>(hi, lo, lane);
-    cmpx<32, 1>(hi, lo, lane);
-    return ((uint64_t)hi << 32) | lo;
-}
 
 template <typename IdT>
 struct TopkSmem {
@@ -194,25 +94,6 @@ __device__ __forceinline__ float trim_user(const TopkSmem<IdT>& sm, int uw, int 
     const uint32_t kb = __builtin_amdgcn_readlane((uint32_t)(key >> 32), K - 1);
     const uint32_t kf = (kb & 0x80000000u) ? (kb & 0x7fffffffu) : ~kb;
     return (n >= K) ? __uint_as_float(kf) : -INFINITY;
-}
-
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
-// wave-wide OR, returned to every lane (uniform)
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ uint32_t dpp_or(uint32_t v) {
-    return v | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
-    v = dpp_or<0xb1>(v); v = dpp_or<0x4e>(v); v = dpp_or<0x124>(v); v = dpp_or<0x128>(v);
-    v = dpp_or<0x142, 0xa>(v); v = dpp_or<0x143, 0xc>(v);
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-
-// how many of the two 15-bit keys packed in xo (each with bit 15 set on top) reach cand: (key | 0x8000) - cand keeps bit 15
-// exactly when key >= cand and never borrows from the neighbouring field; the answers are added up as two 16-bit counters
-__device__ __forceinline__ u16x2 count_ge2(uint32_t xo, uint32_t cand2, u16x2 acc) {
-    return acc + (__builtin_bit_cast(u16x2, xo - cand2) >> (unsigned short)15);
 }
 
 // Scheduled trim of ALL 32 users of a wave at once, one user per lane pair (half h scans entries
@@ -542,34 +423,6 @@ __device__ __forceinline__ void write_rows(const TopkSmem<IdT>& sm, const TopkSl
     }
 }
 
-// ---- bound-and-refine: the exact score of one candidate ------------------------------------------------------------------
-// The fp32 dot product of the fp32-MFMA kernel, bit for bit: v_mfma_f32_32x32x2_f32 adds the product of k-half 0, then the
-// product of k-half 1, one fused multiply-add each (measured: scripts/probe_mfma_order.py, 100 % of 7,680 scores at k = 50,
-// 64, 100, 128) -- so acc <- fma(v[kk], u[kk], acc); acc <- fma(v[KH+kk], u[KH+kk], acc) for kk = 0 .. KH-1, then fl(acc + bias)
-// and -0.0 -> +0.0 as the filter of that kernel does.
-__device__ __forceinline__ float exact_score(const float* __restrict__ up, const float* __restrict__ vp, int k, const float* bias, int col) {
-    const int KH = (k + 1) >> 1;
-    float acc = 0.f;
-    if ((k & 7) == 0) {                                         // both halves 16-byte aligned
-#pragma unroll 8                                                // 32 loads in flight: two memory round trips per 128 factors
-        for (int kk = 0; kk < KH; kk += 4) {
-            const float4 a0 = *reinterpret_cast<const float4*>(vp + kk), a1 = *reinterpret_cast<const float4*>(vp + KH + kk);
-            const float4 b0 = *reinterpret_cast<const float4*>(up + kk), b1 = *reinterpret_cast<const float4*>(up + KH + kk);
-            acc = fmaf(a0.x, b0.x, acc); acc = fmaf(a1.x, b1.x, acc);
-            acc = fmaf(a0.y, b0.y, acc); acc = fmaf(a1.y, b1.y, acc);
-            acc = fmaf(a0.z, b0.z, acc); acc = fmaf(a1.z, b1.z, acc);
-            acc = fmaf(a0.w, b0.w, acc); acc = fmaf(a1.w, b1.w, acc);
-        }
-    } else {
-        for (int kk = 0; kk < KH; ++kk) {
-            acc = fmaf(vp[kk], up[kk], acc);
-            if (KH + kk < k) acc = fmaf(vp[KH + kk], up[KH + kk], acc);
-        }
-    }
-    acc = acc + (bias ? bias[col] : 0.f);
-    return acc + 0.0f;
-}
-
 // Final stage of the bound-and-refine kernel: every list holds a superset of its user's best K (by exact score) among the
 // tiles of this workgroup.  Phase 1 scores the candidates exactly, one per lane, over the FLAT sequence of the wave's 32
 // lists (a rescoring is four dependent memory round trips of 16 loads -- ~5 us whether 34 lanes work or 64; per list that
@@ -857,22 +710,6 @@ __global__ __launch_bounds__(256, 3) void topk_finish_kernel(const uint64_t* __r
         out_ids[(size_t)r * K + lane] = have ? (int32_t)((uint32_t)best - 1u) : -1;
         if (out_scores) out_scores[(size_t)r * K + lane] = have ? __uint_as_float(f) : -INFINITY;
     }
-}
-
-// A compiler hole, ROCm 7.2 / gfx950 (found in round 5; tests/test_gpu_topk.py test_exact_arithmetic_lists caught it): the wait states
-// between a 16-pass MFMA and the first VALU read of its result (19 on this chip; the hardware does NOT interlock them) are counted by
-// hipcc along the LAYOUT of the code, not along the control flow.  On a workgroup's LAST tile the staging code between the chain and
-// the filter is skipped by two scalar branches, the `s_nop 2` hipcc had placed in front of `v_accvgpr_read a15` is all that is left,
-// and the lane reads register 15 -- the last the matrix pipe writes -- one MFMA early: scores of tile rows 27 and 31 came out short
-// of their last two products, depending on how the rest of the file happened to be laid out.  The wait goes in by hand, right behind
-// the chain: 20 states of ~6,400 per tile.
-// (`acc` is an operand of the statement: it cannot move above the chain or below the first read; where the accumulators live in
-// AGPRs hipcc copies them out in front of it -- in line with the chain, where its own count is right)
-__device__ __forceinline__ void mfma_result_guard(f32x16& acc) {            // behind a chain of 16-pass MFMAs (v_mfma_f32_32x32x2_f32)
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));
-}
-__device__ __forceinline__ void mfma_result_guard_8pass(f32x16& acc) {      // behind 8-pass MFMAs (v_mfma_f32_32x32x16_f16 / _bf16): 11 states
-    asm volatile("s_nop 10" : "+v"(acc));
 }
 
 // waves per workgroup of an instantiation: 8 (two per SIMD: one wave's filter overlaps the other's MFMA
@@ -1181,11 +1018,6 @@ __global__ __launch_bounds__(256) void score_topk_slab_kernel(
 // fixtures) give exactly the same scores as the fp32 path.  Why: 48 bf16 MFMAs of 8 passes replace 64 fp32 MFMAs of
 // 16 passes per 32x32xk=128 block (1.8 us against 3.4 us per 256-user tile, scripts/ubench/bf16x3_ubench.hip), and on
 // gfx950 the fp32 MFMA does not overlap other work of the SIMD at all.  Finite inputs only (inf - inf in the split).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
 __device__ __forceinline__ void split3(float a, __bf16& p1, __bf16& p2, __bf16& p3) {
     p1 = (__bf16)a;
     const float r1 = a - (float)p1;
@@ -1219,12 +1051,6 @@ constexpr int topk_waves_bf16() { return sizeof(IdT) == 2 ? (REFINE ? 4 : kTopkM
 // image carries no row padding; bank conflicts of the fragment reads are avoided by an XOR swizzle of the 16-byte chunks of a
 // row instead (chunk j of item row r sits at j ^ swz(r), identical in the image and in the read: the b128 lane groups of
 // MI355X_MICROARCH.md hold 16 distinct values of r & 15).
-template <int KS>
-__device__ __forceinline__ int tile_swizzle(int r) {             // KS in {1, 2, 4, 8}: CR = 2 * KS chunks per row, 16 / CR rows per 256 B
-    constexpr int CR = 2 * KS;
-    return (r / (16 / CR)) & (CR - 1);
-}
-
 template <int KS>
 __global__ __launch_bounds__(256) void topk_image_kernel(const float* __restrict__ Vt, int n_cols, int k, const uint32_t* __restrict__ extra,
                                                         unsigned char* __restrict__ vimg) {
@@ -1749,6 +1575,7 @@ struct ItemTable {
     int n_items, n_blocks, stride;
     int4* d_items;          // [n_items] (block, t_begin, t_end, slot | stride << 16)
     int32_t* d_nslots;      // [n_blocks]
+    int32_t* d_pbase;       // [n_blocks] pieces in front of the block's first (piece-major dumps: csrc/topk_refine.hip)
     uint64_t used;
 };
 static ItemTable g_tables[8];
@@ -1779,6 +1606,8 @@ static const ItemTable* item_table(int n_rows, int users, int n_tiles, int G) {
         pos = end;
     }
     int stride = 1;
+    std::vector<int32_t> pbase(n_blocks, 0);
+    for (int b = 1; b < n_blocks; ++b) pbase[b] = pbase[b - 1] + nslots[b - 1];
     for (int b = 0; b < n_blocks; ++b) stride = std::max(stride, (int)nslots[b]);
     for (auto& it : items) it.w |= (nslots[it.x] > 1 ? stride : 1) << 16;
     std::stable_sort(items.begin(), items.end(), [](const int4& a, const int4& b) { return (a.z - a.y) > (b.z - b.y); });
@@ -1791,10 +1620,13 @@ static const ItemTable* item_table(int n_rows, int users, int n_tiles, int G) {
             if (g_tables[i].used < g_tables[slot].used) slot = i;
         (void)hipFree(g_tables[slot].d_items);
         (void)hipFree(g_tables[slot].d_nslots);
+        (void)hipFree(g_tables[slot].d_pbase);
     }
     ItemTable& t = g_tables[slot];
-    t = ItemTable{dev, n_rows, users, n_tiles, G, (int)items.size(), n_blocks, stride, nullptr, nullptr, g_tables_tick};
+    t = ItemTable{dev, n_rows, users, n_tiles, G, (int)items.size(), n_blocks, stride, nullptr, nullptr, nullptr, g_tables_tick};
     if (hipMalloc(&t.d_items, items.size() * sizeof(int4)) != hipSuccess || hipMalloc(&t.d_nslots, nslots.size() * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(&t.d_pbase, pbase.size() * sizeof(int32_t)) != hipSuccess ||
+        hipMemcpy(t.d_pbase, pbase.data(), pbase.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(t.d_items, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(t.d_nslots, nslots.data(), nslots.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
         t.n_rows = -1;                                           // never matches; fall back to the plain grid
@@ -1807,8 +1639,8 @@ static const ItemTable* item_table(int n_rows, int users, int n_tiles, int G) {
 // dozen tiles (an item costs ~37 us = ~10 tile-times of its own), one span per CU for smaller problems, and 0 (plain
 // grid) when even that would leave fewer than 8 tiles per span.
 static int topk_spans_per_cu();
-static int topk_span_count(long long total) {
-    const int m = topk_spans_per_cu();
+static int topk_span_count(long long total, int spans_per_cu = 0) {
+    const int m = (spans_per_cu > 0 && topk_spans_per_cu() > 0) ? spans_per_cu : topk_spans_per_cu();
     if (m == 0 || total < 8 * 256) return 0;
     return (total >= 64LL * 256 * m) ? 256 * m : 256;
 }
@@ -1834,18 +1666,21 @@ struct TopkPlan {
     const int4* items;        // item table, or null: the plain (block, range) grid
     int merge_lists;          // > 1: merge_topk_kernel over this many slots per row
     const int32_t* nslots;
+    const int32_t* pbase;     // item table: pieces in front of a block's first
+    int n_pieces;             // workgroups of the grid
     uint32_t* extra;          // `extra_words` zeroed uint32 behind the thresholds, or null when they did not fit
+    size_t used_bytes;        // of the workspace
 };
 
 static int plan_topk(int users, int n_rows, int n_cols, int K, void* workspace, size_t workspace_bytes, size_t extra_words,
-                     hipStream_t stream, TopkPlan& p) {
+                     hipStream_t stream, TopkPlan& p, int spans_per_cu = 0) {
     const int grid = (n_rows + users - 1) / users;
     const int n_tiles = (n_cols + 31) / 32;
     const size_t per_split = (size_t)n_rows * K * sizeof(uint64_t);
     const size_t thr_bytes = (size_t)n_rows * sizeof(uint32_t), extra_bytes = extra_words * sizeof(uint32_t);
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     p = TopkPlan{};
-    const int G = topk_span_count((long long)grid * n_tiles);
+    const int G = topk_span_count((long long)grid * n_tiles, spans_per_cu);
     if (workspace && G > 0) {
         const ItemTable* tab = item_table(n_rows, users, n_tiles, G);
         if (tab && workspace_bytes >= (size_t)tab->stride * per_split + thr_bytes) {
@@ -1857,7 +1692,10 @@ static int plan_topk(int users, int n_rows, int n_cols, int K, void* workspace, 
             p.items = tab->d_items;
             p.merge_lists = tab->stride;
             p.nslots = tab->d_nslots;
+            p.pbase = tab->d_pbase;
+            p.n_pieces = tab->n_items;
             p.extra = (fits && extra_words) ? p.thr_shared + n_rows : nullptr;
+            p.used_bytes = lists_bytes + thr_bytes + (p.extra ? extra_bytes : 0);
             TKR_CHECK(hipMemsetAsync(p.thr_shared, 0, thr_bytes + (p.extra ? extra_bytes : 0), stream));
             return TKR_OK;
         }
@@ -1872,8 +1710,10 @@ static int plan_topk(int users, int n_rows, int n_cols, int K, void* workspace, 
     p.tps = tps;
     p.part = reinterpret_cast<uint64_t*>(ws);
     p.merge_lists = S;
+    p.n_pieces = grid * S;
     const size_t lists_bytes = S > 1 ? (size_t)S * per_split : 0;
     const bool fits = workspace && workspace_bytes >= lists_bytes + fixed;
+    p.used_bytes = lists_bytes + (fits ? fixed : 0);
     if (S > 1 || (fits && extra_words)) {                        // thresholds live behind the S partial lists
         p.thr_shared = reinterpret_cast<uint32_t*>(ws + lists_bytes);
         p.extra = (fits && extra_words) ? p.thr_shared + n_rows : nullptr;
@@ -1974,9 +1814,38 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
                                        160 * 1024);
     if (e != hipSuccess) return (int)e;
     const int n_blocks = (n_rows + users - 1) / users;
+    // the second form of bound-and-refine (csrc/topk_refine.hip: packed lists, three workgroups per CU, every row ranked once by
+    // topk_finish2_kernel): 16-bit column ids, the tile image, room for the pieces' dumps.  TKR_TOPK_V2=0: the first form.
+    static const bool v2_off = getenv("TKR_TOPK_V2") && getenv("TKR_TOPK_V2")[0] == '0';
+    const bool want_v2 = REFINE && sizeof(IdT) == 2 && use_img && !v2_off && refine2_supports(n_cols, k) && users == kR2Users;
     TopkPlan p;
-    int rc = plan_topk(users, n_rows, n_cols, K, workspace, workspace_bytes, REFINE ? (size_t)(4 + n_blocks) : 0, stream, p);
+    int rc = plan_topk(users, n_rows, n_cols, K, workspace, workspace_bytes, REFINE ? (size_t)(4 + n_blocks) : 0, stream, p,
+                       want_v2 ? kR2SpansPerCU : 0);
     if (rc != TKR_OK) return rc;
+    if constexpr (REFINE && sizeof(IdT) == 2) {
+        const size_t used = (p.used_bytes + 255) & ~(size_t)255;
+        if (want_v2 && p.extra && used + refine2_dump_bytes((size_t)p.n_pieces) <= workspace_bytes) {
+            hipLaunchKernelGGL(topk_bounds_kernel, dim3(std::min(256, (n_cols + 3) / 4)), dim3(256), 0, stream, Vt, bias, n_cols, k, p.extra);
+            hipLaunchKernelGGL(topk_image_kernel<KS>, dim3(std::min(2048, ((n_cols + 31) / 32 * 32 * 2 * KS + 255) / 256)), dim3(256), 0, stream, Vt,
+                               n_cols, k, p.extra, vimg);
+            Refine2Args a{};
+            a.U = U; a.uidx = uidx; a.n_rows = n_rows; a.Vt = Vt; a.bias = bias; a.n_cols = n_cols; a.k = k;
+            a.mask = mask; a.mask_pitch = pitch; a.K = K;
+            a.grid_x = (int)p.grid.x; a.grid_y = (int)p.grid.y; a.tiles_per_split = p.tps;
+            a.thr_shared = p.thr_shared; a.items = p.items; a.nslots = p.nslots; a.pbase = p.pbase;
+            a.extra = p.extra; a.vimg = vimg;
+            a.dump = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(workspace) + used);
+            a.dhdr = reinterpret_cast<float2*>(a.dump + (size_t)p.n_pieces * kR2Users * kR2Slots);
+            a.out_ids = out_ids; a.out_scores = out_scores;
+            rc = launch_refine2(a, stream);
+            if (rc != TKR_OK) return rc;
+            // blocks with an overflowed list: the fp32 kernel on the same work items, merged where a block was cut
+            rc = launch_fp32_planned<IdT, topk_waves_bf16<KS, IdT, true>()>(p, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores,
+                                                                            p.extra + 4, stream);
+            if (rc != TKR_OK) return rc;
+            return merge_planned(p, users, n_rows, K, out_ids, out_scores, stream, p.extra + 4);
+        }
+    }
     // the dump of the pieces' lists for topk_finish_kernel: behind what the plan uses, when the workspace has the room
     uint64_t* dump = nullptr;
     float2* dhdr = nullptr;
@@ -2162,6 +2031,11 @@ extern "C" int64_t tkr_topk_workspace_bytes_for(int32_t n_rows, int32_t n_cols, 
     // tkr_topk_workspace_bytes + room for the pre-converted item factors of the bound-and-refine arithmetic (k <= 128)
     int64_t n = tkr_topk_workspace_bytes(n_rows, K);
     if (k <= 128 && n_cols > 0) n = ((n + 255) & ~(int64_t)255) + (int64_t)((tkr::topk_image_bytes(n_cols, k) + 255) & ~(size_t)255) + 512;
+    if (tkr::refine2_supports(n_cols, k)) {                      // + the pieces' packed lists for topk_finish2_kernel (csrc/topk_refine.hip)
+        const int64_t blocks = ((int64_t)n_rows + tkr::kR2Users - 1) / tkr::kR2Users, n_tiles = ((int64_t)n_cols + 31) / 32;
+        const int64_t pieces = blocks * n_tiles >= 8 * 256 ? blocks + 256 * 4 : blocks * (n_tiles < tkr::kMaxSplits ? n_tiles : tkr::kMaxSplits);
+        n = ((n + 255) & ~(int64_t)255) + (int64_t)tkr::refine2_dump_bytes((size_t)pieces) + 256;
+    }
     return n;
 }
 
