@@ -616,6 +616,66 @@ def topk_cpu_baseline(r, k, K=30, budget_s=12.0, slice_users=2000):
                        '(single thread), oracle restatement of evaluate.py:78-105' % (done, n_items, dt))
 
 
+def shards_on_one_gpu(r, k, device, B, single_value, limit=10 ** 6, epochs=2):
+    """S user shards with replicated item tables on ONE GPU, each the persistent step of batch size B on CUs // S owners and a HIP
+    stream of its own, reconciled once per epoch by dist.LocalShards (pack, sum, unpack): north_star's sharded semantics (one
+    reconcile per epoch, /root/reference single/bpr.py:136-147 is the loop each shard runs) inside one device -- the rehearsal of the
+    8-GPU run, and what a single sequential stream (10 % of HBM by construction) leaves idle.  Whole epochs WITH their exchanges."""
+    import synth
+    import dist as tdist
+    from single import _engine
+    row_ptr, pos, _, tr_users = synth.positives_csr(r)
+    n_users, n_items = r['n_users'], r['n_in'] + r['n_out']
+    hp = dict(lu=2.5e-3, li=2.5e-3, lj=2.5e-4, lb=0.0, lr=1e-4, mode='l2')
+    out = {'what': 'S shards x (epoch of (limit // B) // S batches + exchange), aggregate over %d epochs after one warm-up epoch; every shard holds a full '
+                   'user table and samples inside its own users (dist.shard_users)' % epochs, 'single_stream_value': single_value}
+    for S in (2, 4, 8):
+        try:
+            nb = tdist.batches_per_rank(limit // B, S)
+            engines, csrs, streams = [], [], []
+            for q in range(S):
+                e = _engine.BprEngine(n_users, n_items, k, hp, device, seed=1234)
+                e.ranks_on_device, e.private_side_stream = S, True
+                e.prepare(B)
+                e.triplets_drawn = q * (epochs + 1) * nb * B
+                engines.append(e)
+                csrs.append(_engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tdist.shard_users(tr_users, q, S), dtype=np.int32), device))
+                streams.append(torch.cuda.Stream(device=device))
+            shards = tdist.LocalShards(engines, streams)
+
+            def epoch(more):
+                shards.begin()
+                for e, c, st in zip(engines, csrs, streams):
+                    with torch.cuda.stream(st):
+                        e.run_batches(c, nb, B, want_loss=WANT_LOSS, then_exchange=nb if more else 0)
+                shards.end()
+            epoch(True)
+            torch.cuda.synchronize(device)
+            shards.timing = []
+            t0 = time.perf_counter()
+            for ep in range(epochs):
+                epoch(ep + 1 < epochs)
+            torch.cuda.synchronize(device)
+            wall = time.perf_counter() - t0
+            gave_up = shards.any_gave_up()
+            parts = [(a.elapsed_time(b), b.elapsed_time(c), c.elapsed_time(d)) for a, b, c, d in shards.timing]
+            x = {'pack': 1e3 * sum(p[0] for p in parts) / len(parts), 'sum': 1e3 * sum(p[1] for p in parts) / len(parts),
+                 'unpack': 1e3 * sum(p[2] for p in parts) / len(parts)}
+            x['total'] = x['pack'] + x['sum'] + x['unpack']
+            value = S * epochs * nb * B / wall
+            out['S%d' % S] = {'shards': S, 'batches_per_shard_per_epoch': nb, 'owners_per_shard': engines[0]._plan_owners(B), 'step': step_kernel(engines[0], B)[0],
+                              'value': value, 'unit': 'triplets/s', 'over_single_stream': value / single_value if single_value else None,
+                              'us_per_batch_per_shard': wall * 1e6 / (epochs * nb), 'ms_per_epoch': wall * 1e3 / epochs, 'exchange_us': x,
+                              'gave_up': bool(gave_up),
+                              # the same exchange beside an 8-rank epoch of the single-stream rate (488 batches): what it costs before the collective
+                              'exchange_share_of_8_rank_epoch': x['total'] * 1e-6 / ((limit // B) // 8 * B / single_value) if single_value else None}
+            del engines, csrs, shards
+            torch.cuda.empty_cache()
+        except Exception as ex:        # a leg of extras never takes the line down
+            out['S%d' % S] = {'error': '%s: %s' % (type(ex).__name__, ex)}
+    return out
+
+
 def summary(out):
     """the numbers VERDICT tracks, compact, as the last key of the line (the driver's record keeps only the tail of stdout)"""
     def leg(key, *path):
@@ -634,9 +694,16 @@ def summary(out):
          'vbpr_ms': leg('vbpr', 'ms_per_step'), 'vbpr_frac': leg('vbpr', 'roofline', 'frac'),
          'vbpr_dc128_ms': leg('vbpr', 'dense_dc128', 'ms_per_step'),
          'cpu_Mtps': (leg('cpu_baseline', 'value') or 0) / 1e6 or None}
+    for S in (2, 4, 8):
+        if leg('shards_on_one_gpu', 'S%d' % S, 'value'):
+            s['shards%d_Mtps' % S] = leg('shards_on_one_gpu', 'S%d' % S, 'value') / 1e6
+            s['shards%d_owners' % S] = leg('shards_on_one_gpu', 'S%d' % S, 'owners_per_shard')
+            s['shards%d_exchange_us' % S] = leg('shards_on_one_gpu', 'S%d' % S, 'exchange_us', 'total')
     if out.get('n_gpus', 1) > 1:
         s['exchange_us'] = leg('epoch_mode', 'exchange_us')
         s['epoch_Mtps'] = (leg('epoch_mode', 'value') or 0) / 1e6 or None
+        s['owners'] = leg('roofline', 'owners')           # K2o owners of this rank (0: K2f / K2) ...
+        s['ranks_on_device'] = out.get('ranks_on_device')  # ... and how many ranks share its GPU: a silently degraded rank shows in the tail
     return {k: v for k, v in s.items() if v is not None}
 
 
@@ -722,6 +789,7 @@ def main():
                      'algorithmic_bytes_per_launch': B * algorithmic_bytes_per_triplet(k)},
     }
     out['epoch_mode'] = em
+    out['ranks_on_device'] = int(getattr(eng, 'ranks_on_device', 1))
     if world == 1:
         out['steady_state'] = em
     if rank == 0 and world == 1 and not args.no_extras and not args.no_live_traffic and eng.layout == 'flow':
@@ -791,6 +859,8 @@ def main():
             out['topk_netflix_shape'] = topk_bench_netflix(k, device)
             out['vbpr'] = vbpr_bench(r, csr, k, device)
             out['bpr_netflix_shape'] = netflix_train_bench(k, device)
+            if B <= 512:
+                out['shards_on_one_gpu'] = shards_on_one_gpu(r, k, device, B, em['value'], args.epoch_sample_limit)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(r, k, B)
     if rank == 0:

@@ -6,6 +6,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -169,6 +170,9 @@ def test_streams_mode_matches_oracle_simulation(tmp_path):
             np.zeros((m.n_items, 1), np.float32)]
     m.fue, m.fie, m.fib = (a.copy() for a in init)
     m.train(epochs=epochs, batch_size=B, epoch_sample_limit=limit, seed=11, verbose=False, streams=S)
+    # every shard ran the persistent step with owned item rows on its share of the CUs (K2o), not the per-batch step
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert m._eng.layout == 'flow' and m._eng._plan_owners(B) == cus // S and m._eng._last_step_kind == 'own'
     hp = dict(lu=m.lu, li=m.li, lj=m.lj, lb=m.lb, lr=lr, mode='l2')
     nb = (limit // B) // S
     row_ptr, pos, srt = P.build_csr(m.tr_data, m.n_users)

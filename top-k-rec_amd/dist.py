@@ -217,6 +217,17 @@ class ItemSync:
         _, w = world()
         if w == 1:
             return
+        marks = []
+        self._mark(marks)
+        self._pack(w)
+        self._mark(marks)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self._mark(marks)
+        self._unpack(self.flat, w)
+        self._mark(marks)
+
+    def _pack(self, w):
+        """first third of an exchange: this shard's deltas and its share of the slot means into ``self.flat`` (w = number of shards)"""
         self._settle(keep_epoch_ahead=True)
         if getattr(self.eng, 'layout_epoch', 0) != self._bound:
             # the engine re-allocated its tables after begin() (a different batch size -> a different layout): the snapshot and the
@@ -224,36 +235,48 @@ class ItemSync:
             # (begin() before the first run_batches) and zeroed the live update counters through the stale binding.
             raise RuntimeError('ItemSync.end(): the engine changed its table layout since begin(); call engine.prepare(batch_size) '
                                'before the first begin()')
-        marks = []
         if self.flow is not None:
             import tkr_hip
             V, msV, tail, rd, icnt, n, k, bufs = self.flow
             total = n * (k + 1)
-            self._mark(marks)
             tkr_hip.sync_flow_pack(V, msV, tail, icnt, self.start_flat, self.flat[:total], self.flat[total:], n, k, 1.0 / w, bufs)
             self._flag_status(total)
-            self._mark(marks)
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self._mark(marks)
-            tkr_hip.sync_flow_unpack(V, msV, tail, rd, icnt, self.start_flat, self.flat[:total], self.flat[total:2 * total], n, k, bufs)
+            return
+        if self.tabs is None:
+            self._cur = {n: self.eng.get(n) for n in self.names}
+            parts = []
+            for n in self.names:
+                p, ms = self._cur[n]
+                parts.append((p - self.start[n]).reshape(-1))
+                parts.append((ms / w).reshape(-1))
+            self.flat = torch.cat(parts)
+            return
+        import tkr_hip
+        total, off = sum(self.sizes), 0
+        for (_, P, ms, cnt), size in zip(self.tabs, self.sizes):
+            n, wd = self._shape(P, cnt)
+            tkr_hip.sync_pack(P, ms, cnt, self.start_flat[off:off + size], self.flat[off:off + size],
+                              self.flat[total + off:total + off + size], n, wd, 1.0 / w)
+            off += size
+        self._flag_status(total)
+
+    def _unpack(self, flat, w):
+        """last third: the summed vector (``flat``: this object's own buffer after an all-reduce, or the sum LocalShards formed)
+        back into the tables"""
+        if self.flow is not None:
+            import tkr_hip
+            V, msV, tail, rd, icnt, n, k, bufs = self.flow
+            total = n * (k + 1)
+            tkr_hip.sync_flow_unpack(V, msV, tail, rd, icnt, self.start_flat, flat[:total], flat[total:2 * total], n, k, bufs)
             self._start_valid = (self._bound, getattr(self.eng, 'item_mutations', 0))
-            self._mark(marks)
             after = getattr(self.eng, 'after_exchange', None)
             if after is not None:
                 after()                  # a chunk planned ahead of this exchange becomes runnable
             return
         if self.tabs is None:
-            cur = {n: self.eng.get(n) for n in self.names}
-            parts = []
-            for n in self.names:
-                p, ms = cur[n]
-                parts.append((p - self.start[n]).reshape(-1))
-                parts.append((ms / w).reshape(-1))
-            flat = torch.cat(parts)
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             new, off = {}, 0
             for n in self.names:
-                p, ms = cur[n]
+                p, ms = self._cur[n]
                 m = p.numel()
                 new[n] = (self.start[n] + flat[off:off + m].view_as(p), flat[off + m:off + 2 * m].view_as(ms))
                 off += 2 * m
@@ -261,25 +284,72 @@ class ItemSync:
             return
         import tkr_hip
         total, off = sum(self.sizes), 0
-        self._mark(marks)
         for (_, P, ms, cnt), size in zip(self.tabs, self.sizes):
             n, wd = self._shape(P, cnt)
-            tkr_hip.sync_pack(P, ms, cnt, self.start_flat[off:off + size], self.flat[off:off + size],
-                              self.flat[total + off:total + off + size], n, wd, 1.0 / w)
-            off += size
-        self._flag_status(total)
-        self._mark(marks)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self._mark(marks)
-        off = 0
-        for (_, P, ms, cnt), size in zip(self.tabs, self.sizes):
-            n, wd = self._shape(P, cnt)
-            tkr_hip.sync_unpack(P, ms, self.start_flat[off:off + size], self.flat[off:off + size],
-                                self.flat[total + off:total + off + size], n, wd)
+            tkr_hip.sync_unpack(P, ms, self.start_flat[off:off + size], flat[off:off + size],
+                                flat[total + off:total + off + size], n, wd)
             off += size
         for cnt in {id(t[3]): t[3] for t in self.tabs if t[3] is not None}.values():
             cnt.zero_()                                       # buffer 0 is current again for every row
-        self._mark(marks)
+
+
+class LocalShards:
+    """The per-epoch exchange of S user shards that live in ONE process on ONE GPU (BPR.train(streams=S), bench.py's
+    shards_on_one_gpu leg): the same rule as between ranks -- P <- P0 + sum of deltas, slots <- mean -- with the collective
+    replaced by a sum of the shards' packed vectors.  Every shard packs and unpacks on its own HIP stream; the sum runs on the
+    calling stream between two joins.  A rehearsal of the 8-GPU run on one device: pack + sum + unpack is everything an epoch
+    boundary costs apart from the collective itself."""
+
+    def __init__(self, engines, streams):
+        self.syncs = [ItemSync(e) for e in engines]
+        self.streams = list(streams)
+        self.acc = None
+        self.timing = None               # a list: end() appends (start, packed, summed, unpacked) events of the calling stream
+
+    def begin(self):
+        for s, st in zip(self.syncs, self.streams):
+            with torch.cuda.stream(st):
+                s.begin()
+
+    def end(self):
+        S = len(self.syncs)
+        main = torch.cuda.current_stream()
+        ev = []
+
+        def mark():
+            if self.timing is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(main)
+                ev.append(e)
+        for st in self.streams:          # (the timing brackets the exchange alone: the epochs' steps are done)
+            main.wait_stream(st)
+        mark()
+        for s, st in zip(self.syncs, self.streams):
+            with torch.cuda.stream(st):
+                st.wait_stream(main)
+                s._pack(S)
+        for st in self.streams:
+            main.wait_stream(st)
+        mark()
+        flats = [s.flat for s in self.syncs]
+        if self.acc is None or self.acc.shape != flats[0].shape:
+            self.acc = torch.empty_like(flats[0])
+        torch.add(flats[0], flats[1], out=self.acc) if S > 1 else self.acc.copy_(flats[0])
+        for f in flats[2:]:
+            self.acc.add_(f)
+        mark()
+        for s, st in zip(self.syncs, self.streams):
+            with torch.cuda.stream(st):
+                st.wait_stream(main)
+                s._unpack(self.acc, S)
+        for st in self.streams:
+            main.wait_stream(st)
+        mark()
+        if self.timing is not None:
+            self.timing.append(tuple(ev))
+
+    def any_gave_up(self, mine=False):
+        return bool(mine) or (self.acc is not None and float(self.acc[-1]) > 0.0)
 
 
 def gather_owned_rows(owned, rows: torch.Tensor, slots: torch.Tensor):

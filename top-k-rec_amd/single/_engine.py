@@ -126,14 +126,17 @@ class PlanPipeline:
 
     _side_streams = {}                   # one planner stream per device and process: creating a HIP stream costs milliseconds
 
-    def __init__(self, device):
+    def __init__(self, device, private_side=False):
         self.device = device
+        self._private = private_side     # a planner stream of its own (shards that run concurrently in one process: BPR.train(streams=S))
         self._side = None                # taken on first overlapped use: an idle second queue is not free
         self.bufs = [None, None]
         self.planned = [None, None]      # event: plan in bufs[i] complete (side stream)
 
     @property
     def side(self):
+        if self._side is None and self._private:
+            self._side = torch.cuda.Stream(device=self.device)
         if self._side is None:
             key = (self.device.type, self.device.index)
             if key not in PlanPipeline._side_streams:
@@ -394,7 +397,7 @@ class PlanMixin:
             self.settle(check=False)
             cur = None
         if self.pipe is None:
-            self.pipe = PlanPipeline(self.device)
+            self.pipe = PlanPipeline(self.device, getattr(self, 'private_side_stream', False))
         self.pipe.ensure(self._cap(B), B, self._plan_flow(), self._plan_cols(B), self._plan_owners(B))
         # K1 of the chunk after this one on the side stream: behind the per-batch launches of a large batch, or behind the ONE
         # persistent launch of a dataflow chunk (100 us of planner per 512 batches that otherwise sit in front of every 1.4 ms launch)

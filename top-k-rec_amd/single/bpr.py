@@ -230,15 +230,15 @@ class BPR(REC):
         self._warm_start()
         if world > 1:                                      # ranks packed on one GPU split its CUs between their K2o launches
             self._eng.ranks_on_device = tdist.ranks_sharing_device(self._eng.device)
-        self._eng.prepare(batch_size, 'bulk' if streams > 1 else None)     # table layout of this batch size (see _engine.BprEngine)
+        self._eng.prepare(batch_size)                      # table layout of this batch size (see _engine.BprEngine)
         # one process per GPU (torch.distributed initialised by the launcher): users sharded, item-side
         # tables replicated and reconciled once per epoch (dist.py; the reference is single-process)
         if streams > 1:
             # opt-in: the multi-GPU layout inside ONE GPU -- `streams` user shards with replicated item tables run
-            # concurrently on separate HIP streams and are reconciled once per epoch by the same rule (dist.py).
-            # One sequential 256-batch stream leaves most of the chip idle (it is launch-latency bound); 4 streams
-            # give ~1.7x the aggregate rate (bench.py streams_mode).  Not the reference's single-stream semantics:
-            # off by default.
+            # concurrently on separate HIP streams, each through the persistent step of its batch size on its share of the
+            # CUs, and are reconciled once per epoch by the same rule (dist.LocalShards).  One sequential stream is bound
+            # by the hand-offs of its dependency chain and leaves most of the chip idle (bench.py shards_on_one_gpu).  Not
+            # the reference's single-stream semantics: off by default.
             assert world == 1, 'streams > 1 and torch.distributed sharding are not combined'
             self._train_streams(epochs, n_batches, batch_size, streams, verbose)
             self._collect()
@@ -296,13 +296,18 @@ class BPR(REC):
         return True
 
     def _train_streams(self, epochs, n_batches, batch_size, S, verbose):
+        """the multi-GPU layout inside ONE GPU: S user shards with replicated item tables, each a persistent step of its own on
+        CUs // S owners (K2o; K2f / K2 where the layout asks for them) on its own HIP stream, reconciled once per epoch by
+        dist.LocalShards -- pack, sum, unpack: the exchange of the sharded loop (bpr.py:136-147) without the collective."""
         import dist as tdist
         dev = self._eng.device
-        names = self._eng.replicated_names
         engines = [self._eng] + [self._make_engine(dev, self._eng.seed) for _ in range(S - 1)]
         lead = engines[0]
+        for e in engines:
+            e.ranks_on_device = S                          # the CUs are split between the shards' launches
+            e.private_side_stream = True                   # ... and every shard plans on a stream of its own
+            e.prepare(batch_size)
         for e in engines[1:]:                              # every shard starts from the same (possibly warm-started) model
-            e.prepare(batch_size, 'bulk')
             e.copy_model_from(lead)
         nb = tdist.batches_per_rank(n_batches, S)
         csrs, hip_streams = [], []
@@ -311,27 +316,22 @@ class BPR(REC):
             e.triplets_drawn = i * epochs * nb * batch_size                      # disjoint stream positions, one key
             hip_streams.append(torch.cuda.Stream(device=dev))
         users_start, users_ms_start = (t.clone() for t in lead.get('U'))
+        shards = tdist.LocalShards(engines, hip_streams)
+        self._shards = shards
+        torch.cuda.synchronize(dev)
         for eid in range(epochs):
             t0 = time.time()
-            start = {n: lead.get(n)[0].clone() for n in names}
-            torch.cuda.synchronize(dev)
-            # plan every shard's epoch first (planner launches would disturb the other streams' step chains) ...
-            planned = [_engine.plan_ahead(e, csr, nb, batch_size) for e, csr in zip(engines, csrs)]
-            torch.cuda.synchronize(dev)
+            shards.begin()
             losses = []
-            for e, pl, st in zip(engines, planned, hip_streams):      # ... then only step chains run concurrently
+            for e, csr, st in zip(engines, csrs, hip_streams):                  # S persistent launches side by side
                 with torch.cuda.stream(st):
-                    losses.append(_engine.run_planned(e, pl, batch_size, True, e.step_fn(batch_size)))
+                    losses.append(e.run_batches(csr, nb, batch_size, want_loss=True, then_exchange=nb if eid + 1 < epochs else 0)[-1:].clone())
+            shards.end()
             torch.cuda.synchronize(dev)
-            new = {}
-            for n in names:                                # P <- P0 + sum of deltas, slots <- mean (dist.py)
-                ps = [e.get(n) for e in engines]
-                new[n] = (start[n] + sum(p - start[n] for p, _ in ps), sum(ms for _, ms in ps) / S)
-            for e in engines:
-                e.set_replicated(new)
-            torch.cuda.synchronize(dev)
+            if shards.any_gave_up():
+                raise tkr_hip.StepGaveUp('BPR.train(streams=%d): a persistent step gave up on one of the shards' % S)
             spent = time.time() - t0
-            self.last_epoch_loss = float(losses[0][-1])
+            self.last_epoch_loss = float(losses[0][0])
             if verbose:
                 sys.stderr.write('\rEpoch=%3d, batch=%6d, loss=%8.4f, time=%4.4fs' % (eid + 1, nb * S, self.last_epoch_loss, spent / (nb * S)))
                 sys.stderr.write(' ... total time collapse %8.4fs' % spent)
