@@ -123,7 +123,8 @@ typedef struct {
  * WRITTEN by the step, which is why `rec` is not const; a plan run again with a loss_out overwrites it), under K2o a {sum, epoch} slot of `xch`, under K2f its workgroup's LDS, under K3 one of
  * 64 slots behind the workspace -- and one small launch per CALL adds them up into loss_out (tkr_bpr_own_run in its default
  * form ASSIGNS loss_out[b]: no fill is needed in front of it). */
-/* k <= 512; 256 < k <= 512 only for batch_size <= 1024 (TKR_E_UNSUPPORTED otherwise) */
+/* any k: up to 512 (256 above batch_size 1024) a wave holds its row in registers; wider rows take the generic form
+ * (csrc/bpr_step.hip bpr_wide_kernel: two passes over k per occurrence, the gradient sum through memory) */
 int tkr_bpr_run(const tkr_bpr_state* st, int32_t* rec, const int32_t* occ, const int32_t* hdr,
                 int32_t batch_size, int32_t n_batches, float* loss_out, void* stream);
 
@@ -347,7 +348,8 @@ int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i, const int3
  *   On gfx950 the fp32 MFMA runs at the vector-ALU rate and overlaps nothing; mode 0 is 1.4-1.6x faster than mode 1,
  *   mode 2 1.5-2.1x.
  * K <= 32 per launch (larger K: rank 32, add the found columns to the mask with tkr_build_rated_mask, rank
- * again -- top-k-rec_amd/tkr_hip.py score_topk does this), k <= 768 (above 256: mode 1 with the k dimension in slabs of 256 --
+ * again -- top-k-rec_amd/tkr_hip.py score_topk does this); any k (above 768: score_topk_wide_kernel, one wave per row, a lane per item,
+ * the same fma chain; 256 < k <= 768: mode 1 with the k dimension in slabs of 256 --
  * the chain of a score runs slab after slab, halves [256 s, 256 s + 128) and [256 s + 128, 256 s + 256) in place of the two
  * halves of k; 63 % of the fp32-MFMA peak at k = 512, register spills above 512). */
 int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K);

@@ -293,43 +293,45 @@ def test_legacy_bpr_api(hip, capfd):
     assert np.all(m2.W.get_value() == 1.0)
 
 
-def test_wide_factors_through_the_class_and_the_stated_limits(tmp_path):
-    """single/bpr.py:20 takes any k: BPR(k=300).train(batch_size=256) runs (plain tables + K2: the granule layout holds k <= 256)
-    and equals the oracle on its stream; what the HIP path does not hold raises a ValueError that names the limit"""
+@pytest.mark.parametrize('k,B,nb', [(300, 256, 6), (600, 256, 4), (1000, 128, 3), (300, 2048, 2), (700, 2048, 2)])
+def test_wide_factors_through_the_class(tmp_path, k, B, nb):
+    """single/bpr.py:20 takes any k: BPR(k).train runs at every width -- plain tables + K2 up to k = 512 (256 above batch 1024),
+    the generic row form (csrc/bpr_step.hip bpr_wide_kernel) beyond, announced by one warning -- and equals the oracle on its stream"""
     sys.path.insert(0, os.path.join(ROOT, 'top-k-rec_amd'))
+    import warnings
     import synth
     import tkr_hip
     from single import BPR, _engine
     r = synth.make_ratings(150, 60, 0, seed=13, mu=2.6, sigma=0.4, min_r=4, max_r=25)
     data = str(tmp_path / 'data')
     synth.write_dataset(data, r)
-    k, B, nb = 300, 256, 6
     m = BPR(k=k, lr=0.02, lambda_b=1e-3)
     m.load_training_data(data + '/uid', data + '/vid', data + '/f0tr.txt')
     rng = np.random.Generator(np.random.PCG64(0))
     init = [(rng.standard_normal((m.n_users, k)) * 0.1).astype(np.float32), (rng.standard_normal((m.n_items, k)) * 0.1).astype(np.float32),
             np.zeros((m.n_items, 1), np.float32)]
     m.fue, m.fie, m.fib = (a.copy() for a in init)
-    m.train(epochs=1, batch_size=B, epoch_sample_limit=B * nb, seed=11, verbose=False)
+    generic = k > 512 or (k > 256 and B > 1024)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter('always')
+        m.train(epochs=1, batch_size=B, epoch_sample_limit=B * nb, seed=11, verbose=False)
+    assert any('generic row form' in str(w.message) for w in seen) == generic
     assert m._eng.layout == 'bulk'
     hp = dict(lu=m.lu, li=m.li, lj=m.lj, lb=m.lb, lr=0.02, mode='l2')
     row_ptr, pos, srt = P.build_csr(m.tr_data, m.n_users)
     st = dict(U=init[0].copy(), V=init[1].copy(), b=init[2].ravel().copy(), msU=np.ones_like(init[0]), msV=np.ones_like(init[1]),
               msb=np.ones(m.n_items, np.float32))
     u, i, j = P.sample_triplets(m.tr_users, row_ptr, pos, srt, m.n_items, 11, 0, nb * B)
+    last = None
     for s in range(nb):
-        R.bpr_step(st, u[s * B:(s + 1) * B], i[s * B:(s + 1) * B], j[s * B:(s + 1) * B], hp)
+        last = R.bpr_step(st, u[s * B:(s + 1) * B], i[s * B:(s + 1) * B], j[s * B:(s + 1) * B], hp)
     np.testing.assert_allclose(m.fue, st['U'], rtol=2e-4, atol=1e-5)
     np.testing.assert_allclose(m.fie, st['V'], rtol=2e-4, atol=1e-5)
     np.testing.assert_allclose(m.fib.ravel(), st['b'], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(m.last_epoch_loss, float(last), rtol=1e-4)
+    if k != 300 or B != 256:
+        return
     dev = torch.device('cuda')
-    csr = m._csr
-    for kk, BB in ((600, 256), (300, 2048)):
-        eng = _engine.BprEngine(m.n_users, m.n_items, kk, hp, dev, seed=1)
-        with pytest.raises(ValueError, match='k <= 512'):
-            eng.run_batches(csr, 1, BB)
-    with pytest.raises(ValueError, match='up to 768'):
-        tkr_hip.score_topk(torch.zeros((4, 800), device=dev), torch.zeros((8, 800), device=dev), 3)
     # ... and what the trainer holds, the scorer ranks (evaluate.py:78 on the k = 300 model above)
     ids = tkr_hip.score_topk(torch.from_numpy(m.fue).to(dev), torch.from_numpy(m.fie).to(dev), 5, bias=torch.from_numpy(m.fib.ravel().copy()).to(dev))
     s = m.fue.astype(np.float64) @ m.fie.astype(np.float64).T + m.fib.ravel()

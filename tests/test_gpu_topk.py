@@ -67,7 +67,9 @@ def _exact(rng, n, k, lim):
                                                # widths above 256: the k dimension in slabs of 256 (csrc/topk.hip score_topk_slab_kernel);
                                                # 2 slabs to k = 512 (what the trainer goes to), 3 to 768; k % 4 != 0: the scalar staging
                                                (300, 1000, 512, 30), (257, 333, 300, 30), (130, 2500, 260, 7), (200, 700, 510, 30),
-                                               (150, 66000, 384, 30), (140, 900, 768, 30), (70, 500, 515, 5)])
+                                               (150, 66000, 384, 30), (140, 900, 768, 30), (70, 500, 515, 5),
+                                               # above 768: the generic form (one wave per row, csrc/topk.hip score_topk_wide_kernel)
+                                               (130, 700, 1024, 30), (40, 2100, 1001, 7)])
 def test_exact_arithmetic_lists(hip, n_rows, n_cols, k, K):
     rng = np.random.Generator(np.random.PCG64(n_rows * 7 + n_cols))
     lim = max(1, int(np.sqrt((1 << 23) / k)) // 2)          # k * (lim/64)^2 * 4096 < 2^24: all partial sums exact

@@ -377,6 +377,133 @@ static int launch_step(const tkr_bpr_state& st, int32_t* rec, const int32_t* occ
                                  : launch_step_t<NE, VEC, 16>(st, rec, occ, hdr, B, loss_out, stream);
 }
 
+// ---- any width: the generic row form (k > 512, and 256 < k <= 512 at batch sizes above 1024) -------------------------------------------
+// The kernel above holds a row in ceil(k / 64) registers per array and the partner rows of a round beside it: 512 factors is where
+// that ends.  Here nothing is resident: a task walks its occurrences one after the other, every occurrence in two passes over the
+// k dimension -- (A) the dot products of the triplet, so s_t = sigma(-x_t); (B) the occurrence's gradient, added to the task's
+// running sum, which lives in the row the task is going to WRITE (buffer par ^ 1 of its own row: nobody reads it in this launch) --
+// and ends with the RMSProp pass over that row.  The waves of a heavy team would each need a running sum of their own: wave 0
+// walks the records of the whole team instead, in wave order.  Slow (every partner row is read twice, the sum goes through
+// memory) but the same step for every k and batch size: same plan, same double buffering, same loss word per task; sums in
+// another order than the register form (lane-strided instead of lane-contiguous), inside the tolerance of the step tests.
+__device__ __forceinline__ float ld_fresh(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int kTeam, bool SGD>
+__global__ __launch_bounds__((kTeam * TKR_WAVE)) void bpr_wide_kernel(tkr_bpr_state st, int32_t* rec_all, const int2* __restrict__ occ,
+                                                                       const int4* __restrict__ hdr, float* __restrict__ loss_out, int reverse) {
+    const int lane = threadIdx.x & (TKR_WAVE - 1), wave = threadIdx.x >> 6;
+    const int4 h = *hdr;
+    const int n_blocks = __builtin_amdgcn_readfirstlane(h.x), nlb = __builtin_amdgcn_readfirstlane(h.y);
+    const int k = st.k;
+    const size_t ustride = (size_t)st.n_users * k, istride = (size_t)st.n_items * k;
+    const bool l2 = st.mode == 0, want_loss = loss_out != nullptr;
+    for (int it = blockIdx.x; it < n_blocks; it += gridDim.x) {
+        const int blk = reverse ? n_blocks - 1 - it : it;
+        const bool heavy = blk >= nlb;
+        if (heavy && wave != 0) continue;                        // (no barrier in this kernel)
+        const int n_rec = heavy ? kTeam : 1;
+        const int head = (lane < 16) ? rec_all[((size_t)blk * kTeam + (heavy ? 0 : wave)) * 16 + lane] : 0;
+        const int rowk = bcast_i(head, 0);
+        if (rowk == -1) continue;
+        const int par = bcast_i(head, 1) & 1;
+        const bool is_item = rowk < 0;
+        const int row = rowk & 0x7fffffff;
+        const size_t roff = (is_item ? par * istride : par * ustride) + (size_t)row * k;
+        const size_t woff = (is_item ? (par ^ 1) * istride : (par ^ 1) * ustride) + (size_t)row * k;
+        const float* own = (is_item ? st.V : st.U) + roff;
+        float* gbuf = (is_item ? st.V : st.U) + woff;            // the running gradient sum, then the new row
+        const float br = is_item ? st.b[(size_t)par * st.n_items + row] : 0.f;
+        float gb = 0.f, loss = 0.f;
+        bool first_occ = true;
+        for (int w = 0; w < n_rec; ++w) {
+            const int word = w == 0 ? head : ((lane < 16) ? rec_all[((size_t)blk * kTeam + w) * 16 + lane] : 0);
+            if (bcast_i(word, 0) == -1) continue;
+            const int n_occ = bcast_i(word, 2), first = bcast_i(word, 3), team = (bcast_i(word, 1) >> 8) & 0xff;
+            for (int q = 0; q < n_occ; ++q) {
+                int oa, ob;
+                if (q < 4) { oa = bcast_i(word, 4 + 2 * q); ob = bcast_i(word, 5 + 2 * q); }
+                else { const int2 o = occ[first + q * team]; oa = o.x; ob = o.y; }
+                const int a = oa & kIdMask, pa = (oa >> 30) & 1, b = ob & kIdMask, pb = (ob >> 30) & 1;
+                const bool role_j = ob < 0;
+                // user task: r1 = v_i, r2 = v_j; item task: r1 = u, r2 = the other item of the triplet
+                const float* r1 = is_item ? st.U + pa * ustride + (size_t)a * k : st.V + pa * istride + (size_t)a * k;
+                const float* r2 = st.V + pb * istride + (size_t)b * k;
+                float d1 = 0.f, d2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;        // pass A
+                for (int e = lane; e < k; e += TKR_WAVE) {
+                    const float o = own[e], x1 = r1[e], x2 = r2[e];
+                    if (is_item) { d1 = fmaf(x1, o, d1); d2 = fmaf(x1, x2, d2); }      // <u, v_row>, <u, v_other>
+                    else { d1 = fmaf(o, x1, d1); d2 = fmaf(o, x2, d2); }               // <u, v_i>, <u, v_j>
+                    if (want_loss && !is_item) {
+                        if (l2) { n0 = fmaf(o, o, n0); n1 = fmaf(x1, x1, n1); n2 = fmaf(x2, x2, n2); }
+                        else { n0 += fabsf(o); n1 += fabsf(x1); n2 += fabsf(x2); }
+                    }
+                }
+                d1 = wave_sum(d1); d2 = wave_sum(d2);
+                float x, coef, lam;
+                if (is_item) {
+                    const float bo = st.b[(size_t)pb * st.n_items + b];
+                    x = role_j ? (bo - br + d2 - d1) : (br - bo + d1 - d2);
+                    const float sg = sigmoid_neg(x);
+                    coef = role_j ? sg : -sg;
+                    lam = role_j ? st.lj : st.li;
+                    gb += coef + st.lb * (l2 ? br : sgn(br));
+                } else {
+                    const float bi = st.b[(size_t)pa * st.n_items + a], bj = st.b[(size_t)pb * st.n_items + b];
+                    x = bi - bj + d1 - d2;
+                    coef = -sigmoid_neg(x);
+                    lam = st.lu;
+                    if (want_loss) {
+                        n0 = wave_sum(n0); n1 = wave_sum(n1); n2 = wave_sum(n2);
+                        loss += softplus_neg(x) + (l2 ? 0.5f * (n0 * st.lu + n1 * st.li + n2 * st.lj) + 0.5f * (bi * bi + bj * bj) * st.lb
+                                                      : (n0 * st.lu + n1 * st.li + n2 * st.lj) + (fabsf(bi) + fabsf(bj)) * st.lb);
+                    }
+                }
+                for (int e = lane; e < k; e += TKR_WAVE) {        // pass B
+                    const float o = own[e];
+                    const float part = is_item ? r1[e] : (r1[e] - r2[e]);
+                    const float prev = first_occ ? 0.f : ld_fresh(gbuf + e);
+                    gbuf[e] = prev + coef * part + lam * (l2 ? o : sgn(o));
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sums are in memory before the next occurrence reads them back
+                first_occ = false;
+            }
+        }
+        if (!is_item && want_loss && lane == 0) rec_all[((size_t)blk * kTeam + (heavy ? 0 : wave)) * 16 + 15] = __float_as_int(loss);
+        const float* msrc = (is_item ? st.msV : st.msU) + (SGD ? 0 : roff);
+        float* mdst = (is_item ? st.msV : st.msU) + (SGD ? 0 : woff);
+        for (int e = lane; e < k; e += TKR_WAVE) {
+            const float g = ld_fresh(gbuf + e), o = own[e];
+            if constexpr (SGD) {
+                gbuf[e] = o - st.lr * g;
+            } else {
+                const float m2 = st.rho * msrc[e] + (1.f - st.rho) * g * g;
+                mdst[e] = m2;
+                gbuf[e] = o - st.lr * g / sqrtf(m2 + st.eps);
+            }
+        }
+        if (is_item && lane == 0) {
+            if constexpr (SGD) {
+                st.b[(size_t)(par ^ 1) * st.n_items + row] = br - st.lr * gb;
+            } else {
+                const float m2 = st.rho * st.msb[(size_t)par * st.n_items + row] + (1.f - st.rho) * gb * gb;
+                st.msb[(size_t)(par ^ 1) * st.n_items + row] = m2;
+                st.b[(size_t)(par ^ 1) * st.n_items + row] = br - st.lr * gb / sqrtf(m2 + st.eps);
+            }
+        }
+    }
+}
+
+template <int TEAM>
+static int launch_wide(const tkr_bpr_state& st, int32_t* rec, const int32_t* occ, const int32_t* hdr, int B, float* loss_out, hipStream_t stream) {
+    if (st.opt == 1)
+        hipLaunchKernelGGL((bpr_wide_kernel<TEAM, true>), dim3(step_grid(B, TEAM)), dim3(TEAM * TKR_WAVE), 0, stream, st, rec,
+                           reinterpret_cast<const int2*>(occ), reinterpret_cast<const int4*>(hdr), loss_out, 1);
+    else
+        hipLaunchKernelGGL((bpr_wide_kernel<TEAM, false>), dim3(step_grid(B, TEAM)), dim3(TEAM * TKR_WAVE), 0, stream, st, rec,
+                           reinterpret_cast<const int2*>(occ), reinterpret_cast<const int4*>(hdr), loss_out, 1);
+    return (int)hipGetLastError();
+}
+
 static int dispatch_step(const tkr_bpr_state& st, int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
                          float* loss_out, hipStream_t stream) {
     const int ne = (st.k + TKR_WAVE - 1) / TKR_WAVE;
@@ -391,9 +518,10 @@ static int dispatch_step(const tkr_bpr_state& st, int32_t* rec, const int32_t* o
                             : launch_step<4, false>(st, rec, occ, hdr, B, loss_out, stream);
         case 5: case 6: case 7: case 8:         // 256 < k <= 512: eight elements per lane, predicated rows; the 4-wave teams of batches
             // up to 1024 only (a 16-wave workgroup leaves a wave 128 registers: four partner-row pairs of eight do not fit)
-            if (tkr_plan_team(B) != 4) return TKR_EUNSUPPORTED;
+            if (tkr_plan_team(B) != 4) return launch_wide<16>(st, rec, occ, hdr, B, loss_out, stream);
             return launch_step_t<8, false, 4>(st, rec, occ, hdr, B, loss_out, stream);
-        default: return TKR_EUNSUPPORTED;       // k > 512
+        default:                                // k > 512: the generic row form
+            return tkr_plan_team(B) == 4 ? launch_wide<4>(st, rec, occ, hdr, B, loss_out, stream) : launch_wide<16>(st, rec, occ, hdr, B, loss_out, stream);
     }
 }
 
@@ -429,7 +557,6 @@ static int check_state(const tkr_bpr_state* st) {
     if (st->opt != 0 && st->opt != 1) return TKR_EINVAL;
     if (st->opt == 0 && (!st->msU || !st->msV || !st->msb)) return TKR_EINVAL;
     if (st->n_users <= 0 || st->n_items <= 0 || st->k <= 0) return TKR_EINVAL;
-    if (st->k > 512) return TKR_EUNSUPPORTED;
     return TKR_OK;
 }
 

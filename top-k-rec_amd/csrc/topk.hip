@@ -1917,6 +1917,51 @@ static int launch_topk_slabs(const float* U, const int32_t* uidx, int n_rows, co
     return merge_planned(p, users, n_rows, K, out_ids, out_scores, stream);
 }
 
+// ---- any width: one wave per row, a lane per item (k > 768) -------------------------------------------------------------------------
+// The MFMA kernels keep a workgroup's users resident as operands: three 256-wide slabs fill the register file.  Beyond that nothing
+// is resident: a wave takes ONE row, its lanes take 64 items at a time and each runs the fp32 fma chain of exact_score over the whole
+// width (k-halves interleaved, k ascending: the chain of the other kernels with KH = ceil(k / 2)); what reaches the K-th best so far
+// is merged into the row's sorted list (lanes 0..31) by the bitonic network.  Slow -- every lane gathers its own item row -- but the
+// same interface and the same canonical order for every k.
+__global__ __launch_bounds__(256) void score_topk_wide_kernel(const float* __restrict__ U, const int32_t* __restrict__ uidx, int n_rows,
+                                                             const float* __restrict__ Vt, const float* __restrict__ bias, int n_cols, int k,
+                                                             const uint32_t* __restrict__ mask, int mask_pitch, int K,
+                                                             int32_t* __restrict__ out_ids, float* __restrict__ out_scores) {
+    const int lane = threadIdx.x & 63;
+    const int r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (r >= n_rows) return;
+    const float* up = U + (size_t)(uidx ? uidx[r] : r) * k;
+    uint64_t best = 0ull;                                        // lanes 0..31: the best so far, descending (0 = none)
+    uint32_t kth = 0u;                                           // ordered bits of the K-th best score so far (0: fewer than K yet)
+    for (int c0 = 0; c0 < n_cols; c0 += 64) {
+        const int col = c0 + lane;
+        bool ok = col < n_cols;
+        if (ok && mask) ok = ((mask[(size_t)(col >> 5) * mask_pitch + r] >> (col & 31)) & 1u) == 0u;
+        uint64_t key = 0ull;
+        if (ok) {
+            const float sc = exact_score(up, Vt + (size_t)col * k, k, bias, col);
+            const uint32_t ob = ordered_bits(sc);
+            if (ob >= kth) key = ((uint64_t)ob << 32) | ((uint32_t)col + 1u);
+        }
+        if (__ballot(key != 0ull) == 0) continue;
+#pragma unroll 1
+        for (int hx = 0; hx < 2; ++hx) {                         // the best 32 so far + 32 of the new ones, twice
+            const uint64_t in = (uint64_t)__shfl((unsigned long long)key, (lane & 31) + 32 * hx, 64);
+            best = wave_sort_desc(lane < 32 ? best : in, lane);
+            if (lane >= 32) best = 0ull;
+        }
+        const uint64_t kb = (uint64_t)__shfl((unsigned long long)best, K - 1, 64);
+        kth = kb ? (uint32_t)(kb >> 32) : 0u;
+    }
+    if (lane < K) {
+        const bool have = best != 0ull;
+        const uint32_t ob = (uint32_t)(best >> 32);
+        const uint32_t f = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
+        out_ids[(size_t)r * K + lane] = have ? (int32_t)((uint32_t)best - 1u) : -1;
+        if (out_scores) out_scores[(size_t)r * K + lane] = have ? __uint_as_float(f) : -INFINITY;
+    }
+}
+
 // arithmetic of the score block: 2 = bound-and-refine (default; k <= 128 and a workspace, else it runs as 1), 0 = bf16-split
 // products on the dense matrix pipe (k <= 128), 1 = fp32 MFMA for every k.
 // Initial value from TKR_TOPK_MATH=refine|bf16x3|fp32; tkr_topk_set_math changes it for the process.
@@ -1976,7 +2021,9 @@ static int dispatch_topk(const float* U, const int32_t* uidx, int n_rows, const 
         return launch_topk_slabs<2, IdT>(U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores, workspace, workspace_bytes, stream);
     if (k <= 768)
         return launch_topk_slabs<3, IdT>(U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores, workspace, workspace_bytes, stream);
-    return TKR_EUNSUPPORTED;
+    hipLaunchKernelGGL(score_topk_wide_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,
+                       out_ids, out_scores);
+    return (int)hipGetLastError();
 }
 
 }  // namespace tkr
@@ -2045,7 +2092,7 @@ extern "C" int tkr_score_topk(const float* U, const int32_t* user_idx, int32_t n
                               int64_t workspace_bytes, void* stream) {
     if (!U || !Vt || !out_ids || n_rows <= 0 || n_cols <= 0 || k <= 0 || K <= 0) return TKR_EINVAL;
     if (mask && mask_pitch < n_rows) return TKR_EINVAL;
-    if (K > tkr::kMaxK || k > 768) return TKR_EUNSUPPORTED;
+    if (K > tkr::kMaxK) return TKR_EUNSUPPORTED;
     if (n_cols <= 65535)
         return tkr::dispatch_topk<uint16_t>(U, user_idx, n_rows, Vt, bias, n_cols, k, mask, mask_pitch, K, out_ids,
                                             out_scores, workspace, (size_t)(workspace_bytes > 0 ? workspace_bytes : 0),

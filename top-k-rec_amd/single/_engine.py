@@ -870,9 +870,12 @@ class BprEngine(PlanMixin):
         """sample + plan + step for n_batches consecutive batches; returns the per-batch
         losses of the LAST chunk as a device tensor (or None).  ``then_exchange`` = m > 0: the caller runs dist.ItemSync.end()
         right after this call and then goes on with an epoch of m batches -- its first chunk is planned ahead (PlanMixin)."""
-        if self.k > 512 or (self.k > 256 and B > 1024):
-            raise ValueError('BPR on the HIP path: k <= 512, and k <= 256 for batch sizes above 1024 (got k = %d, batch_size = %d): a wave '
-                             'holds a row in k / 64 registers per array (csrc/bpr_step.hip)' % (self.k, B))
+        if (self.k > 512 or (self.k > 256 and B > 1024)) and not getattr(self, '_warned_wide', False):
+            self._warned_wide = True
+            import warnings
+            warnings.warn('BPR: k = %d at batch_size = %d is wider than a wave can hold a row in registers beside its partners (k <= 512, '
+                          '<= 256 above batch 1024): the generic row form steps (csrc/bpr_step.hip bpr_wide_kernel: every occurrence in two '
+                          'passes over k, the gradient sum through memory)' % (self.k, B))
         cfg = self.cfg
         again = (id(csr), 0, B, self.layout_epoch, cfg.own, cfg.own_waves, cfg.fuse_short, cfg.fuse_plan, cfg.own_max_batch, cfg.flow, cfg.flow_max_batch, getattr(self, '_flow_disabled', False),
                  getattr(self, '_own_failed', False), getattr(self, 'ranks_on_device', 1), self.seed)

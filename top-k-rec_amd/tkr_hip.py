@@ -7,6 +7,7 @@ missing or a call fails, this module raises.
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 import os
 
 import torch
@@ -472,9 +473,10 @@ def score_topk(U, Vt, K, bias=None, user_idx=None, mask=None, mask_pitch=0, want
     K > 32 (evaluate.py -t above 32) is served exactly by several launches: the best 32, then the best 32
     of what is left (the columns already found are added to a copy of the rated mask), and so on."""
     assert U.dtype == torch.float32 and Vt.dtype == torch.float32 and U.shape[1] == Vt.shape[1]
-    if U.shape[1] > 768:
-        raise ValueError('K4 ranks factor widths up to 768 (got k = %d): the users of a workgroup stay resident as MFMA operands, '
-                         'three 256-wide slabs of them fill the register file' % U.shape[1])
+    if U.shape[1] > 768 and not getattr(score_topk, '_warned_wide', False):
+        score_topk._warned_wide = True
+        warnings.warn('K4: factor width %d is above 768, where a workgroup\'s users no longer stay resident as MFMA operands: the generic '
+                      'form runs (one wave per row, every lane gathers its own item row: csrc/topk.hip score_topk_wide_kernel)' % U.shape[1])
     if K <= TOPK_MAX_K:
         ids, scores = _score_topk_once(U, Vt, K, bias, user_idx, mask, mask_pitch, want_scores, split)
         return (ids, scores) if want_scores else ids
