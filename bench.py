@@ -66,7 +66,9 @@ def topk_roofline(tf, k):
             'bf16x3': 'bf16x3 split, 6 x v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulate: executed bf16 rate %.0f TFLOP/s of %.0f '
                       'dense' % (6 * tf, MFMA_BF16_PEAK_TF),
             'fp32': 'v_mfma_f32_32x32x2_f32'}[math]
-    return {'kernel': ('tkr::score_topk_slab_kernel' if k > 256 else 'tkr::score_topk_kernel') if math == 'fp32' else 'tkr::score_topk_bf16_kernel', 'bound': 'mfma', 'achieved': tf,
+    kernel = {'refine': 'tkr::score_topk_refine2_kernel (+ tkr::topk_finish2_kernel: exact rescoring and order, once per row)', 'bf16x3': 'tkr::score_topk_bf16_kernel',
+              'fp32': 'tkr::score_topk_wide_kernel' if k > 768 else 'tkr::score_topk_slab_kernel' if k > 256 else 'tkr::score_topk_kernel'}[math]
+    return {'kernel': kernel, 'bound': 'mfma', 'achieved': tf,
             'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak, 'arithmetic': what, 'vs_fp32_mfma_peak': tf / MFMA_F32_PEAK_TF}
 
 
@@ -78,7 +80,7 @@ def topk_other_arithmetics(run, k):
         return out
     try:
         for mode in ('refine', 'bf16x3', 'fp32'):
-            if mode == topk_math(k):
+            if mode == topk_math(k) or (mode == 'bf16x3' and not tkr_hip.lab()):      # (bf16x3: measured and dropped, `make LAB=1` only)
                 continue
             tkr_hip.set_topk_math(mode)
             run()
@@ -107,6 +109,26 @@ def pmc_traffic(key):
         return None
 
 
+ROUND = 'r06'                  # the round this bench.py belongs to: counter files of another round are replayed with "stale": true
+
+
+def pmc_k4(shape):
+    """counter summary of the K4 tile kernel at the ML-10M ('ml') or Netflix ('nf') shape from the newest profiles/rNN_pmc_k4.json
+    (scripts/collect_k4_counters.sh + scripts/summarize_k4_counters.py): matrix-pipe busy fraction, cycles and instructions per tile-wave"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_k4.json')))
+    if not files:
+        return None
+    try:
+        v = json.load(open(files[-1]))['shapes'][shape]
+        src = os.path.basename(files[-1])
+        return {'mfma_busy_frac': v['mfma_busy_frac'], 'valu_issue_frac_of_simd_time': v['valu_issue_frac_of_simd_time'],
+                'resident_waves_per_simd': v['resident_waves_per_simd'], 'per_tile_wave': v['per_tile_wave'],
+                'fractions_of_wave_cycles': v['fractions_of_wave_cycles'], 'source': src, 'stale': not src.startswith(ROUND)}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def pmc_mfma(match):
     """matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x elapsed shader cycles)) of the kernel whose name contains
     `match`, measured with rocprofv3 PMC passes in an earlier run of scripts/collect_mfma.sh (profiles/rNN_pmc_mfma.json, newest round)"""
@@ -119,7 +141,8 @@ def pmc_mfma(match):
             if match in name:
                 return {'kernel': name, 'mfma_busy_frac': v.get('mfma_busy_frac'),
                         'SQ_VALU_MFMA_BUSY_CYCLES': v['SQ_VALU_MFMA_BUSY_CYCLES']['per_dispatch'],
-                        'counter_over_expected_cycles': (v.get('expected') or {}).get('counter_over_expected'), 'source': os.path.basename(files[-1])}
+                        'counter_over_expected_cycles': (v.get('expected') or {}).get('counter_over_expected'), 'source': os.path.basename(files[-1]),
+                        'stale': not os.path.basename(files[-1]).startswith(ROUND)}       # a counter file of an earlier round: the kernel may have changed since
     except (OSError, ValueError, KeyError):
         pass
     return None
@@ -451,6 +474,7 @@ def topk_bench(r, k, device, rank, world, K=30, reps=5):
                              traffic_from_profile=pmc_traffic('score_topk_ml10m_k128') if (k == 128 and n_items == 10380 and world == 1) else None,
                              mfma_busy_from_profile=(pmc_mfma('<refine>, 69,878') if topk_math(k) == 'refine' else pmc_mfma('(fp32 MFMA), 69,878'))
                              if (k == 128 and n_items == 10380 and world == 1) else None,
+                             counters_from_profile=pmc_k4('ml') if (k == 128 and n_items == 10380 and world == 1 and topk_math(k) == 'refine') else None,
                              launch_ms=launch_ms, algorithmic_flops_per_launch=flops),
             'ms_per_pass_other_arithmetics': others}
 
@@ -485,7 +509,8 @@ def topk_bench_netflix(k, device, K=30, reps=3):
             'config': {'workload': '%d users x %d items, k=%d, top-%d, %d rated items per user masked' % (n_users, n_items, k, K, deg)},
             'roofline': dict(topk_roofline(tf, k), launch_ms=ms, traffic=None,
                              traffic_from_profile=pmc_traffic('score_topk_netflix_k128') if k == 128 else None,
-                             mfma_busy_from_profile=pmc_mfma('<refine>, 480,189') if (k == 128 and topk_math(k) == 'refine') else None),
+                             mfma_busy_from_profile=pmc_mfma('<refine>, 480,189') if (k == 128 and topk_math(k) == 'refine') else None,
+                             counters_from_profile=pmc_k4('nf') if (k == 128 and topk_math(k) == 'refine') else None),
             'ms_per_pass_other_arithmetics': others}
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TKR_VERSION 117 /* 0.1.17: tkr_vbpr_set_pairs (tkr_vbpr_workspace_floats + 64). 0.1.16: tkr_topk_set_finish (larger tkr_topk_workspace_bytes), tkr_bpr_own_plan_run plans inside the step's launch. 0.1.15: tkr_bpr_own_owners_shared; tkr_bpr_run takes `rec` non-const. 0.1.14: per-task loss sums instead of atomics on loss_out (larger tkr_vbpr_workspace_floats; K2 writes word 15 of its records). 0.1.13: tkr_bpr_own_plan_run, K4 to k = 768. 0.1.12: tkr_bpr_own_run_between. 0.1.11: K2o (tkr_sample_plan_owned, tkr_bpr_own_run: item rows owned by one workgroup each, resident in its LDS); prec[5] = last batch of the call that updated the row. 0.1.10: tkr_topk_workspace_bytes_for (K4 stages pre-converted fp16 tiles). 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
+#define TKR_VERSION 118 /* 0.1.18: K4 second form of bound-and-refine (csrc/topk_refine.hip; tkr_topk_workspace_bytes_for grows by the pieces' packed lists), any k (bpr_wide_kernel, score_topk_wide_kernel), tkr_lab_build; tkr_topk_set_finish is gone, tkr_topk_set_math(0) and tkr_vbpr_set_pairs(1 | 2) need the lab library. 0.1.17: tkr_vbpr_set_pairs (tkr_vbpr_workspace_floats + 64). 0.1.16: tkr_topk_set_finish (larger tkr_topk_workspace_bytes), tkr_bpr_own_plan_run plans inside the step's launch. 0.1.15: tkr_bpr_own_owners_shared; tkr_bpr_run takes `rec` non-const. 0.1.14: per-task loss sums instead of atomics on loss_out (larger tkr_vbpr_workspace_floats; K2 writes word 15 of its records). 0.1.13: tkr_bpr_own_plan_run, K4 to k = 768. 0.1.12: tkr_bpr_own_run_between. 0.1.11: K2o (tkr_sample_plan_owned, tkr_bpr_own_run: item rows owned by one workgroup each, resident in its LDS); prec[5] = last batch of the call that updated the row. 0.1.10: tkr_topk_workspace_bytes_for (K4 stages pre-converted fp16 tiles). 0.1.9: tkr_vbpr_colplan + tkr_vbpr_run_cols (VBPR in three launches per batch). 0.1.8: tkr_sync_flow_* (exchange of the granule tables). 0.1.7: K4 bound-and-refine arithmetic (tkr_topk_set_math(2), the default; larger tkr_topk_workspace_bytes); K2f leaves its ticket words zero. 0.1.6: K2f persistent dataflow step, tkr_plan_rollback, batches above 8192 */
 #define TKR_OK 0
 #define TKR_E_INVAL (-1)
 #define TKR_E_UNSUPPORTED (-2)
@@ -40,6 +40,9 @@ extern "C" {
 #define TKR_E_NOMEM (-5)       /* host text I/O: allocation failed */
 
 int tkr_version(void);
+/* 1: built with `make LAB=1` -- the library also holds the kernel forms that were measured slower and are nobody's default (K2o scalar
+ * exchange / scout / 16 waves / loader ring, K4 bf16x3, the VBPR pair-sum placements 1 and 2); 0: asking for one returns TKR_E_UNSUPPORTED */
+int tkr_lab_build(void);
 
 /* ---- K1: (u,i,j) draw + batch plan ---------------------------------------------------------
  * Replaces BPR._uniform_user_sampling (single/bpr.py:155-165) and the gradient de-duplication
@@ -338,7 +341,7 @@ int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i, const int3
  *     margin of the K-th best approximate score, and the survivors are rescored with the arithmetic of mode 1, which
  *     decides the order: ids and score bits are those of mode 1, at 2.1x its speed.  A list that cannot hold its margin
  *     (massive near-ties) sends its user block through the mode-1 kernel.  Without a workspace the call runs as mode 1.
- *   0 "bf16x3" (k <= 128): each fp32 factor is split exactly into three bf16 parts and a product is the six
+ *   0 "bf16x3" (k <= 128; lab library only, `make LAB=1`: TKR_E_UNSUPPORTED otherwise): each fp32 factor is split exactly into three bf16 parts and a product is the six
  *     leading partial products (each exact in fp32, the dropped ones < 2^-23 |ab|) accumulated in fp32 by
  *     v_mfma_f32_32x32x16_bf16 -- an fp32 dot product with yet another summation order: same error against fp64 as
  *     np.dot / the fp32 kernel, identical results whenever the partial sums are representable; finite inputs only;
@@ -358,11 +361,6 @@ int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K);
  * its tiles with one direct-to-LDS load per thread instead of converting them again (results are identical either way) */
 int64_t tkr_topk_workspace_bytes_for(int32_t n_rows, int32_t n_cols, int32_t k, int32_t K);
 int tkr_topk_set_math(int32_t mode);
-/* bound-and-refine only: 1 = the pieces of a user block dump their candidate lists and one more kernel (topk_finish_kernel)
- * rescores every row ONCE and sorts it; 0 (default: measured no faster, csrc/topk.hip) = every piece rescores and sorts its own
- * lists and the pieces' lists are merged.  Same ids and score bits either way.  Needs the workspace of
- * tkr_topk_workspace_bytes_for; initial value from TKR_TOPK_FINISH. */
-int tkr_topk_set_finish(int32_t on);
 int tkr_build_rated_mask(const int64_t* rated_ptr, const int32_t* rated_cols, int32_t n_rows, int32_t n_cols,
                          uint32_t* mask, int32_t mask_pitch, void* stream);
 int tkr_score_topk(const float* U, const int32_t* user_idx, int32_t n_rows, const float* Vt, const float* bias,

@@ -25,9 +25,9 @@ def per_kernel(leg, C, pat):
     return g
 
 
-LEGS = (('topk', r'score_topk_bf16_kernel<\d+, [a-z ]+, true', 'score_topk_bf16_kernel<refine>, 69,878 x 10,380, k = 128',
+LEGS = (('topk', r'score_topk_refine2_kernel', 'score_topk_refine2_kernel<refine>, 69,878 x 10,380, k = 128',
          dict(users=69878, items=10380, k=128, mfma='v_mfma_f32_32x32x16_f16', cyc=32, per_block=8)),
-        ('topknf', r'score_topk_bf16_kernel<\d+, [a-z ]+, true', 'score_topk_bf16_kernel<refine>, 480,189 x 17,770, k = 128',
+        ('topknf', r'score_topk_refine2_kernel', 'score_topk_refine2_kernel<refine>, 480,189 x 17,770, k = 128',
          dict(users=480189, items=17770, k=128, mfma='v_mfma_f32_32x32x16_f16', cyc=32, per_block=8)),
         ('topk32', r'score_topk_kernel<', 'score_topk_kernel (fp32 MFMA), 69,878 x 10,380, k = 128',
          dict(users=69878, items=10380, k=128, mfma='v_mfma_f32_32x32x2_f32', cyc=64, per_block=64)),

@@ -5,7 +5,7 @@ import pandas as pd
 src, tag = sys.argv[1], sys.argv[2]
 KERN = ('own_loss_kernel', 'step_loss_kernel', 'loss_slots_kernel', 'loss_slots_sum_kernel', 'bpr_own_kernel', 'bpr_flow_kernel', 'bpr_step_kernel', 'sample_plan_kernel', 'resolve_flow_wide_kernel', 'resolve_flow_kernel', 'score_topk_slab_kernel', 'resolve_kernel', 'commit_kernel', 'rollback_kernel',
         'big_draw_kernel', 'big_flag_kernel', 'big_emit_kernel', 'big_count_kernel', 'big_fill_kernel', 'big_parity_kernel', 'big_record_kernel',
-        'DeviceRadixSort', 'radix_sort', 'DeviceScan', 'scan', 'vbpr_pair_kernel', 'score_topk_bf16_kernel', 'score_topk_kernel', 'merge_topk_kernel', 'topk_bounds_kernel',
+        'DeviceRadixSort', 'radix_sort', 'DeviceScan', 'scan', 'vbpr_pair_kernel', 'score_topk_refine2_kernel', 'topk_finish2_kernel', 'score_topk_wide_kernel', 'bpr_wide_kernel', 'score_topk_bf16_kernel', 'score_topk_kernel', 'merge_topk_kernel', 'topk_bounds_kernel',
         'raw_rank_kernel', 'count_hits_rr_kernel',
         'build_mask_kernel', 'vbpr_sproject_kernel', 'vbpr_sdense_kernel', 'vbpr_project_kernel', 'vbpr_reduce_kernel', 'vbpr_occur_kernel', 'vbpr_rows_kernel', 'vbpr_dense_kernel',
         'vbpr_tproject_kernel', 'vbpr_pairsum_kernel', 'vbpr_update_kernel', 'vbpr_colplan_kernel', 'topk_image_kernel',
@@ -74,9 +74,11 @@ def leg(tagdir, pat, key, per, note):
     if n:
         res[key] = {'launches': n, 'hbm_read_bytes_per_launch': rd / n, 'hbm_write_bytes_per_launch': wr / n,
                     'hbm_bytes_per_launch_corrected': (rd + wr) / n, 'per': per, 'note': note}
-leg('topk', r'score_topk_bf16_kernel<\d+, [a-z ]+, true', 'score_topk_ml10m_k128', 'pass over 69,878 users x 10,380 items, k = 128, top-30',
-    'bound-and-refine kernel alone (the bounds / image / merge launches are a few hundred KB)')
-leg('topknf', r'score_topk_bf16_kernel<\d+, [a-z ]+, true', 'score_topk_netflix_k128', 'pass over 480,189 users x 17,770 items, k = 128, top-30', '')
+leg('topk', r'score_topk_refine2_kernel|topk_finish2_kernel', 'score_topk_ml10m_k128', 'pass over 69,878 users x 10,380 items, k = 128, top-30',
+    'the tile kernel + the finish kernel of bound-and-refine (the bounds / image / merge launches are a few hundred KB); launches = 2 per pass: '
+    'hbm_bytes_per_launch_corrected x 2 = bytes per pass')
+leg('topknf', r'score_topk_refine2_kernel|topk_finish2_kernel', 'score_topk_netflix_k128', 'pass over 480,189 users x 17,770 items, k = 128, top-30',
+    'as above: two launches per pass')
 leg('b65536', 'bpr_step_kernel', 'bpr_step_B65536', 'batch of 65,536 triplets', 'algorithmic 406 MB: no credit for the duplicates of 131,072 item draws over 10,380 items')
 for pat, key in (('vbpr_tproject_kernel', 'vbpr_tproject_B256'), ('vbpr_pairsum_kernel', 'vbpr_pairsum_B256'), ('vbpr_update_kernel', 'vbpr_update_B256')):
     leg('vbpr', pat, key, 'batch of 256 triplets, d = 20,000, ~100 nonzeros per feature row', '')

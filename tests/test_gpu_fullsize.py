@@ -256,10 +256,13 @@ def test_topk_full_netflix_shape_properties():
     try:
         tkr_hip.set_topk_math('fp32')
         ids_f, sc_f = tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch, want_scores=True)
-        tkr_hip.set_topk_math('bf16x3')
-        ids_b = tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch)
+        ids_b = None
+        if tkr_hip.lab():
+            tkr_hip.set_topk_math('bf16x3')
+            ids_b = tkr_hip.score_topk(U, V, K, mask=mask, mask_pitch=pitch)
     finally:
         tkr_hip.set_topk_math(tkr_hip.TOPK_MATH_DEFAULT)
     assert torch.equal(ids_f, ids) and torch.equal(sc_f.view(torch.int32), scores.view(torch.int32))
-    assert torch.equal(ids_b[sample][decided], got[decided])
-    assert float((ids_b == ids).all(1).float().mean()) > 0.97
+    if ids_b is not None:
+        assert torch.equal(ids_b[sample][decided], got[decided])
+        assert float((ids_b == ids).all(1).float().mean()) > 0.97

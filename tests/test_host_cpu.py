@@ -134,7 +134,13 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(tkr_hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.tkr_version() == tkr_hip.VERSION
+    # ... and the other direction: every tkr_* symbol the library exports is declared (helpers between its translation units are hidden)
+    import subprocess
+    nm = subprocess.run(['nm', '-D', '--defined-only', tkr_hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    dynamic = {ln.split()[-1] for ln in nm.splitlines() if ln.split() and ln.split()[-1].startswith('tkr_')}
+    extra = {'tkr_k4_prof_read', 'tkr_debug_own_k1_prof'}        # profiling builds only (-DTKR_R2_PROF / -DTKR_PLAN_STAMP)
+    assert dynamic - extra <= declared, (dynamic - extra) - declared
+    assert lib.tkr_version() == tkr_hip.VERSION and lib.tkr_lab_build() in (0, 1)
     assert lib.tkr_plan_team(256) == 4 and lib.tkr_plan_team(8192) == 16
     assert lib.tkr_plan_max_blocks(256) == 192 + 153 and lib.tkr_plan_max_blocks(2048) == 384 + 1228 and lib.tkr_plan_max_blocks(8192) == 1536 + 1445
     # argument validation happens before any device access

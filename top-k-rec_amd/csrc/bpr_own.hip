@@ -1206,12 +1206,21 @@ static int own_launch(const tkr_flow_state* st, const int32_t* prec, const int32
     if (ring_slots) lds = tkr::own_lds_bytes_loader(np, n_batches, st->n_items, n_owner, ring_slots);
     static const int ahead_env = getenv("TKR_OWN_AHEAD") ? atoi(getenv("TKR_OWN_AHEAD")) : 0;       // tuning aid
     const uint32_t ktune = (tune & ~8u & 0xffu) | (fold ? 8u : 0u) | ((uint32_t)ring_slots << 8) | ((uint32_t)(ahead_env > 0 ? ahead_env : tkr::kLoadAhead) << 16);
+#ifdef TKR_LAB
     const void* fn = pa ? (const void*)tkr::bpr_own_kernel<1, 768, false, true>
                    : ring_slots ? (const void*)tkr::bpr_own_kernel<1, 768, false, false, true>
                    : np == 1 ? (wide ? (scalar ? (const void*)tkr::bpr_own_kernel<1, 1024, true> : (const void*)tkr::bpr_own_kernel<1, 1024, false>)
                                 : mid ? (scalar ? (const void*)tkr::bpr_own_kernel<1, 768, true> : (const void*)tkr::bpr_own_kernel<1, 768, false>)
                                      : (scalar ? (const void*)tkr::bpr_own_kernel<1, 512, true> : (const void*)tkr::bpr_own_kernel<1, 512, false>))
                              : (scalar ? (const void*)tkr::bpr_own_kernel<2, 512, true> : (const void*)tkr::bpr_own_kernel<2, 512, false>);
+#else
+    // the default library holds the forms that run by default -- 12 waves and row-read item tasks at k <= 128 (with and without the planner
+    // prologue), 8 waves at k <= 256; the forms that were measured and lost (scalar exchange + scout, 16 and 8 waves at k <= 128, the
+    // loader / consumer ring: DESIGN.md section 4, K2o table) are built by `make LAB=1` only
+    if (scalar || wide || (np == 1 && !mid) || (tune & 1u)) return TKR_EUNSUPPORTED;
+    const void* fn = pa ? (const void*)tkr::bpr_own_kernel<1, 768, false, true>
+                   : np == 1 ? (const void*)tkr::bpr_own_kernel<1, 768, false> : (const void*)tkr::bpr_own_kernel<2, 512, false>;
+#endif
     const int variant = pa ? 4 : ring_slots ? 5 : np == 2 ? 3 : wide ? 2 : mid ? 1 : 0;
     if (lds > 64 * 1024 && !(dev >= 0 && dev < 64 && attr_set[dev][variant][scalar])) {
         TKR_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1234,6 +1243,7 @@ static int own_launch(const tkr_flow_state* st, const int32_t* prec, const int32
 #define TKR_OWN_LAUNCH(NPV, TPBV, SC, PL)                                                                                                 \
     hipLaunchKernelGGL((tkr::bpr_own_kernel<NPV, TPBV, SC, PL>), dim3(n_owner), dim3(TPBV), lds, s, *st, r4, o4, occt, ohdr, ohdr_stride, first_batch, \
                        n_batches, batch_size, n_owner, ow, ktune, ctl, loss_out, static_cast<tkr::u64*>(xch), epoch, PL ? *pa : no_plan)
+#ifdef TKR_LAB
     if (pa) TKR_OWN_LAUNCH(1, 768, false, true);
     else if (ring_slots)
         hipLaunchKernelGGL((tkr::bpr_own_kernel<1, 768, false, false, true>), dim3(n_owner), dim3(768), lds, s, *st, r4, o4, occt, ohdr, ohdr_stride,
@@ -1242,6 +1252,11 @@ static int own_launch(const tkr_flow_state* st, const int32_t* prec, const int32
     else if (np == 1 && mid) { if (scalar) TKR_OWN_LAUNCH(1, 768, true, false); else TKR_OWN_LAUNCH(1, 768, false, false); }
     else if (np == 1) { if (scalar) TKR_OWN_LAUNCH(1, 512, true, false); else TKR_OWN_LAUNCH(1, 512, false, false); }
     else { if (scalar) TKR_OWN_LAUNCH(2, 512, true, false); else TKR_OWN_LAUNCH(2, 512, false, false); }
+#else
+    if (pa) TKR_OWN_LAUNCH(1, 768, false, true);
+    else if (np == 1) TKR_OWN_LAUNCH(1, 768, false, false);
+    else TKR_OWN_LAUNCH(2, 512, false, false);
+#endif
 #undef TKR_OWN_LAUNCH
     TKR_LAUNCH_CHECK();
     if (loss_out && !scalar && !fold) {

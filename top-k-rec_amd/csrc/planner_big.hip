@@ -257,7 +257,7 @@ static BigLayout big_layout(char* base, size_t nB) {
 extern "C" int tkr_plan_team(int32_t batch_size);
 extern "C" int tkr_plan_max_blocks(int32_t batch_size);
 
-extern "C" int64_t tkr_plan_workspace_bytes_for(int32_t batch_size, int32_t n_batches) {
+extern "C" __attribute__((visibility("hidden"))) int64_t tkr_plan_workspace_bytes_for(int32_t batch_size, int32_t n_batches) {      // (a helper between translation units, not an entry point)
     if (batch_size <= 0 || n_batches <= 0) return 0;
     return (int64_t)tkr::big_layout(nullptr, (size_t)batch_size * n_batches).total_bytes;
 }
@@ -267,7 +267,7 @@ extern "C" int64_t tkr_plan_workspace_bytes(int32_t batch_size, int32_t n_batche
 }
 
 // called by tkr_sample_plan for batch_size > 8192
-extern "C" int tkr_sample_plan_big(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,
+extern "C" __attribute__((visibility("hidden"))) int tkr_sample_plan_big(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,
                                    const int32_t* cols_sorted, int32_t n_users, int32_t n_items, uint64_t seed,
                                    uint64_t first_triplet, const int64_t* ctl, int32_t n_batches, int32_t B, int32_t* ucnt,
                                    int32_t* icnt, uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u, int32_t* out_i,

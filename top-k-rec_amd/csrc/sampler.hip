@@ -366,8 +366,8 @@ extern "C" int tkr_plan_max_blocks(int32_t batch_size) {
     return (3 * batch_size + lpb - 1) / lpb + (3 * batch_size) / (tkr::light_max(batch_size) + 1);
 }
 
-extern "C" int64_t tkr_plan_workspace_bytes_for(int32_t batch_size, int32_t n_batches);       // csrc/planner_big.hip, any batch size
-extern "C" int tkr_sample_plan_big(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,
+extern "C" __attribute__((visibility("hidden"))) int64_t tkr_plan_workspace_bytes_for(int32_t batch_size, int32_t n_batches);       // csrc/planner_big.hip, any batch size
+extern "C" __attribute__((visibility("hidden"))) int tkr_sample_plan_big(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,
                                    const int32_t* cols_sorted, int32_t n_users, int32_t n_items, uint64_t seed,
                                    uint64_t first_triplet, const int64_t* ctl, int32_t n_batches, int32_t B, int32_t* ucnt,
                                    int32_t* icnt, uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u, int32_t* out_i,

@@ -530,188 +530,6 @@ __device__ __forceinline__ void write_rows_refine(const TopkSmem<IdT>& sm, const
     write_rows<IdT>(sm, ws, n_rows, K, -INFINITY, out_ids, out_scores, part);
 }
 
-// ---- bound-and-refine, final stage in a kernel of its own (round 5) ------------------------------------------------------------
-// write_rows_refine rescored inside the tile kernel: 8 waves per CU of 256 registers each, every wave waiting out ~17 passes of
-// dependent row gathers per piece of a block, and a block cut into two pieces rescored ~33 candidates per user TWICE -- 17 % of the
-// Netflix pass, 36 % of the ML-10M pass, at an occupancy chosen for the MFMA loop.  Now a piece only DUMPS its lists (approximate
-// scores, scaled units of the user; every list a superset of the exact best K of its tiles) with its final threshold, and
-// topk_finish_kernel -- one wave per row, small, 12+ waves per CU -- takes the union of a row's pieces, drops what lies below the
-// largest threshold any piece reached (each is a lower bound of the K-th best exact score minus the margin: valid for every piece),
-// rescores the survivors ONCE with the fp32 kernel's own fma chain and sorts.  Same ids, same score bits.
-constexpr int kDumpCap = kCap;           // entries per (row, slot)
-template <typename IdT>
-__device__ __forceinline__ void dump_rows(const TopkSmem<IdT>& sm, const TopkSlot& ws, int n_rows, int K, float thr, float m2,
-                                          uint64_t* __restrict__ dump, float2* __restrict__ dhdr, int dstride) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int me = lane & 31, half = lane >> 5;
-    if (__ballot(sm.cnt[wave * 32 + me] > 32) != 0) {
-        thr = trim_all_users<IdT, true>(sm, wave * 32 + me, half, K, thr, m2);
-        __builtin_amdgcn_wave_barrier();
-    }
-    const int r_me = ws.block * sm.users + wave * 32 + me;
-    if (half == 0 && r_me < n_rows)
-        dhdr[(size_t)r_me * dstride + ws.slot] = make_float2(__int_as_float(min(sm.cnt[wave * 32 + me], kCap)), thr);
-    for (int u = 0; u < 32; ++u) {
-        const int uq = wave * 32 + u, r = ws.block * sm.users + uq;
-        if (r >= n_rows) break;                                  // wave-uniform
-        const int n = min(sm.cnt[uq], kCap);
-        if (lane < n)
-            dump[((size_t)r * dstride + ws.slot) * kDumpCap + lane] =
-                ((uint64_t)__float_as_uint(sm.cs[lane * sm.users + uq]) << 32) | (uint32_t)sm.ci[lane * sm.users + uq];
-    }
-}
-
-// one wave per row.  KS > 0: k == 16 * KS (every trip count a constant, all the loads of a candidate's item row in flight at once);
-// KS == 0: any k through exact_score.
-// value of quad lane Q (lane & ~3 | Q) in every lane of the quad: a VALU move, no LDS
-template <int Q>
-__device__ __forceinline__ float quad_bcast(uint32_t v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, (int)v, Q * 0x55, 0xf, 0xf, false));
-}
-
-template <int KS>
-__global__ __launch_bounds__(256, 3) void topk_finish_kernel(const uint64_t* __restrict__ dump, const float2* __restrict__ dhdr, int n_rows,
-                                                            int stride, const int32_t* __restrict__ nslots, int users_per_block,
-                                                            const uint32_t* __restrict__ flagged, const float* __restrict__ U,
-                                                            const int32_t* __restrict__ uidx, const float* __restrict__ Vt,
-                                                            const float* __restrict__ bias, int k, int K, int32_t* __restrict__ out_ids,
-                                                            float* __restrict__ out_scores) {
-    __shared__ uint32_t s_q[4][128];
-    __shared__ uint64_t s_key[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);       // (provably wave-uniform: the user's row comes through the scalar cache)
-    if (r >= n_rows) return;
-    const int block = r / users_per_block;
-    if (flagged && flagged[block]) return;                       // a list of this block overflowed: the fp32 kernel redoes it
-    // ONE round trip for everything that does not depend on anything else: the block's piece count, the headers of up to 64 pieces
-    // (lane s: piece s), the entries of the first four pieces (lane e: entry e of each; lanes past a list's length read what an
-    // earlier call left there and are masked below).  (First version: count -> headers -> per piece its length -> its entries,
-    // one after the other: 8 dependent trips per row.)
-    const int S = nslots ? nslots[block] : stride;
-    float2 hme = make_float2(0.f, -INFINITY);
-    if (lane < stride) hme = dhdr[(size_t)r * stride + lane];
-    uint64_t e4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) e4[j] = dump[((size_t)r * stride + min(j, stride - 1)) * kDumpCap + lane];
-    const int urow_i = __builtin_amdgcn_readfirstlane(uidx ? uidx[r] : r);
-    const float* up = U + (size_t)urow_i * k;
-    float B = lane < S ? hme.y : -INFINITY;                      // the largest threshold any piece reached
-    for (int s0 = 64; s0 < S; s0 += 64)                          // (more than 64 pieces of one block: a one-block problem cut 256 ways)
-        if (s0 + lane < S) B = fmaxf(B, dhdr[(size_t)r * stride + s0 + lane].y);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) B = fmaxf(B, __shfl_xor(B, o, 64));
-    uint32_t* q = s_q[wave];
-    uint64_t* keys = s_key[wave];
-    int queued = 0;
-    uint64_t best = 0ull;                                        // lanes 0..31: the best so far, descending (0 = none)
-    bool first = true;
-    auto flush = [&](int m) {                                    // rescore the first m <= 64 queued columns, merge them into `best`
-        if constexpr (KS > 0) {
-            // FOUR lanes per candidate: quad lane c reads the 16-byte chunks 4i + c of the candidate's item row -- a quad reads 64
-            // contiguous bytes per instruction, a wave 16 rows x 64 B instead of 64 rows x 16 B (one lane per candidate: every
-            // instruction touched 64 different cache lines for 16 bytes each; the kernel ran at the rate of the texture addresser,
-            // 9 B / clock / CU, 268 us at the ML-10M shape).  The exact chain -- element for element the fp32-MFMA kernel's:
-            // k-halves interleaved, k ascending -- runs in all four lanes of the quad on values handed round by DPP (VALU moves);
-            // the user's row sits in scalar registers.
-            constexpr int q4 = 2 * KS;                           // 16-byte chunks per k-half
-            constexpr int NI = (2 * q4 + 3) / 4;                 // loads per lane: chunks 4i + c, i < NI
-            const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vt), 0, 0xfffffff0u, 0x00020000);
-            const float4* urow = reinterpret_cast<const float4*>(up);      // wave-uniform addresses: scalar loads
-            typedef uint32_t ld4 __attribute__((ext_vector_type(4)));
-            const int c4 = lane & 3;
-#pragma unroll 1
-            for (int p0 = 0; p0 < m; p0 += 16) {
-                const int ci = p0 + (lane >> 2);
-                const bool live = ci < m;
-                const int col = live ? (int)q[ci] : 0;
-                const int voff = col * (64 * KS) + c4 * 16;
-                ld4 v[NI];
-#pragma unroll
-                for (int i = 0; i < NI; ++i) v[i] = (4 * i + c4 < 2 * q4) ? __builtin_amdgcn_raw_buffer_load_b128(vr, voff + i * 64, 0, 0) : ld4{0u, 0u, 0u, 0u};
-                float acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < q4; ++j) {                   // chunk j of half 0 and chunk q4 + j of half 1
-                    const float4 b0 = urow[j], b1 = urow[q4 + j];
-                    const int i0 = j >> 2, i1 = (q4 + j) >> 2;
-                    float a0x, a0y, a0z, a0w, a1x, a1y, a1z, a1w;
-                    switch (j & 3) {                             // (compile-time in the unrolled loop; q4 is a multiple of 4 for KS >= 2, so both chunks sit in the same quad lane)
-                        case 0: a0x = quad_bcast<0>(v[i0].x); a0y = quad_bcast<0>(v[i0].y); a0z = quad_bcast<0>(v[i0].z); a0w = quad_bcast<0>(v[i0].w); break;
-                        case 1: a0x = quad_bcast<1>(v[i0].x); a0y = quad_bcast<1>(v[i0].y); a0z = quad_bcast<1>(v[i0].z); a0w = quad_bcast<1>(v[i0].w); break;
-                        case 2: a0x = quad_bcast<2>(v[i0].x); a0y = quad_bcast<2>(v[i0].y); a0z = quad_bcast<2>(v[i0].z); a0w = quad_bcast<2>(v[i0].w); break;
-                        default: a0x = quad_bcast<3>(v[i0].x); a0y = quad_bcast<3>(v[i0].y); a0z = quad_bcast<3>(v[i0].z); a0w = quad_bcast<3>(v[i0].w); break;
-                    }
-                    switch ((q4 + j) & 3) {
-                        case 0: a1x = quad_bcast<0>(v[i1].x); a1y = quad_bcast<0>(v[i1].y); a1z = quad_bcast<0>(v[i1].z); a1w = quad_bcast<0>(v[i1].w); break;
-                        case 1: a1x = quad_bcast<1>(v[i1].x); a1y = quad_bcast<1>(v[i1].y); a1z = quad_bcast<1>(v[i1].z); a1w = quad_bcast<1>(v[i1].w); break;
-                        case 2: a1x = quad_bcast<2>(v[i1].x); a1y = quad_bcast<2>(v[i1].y); a1z = quad_bcast<2>(v[i1].z); a1w = quad_bcast<2>(v[i1].w); break;
-                        default: a1x = quad_bcast<3>(v[i1].x); a1y = quad_bcast<3>(v[i1].y); a1z = quad_bcast<3>(v[i1].z); a1w = quad_bcast<3>(v[i1].w); break;
-                    }
-                    acc = fmaf(a0x, b0.x, acc); acc = fmaf(a1x, b1.x, acc);
-                    acc = fmaf(a0y, b0.y, acc); acc = fmaf(a1y, b1.y, acc);
-                    acc = fmaf(a0z, b0.z, acc); acc = fmaf(a1z, b1.z, acc);
-                    acc = fmaf(a0w, b0.w, acc); acc = fmaf(a1w, b1.w, acc);
-                    __builtin_amdgcn_sched_barrier(0);           // (or every DPP move of the row is hoisted in front of the chain: 128 temporaries)
-                }
-                acc = acc + (bias ? bias[col] : 0.f);
-                const float sc = acc + 0.0f;
-                if (c4 == 0) keys[ci & 63] = live ? (((uint64_t)ordered_bits(sc) << 32) | ((uint32_t)col + 1u)) : 0ull;
-            }
-            for (int ci = ((m + 15) & ~15) + lane; ci < 64; ci += 64) keys[ci] = 0ull;       // the slots no pass wrote
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            const bool live = lane < m;
-            const int col = live ? (int)q[lane] : 0;
-            const float sc = live ? exact_score(up, Vt + (size_t)col * k, k, bias, col) : 0.f;
-            keys[lane] = live ? (((uint64_t)ordered_bits(sc) << 32) | ((uint32_t)col + 1u)) : 0ull;
-            __builtin_amdgcn_wave_barrier();
-        }
-        const uint64_t key = keys[lane];
-        if (first) {                                             // nothing to merge with: one sort of the 64
-            best = wave_sort_desc(key, lane);
-            first = false;
-        } else {                                                 // best 32 so far in lanes 0..31 + 32 new ones, twice
-#pragma unroll 1
-            for (int hx = 0; hx < 2; ++hx) {
-                const uint64_t in = (uint64_t)__shfl((unsigned long long)key, (lane & 31) + 32 * hx, 64);
-                best = wave_sort_desc(lane < 32 ? best : in, lane);
-            }
-        }
-        if (lane >= 32) best = 0ull;
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t rest = (lane + m < queued) ? q[lane + m] : 0u;       // what stays queued moves to the front
-        const uint32_t rest2 = (lane + 64 + m < queued) ? q[lane + 64 + m] : 0u;
-        __builtin_amdgcn_wave_barrier();
-        q[lane] = rest;
-        q[lane + 64] = rest2;
-        queued -= m;
-        __builtin_amdgcn_wave_barrier();
-    };
-    __builtin_amdgcn_wave_barrier();
-    int s = 0;
-    while (s < S || queued > 0) {                                // (one call site of the rescoring)
-        while (s < S && queued < 64) {
-            const size_t at = (size_t)r * stride + s;
-            const int n = s < 64 ? __shfl(__float_as_int(hme.x), s, 64) : __float_as_int(dhdr[at].x);
-            uint64_t e = s == 0 ? e4[0] : s == 1 ? e4[1] : s == 2 ? e4[2] : e4[3];
-            if (s >= 4) e = dump[at * kDumpCap + lane];
-            const bool keep = lane < n && __uint_as_float((uint32_t)(e >> 32)) >= B;
-            const uint64_t m = __ballot(keep);
-            if (keep) q[queued + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)e;
-            queued += __popcll(m);
-            __builtin_amdgcn_wave_barrier();
-            ++s;
-        }
-        if (queued > 0) flush(min(queued, 64));
-    }
-    if (lane < K) {
-        const bool have = best != 0ull;
-        const uint32_t ob = (uint32_t)(best >> 32);
-        const uint32_t f = (ob & 0x80000000u) ? (ob & 0x7fffffffu) : ~ob;
-        out_ids[(size_t)r * K + lane] = have ? (int32_t)((uint32_t)best - 1u) : -1;
-        if (out_scores) out_scores[(size_t)r * K + lane] = have ? __uint_as_float(f) : -INFINITY;
-    }
-}
-
 // waves per workgroup of an instantiation: 8 (two per SIMD: one wave's filter overlaps the other's MFMA
 // chain); 6 when candidate ids need 32 bits (LDS); 4 for wide factor rows (100+ operand registers)
 template <int KHP, typename IdT>
@@ -1077,8 +895,7 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT, REFINE>() * TKR_WAVE), 2)
     const float* __restrict__ bias, int n_cols, int k, const uint32_t* __restrict__ mask, int mask_pitch, int K,
     int32_t* __restrict__ out_ids, float* __restrict__ out_scores, int tiles_per_split, uint64_t* __restrict__ part,
     uint32_t* __restrict__ thr_shared, const int4* __restrict__ items /*(block, t_begin, t_end, slot | stride << 16) or null*/,
-    uint32_t* __restrict__ extra, const unsigned char* __restrict__ vimg, uint64_t* __restrict__ dump /*or null: rescore here*/,
-    float2* __restrict__ dhdr, int dump_stride /*list slots per row in the dump*/) {
+    uint32_t* __restrict__ extra, const unsigned char* __restrict__ vimg) {
     static_assert(!IMG || REFINE, "the tile image is the scaled fp16 operand of the bound-and-refine arithmetic");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 #if TKR_ABL & 256
@@ -1404,10 +1221,6 @@ __global__ __launch_bounds__((topk_waves_bf16<KS, IdT, REFINE>() * TKR_WAVE), 2)
     if constexpr (REFINE) {
         if (__ballot(lost) != 0 && lane == 0) extra[4 + ws.block] = 1u;       // the exact kernel redoes this block
 #if !(TKR_ABL & 64)
-        if (dump) {                                               // the final stage runs in topk_finish_kernel
-            dump_rows<IdT>(sm, ws, n_rows, K, thr, m2, dump, dhdr, dump_stride);
-            return;
-        }
         // (the kernel that stages its tiles through registers has fewer to spare: 4 instead of 8 loads per half in flight, no scratch)
         write_rows_refine<IdT, KS, IMG ? kRescoreInFlight : 4>(sm, ws, n_rows, K, thr, m2, U, uidx, Vt, bias, k, out_ids, out_scores, part,
                                                                tile, 2 * TILEB);                                // the tile buffers are free now
@@ -1480,7 +1293,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const uint64_t* __restr
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
-    if (only_flagged && !only_flagged[r / users_per_block]) return;      // topk_finish_kernel wrote this block's rows
+    if (only_flagged && !only_flagged[r / users_per_block]) return;      // topk_finish2_kernel wrote this block's rows
     const uint64_t* p = part + (size_t)r * S * K;                // S slots per row; the block's first nslots are used
     if (nslots) {
         S = nslots[r / users_per_block];
@@ -1783,7 +1596,6 @@ static size_t topk_image_bytes(int n_cols, int k) {               // the fp16 ti
     return (size_t)((n_cols + 31) / 32) * 32 * KS * 32;
 }
 
-static int g_topk_finish = -1;     // the final stage of bound-and-refine in topk_finish_kernel: tkr_topk_set_finish / TKR_TOPK_FINISH=1
 
 template <int KS, typename IdT, bool REFINE>
 static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, const float* Vt, const float* bias, int n_cols,
@@ -1846,27 +1658,6 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
             return merge_planned(p, users, n_rows, K, out_ids, out_scores, stream, p.extra + 4);
         }
     }
-    // the dump of the pieces' lists for topk_finish_kernel: behind what the plan uses, when the workspace has the room
-    uint64_t* dump = nullptr;
-    float2* dhdr = nullptr;
-    const int slots = p.merge_lists > 1 ? p.merge_lists : 1;
-    if constexpr (REFINE) {
-        // OFF unless TKR_TOPK_FINISH=1 (round 5, measured; tests/test_gpu_topk.py runs both): the main kernel drops to 0.81 ms at the
-        // ML-10M shape without its final stage (1.06 with), but topk_finish_kernel takes 0.27-0.29 ms whatever its gather looks like
-        // (a lane per candidate, 16 loads in flight; four lanes per candidate on 64-byte runs) -- ~12 us of dependent latency per
-        // row (headers + entries, the row gathers, a 128-deep fma chain, a 21-stage sort) over the 12 waves per CU its 157-168
-        // registers allow; in the tile kernel the same stage hides behind the second workgroup of the CU.  ML-10M 1.13 vs 1.12 ms,
-        // Netflix shape 8.9-9.1 vs 8.45 ms: kept selectable, not the default.
-        if (g_topk_finish < 0) g_topk_finish = (getenv("TKR_TOPK_FINISH") && getenv("TKR_TOPK_FINISH")[0] == '1') ? 1 : 0;
-        if (p.extra && g_topk_finish == 1) {
-            const size_t used = ((size_t)((unsigned char*)(p.extra + 4 + n_blocks) - (unsigned char*)workspace) + 255) & ~(size_t)255;
-            const size_t need = (size_t)n_rows * slots * (kDumpCap * sizeof(uint64_t) + sizeof(float2));
-            if (used + need <= workspace_bytes) {
-                dump = reinterpret_cast<uint64_t*>(static_cast<unsigned char*>(workspace) + used);
-                dhdr = reinterpret_cast<float2*>(dump + (size_t)n_rows * slots * kDumpCap);
-            }
-        }
-    }
     if constexpr (REFINE) {
         if (!p.extra) return TKR_EAGAIN_EXACT;                    // no room for the block flags: the caller runs the fp32 kernel
         hipLaunchKernelGGL(topk_bounds_kernel, dim3(std::min(256, (n_cols + 3) / 4)), dim3(256), 0, stream, Vt, bias, n_cols, k, p.extra);
@@ -1875,27 +1666,16 @@ static int launch_topk_bf16(const float* U, const int32_t* uidx, int n_rows, con
                                n_cols, k, p.extra, vimg);
     }
     hipLaunchKernelGGL(use_img ? kern_img : kern, p.grid, dim3(W * 64), lds, stream, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K,
-                       out_ids, out_scores, p.tps, p.part, p.thr_shared, p.items, p.extra, (const unsigned char*)vimg, dump, dhdr, slots);
+                       out_ids, out_scores, p.tps, p.part, p.thr_shared, p.items, p.extra, (const unsigned char*)vimg);
     rc = (int)hipGetLastError();
     if (rc != TKR_OK) return rc;
     if constexpr (REFINE) {
-        if (dump) {
-            const dim3 fg((n_rows + 3) / 4);
-            if (k == 16 * KS)
-                hipLaunchKernelGGL(topk_finish_kernel<KS>, fg, dim3(256), 0, stream, dump, dhdr, n_rows, slots, p.merge_lists > 1 ? p.nslots : nullptr,
-                                   users, p.extra + 4, U, uidx, Vt, bias, k, K, out_ids, out_scores);
-            else
-                hipLaunchKernelGGL(topk_finish_kernel<0>, fg, dim3(256), 0, stream, dump, dhdr, n_rows, slots, p.merge_lists > 1 ? p.nslots : nullptr,
-                                   users, p.extra + 4, U, uidx, Vt, bias, k, K, out_ids, out_scores);
-            rc = (int)hipGetLastError();
-            if (rc != TKR_OK) return rc;
-        }
         // blocks with an overflowed list: the fp32 kernel, same work items
         rc = launch_fp32_planned<IdT, topk_waves_bf16<KS, IdT, true>()>(p, U, uidx, n_rows, Vt, bias, n_cols, k, mask, pitch, K, out_ids, out_scores,
                                                                         p.extra + 4, stream);
         if (rc != TKR_OK) return rc;
     }
-    return merge_planned(p, users, n_rows, K, out_ids, out_scores, stream, (REFINE && dump) ? p.extra + 4 : nullptr);
+    return merge_planned(p, users, n_rows, K, out_ids, out_scores, stream);
 }
 
 template <int SLABS, typename IdT>
@@ -1993,6 +1773,7 @@ static int dispatch_topk(const float* U, const int32_t* uidx, int n_rows, const 
         TKR_TOPK_REFINE_CASE(8)
 #undef TKR_TOPK_REFINE_CASE
     }
+#ifdef TKR_LAB                                                   // bf16x3 (six exact partial products): measured slower than bound-and-refine; `make LAB=1`
     if (k <= 128 && topk_math() == 0) {
 #define TKR_TOPK_BF16_CASE(KS)                                                                                          \
     if (k <= 16 * KS)                                                                                                   \
@@ -2004,6 +1785,7 @@ static int dispatch_topk(const float* U, const int32_t* uidx, int n_rows, const 
         TKR_TOPK_BF16_CASE(8)
 #undef TKR_TOPK_BF16_CASE
     }
+#endif
     const int kh = (k + 1) / 2;
 #define TKR_TOPK_CASE(KHP)                                                                                   \
     if (kh <= KHP)                                                                                           \
@@ -2046,14 +1828,11 @@ extern "C" int tkr_k4_prof_read(unsigned long long* out8) {      // timing build
 }
 #endif
 
-extern "C" int tkr_topk_set_finish(int32_t on) {
-    if (on != 0 && on != 1) return TKR_EINVAL;
-    tkr::g_topk_finish = on;
-    return TKR_OK;
-}
-
 extern "C" int tkr_topk_set_math(int32_t mode) {
     if (mode < 0 || mode > 2) return TKR_EINVAL;
+#ifndef TKR_LAB
+    if (mode == 0) return TKR_EUNSUPPORTED;                      // bf16x3 lives in the lab library (make LAB=1)
+#endif
     tkr::g_topk_math = mode;
     return TKR_OK;
 }
@@ -2069,9 +1848,7 @@ extern "C" int64_t tkr_topk_workspace_bytes(int32_t n_rows, int32_t K) {
     const int64_t pieces = (1024 + blocks - 1) / blocks + 1;     // 256 x (spans per CU <= 4)
     const int64_t lists = splits > pieces ? splits : pieces;
     const int64_t refine_words = 4 + ((int64_t)n_rows + 127) / 128;      // bounds + one flag per user block (>= 128 users each)
-    // + the pieces' list dumps for topk_finish_kernel (bound-and-refine): kDumpCap entries + a header per (row, piece)
-    const int64_t dump = lists * n_rows * (tkr::kDumpCap * (int64_t)sizeof(uint64_t) + 8) + 512;
-    return lists * n_rows * K * (int64_t)sizeof(uint64_t) + (int64_t)n_rows * (int64_t)sizeof(uint32_t) + refine_words * 4 + dump;
+    return lists * n_rows * K * (int64_t)sizeof(uint64_t) + (int64_t)n_rows * (int64_t)sizeof(uint32_t) + refine_words * 4 + 512;
 }
 
 extern "C" int64_t tkr_topk_workspace_bytes_for(int32_t n_rows, int32_t n_cols, int32_t k, int32_t K) {

@@ -48,7 +48,7 @@
 extern "C" int tkr_plan_team(int32_t batch_size);
 extern "C" int tkr_plan_max_blocks(int32_t batch_size);
 extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d);
-extern "C" int64_t tkr_vbpr_workspace_core_floats(int32_t batch_size, int32_t kh, int32_t d);
+extern "C" __attribute__((visibility("hidden"))) int64_t tkr_vbpr_workspace_core_floats(int32_t batch_size, int32_t kh, int32_t d);
 
 namespace tkr {
 
@@ -616,6 +616,7 @@ static void launch_update(const tkr_vbpr_state& st, const int32_t* rec, const in
     if (cpb <= 0 || cpb > G) cpb = G;
     const int n_row_blocks = vbpr_grid(B, 4);
     const int n_col_blocks = (st.d + cpb - 1) / cpb;
+#ifdef TKR_LAB                                                   // the two placements of the pair sums that lost to a launch of their own: make LAB=1
     if (ab_fused) {
         const dim3 grid((B + 3) / 4 + n_row_blocks + n_col_blocks);
         if (long_runs)
@@ -627,7 +628,9 @@ static void launch_update(const tkr_vbpr_state& st, const int32_t* rec, const in
     } else if (ab_inline)
         hipLaunchKernelGGL((vbpr_update_kernel<NE, LPC, true>), dim3(n_row_blocks + n_col_blocks + (loss ? (B + 3) / 4 : 0)), dim3(256), 0, stream, st, rec,
                            occ2, occt, hdr4, ab_inline, nullptr, P, Wm, colh, cent, n_row_blocks, n_col_blocks, cpb, loss, B, tune);
-    else if (long_runs)           // a narrow dense feat: every column's run is split over the block's groups, 16 entries in flight (168 registers; 32: slower, 21.5 vs 19.7 us)
+    else
+#endif
+    if (long_runs)           // a narrow dense feat: every column's run is split over the block's groups, 16 entries in flight (168 registers; 32: slower, 21.5 vs 19.7 us)
         hipLaunchKernelGGL((vbpr_update_kernel<NE, LPC, false, 16>), dim3(n_row_blocks + n_col_blocks), dim3(256), 0, stream, st, rec, occ2, occt, hdr4,
                            s_buf, t_buf, P, Wm, colh, cent, n_row_blocks, n_col_blocks, cpb, loss, B, tune);
     else
@@ -665,13 +668,21 @@ static int vbpr_pairs_mode() {
     if (g_vbpr_pairs < 0) {
         const char* e = getenv("TKR_VBPR_PAIRS");
         const int v = e ? atoi(e) : kVbprPairsDefault;
+#ifdef TKR_LAB
         g_vbpr_pairs = (v >= 0 && v <= 2) ? v : kVbprPairsDefault;
+#else
+        (void)v;
+        g_vbpr_pairs = kVbprPairsDefault;
+#endif
     }
     return g_vbpr_pairs;
 }
 }  // namespace tkr
 extern "C" int tkr_vbpr_set_pairs(int32_t mode) {
     if (mode < 0 || mode > 2) return TKR_EINVAL;
+#ifndef TKR_LAB
+    if (mode != 0) return TKR_EUNSUPPORTED;                      // placements 1 and 2 live in the lab library (make LAB=1)
+#endif
     tkr::g_vbpr_pairs = mode;
     return TKR_OK;
 }

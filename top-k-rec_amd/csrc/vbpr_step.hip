@@ -47,7 +47,7 @@
 extern "C" int tkr_plan_team(int32_t batch_size);
 extern "C" int tkr_plan_max_blocks(int32_t batch_size);
 extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d);
-extern "C" int64_t tkr_vbpr_workspace_core_floats(int32_t batch_size, int32_t kh, int32_t d);
+extern "C" __attribute__((visibility("hidden"))) int64_t tkr_vbpr_workspace_core_floats(int32_t batch_size, int32_t kh, int32_t d);
 
 namespace tkr {
 
@@ -699,7 +699,7 @@ static int launch_vbpr(const tkr_vbpr_state& st, const int32_t* ti, const int32_
 extern "C" int tkr_plan_max_blocks(int32_t batch_size);
 
 // the step's own scratch ...
-extern "C" int64_t tkr_vbpr_workspace_core_floats(int32_t batch_size, int32_t kh, int32_t d) {
+extern "C" __attribute__((visibility("hidden"))) int64_t tkr_vbpr_workspace_core_floats(int32_t batch_size, int32_t kh, int32_t d) {
     const int64_t S = tkr::vbpr_slices(d);
     const int64_t slots = (int64_t)tkr_plan_max_blocks(batch_size) * tkr_plan_team(batch_size);     // sparse view: A, a per item task
     return S * batch_size * (kh + 1) + 2ll * batch_size + 2ll * batch_size * kh + slots * (kh + 1) + 5ll * batch_size;

@@ -52,6 +52,8 @@ class Tuning:
     epoch_ahead: bool = True         # TKR_EPOCH_AHEAD: plan the first chunk after an exchange ahead of it
     call_ahead: bool = False         # TKR_CALL_AHEAD: plain layout (batch > 512): plan the NEXT call's first chunk behind the last steps of this one
                                      #   (epoch-sized calls at batch 8192: 25.5 -> 24.7 us per batch; a call nobody follows up pays for the plan: 24.1 -> 24.7)
+    restart: bool = True             # TKR_RESTART: BPR.train keeps a copy of the state it starts from (371 MB at the ML-10M shape, 2.2 GB at the
+                                     #   Netflix shape) so that a persistent step that gives up restarts one kernel down; 0: no copy, such a run raises
     vbpr_cols: bool = True           # TKR_VBPR_COLS: the column-plan form of the VBPR step
     vbpr_overlap: bool = True        # TKR_VBPR_OVERLAP: its column plan on the side stream
 
@@ -64,7 +66,7 @@ class Tuning:
             'flow': _flag, 'flow_max_batch': _int_in(0, 1 << 20), 'flow_waves_per_cu': _int_in(0, 32),
             'flow_item_bufs': lambda n, r: int(_choice('2', '4')(n, r)), 'own': _choice('0', '1', '2'),
             'own_max_batch': _int_in(0, 1024), 'own_waves': _int_in(0, 0xffff), 'fuse_short': _flag, 'fuse_plan': _flag,
-            'overlap_min_batch': _int_in(1, 1 << 30), 'epoch_ahead': _flag, 'call_ahead': _flag, 'vbpr_cols': _flag, 'vbpr_overlap': _flag,
+            'overlap_min_batch': _int_in(1, 1 << 30), 'epoch_ahead': _flag, 'call_ahead': _flag, 'restart': _flag, 'vbpr_cols': _flag, 'vbpr_overlap': _flag,
         }
         out = cls()
         for f in fields(cls):

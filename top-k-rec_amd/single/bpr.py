@@ -253,7 +253,8 @@ class BPR(REC):
         # gives up after a bounded spin and leaves half-updated tables; the engine then steps down one kernel (K2o -> K2f -> K2).
         # The run starts again from the state kept here, on the same counter-based sample stream: it degrades instead of raising.
         for attempt in range(3):
-            start = self._eng.snapshot() if getattr(self._eng, 'layout', None) == 'flow' else None      # (VBPR steps one launch at a time: nothing to give up)
+            # (VBPR steps one launch at a time: nothing to give up; TKR_RESTART=0: no copy of the tables, a step that gives up raises)
+            start = self._eng.snapshot() if (getattr(self._eng, 'layout', None) == 'flow' and self._eng.cfg.restart) else None
             if self._train_epochs(epochs, n_batches, batch_size, world, verbose):
                 break
             if start is None or attempt == 2:

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TKR_HIP_LIB') or os.path.join(_HERE, 'libtkr_hip.so')      # the override is for A/B builds of the kernels (scripts/)
 
 _lib = None
-VERSION = 117          # TKR_VERSION of include/tkr.h this binding was written against
+VERSION = 118          # TKR_VERSION of include/tkr.h this binding was written against
 
 
 class TkrError(RuntimeError):
@@ -82,7 +82,7 @@ EXPORTS = ('tkr_version', 'tkr_plan_team', 'tkr_plan_max_blocks', 'tkr_sample_pl
            'tkr_vbpr_run', 'tkr_vbpr_colplan', 'tkr_vbpr_run_cols', 'tkr_build_rated_mask', 'tkr_score_topk', 'tkr_count_hits', 'tkr_calib_rowcopy',
            'tkr_idmap_create', 'tkr_idmap_destroy', 'tkr_ratings_parse', 'tkr_ratings_sizes', 'tkr_ratings_copy',
            'tkr_ratings_destroy', 'tkr_matrix_read', 'tkr_matrix_sizes', 'tkr_matrix_copy', 'tkr_matrix_destroy',
-           'tkr_matrix_write', 'tkr_raw_ranks', 'tkr_count_hits_rr', 'tkr_topk_set_math', 'tkr_topk_set_finish', 'tkr_vbpr_set_pairs',
+           'tkr_matrix_write', 'tkr_raw_ranks', 'tkr_count_hits_rr', 'tkr_topk_set_math', 'tkr_vbpr_set_pairs', 'tkr_lab_build',
            'tkr_sync_snapshot', 'tkr_sync_pack', 'tkr_sync_unpack', 'tkr_sync_flow_snapshot', 'tkr_sync_flow_pack',
            'tkr_sync_flow_unpack')
 EXPORTS_I64 = ('tkr_vbpr_workspace_floats', 'tkr_vbpr_colplan_lds_bytes', 'tkr_topk_workspace_bytes_for', 'tkr_topk_workspace_bytes', 'tkr_plan_workspace_bytes')
@@ -462,9 +462,10 @@ def set_topk_math(mode):
     _check(lib().tkr_topk_set_math(C.c_int32({'bf16x3': 0, 'fp32': 1, 'refine': 2}[mode])), 'tkr_topk_set_math')
 
 
-def set_topk_finish(on):
-    """bound-and-refine: the final stage (exact rescoring + sort) in a kernel of its own, once per row -- see include/tkr.h"""
-    _check(lib().tkr_topk_set_finish(C.c_int32(1 if on else 0)), 'tkr_topk_set_finish')
+def lab():
+    """True when the loaded library was built with `make LAB=1` (csrc/Makefile): it then also holds the kernel forms that were measured
+    and dropped (K2o scalar exchange / scout / 16 waves / loader ring, K4 bf16x3, the VBPR pair-sum placements 1 and 2)"""
+    return bool(lib().tkr_lab_build())
 
 
 def score_topk(U, Vt, K, bias=None, user_idx=None, mask=None, mask_pitch=0, want_scores=False, split=True):
