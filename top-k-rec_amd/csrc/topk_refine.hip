@@ -479,7 +479,11 @@ __global__ __launch_bounds__(256, 3) void score_topk_refine2_kernel(const Refine
     }
     int cnt = (int)((wp - seg0) >> 9);
     if (__ballot(lost) != 0 && lane == 0) a.extra[4 + block] = 1u;          // the exact kernel redoes this block
-    if (__ballot(cnt + (int)xor32((uint32_t)cnt, lane) > kSeg) != 0) thr = trim_all2(ent, uw, h, a.K, thr, m2, cnt);
+    if (__ballot(cnt + (int)xor32((uint32_t)cnt, lane) > kSeg) != 0) {
+        thr = trim_all2(ent, uw, h, a.K, thr, m2, cnt);
+        // what this piece knows at its end, for the pieces of the block that start later (the lead pieces: csrc/topk.hip item_table)
+        thr = share_bound(a.thr_shared, row, user_ok && h == 0, thr, margin, bscale, __uint_as_float((254u - ((__float_as_uint(bscale) >> 23) & 0xffu)) << 23));
+    }
     __builtin_amdgcn_wave_barrier();
     // ---- dump: piece-major, a user's 64 slots as one 256-byte line; the header says how much of each segment is used
     const size_t piece = a.pbase ? (size_t)a.pbase[block] + slot : (size_t)block * stride + slot;
