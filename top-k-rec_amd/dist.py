@@ -32,9 +32,15 @@ def ranks_sharing_device(device) -> int:
     ident = 'cpu'
     if device is not None and getattr(device, 'type', 'cpu') == 'cuda':
         prop = torch.cuda.get_device_properties(device)
-        ident = str(getattr(prop, 'uuid', '')) or ''
+        import os
+        ident = os.environ.get('TKR_DEVICE_IDENTITY', '') or str(getattr(prop, 'uuid', '')) or ''
         if not ident or set(ident) <= set('0-'):          # no uuid reported: the PCI address is as good
-            ident = '%s:%s:%s' % (getattr(prop, 'pci_domain_id', 0), getattr(prop, 'pci_bus_id', device.index), getattr(prop, 'pci_device_id', 0))
+            if hasattr(prop, 'pci_bus_id'):
+                ident = '%s:%s:%s' % (getattr(prop, 'pci_domain_id', 0), prop.pci_bus_id, getattr(prop, 'pci_device_id', 0))
+            else:
+                # neither a uuid nor a PCI address: every rank behind HIP_VISIBLE_DEVICES would report index 0 and all ranks
+                # of a host would count as sharing one GPU.  An unknown identity is NOT shared: rank-unique (TKR_DEVICE_IDENTITY overrides)
+                ident = 'unknown-rank-%d' % rank
     mine = (socket.gethostname(), ident)
     everyone = [None] * w
     dist.all_gather_object(everyone, mine)

@@ -657,8 +657,9 @@ class BprEngine(PlanMixin):
             cache[share] = tkr_hip.bpr_own_owners(self.n_items, self.k, self.device, share)
             if cache[share] == 0 and share > 1:
                 import warnings
+                cus = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == 'cuda' else 0
                 warnings.warn('K2o is off: %d ranks share this GPU and %d item rows of width %d do not fit %d owners\' LDS; the persistent '
-                              'step without owned rows (K2f) runs instead' % (share, self.n_items, self.k, cache[share]))
+                              'step without owned rows (K2f) runs instead' % (share, self.n_items, self.k, cus // share))
         return cache[share]
 
     def wants_flow(self, B):
@@ -732,6 +733,18 @@ class BprEngine(PlanMixin):
         self._step_key = None
         raise tkr_hip.StepGaveUp('persistent BPR step gave up waiting for a row version (status %d): tables are invalid; this engine uses %s '
                                'from now on; post-mortem words (csrc/bpr_flow.hip kCtlDebug) %r' % (code, nxt, post))
+
+    def step_down(self):
+        """what _failed() does to the choice of kernel, without a failure of this engine's own: a sharded run restarts every rank
+        together when ANY rank's persistent step gave up, and the ranks that did not fail themselves step down with it -- otherwise
+        they retry the same kernel while the failed rank is one form further, every rank burns an attempt per try, and ranks on
+        different layouts would meet in one all-reduce"""
+        if getattr(self, '_last_step_kind', None) == 'own':
+            self._own_failed = True
+        else:
+            self._flow_disabled = True
+        self._step_key = None
+        self._again_key = None
 
     def _raise_pending(self):
         ev, self._status_event = self._status_event, None
@@ -909,6 +922,8 @@ class BprEngine(PlanMixin):
             return False
         if n_batches > self._cap(B):                  # more than one chunk: K1 of the second belongs on the side stream
             return False
+        if n_batches <= 0 or (want_loss and not getattr(self._step, 'assigns_loss', False)):
+            return False                              # nothing to run / a step form that ADDS to the loss words: _run zeroes them
         idx = self._again_buf ^ 1                     # the other plan buffer, as _next_chunk alternates them
         call = self._fused_calls.get(idx)
         if call is None or call[1] is not csr or call[2] is not pipe.bufs[idx]:       # planned for other data / a replaced buffer

@@ -273,7 +273,7 @@ class BPR(REC):
                 sync.begin()
             # sharded: the exchange follows this call, then an epoch of n_batches more -- its first chunk is planned behind this
             # epoch's last steps (PlanMixin), and the host looks at the loss only after the exchange is queued
-            gave_up = False
+            gave_up = mine = False
             try:
                 loss = self._run_epoch(n_batches, batch_size, n_batches if (sync is not None and eid + 1 < epochs) else 0, defer=sync is not None)
                 if sync is not None:
@@ -281,10 +281,12 @@ class BPR(REC):
                     loss = self._epoch_loss(loss)
             except tkr_hip.StepGaveUp as e:
                 warnings.warn('BPR.train restarts from its initial state: %s' % e)
-                gave_up = True
+                gave_up = mine = True
             if sync is not None:
                 gave_up = sync.any_gave_up(gave_up)          # the flag rode in the exchange: every rank agrees, no extra collective
             if gave_up:
+                if not mine and hasattr(self._eng, 'step_down'):
+                    self._eng.step_down()                    # in lockstep with the rank whose step gave up
                 return False
             torch.cuda.synchronize(self._eng.device)
             spent = time.time() - t0
