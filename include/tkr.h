@@ -287,13 +287,14 @@ int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int32_t d);
  * bit for bit (1: within fp32 rounding of the others).  Initial value from TKR_VBPR_PAIRS. */
 int tkr_vbpr_set_pairs(int32_t mode);
 /* n_batches consecutive batches planned by tkr_sample_plan (tri_i / tri_j = its out_i / out_j);
- * kh <= 128, batch_size <= 65536 (batches above 8192 are planned grid-wide, see tkr_sample_plan); loss_out as in tkr_bpr_run */
+ * kh <= 128 (any kh: tkr_vbpr_run_cols), batch_size <= 65536 (batches above 8192 are planned grid-wide, see tkr_sample_plan); loss_out as in tkr_bpr_run */
 int tkr_vbpr_run(const tkr_vbpr_state* st, const int32_t* tri_i, const int32_t* tri_j, const int32_t* rec,
                  const int32_t* occ, const int32_t* hdr, const int32_t* occt, const int32_t* tri_u /*nullable*/,
                  const int32_t* tpar /*nullable*/, int32_t batch_size,
                  int32_t n_batches, float* workspace, float* loss_out, void* stream);
 
-/* Column-plan form of the same step (batch_size <= 1024, kh % 4 == 0, CSR view of feat): three launches per batch
+/* Column-plan form of the same step (batch_size <= 1024, CSR view of feat; kh % 4 == 0 and kh <= 128: rows and cem rows in registers,
+ * any other kh: the generic kernels of csrc/vbpr_wide.hip on the same plan): three launches per batch
  * (project + score / pair sums / row tasks and column tasks side by side) instead of four to six, csrc/vbpr_cols.hip.
  * Which (triplet, feature column) pairs a batch touches depends on the sampled triplets and on the structure of feat only,
  * so it is prepared beside K1, off the step's critical path:

@@ -21,14 +21,19 @@ def _toy(n_users, n_items, seed):
 
 @pytest.mark.parametrize('k,d,B,nb,mode,dense', [(16, 40, 64, 6, 'l2', True), (128, 700, 256, 4, 'l2', False),
                                                  (50, 333, 128, 3, 'l1', False), (128, 1030, 1024, 2, 'l2', False),
-                                                 (200, 130, 96, 3, 'l2', True)])
+                                                 (200, 130, 96, 3, 'l2', True),
+                                                 # k // 2 > 128: the generic form of the column-plan step (csrc/vbpr_wide.hip), any width
+                                                 (600, 333, 128, 3, 'l2', False), (1000, 60, 64, 3, 'l1', True), (270, 200, 256, 2, 'l2', False)])
 @pytest.mark.parametrize('view', ['dense', 'sparse'])
 def test_vbpr_step_parity(k, d, B, nb, mode, dense, view):
-    """both implementations of the feature contraction: the dense MFMA kernels (V1/V3) and the CSR/CSC view (S1/S3)"""
+    """both implementations of the feature contraction: the dense MFMA kernels (V1/V3) and the CSR/CSC view (S1/S3); k // 2 > 128: the
+    generic form (gather view only), announced by one warning"""
     import tkr_hip
     from single import _engine
     n_users, n_items = 300, 90
     kh = k // 2
+    if kh > 128 and view == 'dense':
+        pytest.skip('the generic form gathers: CSR view')
     tr, tr_users = _toy(n_users, n_items, seed=k + d)
     rng = np.random.Generator(np.random.PCG64(d))
     feat = np.abs(rng.standard_normal((n_items, d))).astype(np.float32)
@@ -50,7 +55,11 @@ def test_vbpr_step_parity(k, d, B, nb, mode, dense, view):
         ref['ms_' + n] = np.ones_like(ref[n])
     row_ptr, pos, srt = P.build_csr(tr, n_users)
     csr = _engine.TrainingCSR.from_arrays(row_ptr, pos, np.asarray(tr_users, np.int32), dev)
-    loss = eng.run_batches(csr, nb, B).cpu().numpy()
+    import warnings
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter('always')
+        loss = eng.run_batches(csr, nb, B).cpu().numpy()
+    assert any('generic form' in str(w.message) for w in seen) == (kh > 128)
     torch.cuda.synchronize()
     u, i, j = P.sample_triplets(tr_users, row_ptr, pos, srt, n_items, 5, 0, nb * B)
     np.testing.assert_array_equal(eng.plan.u.cpu().numpy()[: nb * B], u)

@@ -51,6 +51,14 @@ extern "C" int64_t tkr_vbpr_workspace_floats(int32_t batch_size, int32_t kh, int
 extern "C" __attribute__((visibility("hidden"))) int64_t tkr_vbpr_workspace_core_floats(int32_t batch_size, int32_t kh, int32_t d);
 
 namespace tkr {
+// the generic form for any kh (csrc/vbpr_wide.hip)
+__attribute__((visibility("hidden"))) void vbpr_wide_project(const tkr_vbpr_state& st, const int32_t* ti, const int32_t* tj, const int32_t* tu, const int32_t* tp,
+                                                             const int32_t* tc, const int2* te, int tcap, int B, float* P, float* ab2, float* Wm,
+                                                             float* loss, hipStream_t s);
+__attribute__((visibility("hidden"))) int vbpr_wide_col_blocks(int d);
+__attribute__((visibility("hidden"))) void vbpr_wide_update(const tkr_vbpr_state& st, const int32_t* rec, const int2* occ2, const int32_t* occt, const int4* hdr4,
+                                                            const float* s_buf, const float* t_buf, const float* P, const float* Wm, const int4* colh,
+                                                            const int2* cent, int B, float* loss, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // K1-side: one workgroup per batch, wave w OWNS the columns [w*RW, (w+1)*RW) and their counters in LDS.  Every wave reads every
@@ -734,7 +742,8 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
     if (!tri_i || !tri_j || !rec || !occ || !hdr || !occt || !tri_u || !tpar || !colh || !cent || !tcnt || !tent || !workspace ||
         batch_size <= 0 || n_batches < 0 || row_cap <= 0)
         return TKR_EINVAL;
-    if (st->kh > 128 || (st->kh & 3) || batch_size > 1024) return TKR_EUNSUPPORTED;
+    if (batch_size > 1024) return TKR_EUNSUPPORTED;
+    const bool wide = st->kh > 128 || (st->kh & 3);               // the generic form (csrc/vbpr_wide.hip): any kh
     const int B = batch_size, kh = st->kh, tcap = 2 * row_cap;
     const size_t stride_r = (size_t)tkr_plan_max_blocks(B) * tkr_plan_team(B) * 16;
     const size_t stride_o = (size_t)3 * B;
@@ -756,7 +765,7 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
     // the loss words of the call's batches: behind the step's own scratch, every word written by its task (nothing to zero)
     const int lpc_ = kh <= 16 ? 4 : (kh <= 32 ? 8 : (kh <= 64 ? 16 : 32));
     const int cpb_ = (cols_per_block <= 0 || cols_per_block > 256 / lpc_) ? 256 / lpc_ : cols_per_block;
-    const int n_col_blocks = (st->d + cpb_ - 1) / cpb_;
+    const int n_col_blocks = wide ? tkr::vbpr_wide_col_blocks(st->d) : (st->d + cpb_ - 1) / cpb_;
     const size_t loss_stride = (size_t)2 * B + n_col_blocks;
     float* slots = loss_out ? workspace + tkr_vbpr_workspace_core_floats(B, kh, st->d) : nullptr;
     if (slots && (n_batches > 512 || (int64_t)n_batches * (int64_t)loss_stride > tkr_vbpr_workspace_floats(B, kh, st->d) - tkr_vbpr_workspace_core_floats(B, kh, st->d)))
@@ -767,7 +776,7 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
     // 100-250 reciprocals per lane in front of its stores.  Parity-green, not the default.
     // TKR_VBPR_PAIRS=2: the pair sums by the first blocks of the update launch (vbpr_update_kernel FUSED) -- two launches per batch
     // and nothing recomputed; 0: the three-launch form.
-    const int pairs_mode = tkr::vbpr_pairs_mode();
+    const int pairs_mode = wide ? 0 : tkr::vbpr_pairs_mode();
     const bool inline_pairs = pairs_mode == 1 && B <= 256;
     const bool fused_pairs = pairs_mode == 2;
     uint32_t* pair_done = reinterpret_cast<uint32_t*>(workspace + tkr_vbpr_workspace_floats(B, kh, st->d) - 64);     // the call's counter: last 64 words
@@ -787,6 +796,13 @@ extern "C" int tkr_vbpr_run_cols(const tkr_vbpr_state* st, const int32_t* tri_i,
         const int32_t* tc = tcnt + (size_t)b * B;
         const int2* te = reinterpret_cast<const int2*>(tent) + (size_t)b * B * tcap;
         float* l = slots ? slots + (size_t)b * loss_stride : nullptr;
+        if (wide) {
+            tkr::vbpr_wide_project(*st, ti, tj, tu, tp, tc, te, tcap, B, P, ab2, Wm, l, s);
+            hipLaunchKernelGGL(tkr::vbpr_pairsum_kernel, dim3((B + 3) / 4), dim3(256), 0, s, ab2, B, s_buf, t_buf, l);
+            tkr::vbpr_wide_update(*st, r, o2, ot, h4, s_buf, t_buf, P, Wm, ch, ce, B, l, s);
+            TKR_LAUNCH_CHECK();
+            continue;
+        }
         if (tune & 64) {
         } else if (NH == 1 && pw == 4) hipLaunchKernelGGL((tkr::vbpr_tproject_kernel<1, 4>), dim3(B), dim3(256), 0, s, *st, ti, tj, tu, tp, tc, te, tcap, B, P, ab2, Wm, l, tune);
         else if (NH == 1 && pw == 8) hipLaunchKernelGGL((tkr::vbpr_tproject_kernel<1, 8>), dim3(B), dim3(512), 0, s, *st, ti, tj, tu, tp, tc, te, tcap, B, P, ab2, Wm, l, tune);

@@ -984,7 +984,8 @@ class VbprEngine(PlanMixin):
         nnz = int(torch.count_nonzero(self.feat))
         # the gather view: sparse features (tf-idf-like, ~0.5 % dense at d = 20,000), and narrow dense ones (BASELINE.json's literal
         # "d = 128"): the fp32-MFMA kernels tile d by 128 / 64 columns and run on 1-2 workgroups there
-        if sparse or (sparse is None and (nnz <= self.SPARSE_DENSITY * n_items * d or d <= self.NARROW_D)):
+        # (k // 2 > 128: only the column-plan step has a generic form, and it gathers: the CSR view whatever the density)
+        if sparse or (sparse is None and (nnz <= self.SPARSE_DENSITY * n_items * d or d <= self.NARROW_D or self.kh > 128)):
             self.sparse = self._sparse_view(self.feat)
             per_row = (self.sparse['f_ptr'][1:] - self.sparse['f_ptr'][:-1])
             self.max_row_nnz, self.avg_row_nnz = int(per_row.max()), float(per_row.float().mean())
@@ -1010,7 +1011,8 @@ class VbprEngine(PlanMixin):
     def wants_cols(self, B):
         if self.sparse is None or not self.cfg.vbpr_cols:
             return False
-        return (self.kh % 4 == 0 and self.kh <= 128 and B <= self.COLS_MAX_BATCH and 0 < self.max_row_nnz <= 1024 and
+        # (kh % 4 == 0 and kh <= 128: the register form; kh > 128: the generic form of csrc/vbpr_wide.hip on the same plan)
+        return (((self.kh % 4 == 0 and self.kh <= 128) or self.kh > 128) and B <= self.COLS_MAX_BATCH and 0 < self.max_row_nnz <= 1024 and
                 tkr_hip.vbpr_colplan_lds_bytes(B, self.d) <= 160 * 1024)
 
     def _plan_cols(self, B):
@@ -1095,8 +1097,14 @@ class VbprEngine(PlanMixin):
     copy_model_from = BprEngine.copy_model_from
 
     def run_batches(self, csr: TrainingCSR, n_batches: int, B: int, want_loss=True, then_exchange=0):
-        if self.kh > 128 or B > 65536:
-            raise ValueError('VBPR on the HIP path: k // 2 <= 128 and batch_size <= 65536 (got k = %d, batch_size = %d)' % (self.k, B))
+        if B > 65536 or (self.kh > 128 and not self.wants_cols(B)):
+            raise ValueError('VBPR on the HIP path: batch_size <= 65536, and k // 2 > 128 only through the column-plan step (batch_size <= %d, '
+                             'feature rows of at most 1024 nonzeros; got k = %d, batch_size = %d)' % (self.COLS_MAX_BATCH, self.k, B))
+        if self.kh > 128 and not getattr(self, '_warned_wide', False):
+            self._warned_wide = True
+            import warnings
+            warnings.warn('VBPR: k // 2 = %d is wider than the step\'s kernels hold a row in registers (128): the generic form steps '
+                          '(csrc/vbpr_wide.hip: every kernel walks the factors in strides of its threads)' % self.kh)
         if getattr(self, '_step_key', None) != B:           # the C struct and the closure are built once per batch size, not per call
             self._step_key, self._step = B, self.step_fn(B)
         return self._run(csr, n_batches, B, want_loss, self._step)
