@@ -77,7 +77,7 @@ int tkr_lab_build(void);
  *                            instead of one workgroup per batch -- single/bpr.py:103-113 accepts any batch_size
  * n_batches <= 512, ids < 2^30, batch_size <= 2^20 (the dataflow form: batch_size <= 8192).  Output is bit-exact against
  * oracle/plan_np.py for every batch size. */
-int tkr_plan_team(int32_t batch_size);        /* waves per step workgroup / heavy-row team: 4 (B <= 1024) or 16 */
+int tkr_plan_team(int32_t batch_size);        /* waves per step workgroup / heavy-row team: 4 (B <= 1024), 8 (<= 16384) or 16 */
 int tkr_plan_max_blocks(int32_t batch_size);  /* workgroups a batch can need */
 int tkr_sample_plan(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,
                     const int32_t* cols_sorted, int32_t n_users, int32_t n_items, uint64_t seed,

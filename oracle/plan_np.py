@@ -36,7 +36,7 @@ Plan definition (per batch of B triplets, consumed by the step kernels):
 Launch plan (what the step kernel actually reads; derived from the above):
   a task with <= light_max(B) occurrences (4 for B <= 4096, else 16) is LIGHT (one wave), otherwise HEAVY (a team of TEAM
   waves = one workgroup, wave w takes occurrences w, w+TEAM, ...; TEAM = team_for(B): 4 up to
-  B = 1024, 16 above).  Workgroups hold TEAM wave
+  B = 1024, 8 up to 16,384, 16 above).  Workgroups hold TEAM wave
   records; light tasks fill workgroups 0..nlb-1 in task order, heavy task h is workgroup nlb+h.
   wave record = 16 int32: [0] row|kind<<31 (-1 = idle)  [1] parity | team<<8 | rank<<16
                           [2] occurrences of this wave   [3] index of its first occurrence
@@ -55,7 +55,9 @@ U64 = np.uint64
 MAX_ROUNDS = 64
 LIGHT_MAX = 4          # occurrences a single wave handles for B <= 4096 (csrc/sampler.hip)
 LIGHT_MAX_BIG = 16     # ... and for larger batches (fewer, fuller 16-wave teams: dispatching them dominates)
-TEAM = 16              # waves per workgroup / per heavy task for batches > TEAM_SMALL_MAX_B
+TEAM = 16              # waves per workgroup / per heavy task for batches > TEAM_MID_MAX_B
+TEAM_MID = 8           # ... for TEAM_SMALL_MAX_B < batch <= TEAM_MID_MAX_B (three 8-wave workgroups share a CU where one of 16 waves sits alone)
+TEAM_MID_MAX_B = 16384
 TEAM_SMALL = 4         # ... and for small batches: 4-wave workgroups spread a 256-batch over ~180 CUs
 TEAM_SMALL_MAX_B = 1024
 
@@ -74,7 +76,7 @@ def light_max(B):
 
 def team_for(B):
     """tkr_plan_team: waves per workgroup (= per heavy-row team) of the step kernels"""
-    return TEAM_SMALL if B <= TEAM_SMALL_MAX_B else TEAM
+    return TEAM_SMALL if B <= TEAM_SMALL_MAX_B else TEAM_MID if B <= TEAM_MID_MAX_B else TEAM
 PAR_BIT = 1 << 30
 
 _M0, _M1 = U64(0xD2511F53), U64(0xCD9E8D57)

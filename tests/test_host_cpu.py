@@ -141,8 +141,8 @@ def test_library_exports_every_declared_symbol():
     extra = {'tkr_k4_prof_read', 'tkr_debug_own_k1_prof'}        # profiling builds only (-DTKR_R2_PROF / -DTKR_PLAN_STAMP)
     assert dynamic - extra <= declared, (dynamic - extra) - declared
     assert lib.tkr_version() == tkr_hip.VERSION and lib.tkr_lab_build() in (0, 1)
-    assert lib.tkr_plan_team(256) == 4 and lib.tkr_plan_team(8192) == 16
-    assert lib.tkr_plan_max_blocks(256) == 192 + 153 and lib.tkr_plan_max_blocks(2048) == 384 + 1228 and lib.tkr_plan_max_blocks(8192) == 1536 + 1445
+    assert lib.tkr_plan_team(256) == 4 and lib.tkr_plan_team(8192) == 8 and lib.tkr_plan_team(65536) == 16
+    assert lib.tkr_plan_max_blocks(256) == 192 + 153 and lib.tkr_plan_max_blocks(2048) == 768 + 1228 and lib.tkr_plan_max_blocks(8192) == 3072 + 1445
     # argument validation happens before any device access
     assert lib.tkr_score_topk(None, None, 0, None, None, 0, 0, None, 0, 0, None, None, None, 0, None) == -1
 

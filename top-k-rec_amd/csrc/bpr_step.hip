@@ -373,8 +373,11 @@ static int launch_step_t(const tkr_bpr_state& st, int32_t* rec, const int32_t* o
 template <int NE, bool VEC>
 static int launch_step(const tkr_bpr_state& st, int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
                        float* loss_out, hipStream_t stream) {
-    return tkr_plan_team(B) == 4 ? launch_step_t<NE, VEC, 4>(st, rec, occ, hdr, B, loss_out, stream)
-                                 : launch_step_t<NE, VEC, 16>(st, rec, occ, hdr, B, loss_out, stream);
+    switch (tkr_plan_team(B)) {                    // csrc/plan_parts.h team_for
+        case 4: return launch_step_t<NE, VEC, 4>(st, rec, occ, hdr, B, loss_out, stream);
+        case 8: return launch_step_t<NE, VEC, 8>(st, rec, occ, hdr, B, loss_out, stream);
+        default: return launch_step_t<NE, VEC, 16>(st, rec, occ, hdr, B, loss_out, stream);
+    }
 }
 
 // ---- any width: the generic row form (k > 512, and 256 < k <= 512 at batch sizes above 1024) -------------------------------------------
@@ -504,6 +507,14 @@ static int launch_wide(const tkr_bpr_state& st, int32_t* rec, const int32_t* occ
     return (int)hipGetLastError();
 }
 
+static int launch_wide_team(const tkr_bpr_state& st, int32_t* rec, const int32_t* occ, const int32_t* hdr, int B, float* loss_out, hipStream_t stream) {
+    switch (tkr_plan_team(B)) {
+        case 4: return launch_wide<4>(st, rec, occ, hdr, B, loss_out, stream);
+        case 8: return launch_wide<8>(st, rec, occ, hdr, B, loss_out, stream);
+        default: return launch_wide<16>(st, rec, occ, hdr, B, loss_out, stream);
+    }
+}
+
 static int dispatch_step(const tkr_bpr_state& st, int32_t* rec, const int32_t* occ, const int32_t* hdr, int B,
                          float* loss_out, hipStream_t stream) {
     const int ne = (st.k + TKR_WAVE - 1) / TKR_WAVE;
@@ -516,12 +527,13 @@ static int dispatch_step(const tkr_bpr_state& st, int32_t* rec, const int32_t* o
         case 3: return launch_step<3, false>(st, rec, occ, hdr, B, loss_out, stream);
         case 4: return full ? launch_step<4, true>(st, rec, occ, hdr, B, loss_out, stream)
                             : launch_step<4, false>(st, rec, occ, hdr, B, loss_out, stream);
-        case 5: case 6: case 7: case 8:         // 256 < k <= 512: eight elements per lane, predicated rows; the 4-wave teams of batches
-            // up to 1024 only (a 16-wave workgroup leaves a wave 128 registers: four partner-row pairs of eight do not fit)
-            if (tkr_plan_team(B) != 4) return launch_wide<16>(st, rec, occ, hdr, B, loss_out, stream);
-            return launch_step_t<8, false, 4>(st, rec, occ, hdr, B, loss_out, stream);
+        case 5: case 6: case 7: case 8:         // 256 < k <= 512: eight elements per lane, predicated rows; the 4- and 8-wave teams of batches
+            // up to 16,384 only (a 16-wave workgroup leaves a wave 128 registers: four partner-row pairs of eight do not fit)
+            if (tkr_plan_team(B) == 4) return launch_step_t<8, false, 4>(st, rec, occ, hdr, B, loss_out, stream);
+            if (tkr_plan_team(B) == 8) return launch_step_t<8, false, 8>(st, rec, occ, hdr, B, loss_out, stream);
+            return launch_wide_team(st, rec, occ, hdr, B, loss_out, stream);
         default:                                // k > 512: the generic row form
-            return tkr_plan_team(B) == 4 ? launch_wide<4>(st, rec, occ, hdr, B, loss_out, stream) : launch_wide<16>(st, rec, occ, hdr, B, loss_out, stream);
+            return launch_wide_team(st, rec, occ, hdr, B, loss_out, stream);
     }
 }
 

@@ -21,9 +21,13 @@ constexpr int kPlanThreadsBig = 1024;  // sample_plan for larger batches (the LD
 constexpr int kLightMax = 4;     // oracle/plan_np.py LIGHT_MAX: occurrences one wave handles, B <= 4096
 constexpr int kLightMaxBig = 16; // ... LIGHT_MAX_BIG for larger batches
 __host__ __device__ inline int light_max(int B) { return B <= 4096 ? kLightMax : kLightMaxBig; }
-constexpr int kTeamBig = 16;     // oracle/plan_np.py TEAM: waves per workgroup / heavy task, B > 1024
+constexpr int kTeamBig = 16;     // oracle/plan_np.py TEAM: waves per workgroup / heavy task, B > 16384
+constexpr int kTeamMid = 8;      // ... TEAM_MID, 1024 < B <= 16384: at ~72 registers a CU holds three 8-wave workgroups (24 waves) but one of
+                                 // 16 waves -- step kernel per batch, 16 vs 8 (round 6): 9.5 / 7.9 us at 2048, 13.0 / 11.5 at 4096, 19.3 / 17.1 at
+                                 // 8192, 30.7 / 29.5 at 16,384; 50.4 / 55.4 at 32,768 and 133 / 159 at 65,536 (a popular item's heavy team is
+                                 // half as wide); 6 and 4 waves lose to 8 everywhere
 constexpr int kTeamSmall = 4;    // ... TEAM_SMALL for B <= 1024 (spreads a small batch over many CUs)
-__host__ __device__ inline int team_for(int B) { return B <= 1024 ? kTeamSmall : kTeamBig; }
+__host__ __device__ inline int team_for(int B) { return B <= 1024 ? kTeamSmall : B <= 16384 ? kTeamMid : kTeamBig; }
 // light tasks per workgroup (oracle light_per_block): every wave slot (half-filled groups measured slower)
 __host__ __device__ inline int light_per_block(int B) { return team_for(B); }
 constexpr int kTouchWords = 16;  // bitmap words per row -> at most 512 batches per call

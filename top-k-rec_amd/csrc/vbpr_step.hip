@@ -690,8 +690,11 @@ template <int NT>
 static int launch_vbpr(const tkr_vbpr_state& st, const int32_t* ti, const int32_t* tj, const int32_t* rec,
                        const int32_t* occ, const int32_t* hdr, const int32_t* occt, int B, float* ws, float* loss,
                        hipStream_t stream, const int32_t* tu, const int32_t* tpar) {
-    return tkr_plan_team(B) == 4 ? launch_vbpr_t<NT, 4>(st, ti, tj, rec, occ, hdr, occt, B, ws, loss, stream, tu, tpar)
-                                 : launch_vbpr_t<NT, 16>(st, ti, tj, rec, occ, hdr, occt, B, ws, loss, stream, tu, tpar);
+    switch (tkr_plan_team(B)) {                    // csrc/plan_parts.h team_for
+        case 4: return launch_vbpr_t<NT, 4>(st, ti, tj, rec, occ, hdr, occt, B, ws, loss, stream, tu, tpar);
+        case 8: return launch_vbpr_t<NT, 8>(st, ti, tj, rec, occ, hdr, occt, B, ws, loss, stream, tu, tpar);
+        default: return launch_vbpr_t<NT, 16>(st, ti, tj, rec, occ, hdr, occt, B, ws, loss, stream, tu, tpar);
+    }
 }
 
 }  // namespace tkr
