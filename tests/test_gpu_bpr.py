@@ -69,7 +69,13 @@ def _run_plan(hip, tr, tr_users, n_users, n_items, seed, first, nb, B, chunks=1)
 @pytest.mark.parametrize('n_users,n_items,B,nb,chunks', [(60, 40, 32, 5, 1), (300, 150, 256, 7, 3), (300, 150, 100, 3, 2),
                                                          (5000, 900, 1024, 3, 1), (5000, 900, 8192, 2, 2), (40, 30, 1, 4, 1),
                                                          (300, 150, 64, 512, 2),
-                                                         # above 8192 the plan comes from the grid-wide planner (csrc/planner_big.hip)
+                                                         # 1024 < batch <= 16,384: the counting planner (csrc/planner_mid.hip) -- several user ranges;
+                                                         # runs of ~55 / ~140 occurrences (ranked by a wave) and of > 512 (the bitmap form)
+                                                         (5000, 900, 2048, 3, 2), (70000, 10000, 4096, 3, 2), (300, 150, 4096, 2, 2),
+                                                         (40, 30, 2048, 2, 1), (40, 6, 4096, 2, 1), (40, 30, 16384, 1, 2), (5000, 900, 1025, 2, 1),
+                                                         # ... 512 batches over 150 items do not fit its batch-major touch maps: the row-major lookups
+                                                         (300, 150, 1100, 512, 1), (70000, 10000, 2048, 70, 2),
+                                                         # above 16,384 the plan comes from the grid-wide planner (csrc/planner_big.hip)
                                                          (5000, 900, 8193, 3, 2), (20000, 3000, 16384, 2, 2), (50000, 9000, 65536, 2, 1),
                                                          (300, 150, 20000, 2, 1)])
 def test_sample_plan_bit_exact(hip, n_users, n_items, B, nb, chunks):
@@ -216,7 +222,10 @@ def test_abi_rejects_bad_arguments(hip):
     args = [None] * 24
     assert hip.lib().tkr_sample_plan(None, 0, None, None, None, 5, 10, 0, 0, None, 1, 256, *([None] * 15), None, C.c_int64(0), None) == -1
     assert hip.lib().tkr_sample_plan(None, 1, None, None, None, 5, 10, 0, 0, None, 513, 256, *([None] * 15), None, C.c_int64(0), None) == -2
-    assert hip.lib().tkr_plan_workspace_bytes(2048, 128) == 0 and hip.plan_workspace_bytes(16384, 4) > 16384 * 4 * 8 * 6
+    # batches up to 1024 plan inside one workgroup; above, a few KB of range sums (csrc/planner_mid.hip); from 4096 on also the key arrays of the
+    # grid-wide planner (csrc/planner_big.hip: what takes over when the counting planner cannot)
+    assert hip.lib().tkr_plan_workspace_bytes(1024, 128) == 0 and 0 < hip.lib().tkr_plan_workspace_bytes(2048, 128) <= 128 * 128 * 16
+    assert hip.plan_workspace_bytes(16384, 4) > 16384 * 4 * 8 * 6
 
 
 @pytest.mark.parametrize('k,B,nb', [(16, 64, 12), (128, 256, 10), (50, 512, 5), (128, 2048, 3), (64, 2048, 9)])

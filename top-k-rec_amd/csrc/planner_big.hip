@@ -261,9 +261,12 @@ extern "C" __attribute__((visibility("hidden"))) int64_t tkr_plan_workspace_byte
     if (batch_size <= 0 || n_batches <= 0) return 0;
     return (int64_t)tkr::big_layout(nullptr, (size_t)batch_size * n_batches).total_bytes;
 }
+extern "C" __attribute__((visibility("hidden"))) int64_t tkr_plan_mid_workspace_bytes(int32_t batch_size, int32_t n_batches);     // csrc/planner_mid.hip
 extern "C" int64_t tkr_plan_workspace_bytes(int32_t batch_size, int32_t n_batches) {
     static const int big_from = [] { const char* e = getenv("TKR_PLAN_BIG_FROM"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();
-    return batch_size >= big_from ? tkr_plan_workspace_bytes_for(batch_size, n_batches) : 0;
+    const int64_t big = batch_size >= big_from ? tkr_plan_workspace_bytes_for(batch_size, n_batches) : 0;
+    const int64_t mid = tkr_plan_mid_workspace_bytes(batch_size, n_batches);          // (a few KB: the range sums of every batch)
+    return big > mid ? big : mid;
 }
 
 // called by tkr_sample_plan for batch_size > 8192

@@ -361,12 +361,27 @@ __global__ void rollback_kernel(const int4* __restrict__ task, size_t n_slots, i
 
 extern "C" int tkr_plan_team(int32_t batch_size) { return tkr::team_for(batch_size); }
 
+extern "C" __attribute__((visibility("hidden"))) int tkr_plan_commit(int32_t n_users, int32_t n_items, int32_t* ucnt, int32_t* icnt, uint32_t* touch_u,
+                                                                     uint32_t* touch_i, void* stream) {      // (for csrc/planner_mid.hip)
+    const int rows = n_users + n_items;
+    hipLaunchKernelGGL(tkr::commit_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_users, n_items, ucnt, icnt, touch_u, touch_i);
+    TKR_LAUNCH_CHECK();
+    return TKR_OK;
+}
+
 extern "C" int tkr_plan_max_blocks(int32_t batch_size) {
     const int lpb = tkr::light_per_block(batch_size);
     return (3 * batch_size + lpb - 1) / lpb + (3 * batch_size) / (tkr::light_max(batch_size) + 1);
 }
 
 extern "C" __attribute__((visibility("hidden"))) int64_t tkr_plan_workspace_bytes_for(int32_t batch_size, int32_t n_batches);       // csrc/planner_big.hip, any batch size
+extern "C" __attribute__((visibility("hidden"))) int tkr_plan_mid_ok(int32_t n_users, int32_t n_items, int32_t B);                  // csrc/planner_mid.hip
+extern "C" __attribute__((visibility("hidden"))) int64_t tkr_plan_mid_workspace_bytes(int32_t batch_size, int32_t n_batches);
+extern "C" __attribute__((visibility("hidden"))) int tkr_sample_plan_mid(
+    const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols, const int32_t* cols_sorted, int32_t n_users,
+    int32_t n_items, uint64_t seed, uint64_t first_triplet, const int64_t* ctl, int32_t n_batches, int32_t B, int32_t* ucnt, int32_t* icnt,
+    uint32_t* touch_u, uint32_t* touch_i, int32_t* out_u, int32_t* out_i, int32_t* out_j, int32_t* task, int32_t* occ, int32_t* rec,
+    int32_t* hdr, int32_t* occt, int32_t* tpar, void* workspace, int64_t workspace_bytes, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int tkr_sample_plan_big(const int32_t* tr_users, int32_t n_tr, const int32_t* row_ptr, const int32_t* pos_cols,
                                    const int32_t* cols_sorted, int32_t n_users, int32_t n_items, uint64_t seed,
                                    uint64_t first_triplet, const int64_t* ctl, int32_t n_batches, int32_t B, int32_t* ucnt,
@@ -392,6 +407,15 @@ static int sample_plan_impl(const int32_t* tr_users, int32_t n_tr, const int32_t
     if (!ucnt || !icnt || !touch_u || !touch_i || !occt) return TKR_EINVAL;
     const bool flow = prec != nullptr;                      // dataflow form of the plan (csrc/bpr_flow.hip)
     if (flow ? !pocc : (!rec || !hdr)) return TKR_EINVAL;
+    if (!flow && tkr_plan_mid_ok(n_users, n_items, batch_size) && workspace &&
+        workspace_bytes >= tkr_plan_mid_workspace_bytes(batch_size, n_batches)) {
+        // 1024 < batch <= 16,384: the counting planner of csrc/planner_mid.hip (four launches, no library sort; TKR_PLAN_MID_FROM moves
+        // its lower end, a value above 16,384 switches it off)
+        const int rc = tkr_sample_plan_mid(tr_users, n_tr, row_ptr, pos_cols, cols_sorted, n_users, n_items, seed, first_triplet, ctl,
+                                           n_batches, batch_size, ucnt, icnt, touch_u, touch_i, out_u, out_i, out_j, task, occ, rec,
+                                           hdr, occt, tpar, workspace, workspace_bytes, stream);
+        return rc;                                          // (the counters advance inside: its own fold of batch-major touch maps, or K1c)
+    }
     static const int big_from = [] { const char* e = getenv("TKR_PLAN_BIG_FROM"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4096; }();
     if (batch_size > 8192 || (batch_size >= big_from && !flow && workspace &&
                               workspace_bytes >= tkr_plan_workspace_bytes_for(batch_size, n_batches))) {
