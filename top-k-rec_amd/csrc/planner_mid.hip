@@ -582,8 +582,11 @@ extern "C" __attribute__((visibility("hidden"))) int tkr_plan_commit(int32_t n_u
 extern "C" __attribute__((visibility("hidden"))) int tkr_plan_mid_ok(int32_t n_users, int32_t n_items, int32_t B) {
     static const int from = [] { const char* e = getenv("TKR_PLAN_MID_FROM"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1025; }();
     if (B < from || B > tkr::kMidMaxB) return 0;
+    // every range's workgroup walks all of the batch's draws: worth it while a range keeps a fair share of them -- 480,189 users are 59
+    // ranges, fine at batch 8192 (Netflix shape: 311 -> 330 M triplets/s on the line), a loss at 2048 (208 -> 183)
     const tkr::MidGeom g = tkr::mid_geom(n_users, n_items, B);
-    return g.gu + g.gi <= tkr::kMidMaxRanges;
+    const int G = g.gu + g.gi, worth = B / 128 > 16 ? B / 128 : 16;
+    return G <= tkr::kMidMaxRanges && G <= worth;
 }
 extern "C" __attribute__((visibility("hidden"))) int64_t tkr_plan_mid_workspace_bytes(int32_t batch_size, int32_t n_batches) {
     if (batch_size <= 1024 || batch_size > tkr::kMidMaxB || n_batches <= 0) return 0;
