@@ -72,9 +72,11 @@ int tkr_lab_build(void);
  *                            first occurrence in pocc counted from batch 0 [4] batch [5] last batch < [4] of this call
  *                            that updated the row (-1: none) [8+4q..] pocc of occurrence q < 4 [24+q] the index of that
  *                            occurrence's triplet in its batch (= occt)
- *   workspace                (batch_size > 8192 only, else NULL) tkr_plan_workspace_bytes(batch_size, n_batches) bytes of device
- *                            scratch: such batches are planned grid-wide (device radix sort of batch|row|occurrence keys, scans)
- *                            instead of one workgroup per batch -- single/bpr.py:103-113 accepts any batch_size
+ *   workspace                (required for batch_size > 8192, nullable below) tkr_plan_workspace_bytes(batch_size, n_batches) bytes
+ *                            of device scratch.  With it, batches of 1025 .. 16,384 are planned by a counting sort over row ranges
+ *                            (csrc/planner_mid.hip: six launches; a few KB of range sums) and larger ones grid-wide (device radix
+ *                            sort of batch|row|occurrence keys, scans) instead of one workgroup per batch -- single/bpr.py:103-113
+ *                            accepts any batch_size.  The touch maps are scratch INSIDE a call (zero before and after)
  * n_batches <= 512, ids < 2^30, batch_size <= 2^20 (the dataflow form: batch_size <= 8192).  Output is bit-exact against
  * oracle/plan_np.py for every batch size. */
 int tkr_plan_team(int32_t batch_size);        /* waves per step workgroup / heavy-row team: 4 (B <= 1024), 8 (<= 16384) or 16 */
