@@ -75,6 +75,8 @@ def _run_plan(hip, tr, tr_users, n_users, n_items, seed, first, nb, B, chunks=1)
                                                          (40, 30, 2048, 2, 1), (40, 6, 4096, 2, 1), (40, 30, 16384, 1, 2), (5000, 900, 1025, 2, 1),
                                                          # ... 512 batches over 150 items do not fit its batch-major touch maps: the row-major lookups
                                                          (300, 150, 1100, 512, 1), (70000, 10000, 2048, 70, 2),
+                                                         # ... the Netflix shape's 59 user ranges per batch
+                                                         (480189, 17770, 8192, 2, 1),
                                                          # above 16,384 the plan comes from the grid-wide planner (csrc/planner_big.hip)
                                                          (5000, 900, 8193, 3, 2), (20000, 3000, 16384, 2, 2), (50000, 9000, 65536, 2, 1),
                                                          (300, 150, 20000, 2, 1)])
