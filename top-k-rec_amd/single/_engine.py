@@ -264,6 +264,8 @@ class PlanMixin:
 
     def _plan_overlap(self, B):
         """plan the chunk after the running one on the side stream?"""
+        if getattr(self, 'plan_in_order', False):      # one of several shards on one GPU: no planner stream (see BPR._train_streams)
+            return False
         return B >= self.cfg.overlap_min_batch or self._plan_flow()
 
     def _plan_cols(self, B):
@@ -382,7 +384,7 @@ class PlanMixin:
         """may the first chunk of the epoch AFTER an exchange be planned before it?  Only where the exchange leaves the tables in
         a state K1 can name in advance without touching them (the granule layout: every item at version 0, dist.ItemSync's
         fused unpack) and takes no snapshot at the next begin()."""
-        return self._plan_flow() and self.cfg.epoch_ahead
+        return self._plan_flow() and self.cfg.epoch_ahead and not getattr(self, 'plan_in_order', False)
 
     def _next_chunk(self, csr, B, want, then_exchange=0):
         """the chunk that holds the batch at the current stream position; `want` = batches the running call still has to run;

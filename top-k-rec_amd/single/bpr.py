@@ -308,7 +308,11 @@ class BPR(REC):
         lead = engines[0]
         for e in engines:
             e.ranks_on_device = S                          # the CUs are split between the shards' launches
-            e.private_side_stream = True                   # ... and every shard plans on a stream of its own
+            e.private_side_stream = True                   # ... and every shard plans on a stream of its own --
+            # unless that takes the process past HIP's four hardware queues while the step streams alone fit them (S = 2, 3): queues are
+            # in-order, two shards' planner streams on one queue made the second shard's launches wait for the first shard's epoch
+            # (S = 2: 105 -> 133 M triplets/s with K1 in order on the shard's stream; S = 4 / 8: 127 / 125 -> 123 / 123, kept as they were)
+            e.plan_in_order = S + 1 <= 4 < 2 * S + 1
             e.prepare(batch_size)
         for e in engines[1:]:                              # every shard starts from the same (possibly warm-started) model
             e.copy_model_from(lead)
