@@ -1,4 +1,4 @@
-// K1 for MID-SIZE batches (1024 < batch_size <= 16,384): the plan of csrc/sampler.hip / oracle/plan_np.py, word for word, in FOUR
+// K1 for MID-SIZE batches (1024 < batch_size <= 16,384): the plan of csrc/sampler.hip / oracle/plan_np.py, word for word, in SIX
 // launches and without a library sort.
 //
 // single/bpr.py:103-113 takes any batch_size.  One workgroup per batch (sampler.hip) leaves most of the chip idle from a few
@@ -11,15 +11,23 @@
 //   count     one workgroup per (batch, row range): the rows of its range that the batch draws, counted in LDS ->
 //             (tasks, occurrences, light tasks, heavy tasks) of the range
 //   build     the same workgroups, with the sums over the ranges in front of theirs: counts again, exclusive scan -> every row's
-//             run in the range's occurrence list, filled through an LDS cursor per row; a row's run is then put in ascending
-//             occurrence order (the order of the oracle's stable sort: at most 16 entries by one thread, up to 512 by one wave
-//             ranking by counting, more through a bitmap over the batch's occurrence indices); tasks, touch bits, occ, occt out
-//   resolve   the same workgroups: parities from the touch bitmaps (all batches' bits are set by now), light / heavy ranks from the
-//             range sums, the 64-byte wave records, the header
+//             run in the range's occurrence list, filled through an LDS word per row {run start, cursor}; a row's run is then put in
+//             ascending occurrence order (the order of the oracle's stable sort: up to 4 entries a comparator network by the row's
+//             thread, up to 64 one wave ranking by counting through readlane, up to 512 the same over LDS, more through a bitmap over
+//             the batch's occurrence indices); tasks, touch bits, occ, occt out
+//   prefix    the touch maps are BATCH-MAJOR inside this call (touch[b][row / 32]; the other planners use the same bytes row-major and
+//             every planner leaves them zero): a wave per word turns them into the rows' parities at the start of every batch and
+//             advances the rows' counters (K1c)
+//   resolve   the workgroups of count / build again: parities (one word of a compact per-batch table per lookup), light / heavy ranks
+//             from the range sums, the 64-byte wave records, the header
+//   zero      the touch maps back to zero
+// (When the call's batches do not fit the maps batch-major -- the last few of 512 batches when n_rows is not a multiple of 32 -- the maps
+// stay row-major, resolve looks parities up as the other planners do and K1c is csrc/sampler.hip's commit_kernel.)
 //
 // A range is at most 8192 rows (one LDS word each) and is sized for ~2048 user / ~4096 item occurrences; every workgroup walks the
-// batch's draws (32-64 KB from L2 at batch 8192) and keeps what falls into its range.  Integer work; every output word is
-// defined by oracle/plan_np.py and must match it bit for bit (tests/test_gpu_bpr.py test_sample_plan_bit_exact).
+// batch's draws (32-64 KB from L2 at batch 8192) and keeps what falls into its range -- worth it while a range keeps a fair share of
+// them (tkr_plan_mid_ok).  Integer work; every output word is defined by oracle/plan_np.py and must match it bit for bit
+// (tests/test_gpu_bpr.py test_sample_plan_bit_exact).
 #include <stdlib.h>
 #include <utility>
 
@@ -59,8 +67,8 @@ static MidGeom mid_geom(int n_users, int n_items, int B) {
         const int r = (n + g - 1) / g;
         return std::pair<int, int>((n + r - 1) / r, r);
     };
-    static const int per_u = getenv("TKR_MID_PER_U") ? atoi(getenv("TKR_MID_PER_U")) : 2048, per_i = getenv("TKR_MID_PER_I") ? atoi(getenv("TKR_MID_PER_I")) : 4096;
-    const auto u = ranges(n_users, (B + per_u - 1) / per_u), i = ranges(n_items, (2 * B + per_i - 1) / per_i);
+    // (1024 ... 4096 occurrences per range measured alike at batch 8192: 20.7-21.3 us per batch on the line)
+    const auto u = ranges(n_users, (B + 2047) / 2048), i = ranges(n_items, (2 * B + 4095) / 4096);
     return MidGeom{u.first, i.first, u.second, i.second};
 }
 
