@@ -661,6 +661,7 @@ def shards_on_one_gpu(r, k, device, B, single_value, limit=10 ** 6, epochs=2):
             for q in range(S):
                 e = _engine.BprEngine(n_users, n_items, k, hp, device, seed=1234)
                 e.ranks_on_device, e.private_side_stream = S, True
+                e.own_min_owners = torch.cuda.get_device_properties(device).multi_processor_count // 2      # as BPR._train_streams
                 e.plan_in_order = S + 1 <= 4 < 2 * S + 1              # as BPR._train_streams: no planner streams where they would share hardware queues
                 e.prepare(B)
                 e.triplets_drawn = q * (epochs + 1) * nb * B

@@ -151,8 +151,9 @@ def test_sharded_accuracy_tracks_single_stream(tmp_path):
     assert single.mean(0)[-1] > 2 * base[-1] and sharded.mean(0)[-1] > 2 * base[-1]
 
 
-def test_streams_mode_matches_oracle_simulation(tmp_path):
-    """train(streams=3): three user shards on three HIP streams of one GPU == oracle simulation of three shards
+@pytest.mark.parametrize('S', [2, 3])
+def test_streams_mode_matches_oracle_simulation(tmp_path, S):
+    """train(streams=S): S user shards on S HIP streams of one GPU == oracle simulation of S shards
     with the per-epoch sum-of-deltas exchange (the multi-GPU rule applied inside one GPU)."""
     sys.path[:0] = [ROOT, os.path.join(ROOT, 'top-k-rec_amd')]
     import synth
@@ -162,7 +163,7 @@ def test_streams_mode_matches_oracle_simulation(tmp_path):
     r = synth.make_ratings(150, 60, 0, seed=17, mu=2.6, sigma=0.4, min_r=4, max_r=25)
     data = str(tmp_path / 'data')
     synth.write_dataset(data, r)
-    k, B, epochs, limit, lr, S = 16, 32, 2, 32 * 13, 0.02, 3
+    k, B, epochs, limit, lr = 16, 32, 2, 32 * 13, 0.02
     m = BPR(k=k, lr=lr, lambda_b=1e-3)
     m.load_training_data(data + '/uid', data + '/vid', data + '/f0tr.txt')
     rng = np.random.Generator(np.random.PCG64(0))
@@ -170,9 +171,14 @@ def test_streams_mode_matches_oracle_simulation(tmp_path):
             np.zeros((m.n_items, 1), np.float32)]
     m.fue, m.fie, m.fib = (a.copy() for a in init)
     m.train(epochs=epochs, batch_size=B, epoch_sample_limit=limit, seed=11, verbose=False, streams=S)
-    # every shard ran the persistent step with owned item rows on its share of the CUs (K2o), not the per-batch step
+    # every shard ran a persistent step, not the per-batch one: with owned item rows (K2o) on half the CUs each at two shards, K2f from
+    # three shards on (a third of the CUs as owners is slower than K2f beside the other shards)
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    assert m._eng.layout == 'flow' and m._eng._plan_owners(B) == cus // S and m._eng._last_step_kind == 'own'
+    assert m._eng.layout == 'flow'
+    if S == 2:
+        assert m._eng._plan_owners(B) == cus // S and m._eng._last_step_kind == 'own'
+    else:
+        assert m._eng._plan_owners(B) == 0 and m._eng._last_step_kind == 'flow'
     hp = dict(lu=m.lu, li=m.li, lj=m.lj, lb=m.lb, lr=lr, mode='l2')
     nb = (limit // B) // S
     row_ptr, pos, srt = P.build_csr(m.tr_data, m.n_users)

@@ -662,6 +662,8 @@ class BprEngine(PlanMixin):
                 cus = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == 'cuda' else 0
                 warnings.warn('K2o is off: %d ranks share this GPU and %d item rows of width %d do not fit %d owners\' LDS; the persistent '
                               'step without owned rows (K2f) runs instead' % (share, self.n_items, self.k, cus // share))
+        if cache[share] < getattr(self, 'own_min_owners', 0):          # shards of one process (BPR._train_streams): K2f below that many owners
+            return 0
         return cache[share]
 
     def wants_flow(self, B):

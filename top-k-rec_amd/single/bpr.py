@@ -308,6 +308,9 @@ class BPR(REC):
         lead = engines[0]
         for e in engines:
             e.ranks_on_device = S                          # the CUs are split between the shards' launches
+            # ... through K2o down to half the CUs per shard; on fewer owners a shard's K2o is slower than K2f beside the other shards
+            # (ML-10M shape, aggregate: S = 2: K2o 135 / K2f 139 M triplets/s; S = 3: K2o on 85 owners each 91 M, K2f 145 M)
+            e.own_min_owners = torch.cuda.get_device_properties(dev).multi_processor_count // 2
             e.private_side_stream = True                   # ... and every shard plans on a stream of its own --
             # unless that takes the process past HIP's four hardware queues while the step streams alone fit them (S = 2, 3): queues are
             # in-order, two shards' planner streams on one queue made the second shard's launches wait for the first shard's epoch
