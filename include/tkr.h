@@ -73,8 +73,8 @@ int tkr_lab_build(void);
  *                            that updated the row (-1: none) [8+4q..] pocc of occurrence q < 4 [24+q] the index of that
  *                            occurrence's triplet in its batch (= occt)
  *   workspace                (required for batch_size > 8192, nullable below) tkr_plan_workspace_bytes(batch_size, n_batches) bytes
- *                            of device scratch.  With it, batches of 1025 .. 16,384 are planned by a counting sort over row ranges
- *                            (csrc/planner_mid.hip: six launches; a few KB of range sums) and larger ones grid-wide (device radix
+ *                            of device scratch.  With it, batches of 1025 .. 65,536 are planned by a counting sort over row ranges
+ *                            (csrc/planner_mid.hip: six launches; range sums, above 16,384 also 12 bytes per triplet of run lists) and larger ones grid-wide (device radix
  *                            sort of batch|row|occurrence keys, scans) instead of one workgroup per batch -- single/bpr.py:103-113
  *                            accepts any batch_size.  The touch maps are scratch INSIDE a call (zero before and after)
  * n_batches <= 512, ids < 2^30, batch_size <= 2^20 (the dataflow form: batch_size <= 8192).  Output is bit-exact against

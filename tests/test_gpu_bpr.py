@@ -77,7 +77,9 @@ def _run_plan(hip, tr, tr_users, n_users, n_items, seed, first, nb, B, chunks=1)
                                                          (300, 150, 1100, 512, 1), (70000, 10000, 2048, 70, 2),
                                                          # ... the Netflix shape's 59 user ranges per batch
                                                          (480189, 17770, 8192, 2, 1),
-                                                         # above 16,384 the plan comes from the grid-wide planner (csrc/planner_big.hip)
+                                                         # 16,384 < batch <= 65,536: its wide form (run lists in the workspace); above: the grid-wide planner
+                                                         # (csrc/planner_big.hip)
+                                                         (40, 6, 32768, 1, 1), (300, 150, 65536, 1, 2), (70000, 10000, 32768, 2, 1),
                                                          (5000, 900, 8193, 3, 2), (20000, 3000, 16384, 2, 2), (50000, 9000, 65536, 2, 1),
                                                          (300, 150, 20000, 2, 1)])
 def test_sample_plan_bit_exact(hip, n_users, n_items, B, nb, chunks):

@@ -1,5 +1,5 @@
-// K1 for MID-SIZE batches (1024 < batch_size <= 16,384): the plan of csrc/sampler.hip / oracle/plan_np.py, word for word, in SIX
-// launches and without a library sort.
+// K1 for MID-SIZE batches (1024 < batch_size <= 65,536): the plan of csrc/sampler.hip / oracle/plan_np.py, word for word, in SIX
+// launches and without a library sort (to 16,384 with the ranges' run lists as 16-bit entries in LDS; above: the wide form of build).
 //
 // single/bpr.py:103-113 takes any batch_size.  One workgroup per batch (sampler.hip) leaves most of the chip idle from a few
 // thousand triplets on and takes a millisecond per batch; the grid-wide planner (planner_big.hip) sorts (batch | row | occurrence)
@@ -59,16 +59,27 @@ constexpr int kMidHuge = 2 * kMidMaxB / (kMidWaveSort + 1) + 1;
 
 struct MidGeom { int gu, gi, ru, ri; };   // user / item ranges per batch, rows per range
 
+// batches above kMidMaxB (to kMidWideMaxB): the WIDE form of the build step -- the ranges' occurrence lists live in the workspace (32-bit
+// entries at exact offsets: the count step's sums), a row has two LDS words {run start, cursor}, ranges are at most kMidWideRows rows
+constexpr int kMidWideMaxB = 65536;
+constexpr int kMidWideRows = 4096;
+constexpr int kMidWideThreadSort = 32;    // wide form: a run up to this long is sorted in the registers of the row's thread (a bitonic network of 16 or
+                                          // 32; a wave per run of 17 .. 64 entries -- one in eight of an item range's runs at batch 65,536 -- was 25 of its 83 us)
+__host__ __device__ inline bool mid_wide(int B) { return B > kMidMaxB; }
+
 static MidGeom mid_geom(int n_users, int n_items, int B) {
-    auto ranges = [](int n, int by_keys) {
-        int g = (n + kMidRows - 1) / kMidRows;
+    const int cap = mid_wide(B) ? kMidWideRows : kMidRows;
+    auto ranges = [cap](int n, int by_keys) {
+        int g = (n + cap - 1) / cap;
         if (by_keys > g) g = by_keys;
         if (g > n) g = n;
         const int r = (n + g - 1) / g;
         return std::pair<int, int>((n + r - 1) / r, r);
     };
-    // (1024 ... 4096 occurrences per range measured alike at batch 8192: 20.7-21.3 us per batch on the line)
-    const auto u = ranges(n_users, (B + 2047) / 2048), i = ranges(n_items, (2 * B + 4095) / 4096);
+    // (1024 ... 4096 occurrences per range measured alike at batch 8192: 20.7-21.3 us per batch on the line; the wide form walks 4x to
+    // 8x the draws per workgroup and takes twice the occurrences per range)
+    const int per_u = mid_wide(B) ? 4096 : 2048, per_i = mid_wide(B) ? 8192 : 4096;      // (wide form at 65,536: 2048/4096 ... 16,384/16,384 within 2 %)
+    const auto u = ranges(n_users, (B + per_u - 1) / per_u), i = ranges(n_items, (2 * B + per_i - 1) / per_i);
     return MidGeom{u.first, i.first, u.second, i.second};
 }
 
@@ -106,14 +117,37 @@ __device__ __forceinline__ MidRange mid_range(const MidGeom& g, int B, int n_use
 
 __device__ __forceinline__ int mid_row_of(const MidRange& r, int B, int o) { return (r.item && o >= B) ? r.a1[o - B] : r.a0[o]; }
 
-// the rows of kMidUnroll occurrences of the batch, asked for together (one at a time every L2 round trip stood alone: 9 us of an item
-// range's 51 went into reading 16 values per thread)
-constexpr int kMidUnroll = 8;
-__device__ __forceinline__ void mid_rows(const MidRange& r, int B, int o0, unsigned (&rl)[kMidUnroll]) {
+// Walk the batch's draws and call hit(occurrence, row - lo) for those of the range.  Sixteen draws per thread are asked for together, as
+// four 16-byte loads (one at a time every L2 round trip stood alone: 9 us of an item range's 51 at batch 8192 went into reading 16
+// values per thread; as 4-byte loads the walk of 131,072 draws took 45 us per pass at batch 65,536); batch sizes that are not a
+// multiple of four take the plain walk.
+template <class F>
+__device__ __forceinline__ void mid_walk(const MidRange& r, int B, F&& hit) {
+    if ((B & 3) == 0) {
+        constexpr int UN = 4;
+        for (int o0 = threadIdx.x * 4; o0 < r.n_occ; o0 += UN * 4 * kMidThreads) {
+            int4 v[UN];
 #pragma unroll
-    for (int x = 0; x < kMidUnroll; ++x) {
-        const int o = o0 + x * kMidThreads;
-        rl[x] = o < r.n_occ ? (unsigned)(mid_row_of(r, B, o) - r.lo) : 0xffffffffu;
+            for (int x = 0; x < UN; ++x) {
+                const int o = o0 + x * 4 * kMidThreads;
+                v[x] = make_int4(-1, -1, -1, -1);             // (-1 - lo is no row of any range)
+                if (o < r.n_occ) v[x] = *reinterpret_cast<const int4*>((r.item && o >= B) ? r.a1 + (o - B) : r.a0 + o);
+            }
+#pragma unroll
+            for (int x = 0; x < UN; ++x) {
+                const int o = o0 + x * 4 * kMidThreads;
+                const unsigned r0 = (unsigned)(v[x].x - r.lo), r1 = (unsigned)(v[x].y - r.lo), r2 = (unsigned)(v[x].z - r.lo), r3 = (unsigned)(v[x].w - r.lo);
+                if (r0 < (unsigned)r.rows) hit(o, r0);
+                if (r1 < (unsigned)r.rows) hit(o + 1, r1);
+                if (r2 < (unsigned)r.rows) hit(o + 2, r2);
+                if (r3 < (unsigned)r.rows) hit(o + 3, r3);
+            }
+        }
+    } else {
+        for (int o = threadIdx.x; o < r.n_occ; o += kMidThreads) {
+            const unsigned rl = (unsigned)(mid_row_of(r, B, o) - r.lo);
+            if (rl < (unsigned)r.rows) hit(o, rl);
+        }
     }
 }
 
@@ -121,13 +155,7 @@ __device__ __forceinline__ void mid_rows(const MidRange& r, int B, int o0, unsig
 __device__ __forceinline__ void mid_count(const MidRange& r, int B, uint32_t* cnt) {
     for (int q = threadIdx.x; q < r.rows; q += kMidThreads) cnt[q] = 0;
     __syncthreads();
-    for (int o0 = threadIdx.x; o0 < r.n_occ; o0 += kMidUnroll * kMidThreads) {
-        unsigned rl[kMidUnroll];
-        mid_rows(r, B, o0, rl);
-#pragma unroll
-        for (int x = 0; x < kMidUnroll; ++x)
-            if (rl[x] < (unsigned)r.rows) atomicAdd(&cnt[rl[x]], 1u);
-    }
+    mid_walk(r, B, [&](int, unsigned rl) { atomicAdd(&cnt[rl], 1u); });
     __syncthreads();
 }
 
@@ -273,16 +301,10 @@ __global__ __launch_bounds__(kMidThreads, 8) void mid_build_kernel(MidGeom g, in
     if (tw) atomicOr(&touch[(size_t)r.b * wt + tw_at], tw);
     __syncthreads();
     MID_STAMP(2);
-    for (int o0 = tid; o0 < r.n_occ; o0 += kMidUnroll * kMidThreads) {
-        unsigned rl[kMidUnroll];
-        mid_rows(r, B, o0, rl);
-#pragma unroll
-        for (int x = 0; x < kMidUnroll; ++x)
-            if (rl[x] < (unsigned)r.rows) {
-                const uint32_t old = atomicAdd(&cnt[rl[x]], 1u);
-                list[(old >> 16) + (old & 0xffffu)] = (uint16_t)(o0 + x * kMidThreads);
-            }
-    }
+    mid_walk(r, B, [&](int o, unsigned rl) {
+        const uint32_t old = atomicAdd(&cnt[rl], 1u);
+        list[(old >> 16) + (old & 0xffffu)] = (uint16_t)o;
+    });
     __syncthreads();
     MID_STAMP(3);
     // ascending occurrence order inside every run (the fill above is in arrival order)
@@ -396,6 +418,281 @@ __global__ __launch_bounds__(kMidThreads, 8) void mid_build_kernel(MidGeom g, in
         for (int q = all.x + tid; q < 3 * B; q += kMidThreads) task[q] = make_int4(-1, 0, 0, 0);
 }
 
+// ---- the WIDE form of build (kMidMaxB < batch <= kMidWideMaxB) ---------------------------------------------------------------------
+// dynamic LDS: start[kMidWideRows] | cur[kMidWideRows] | list[kMidWideList] | stage[kMidWaves][kMidWaveSort] | bitmap[2B / 32] | queue (16-bit) |
+// huge (16-bit).  A range's occurrence list lives in LDS while it has at most kMidWideList entries (its count is known: the range sums) and
+// in the workspace otherwise (heavily skewed data: scattered 4-byte stores to memory are partial-line writes, 16 of an item range's 83 us at
+// batch 65,536 before the list moved into LDS); the code is the same, through a generic pointer.
+constexpr int kMidWideList = 16384;
+__host__ __device__ inline int mid_wide_queue_cap(int B) { return 2 * B / (kMidWideThreadSort + 1) + 1; }
+__host__ __device__ inline int mid_wide_huge_cap(int B) { return 2 * B / (kMidWaveSort + 1) + 1; }
+__host__ __device__ inline size_t mid_build_wide_lds(int B) {
+    return (size_t)4 * (2 * kMidWideRows + kMidWideList + kMidWaves * kMidWaveSort + (2 * B + 31) / 32) + (size_t)(mid_wide_queue_cap(B) + mid_wide_huge_cap(B) + 2) / 2 * 4 + 16;
+}
+
+template <int N>
+__device__ __forceinline__ void reg_sort_asc(uint32_t (&v)[N]) {           // bitonic network on registers, N a power of two
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint32_t lo = min(v[i], v[l]), hi = max(v[i], v[l]);
+                    const bool asc = (i & k) == 0;
+                    v[i] = asc ? lo : hi;
+                    v[l] = asc ? hi : lo;
+                }
+            }
+}
+
+__global__ __launch_bounds__(kMidThreads) void mid_build_wide_kernel(MidGeom g, int B, int n_users, int n_items,
+                                                                      const int32_t* __restrict__ out_u, const int32_t* __restrict__ out_i,
+                                                                      const int32_t* __restrict__ out_j, const int4* __restrict__ agg,
+                                                                      int4* __restrict__ task_all, int2* __restrict__ occ_all,
+                                                                      int32_t* __restrict__ occt_all, uint32_t* __restrict__ touch_u,
+                                                                      uint32_t* __restrict__ touch_i, int wu, int wi, uint32_t* olist_all /*[n_batches][3B]*/) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t mid_lds[];
+    __shared__ int scr[2 * kMidWaves];
+    __shared__ int4 scr4[4];
+    __shared__ int qn, hn;
+    const int words = (2 * B + 31) / 32;
+    uint32_t* start = mid_lds;
+    uint32_t* cur = start + kMidWideRows;
+    uint32_t* lds_list = cur + kMidWideRows;
+    uint32_t* stage = lds_list + kMidWideList;
+    uint32_t* bitmap = stage + kMidWaves * kMidWaveSort;
+    uint16_t* queue = reinterpret_cast<uint16_t*>(bitmap + words);
+    uint16_t* huge = queue + mid_wide_queue_cap(B);
+    const int tid = threadIdx.x, lane = tid & (TKR_WAVE - 1), wave = tid >> 6;
+    const int G = g.gu + g.gi;
+    const MidRange r = mid_range(g, B, n_users, n_items, out_u, out_i, out_j);
+    MID_STAMP_INIT();
+    int4 pre, all;
+    mid_sums(agg + (size_t)r.b * G, G, r.c, scr4, pre, all);
+    MID_STAMP(0);
+    if (tid == 0) { qn = 0; hn = 0; }
+    mid_count(r, B, start);
+    MID_STAMP(1);                                // start[] holds the counts for now
+
+    const int per = (r.rows + kMidThreads - 1) / kMidThreads;
+    const int r0 = min(tid * per, r.rows), r1 = min(r0 + per, r.rows);
+    int my_k = 0, my_t = 0;
+    for (int q = r0; q < r1; ++q) { const int c = (int)start[q]; my_k += c; my_t += c > 0; }
+    int ex_k, ex_t, tot_k, tot_t;
+    mid_scan2(my_k, my_t, scr, ex_k, ex_t, tot_k, tot_t);
+    int4* task = task_all + (size_t)r.b * 3 * B;
+    uint32_t* touch = r.item ? touch_i : touch_u;
+    const int wt = r.item ? wi : wu;
+    // this range's runs, in the order of its rows
+    uint32_t* olist = (tot_k <= kMidWideList) ? lds_list : olist_all + (size_t)r.b * 3 * B + pre.y;
+    uint32_t tw = 0;
+    int tw_at = -1;
+    for (int q = r0; q < r1; ++q) {
+        const int c = (int)start[q];
+        if (c > 0) {
+            const int row = r.lo + q;
+            task[pre.x + ex_t] = make_int4((int)((uint32_t)row | ((uint32_t)r.item << 31)), pre.y + ex_k, c, 0);
+            if (wt) {
+                if ((row >> 5) != tw_at) {
+                    if (tw) atomicOr(&touch[(size_t)r.b * wt + tw_at], tw);
+                    tw = 0; tw_at = row >> 5;
+                }
+                tw |= 1u << (row & 31);
+            } else {
+                atomicOr(&touch[(size_t)row * kTouchWords + (r.b >> 5)], 1u << (r.b & 31));
+            }
+            ++ex_t;
+        }
+        start[q] = (uint32_t)ex_k;
+        cur[q] = 0;
+        ex_k += c;
+    }
+    if (tw) atomicOr(&touch[(size_t)r.b * wt + tw_at], tw);
+    __syncthreads();
+    MID_STAMP(2);
+    // (A draw in sixteen is a hit: the hits of eight slots are compacted through the wave's stage and then taken a lane each, instead of
+    // every slot running the cursor's round trip for three or four lanes.  What the fill costs at batch 65,536 is the WALK, though --
+    // 25 of its 31 % of the kernel wait for the draws: every one of a batch's 32 ranges reads all of them, 110 MB per pass and call.)
+    {
+        uint32_t* hits = stage + wave * kMidWaveSort;               // <= 8 slots x 64 lanes
+        const auto take = [&](int n) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int i = lane; i < n; i += TKR_WAVE) {
+                const uint32_t e = hits[i];
+                olist[start[e >> 17] + atomicAdd(&cur[e >> 17], 1u)] = e & 0x1ffffu;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        int n = 0;
+        const auto put = [&](bool pred, int o, unsigned rl) {
+            const unsigned long long m = __ballot(pred);
+            if (pred) hits[n + __popcll(m & ((1ull << lane) - 1ull))] = (rl << 17) | (uint32_t)o;
+            n += __popcll(m);
+        };
+        if ((B & 3) == 0) {
+            for (int o0 = tid * 4; o0 < ((r.n_occ + 4 * kMidThreads - 1) / (4 * kMidThreads)) * 4 * kMidThreads; o0 += 4 * 4 * kMidThreads) {     // (wave-uniform trip count)
+                int4 v[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int o = o0 + x * 4 * kMidThreads;
+                    v[x] = make_int4(-1, -1, -1, -1);
+                    if (o < r.n_occ) v[x] = *reinterpret_cast<const int4*>((r.item && o >= B) ? r.a1 + (o - B) : r.a0 + o);
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int o = o0 + x * 4 * kMidThreads;
+                    const unsigned q0 = (unsigned)(v[x].x - r.lo), q1 = (unsigned)(v[x].y - r.lo), q2 = (unsigned)(v[x].z - r.lo), q3 = (unsigned)(v[x].w - r.lo);
+                    put(q0 < (unsigned)r.rows, o, q0);
+                    put(q1 < (unsigned)r.rows, o + 1, q1);
+                    put(q2 < (unsigned)r.rows, o + 2, q2);
+                    put(q3 < (unsigned)r.rows, o + 3, q3);
+                    if (x & 1) { take(n); n = 0; }
+                }
+            }
+        } else {
+            for (int o0 = 0; o0 < r.n_occ; o0 += kMidThreads) {
+                const int o = o0 + tid;
+                const unsigned rl = o < r.n_occ ? (unsigned)(mid_row_of(r, B, o) - r.lo) : 0xffffffffu;
+                put(rl < (unsigned)r.rows, o, rl);
+                take(n); n = 0;
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    MID_STAMP(3);
+    // ascending occurrence order inside every run
+    for (int q = r0; q < r1; ++q) {
+        const int c = (int)cur[q], s = (int)start[q];
+        if (c >= 2 && c <= 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int x = 0; x < 16; ++x) v[x] = x < c ? olist[s + x] : 0xffffffffu;
+            reg_sort_asc<16>(v);
+#pragma unroll
+            for (int x = 0; x < 16; ++x)
+                if (x < c) olist[s + x] = v[x];
+        } else if (c > 16 && c <= kMidWideThreadSort) {
+            uint32_t v[kMidWideThreadSort];
+#pragma unroll
+            for (int x = 0; x < kMidWideThreadSort; ++x) v[x] = x < c ? olist[s + x] : 0xffffffffu;
+            reg_sort_asc<kMidWideThreadSort>(v);
+#pragma unroll
+            for (int x = 0; x < kMidWideThreadSort; ++x)
+                if (x < c) olist[s + x] = v[x];
+        } else if (c > kMidWideThreadSort) {
+            queue[atomicAdd(&qn, 1)] = (uint16_t)q;
+        }
+    }
+    __syncthreads();
+    MID_STAMP(4);
+    const int n_q = qn;
+    uint32_t* mine_stage = stage + wave * kMidWaveSort;
+    for (int qi = wave; qi < n_q; qi += kMidWaves) {
+        const int q = queue[qi];
+        const int c = (int)cur[q], s = (int)start[q];
+        if (c > kMidWaveSort) {
+            if (lane == 0) huge[atomicAdd(&hn, 1)] = (uint16_t)q;
+            continue;
+        }
+        if (c <= TKR_WAVE) {
+            const uint32_t e = lane < c ? olist[s + lane] : 0xffffffffu;
+            int rk = 0;
+            for (int y = 0; y < c; ++y) rk += (uint32_t)__builtin_amdgcn_readlane((int)e, y) < e;
+            if (lane < c) olist[s + rk] = e;
+            continue;
+        }
+        constexpr int E = kMidWaveSort / TKR_WAVE;
+        uint32_t e[E];
+        int rk[E];
+#pragma unroll
+        for (int x = 0; x < E; ++x) {
+            const int idx = lane + x * TKR_WAVE;
+            e[x] = idx < c ? olist[s + idx] : 0xffffffffu;
+            mine_stage[idx] = e[x];
+            rk[x] = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int y0 = 0; y0 < c; y0 += 4) {
+            uint32_t v[4];
+#pragma unroll
+            for (int z = 0; z < 4; ++z) v[z] = mine_stage[y0 + z];          // (past the run: the padding stored above, never below an entry)
+#pragma unroll
+            for (int z = 0; z < 4; ++z)
+#pragma unroll
+                for (int x = 0; x < E; ++x) rk[x] += v[z] < e[x];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int x = 0; x < E; ++x)
+            if (lane + x * TKR_WAVE < c) olist[s + rk[x]] = e[x];
+    }
+    __syncthreads();
+    MID_STAMP(5);
+    const int n_h = hn, wpt = (words + kMidThreads - 1) / kMidThreads;       // bitmap words per thread
+    for (int hi = 0; hi < n_h; ++hi) {
+        const int q = huge[hi];
+        const int c = (int)cur[q], s = (int)start[q];
+        for (int w = tid; w < words; w += kMidThreads) bitmap[w] = 0;
+        __syncthreads();
+        for (int x = tid; x < c; x += kMidThreads) { const uint32_t o = olist[s + x]; atomicOr(&bitmap[o >> 5], 1u << (o & 31)); }
+        __syncthreads();
+        const int w0 = min(tid * wpt, words), w1 = min(w0 + wpt, words);
+        int pc = 0;
+        for (int w = w0; w < w1; ++w) pc += __popc(bitmap[w]);
+        int ex, ex2, tot, tot2;
+        mid_scan2(pc, 0, scr, ex, ex2, tot, tot2);
+        int pos = s + ex;
+        for (int w = w0; w < w1; ++w) {
+            uint32_t bits = bitmap[w];
+            while (bits) {
+                const int bit = __ffs(bits) - 1;
+                olist[pos++] = (uint32_t)(w * 32 + bit);
+                bits &= bits - 1;
+            }
+        }
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    MID_STAMP(6);
+    int2* occ = occ_all + (size_t)r.b * 3 * B + pre.y;
+    int32_t* occt = occt_all + (size_t)r.b * 3 * B + pre.y;
+    const int32_t* bu = out_u + (size_t)r.b * B;
+    const int32_t* bi = out_i + (size_t)r.b * B;
+    const int32_t* bj = out_j + (size_t)r.b * B;
+    constexpr int EU = 8;
+    for (int p0 = tid; p0 < tot_k; p0 += EU * kMidThreads) {
+        int o[EU], a[EU], c2[EU];
+#pragma unroll
+        for (int x = 0; x < EU; ++x) o[x] = p0 + x * kMidThreads < tot_k ? (int)olist[p0 + x * kMidThreads] : 0;
+#pragma unroll
+        for (int x = 0; x < EU; ++x) {
+            if (r.item) {
+                const bool role = o[x] >= B;
+                const int t = role ? o[x] - B : o[x];
+                a[x] = bu[t];
+                c2[x] = (int)((uint32_t)(role ? bi[t] : bj[t]) | ((uint32_t)role << 31));
+                o[x] = t;
+            } else {
+                a[x] = bi[o[x]];
+                c2[x] = bj[o[x]];
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < EU; ++x) {
+            const int p = p0 + x * kMidThreads;
+            if (p < tot_k) { occ[p] = make_int2(a[x], c2[x]); occt[p] = o[x]; }
+        }
+    }
+    MID_STAMP(7);
+    if (r.c == G - 1)
+        for (int q = all.x + tid; q < 3 * B; q += kMidThreads) task[q] = make_int4(-1, 0, 0, 0);
+}
+
 // Batch-major touch maps (touch[b][row / 32], bit row % 32: the same n_rows * 64 bytes as the row-major maps of the other planners,
 // which leave them zero between calls): every word becomes the PARITY of its 32 rows at the start of batch b -- the rows' counters
 // and the exclusive XOR over the batches in front -- and the counters advance by the rows' touches.  A batch's parities are then one
@@ -459,8 +756,7 @@ __global__ __launch_bounds__(kMidThreads, 8) void mid_resolve_kernel(int wu, int
                                                                    int4* __restrict__ hdr_all) {
     __shared__ int scr[2 * kMidWaves];
     __shared__ int4 scr4[4];
-    __shared__ int4 heavy[2 * kMidMaxB / (kLightMaxBig + 1) + 1];    // the range's heavy tasks: more than light_max(B) of the <= 2B occurrences each
-    static_assert(2 * 4096 / (kLightMax + 1) <= 2 * kMidMaxB / (kLightMaxBig + 1), "batches up to 4096 have light_max = 4");
+    __shared__ int4 heavy[kMidThreads];                               // the heavy tasks of one round of kMidThreads tasks
     const int tid = threadIdx.x, b = blockIdx.y, c = blockIdx.x;
     int4 pre, all;
     mid_sums(agg + (size_t)b * G, G, c, scr4, pre, all);
@@ -510,6 +806,7 @@ __global__ __launch_bounds__(kMidThreads, 8) void mid_resolve_kernel(int wu, int
     const int nlb = (tot_l + team - 1) / team;                        // light tasks per workgroup = team (plan_parts.h light_per_block)
     int32_t* rec = rec_all + (size_t)b * rec_stride * 16;
     int base_l = pre.z, n_heavy = 0;
+    const int lane = tid & (TKR_WAVE - 1), wave = tid >> 6;
     for (int base = 0; base < mine.x; base += kMidThreads) {
         const int s = pre.x + base + tid;
         const bool valid = base + tid < mine.x;
@@ -537,32 +834,31 @@ __global__ __launch_bounds__(kMidThreads, 8) void mid_resolve_kernel(int wu, int
             r[2] = make_int4(o[2].x, o[2].y, o[3].x, o[3].y);
             r[3] = make_int4(t.z, mid_pack_t16(tt[0], tt[1]), mid_pack_t16(tt[2], tt[3]), 0);
         } else if (h) {
-            heavy[n_heavy + ex_h] = t;                                 // its records: below, a lane per wave record
+            heavy[ex_h] = t;                                           // its records: below, a lane per wave record
+        }
+        __syncthreads();
+        for (int e = wave * (TKR_WAVE / 16); e < n_h; e += kMidWaves * (TKR_WAVE / 16)) {       // four heavy tasks per wave: team <= 16
+            const int mine_e = e + (lane >> 4), w = lane & 15;
+            if (mine_e < n_h && w < team) {
+                const int4 th = heavy[mine_e];
+                const int hi = pre.w + n_heavy + mine_e;
+                int4* r = reinterpret_cast<int4*>(rec + ((size_t)(nlb + hi) * team + w) * 16);
+                const int n_mine = (th.z > w) ? (th.z - w + team - 1) / team : 0;
+                int2 o[4];
+                int tt[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    o[q] = (q < n_mine) ? occ[th.y + w + q * team] : make_int2(0, 0);
+                    tt[q] = (q < n_mine) ? occt[th.y + w + q * team] : 0;
+                }
+                r[0] = make_int4(th.x, th.w | (team << 8) | (w << 16), n_mine, th.y + w);
+                r[1] = make_int4(o[0].x, o[0].y, o[1].x, o[1].y);
+                r[2] = make_int4(o[2].x, o[2].y, o[3].x, o[3].y);
+                r[3] = make_int4(th.z, mid_pack_t16(tt[0], tt[1]), mid_pack_t16(tt[2], tt[3]), 0);
+            }
         }
         base_l += n_l;
         n_heavy += n_h;
-    }
-    __syncthreads();
-    const int lane = tid & (TKR_WAVE - 1), wave = tid >> 6;
-    for (int e = wave * (TKR_WAVE / 16); e < n_heavy; e += kMidWaves * (TKR_WAVE / 16)) {       // four heavy tasks per wave: team <= 16
-        const int mine_e = e + (lane >> 4), w = lane & 15;
-        if (mine_e < n_heavy && w < team) {
-            const int4 t = heavy[mine_e];
-            const int hi = pre.w + mine_e;
-            int4* r = reinterpret_cast<int4*>(rec + ((size_t)(nlb + hi) * team + w) * 16);
-            const int n_mine = (t.z > w) ? (t.z - w + team - 1) / team : 0;
-            int2 o[4];
-            int tt[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                o[q] = (q < n_mine) ? occ[t.y + w + q * team] : make_int2(0, 0);
-                tt[q] = (q < n_mine) ? occt[t.y + w + q * team] : 0;
-            }
-            r[0] = make_int4(t.x, t.w | (team << 8) | (w << 16), n_mine, t.y + w);
-            r[1] = make_int4(o[0].x, o[0].y, o[1].x, o[1].y);
-            r[2] = make_int4(o[2].x, o[2].y, o[3].x, o[3].y);
-            r[3] = make_int4(t.z, mid_pack_t16(tt[0], tt[1]), mid_pack_t16(tt[2], tt[3]), 0);
-        }
     }
     if (c == G - 1) {
         if (tid == 0) hdr_all[b] = make_int4(nlb + tot_h, nlb, tot_h, tot_l + tot_h);
@@ -589,7 +885,8 @@ extern "C" __attribute__((visibility("hidden"))) int tkr_plan_commit(int32_t n_u
 // (helpers between translation units, not entry points)
 extern "C" __attribute__((visibility("hidden"))) int tkr_plan_mid_ok(int32_t n_users, int32_t n_items, int32_t B) {
     static const int from = [] { const char* e = getenv("TKR_PLAN_MID_FROM"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1025; }();
-    if (B < from || B > tkr::kMidMaxB) return 0;
+    static const int upto = [] { const char* e = getenv("TKR_PLAN_MID_UPTO"); const int v = e ? atoi(e) : 0; return v > 0 ? v : tkr::kMidWideMaxB; }();
+    if (B < from || B > upto || B > tkr::kMidWideMaxB) return 0;
     // every range's workgroup walks all of the batch's draws: worth it while a range keeps a fair share of them -- 480,189 users are 59
     // ranges, fine at batch 8192 (Netflix shape: 311 -> 330 M triplets/s on the line), a loss at 2048 (208 -> 183)
     const tkr::MidGeom g = tkr::mid_geom(n_users, n_items, B);
@@ -597,8 +894,9 @@ extern "C" __attribute__((visibility("hidden"))) int tkr_plan_mid_ok(int32_t n_u
     return G <= tkr::kMidMaxRanges && G <= worth;
 }
 extern "C" __attribute__((visibility("hidden"))) int64_t tkr_plan_mid_workspace_bytes(int32_t batch_size, int32_t n_batches) {
-    if (batch_size <= 1024 || batch_size > tkr::kMidMaxB || n_batches <= 0) return 0;
-    return (int64_t)n_batches * tkr::kMidMaxRanges * (int64_t)sizeof(int4);
+    if (batch_size <= 1024 || batch_size > tkr::kMidWideMaxB || n_batches <= 0) return 0;
+    const int64_t sums = (int64_t)n_batches * tkr::kMidMaxRanges * (int64_t)sizeof(int4);
+    return tkr::mid_wide(batch_size) ? sums + (int64_t)n_batches * 3 * batch_size * 4 : sums;         // the wide form's occurrence lists
 }
 
 extern "C" __attribute__((visibility("hidden"))) int tkr_sample_plan_mid(
@@ -614,12 +912,15 @@ extern "C" __attribute__((visibility("hidden"))) int tkr_sample_plan_mid(
     hipStream_t s = (hipStream_t)stream;
     int4* agg = reinterpret_cast<int4*>(workspace);
     const size_t nB = (size_t)B * n_batches;
-    const size_t lds_build = mid_build_lds(B), lds_count = (size_t)kMidRows * 4;
+    const bool wide = mid_wide(B);
+    uint32_t* olist = reinterpret_cast<uint32_t*>(agg + (size_t)n_batches * kMidMaxRanges);
+    const size_t lds_build = wide ? mid_build_wide_lds(B) : mid_build_lds(B), lds_count = (size_t)kMidRows * 4;
     static bool attr_set[64] = {};                 // per device: the attribute belongs to the device's code object
     int dev = 0;
     TKR_CHECK(hipGetDevice(&dev));
-    if (lds_build > 64 * 1024 && !(dev >= 0 && dev < 64 && attr_set[dev])) {
+    if (!(dev >= 0 && dev < 64 && attr_set[dev])) {
         TKR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mid_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_build_lds(kMidMaxB)));      // (+ the kernel's static LDS: 160 KB would be refused)
+        TKR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mid_build_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_build_wide_lds(kMidWideMaxB)));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(mid_draw_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, s, tr_users, (uint32_t)n_tr, row_ptr, pos_cols,
@@ -634,8 +935,12 @@ extern "C" __attribute__((visibility("hidden"))) int tkr_sample_plan_mid(
     static const bool rowmajor = getenv("TKR_PLAN_MID_ROWMAJOR") && getenv("TKR_PLAN_MID_ROWMAJOR")[0] == '1';
     const int wu = (n_users + 31) / 32, wi = (n_items + 31) / 32;
     const bool tr = !rowmajor && (size_t)n_batches * wu <= (size_t)n_users * kTouchWords && (size_t)n_batches * wi <= (size_t)n_items * kTouchWords;
-    hipLaunchKernelGGL(mid_build_kernel, dim3(G, n_batches), dim3(kMidThreads), lds_build, s, g, B, n_users, n_items, out_u, out_i, out_j,
-                       agg, reinterpret_cast<int4*>(task), reinterpret_cast<int2*>(occ), occt, touch_u, touch_i, tr ? wu : 0, tr ? wi : 0);
+    if (wide)
+        hipLaunchKernelGGL(mid_build_wide_kernel, dim3(G, n_batches), dim3(kMidThreads), lds_build, s, g, B, n_users, n_items, out_u, out_i, out_j,
+                           agg, reinterpret_cast<int4*>(task), reinterpret_cast<int2*>(occ), occt, touch_u, touch_i, tr ? wu : 0, tr ? wi : 0, olist);
+    else
+        hipLaunchKernelGGL(mid_build_kernel, dim3(G, n_batches), dim3(kMidThreads), lds_build, s, g, B, n_users, n_items, out_u, out_i, out_j,
+                           agg, reinterpret_cast<int4*>(task), reinterpret_cast<int2*>(occ), occt, touch_u, touch_i, tr ? wu : 0, tr ? wi : 0);
     TKR_LAUNCH_CHECK();
     if (tr) {
         hipLaunchKernelGGL(mid_prefix_kernel, dim3((wu + wi + 3) / 4), dim3(256), 0, s, n_users, n_items, wu, wi, n_batches, ucnt, icnt,
