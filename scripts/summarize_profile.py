@@ -4,6 +4,7 @@ import csv, json, os, re, sys
 import pandas as pd
 src, tag = sys.argv[1], sys.argv[2]
 KERN = ('own_loss_kernel', 'step_loss_kernel', 'loss_slots_kernel', 'loss_slots_sum_kernel', 'bpr_own_kernel', 'bpr_flow_kernel', 'bpr_step_kernel', 'sample_plan_kernel', 'resolve_flow_wide_kernel', 'resolve_flow_kernel', 'score_topk_slab_kernel', 'resolve_kernel', 'commit_kernel', 'rollback_kernel',
+        'mid_draw_kernel', 'mid_count_kernel', 'mid_build_wide_kernel', 'mid_build_kernel', 'mid_prefix_kernel', 'mid_resolve_kernel', 'mid_zero_kernel',
         'big_draw_kernel', 'big_flag_kernel', 'big_emit_kernel', 'big_count_kernel', 'big_fill_kernel', 'big_parity_kernel', 'big_record_kernel',
         'DeviceRadixSort', 'radix_sort', 'DeviceScan', 'scan', 'vbpr_pair_kernel', 'score_topk_refine2_kernel', 'topk_finish2_kernel', 'score_topk_wide_kernel', 'bpr_wide_kernel', 'score_topk_bf16_kernel', 'score_topk_kernel', 'merge_topk_kernel', 'topk_bounds_kernel',
         'raw_rank_kernel', 'count_hits_rr_kernel',
