@@ -51,8 +51,8 @@ constexpr int kMidWaves = kMidThreads / TKR_WAVE;
 constexpr int kMidRows = 8192;            // rows per range at most (kMidThreads * 8)
 constexpr int kMidMaxRanges = 128;        // per batch; more (tens of millions of users): the grid-wide planner
 constexpr int kMidMaxB = 16384;           // run starts and cursors are 16-bit halves of one LDS word, occurrence indices 16-bit
-constexpr int kMidThreadSort = 4;         // a run up to this long: a compare / a five-comparator network by the row's thread (an insertion sort
-                                          // of 5 .. 16 entries on LDS made its thread the one the workgroup waited for: 6 us of an item range's 51)
+constexpr int kMidThreadSort = 16;        // a run up to this long is sorted by the row's thread: a compare, a five-comparator network, a bitonic network of
+                                          // 16 on registers (an insertion sort of 5 .. 16 entries ON LDS made its thread the one the workgroup waited for)
 constexpr int kMidWaveSort = 512;         // ... up to this long: one wave ranks it by counting (up to 64: through readlane; else 8 entries per lane)
 __host__ __device__ inline int mid_queue_cap(int B) { return 2 * B / (kMidThreadSort + 1) + 1; }        // longer runs of one range: at most
 constexpr int kMidHuge = 2 * kMidMaxB / (kMidWaveSort + 1) + 1;
@@ -236,6 +236,24 @@ __global__ __launch_bounds__(kMidThreads) void mid_count_kernel(MidGeom g, int B
     }
 }
 
+template <int N>
+__device__ __forceinline__ void reg_sort_asc(uint32_t (&v)[N]) {           // bitonic network on registers, N a power of two
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint32_t lo = min(v[i], v[l]), hi = max(v[i], v[l]);
+                    const bool asc = (i & k) == 0;
+                    v[i] = asc ? lo : hi;
+                    v[l] = asc ? hi : lo;
+                }
+            }
+}
+
 // dynamic LDS of the build kernel: cnt[kMidRows] | list[2B] (16-bit) | queue[mid_queue_cap(B)] (16-bit) | huge[kMidHuge] (16-bit) | bitmap[2B / 32]
 __host__ __device__ inline size_t mid_build_lds(int B) {
     return (size_t)kMidRows * 4 + (size_t)2 * B * 2 + (size_t)(mid_queue_cap(B) + kMidHuge + 2) / 2 * 4 + (size_t)((2 * B + 31) / 32) * 4 + 16;
@@ -320,6 +338,14 @@ __global__ __launch_bounds__(kMidThreads, 8) void mid_build_kernel(MidGeom g, in
             cx(a0, a1); cx(a2, a3); cx(a0, a2); cx(a1, a3); cx(a1, a2);
             list[s] = (uint16_t)a0; list[s + 1] = (uint16_t)a1; list[s + 2] = (uint16_t)a2;
             if (c == 4) list[s + 3] = (uint16_t)a3;
+        } else if (c > 4 && c <= kMidThreadSort) {         // a bitonic network of 16 on registers (one run in forty of an item range at batch 8192;
+            uint32_t v[16];                                // a wave each, they were most of the 28 % of the kernel in its wave tier)
+#pragma unroll
+            for (int x = 0; x < 16; ++x) v[x] = x < c ? (uint32_t)list[s + x] : 0xffffffffu;
+            reg_sort_asc<16>(v);
+#pragma unroll
+            for (int x = 0; x < 16; ++x)
+                if (x < c) list[s + x] = (uint16_t)v[x];
         } else if (c > kMidThreadSort) {
             queue[atomicAdd(&qn, 1)] = (uint16_t)q;
         }
@@ -428,24 +454,6 @@ __host__ __device__ inline int mid_wide_queue_cap(int B) { return 2 * B / (kMidW
 __host__ __device__ inline int mid_wide_huge_cap(int B) { return 2 * B / (kMidWaveSort + 1) + 1; }
 __host__ __device__ inline size_t mid_build_wide_lds(int B) {
     return (size_t)4 * (2 * kMidWideRows + kMidWideList + kMidWaves * kMidWaveSort + (2 * B + 31) / 32) + (size_t)(mid_wide_queue_cap(B) + mid_wide_huge_cap(B) + 2) / 2 * 4 + 16;
-}
-
-template <int N>
-__device__ __forceinline__ void reg_sort_asc(uint32_t (&v)[N]) {           // bitonic network on registers, N a power of two
-#pragma unroll
-    for (int k = 2; k <= N; k <<= 1)
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1)
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const uint32_t lo = min(v[i], v[l]), hi = max(v[i], v[l]);
-                    const bool asc = (i & k) == 0;
-                    v[i] = asc ? lo : hi;
-                    v[l] = asc ? hi : lo;
-                }
-            }
 }
 
 __global__ __launch_bounds__(kMidThreads) void mid_build_wide_kernel(MidGeom g, int B, int n_users, int n_items,
